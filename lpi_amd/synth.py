@@ -1,0 +1,162 @@
+"""Deterministic synthetic CLIP weights, prompt factors and inputs.
+
+Real CLIP ViT-B/16 weights cannot be fetched (no network; the reference downloads them in
+``retrieval/models/clip/prompt_learner.py:10-13`` / ``clip.py:39-68``).  Everything here is drawn from
+numpy's Philox bit generator keyed by ``(seed, crc32(tensor name))`` so that the golden generator
+(which loads the tensors into the imported reference in the build container) and the GPU box
+(which has no reference) regenerate bit-identical tensors without shipping any file.
+
+Scales follow the reference's own initialiser ``CLIP.initialize_parameters``
+(``retrieval/models/clip/model.py:318-345``) so activations are well conditioned; biases and LayerNorm
+affine terms get small non-trivial values so every term of every kernel is exercised.
+
+The state-dict key names are the reference's (``model.py:418-441`` infers the architecture from them),
+so a real CLIP state dict can be passed to the engine in place of the synthetic one.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+WEIGHT_SEED = 20240101
+PROMPT_SEED = 3000
+IMAGE_SEED = 1000               # + rank
+TOKEN_SEED = 2000               # + rank
+
+SOT, EOT, X_TOKEN, DOT_TOKEN = 49406, 49407, 343, 269   # [probed] ids of "<|startoftext|>", "<|endoftext|>", "x</w>", ".</w>"
+
+
+@dataclass(frozen=True)
+class ClipConfig:
+    """Architecture numbers exactly as ``CLIP.__init__`` takes them (``model.py:262-277``)."""
+    name: str
+    embed_dim: int
+    image_resolution: int
+    vision_layers: int
+    vision_width: int
+    vision_patch_size: int
+    context_length: int
+    vocab_size: int
+    transformer_width: int
+    transformer_heads: int
+    transformer_layers: int
+
+    @property
+    def vision_heads(self) -> int:
+        return self.vision_width // 64
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image_resolution // self.vision_patch_size) ** 2
+
+    def as_clip_args(self):
+        d = asdict(self)
+        d.pop("name")
+        return tuple(d.values())
+
+
+# head_dim is 64 for every CLIP ViT (vision_heads = width // 64, model.py:292)
+VIT_B16 = ClipConfig("ViT-B/16", 512, 224, 12, 768, 16, 77, 49408, 512, 8, 12)
+VIT_L14 = ClipConfig("ViT-L/14", 768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12)
+# small config used by fast tests: 2 layers, 2 heads, 4 patches; same code paths
+TINY = ClipConfig("tiny", 128, 32, 2, 128, 16, 77, 49408, 128, 2, 2)
+
+CONFIGS = {c.name: c for c in (VIT_B16, VIT_L14, TINY)}
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
+    x = _rng(seed, name).standard_normal(size=shape, dtype=np.float32)
+    if std != 1.0:
+        x *= np.float32(std)
+    if mean != 0.0:
+        x += np.float32(mean)
+    return x
+
+
+def _block(sd, seed, prefix, width, layers):
+    attn_std = width ** -0.5
+    proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+    fc_std = (2 * width) ** -0.5
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        for nm, shape, std, mean in (
+            ("attn.in_proj_weight", (3 * width, width), attn_std, 0.0),
+            ("attn.in_proj_bias", (3 * width,), 0.02, 0.0),
+            ("attn.out_proj.weight", (width, width), proj_std, 0.0),
+            ("attn.out_proj.bias", (width,), 0.02, 0.0),
+            ("ln_1.weight", (width,), 0.1, 1.0),
+            ("ln_1.bias", (width,), 0.05, 0.0),
+            ("mlp.c_fc.weight", (4 * width, width), fc_std, 0.0),
+            ("mlp.c_fc.bias", (4 * width,), 0.02, 0.0),
+            ("mlp.c_proj.weight", (width, 4 * width), proj_std, 0.0),
+            ("mlp.c_proj.bias", (width,), 0.02, 0.0),
+            ("ln_2.weight", (width,), 0.1, 1.0),
+            ("ln_2.bias", (width,), 0.05, 0.0),
+        ):
+            sd[p + nm] = normal(seed, p + nm, shape, std, mean)
+
+
+def clip_state_dict(cfg: ClipConfig, seed: int = WEIGHT_SEED) -> dict:
+    """Synthetic state dict with the reference's key names / shapes (``model.py:418-441``)."""
+    sd = {}
+    vw, tw = cfg.vision_width, cfg.transformer_width
+    ps = cfg.vision_patch_size
+    scale = vw ** -0.5
+    sd["visual.class_embedding"] = normal(seed, "visual.class_embedding", (vw,), scale)
+    sd["visual.positional_embedding"] = normal(seed, "visual.positional_embedding", (cfg.n_patches + 1, vw), scale)
+    sd["visual.proj"] = normal(seed, "visual.proj", (vw, cfg.embed_dim), scale)
+    sd["visual.conv1.weight"] = normal(seed, "visual.conv1.weight", (vw, 3, ps, ps), (3 * ps * ps) ** -0.5)
+    for nm in ("ln_pre", "ln_post"):
+        sd[f"visual.{nm}.weight"] = normal(seed, f"visual.{nm}.weight", (vw,), 0.1, 1.0)
+        sd[f"visual.{nm}.bias"] = normal(seed, f"visual.{nm}.bias", (vw,), 0.05)
+    _block(sd, seed, "visual.transformer.", vw, cfg.vision_layers)
+    _block(sd, seed, "transformer.", tw, cfg.transformer_layers)
+    sd["token_embedding.weight"] = normal(seed, "token_embedding.weight", (cfg.vocab_size, tw), 0.02)
+    sd["positional_embedding"] = normal(seed, "positional_embedding", (cfg.context_length, tw), 0.01)
+    sd["ln_final.weight"] = normal(seed, "ln_final.weight", (tw,), 0.1, 1.0)
+    sd["ln_final.bias"] = normal(seed, "ln_final.bias", (tw,), 0.05)
+    sd["text_projection"] = normal(seed, "text_projection", (tw, cfg.embed_dim), tw ** -0.5)
+    sd["logit_scale"] = np.array(np.log(1 / 0.07), dtype=np.float32)
+    return sd
+
+
+PROMPT_NAMES = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")
+
+
+def prompt_factors(layer_num: int, prompt_num: int, vis_dim: int, txt_dim: int, r: int = 4,
+                   seed: int = PROMPT_SEED, task: int = 0) -> dict:
+    """Five CP factors ~ N(0, 0.5^2), the reference's init (``prompts.py:21-25``)."""
+    shapes = {
+        "dim_1_share": (layer_num, r),
+        "dim_2_visual": (prompt_num, r),
+        "dim_2_textual": (prompt_num, r),
+        "dim_3_visual": (vis_dim, r),
+        "dim_3_textual": (txt_dim, r),
+    }
+    return {k: normal(seed, f"prompts.{task}.{k}", s, 0.5) for k, s in shapes.items()}
+
+
+def images(batch: int, resolution: int, seed: int = IMAGE_SEED) -> np.ndarray:
+    """N(0,1) stand-in for ImageNet-normalised pixels (``utils/data.py:310-313``)."""
+    return normal(seed, "images", (batch, 3, resolution, resolution))
+
+
+def token_ids(batch: int, context_length: int = 77, n_ctx: int = 16, seed: int = TOKEN_SEED,
+              min_len: int = 5, max_len: int = 40) -> np.ndarray:
+    """Token ids shaped like ``PromptLearner.forward`` builds them (``prompt_learner.py:128-133``):
+    SOT, n_ctx placeholder "X" tokens, caption ids, '.', EOT, zero padding."""
+    g = _rng(seed, "token_ids")
+    ids = np.zeros((batch, context_length), dtype=np.int64)
+    max_len = min(max_len, context_length - n_ctx - 3)
+    for b in range(batch):
+        n = int(g.integers(min_len, max_len + 1))
+        body = g.integers(320, 49405, size=n)
+        row = [SOT] + [X_TOKEN] * n_ctx + body.tolist() + [DOT_TOKEN, EOT]
+        ids[b, :len(row)] = row
+    return ids

@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (Kelvin-ywc/LPI, retrieval/) in this container.
+
+Runs only where /root/reference exists (the build container).  Nothing of the reference travels:
+the outputs are small ``.npz`` files of inputs/expected outputs under ``tests/golden/``.
+
+The reference cannot run on CPU or offline unmodified.  The harness applies
+exactly the shim list of SURVEY.md section 8(c):
+
+  module stubs : torchvision(+transforms,+datasets), ftfy, loguru, models.sinet
+  runtime shims: Tensor.cuda -> identity, torch.cuda.current_device -> 0, torch.cuda.device_count -> 1,
+                 models.slinet.load_clip_to_cpu -> CLIP(...).float().eval() with synthetic weights
+                 (skips the download and the fp16 convert_weights: F3), cwd = retrieval/ (./MID/...)
+
+Two golden families (F1):
+  * ``*_d1``          true oracle: the shipped code, whose deep-prompt guard is dead => depth 1.
+  * ``*_d3_patched``  patched oracle: ResidualAttentionBlock.forward re-stated in this harness with the
+                      intended guard ``0 < layer_id < depth`` (model.py:190-193), depth = 3.
+
+Usage:  python tests/golden/gen_golden.py [--only tiny|vitb16]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/retrieval"
+sys.path.insert(0, REPO)
+
+from lpi_amd import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+# ----------------------------------------------------------------------------- shims
+def install_shims():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _T:  # transform placeholder
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    tv = stub("torchvision")
+    names = ["Compose", "Resize", "CenterCrop", "ToTensor", "Normalize", "RandomResizedCrop",
+             "RandomHorizontalFlip", "ColorJitter"]
+    tr = stub("torchvision.transforms", **{n: _T for n in names})
+    tr.InterpolationMode = types.SimpleNamespace(BICUBIC=3)
+    tv.transforms = tr
+    tv.datasets = stub("torchvision.datasets")
+    stub("ftfy", fix_text=lambda s: s)
+
+    class _Logger:
+        def add(self, *a, **k):
+            return 0
+
+        def info(self, *a, **k):
+            pass
+
+    stub("loguru", logger=_Logger())
+    stub("models.sinet", SiNet=object)
+
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.device_count = lambda: 1
+
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # slinet.py:171 reads ./MID/task_sim_matrix.txt relative to cwd
+
+
+def ref_args(cfg: synth.ClipConfig):
+    with open(os.path.join(REF, "configs/lpi/coco_lpi.json")) as f:
+        args = json.load(f)
+    args["device"] = [torch.device("cpu")]
+    args["visual_dim"] = cfg.vision_width
+    args["textual_dim"] = cfg.transformer_width
+    return args
+
+
+def build_slinet(cfg: synth.ClipConfig):
+    import models.slinet as slinet
+    from models.clip.model import CLIP
+
+    def load_clip_to_cpu(_args):
+        model = CLIP(*cfg.as_clip_args()).float().eval()
+        sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(cfg).items()}
+        model.load_state_dict(sd)
+        return model
+
+    slinet.load_clip_to_cpu = load_clip_to_cpu
+    net = slinet.SliNet(ref_args(cfg))
+    for t in range(len(net.prompts)):
+        fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width, task=t)
+        for k, v in fac.items():
+            getattr(net.prompts[t], k).data = torch.from_numpy(v.copy())
+    return net
+
+
+def patch_depth(depth):
+    """Re-state ResidualAttentionBlock.forward with the intended guard (model.py:187-196)."""
+    from models.clip import model as M
+
+    orig = M.ResidualAttentionBlock.forward
+
+    def forward(self, inp):
+        x, prompts = inp[0], inp[1]
+        if 0 < self.layer_id < depth and prompts is not None:
+            P = prompts.shape[-2]
+            tmp = prompts[:, self.layer_id, :, :].permute(1, 0, 2)
+            x = torch.cat([x[:1], x[1:P + 1] + tmp, x[P + 1:]], dim=0)
+        x = x + self.attention(self.ln_1(x))
+        x = x + self.mlp(self.ln_2(x))
+        return [x, prompts]
+
+    M.ResidualAttentionBlock.forward = forward
+    return lambda: setattr(M.ResidualAttentionBlock, "forward", orig)
+
+
+CAPTIONS = [
+    "a man riding a wave on top of a surfboard",
+    "two dogs play with a red frisbee in the park",
+    "a plate of food with broccoli and rice",
+    "an old clock tower stands over the city street",
+    "a woman holding an umbrella while it rains",
+    "several giraffes eating leaves from tall trees",
+    "a kitchen with stainless steel appliances and a wooden table",
+    "a baseball player swings his bat at the ball",
+    "a cat sleeping on a laptop keyboard",
+    "people walking through a busy train station at night",
+    "a red double decker bus driving down a street",
+    "a small child flying a colorful kite on the beach",
+]
+
+
+def captions_for(batch):
+    return [CAPTIONS[i % len(CAPTIONS)] + ("" if i < len(CAPTIONS) else f" number {i}") for i in range(batch)]
+
+
+def train_step(net, cfg, batch, numtask):
+    """SliNet.forward + cal_loss + backward exactly as SPrompts.train_function does (sprompt.py:297-311)."""
+    net.numtask = numtask
+    net.train()
+    names = []
+    for name, p in net.named_parameters():
+        p.requires_grad_(False)
+        if "prompts." + str(numtask - 1) + "." in name:  # sprompt.py:235
+            p.requires_grad_(True)
+            names.append(name)
+            p.grad = None
+    img = torch.from_numpy(synth.images(batch, cfg.image_resolution))
+    caps = captions_for(batch)
+    img_f, txt_f, vp, tp = net(img, caps)
+    out = net.cal_loss(img_f, txt_f, vp, tp)
+    loss = sum(v for v in out["loss"].values())
+    loss.backward()
+    with torch.no_grad():
+        logits = net.logit_scale.exp() * img_f @ txt_f.t()
+        ids = torch.cat([__import__("models.clip.clip", fromlist=["tokenize"]).tokenize(
+            " ".join(["X"] * 16) + " " + c + ".") for c in caps])
+    res = {
+        "token_ids": ids.numpy(),
+        "img_f": img_f.detach().numpy(), "txt_f": txt_f.detach().numpy(),
+        "logits": logits.numpy(),
+        "vis_prompt": vp[0].detach().numpy(), "txt_prompt": tp[0].detach().numpy(),
+        "trainable": np.array(names),
+    }
+    for k, v in out["loss"].items():
+        res[k] = np.float32(v.item())
+    for name, p in net.named_parameters():
+        if p.requires_grad:
+            res["grad." + name.split(".")[-1]] = p.grad.detach().numpy().copy()
+    # per-row top-5 with margins (F8): index parity is only asserted where the margin is large
+    for tag, S in (("i2t", logits), ("t2i", logits.t())):
+        srt, idx = torch.sort(S, dim=1, descending=True, stable=True)
+        k = min(5, S.shape[1] - 1)
+        res[f"top5_{tag}"] = idx[:, :k].numpy()
+        res[f"top5_margin_{tag}"] = (srt[:, :k] - srt[:, 1:k + 1]).numpy()
+    return res
+
+
+def eval_case(net, cfg, batch):
+    """Eval interfaces (slinet.py:85-107, 185-220) + task-id selection and itm_eval (sprompt.py:336-368, 550-646)."""
+    from methods.sprompt import SPrompts
+
+    net.numtask = 3
+    net.eval()
+    img = torch.from_numpy(synth.images(batch, cfg.image_resolution, seed=synth.IMAGE_SEED + 7))
+    caps = captions_for(batch)
+    rng = np.random.Generator(np.random.Philox(key=[77, 1]))
+    sel_v = torch.from_numpy(rng.integers(0, 3, size=batch))
+    sel_t = torch.from_numpy(rng.integers(0, 3, size=batch))
+    with torch.no_grad():
+        ev = net.extract_vector(img)
+        et = net.extract_textual_vector(caps)
+        vi = net.visual_interface(img, sel_v)
+        ti = net.textual_interface(caps, sel_t)
+    from models.clip.clip import tokenize
+    ids = torch.cat([tokenize(" ".join(["X"] * 16) + " " + c + ".") for c in caps])
+    res = {"token_ids": ids.numpy(), "captions": np.array(caps),
+           "sel_v": sel_v.numpy(), "sel_t": sel_t.numpy(), "extract_vector": ev.numpy(),
+           "extract_textual_vector": et.numpy(), "visual_interface": vi.numpy(),
+           "textual_interface": ti.numpy()}
+
+    # task-id selection by L1 distance to per-task centres (sprompt.py:336-351)
+    sp = object.__new__(SPrompts)
+    sp._network = net
+    keys = [torch.from_numpy(synth.normal(5, f"keys{t}", (5, cfg.embed_dim), 0.05)) for t in range(3)]
+    sp.all_keys = keys
+    sp.textual_all_keys = keys
+    res["task_keys"] = torch.stack(keys).numpy()
+    res["visual_task_id"] = sp.get_visual_task_id(img).numpy()
+    res["textual_task_id"] = sp.get_textual_task_id(caps).numpy()
+
+    # itm_eval on a fixed score matrix: 2 captions per image, 3 tasks
+    n_img, n_txt = 24, 48
+    scores = synth.normal(9, "scores", (n_img, n_txt))
+    img2txt = {i: [2 * i, 2 * i + 1] for i in range(n_img)}
+    txt2img = {t: t // 2 for t in range(n_txt)}
+    cat_i = [i % 3 for i in range(n_img)]
+    cat_t = [(t // 2) % 3 for t in range(n_txt)]
+    sp.cur_id = 2
+    fr = sp.itm_eval(scores, scores.T.copy(), txt2img, img2txt, cat_i, torch.tensor(cat_t))
+    res["itm_scores"] = scores
+    res["itm_cat_i"] = np.array(cat_i)
+    res["itm_cat_t"] = np.array(cat_t)
+    res["itm_i2t"] = np.array([fr["mscoco"]["i2t"][t] for t in range(3)])
+    res["itm_t2i"] = np.array([fr["mscoco"]["t2i"][t] for t in range(3)])
+    return res
+
+
+def save(name, res, meta):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **res)
+    meta[name] = {k: (list(v.shape) if hasattr(v, "shape") else None) for k, v in res.items()}
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    install_shims()
+    meta_path = os.path.join(HERE, "MANIFEST.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    meta["_generator"] = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(),
+                          "reference": "Kelvin-ywc/LPI @ 2024-12-23, retrieval/", "dtype": "float32 (CPU)"}
+
+    if a.only in (None, "tiny"):
+        cfg = synth.TINY
+        net = build_slinet(cfg)
+        save("tiny_d1", train_step(net, cfg, 4, 1), meta)
+        save("tiny_task2", train_step(net, cfg, 4, 2), meta)     # exercises task_loss (numtask != 1)
+        undo = patch_depth(2)
+        save("tiny_d2_patched", train_step(net, cfg, 4, 1), meta)   # tiny has 2 layers: depth 2 is the deep case
+        undo()
+        save("tiny_eval", eval_case(net, cfg, 6), meta)
+
+    if a.only in (None, "vitb16"):
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        r = train_step(net, cfg, 8, 1)          # BASELINE.json configs[0]: bs=8, r=4
+        for k in ("vis_prompt", "txt_prompt"):  # keep the fixture small: layer 0 only (the live one, F1)
+            r[k] = r[k][:1]
+        save("vitb16_d1", r, meta)
+        undo = patch_depth(3)
+        r = train_step(net, cfg, 8, 1)
+        for k in ("vis_prompt", "txt_prompt"):
+            r[k] = r[k][:3]
+        save("vitb16_d3_patched", r, meta)
+        undo()
+
+    with open(meta_path, "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

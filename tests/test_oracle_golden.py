@@ -1,0 +1,105 @@
+"""Pin the oracle (oracle/lpi_oracle.py) against fixtures captured from the imported reference
+(tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lpi_amd import synth
+from oracle import lpi_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TASK_SIM = np.loadtxt(os.path.join(REPO, "lpi_amd", "retrieval", "MID", "task_sim_matrix.txt"))
+GRADS = ["grad." + n for n in synth.PROMPT_NAMES]
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return O.Oracle(synth.TINY, synth.clip_state_dict(synth.TINY))
+
+
+def factors(cfg, task=0):
+    return synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width, task=task)
+
+
+def check_step(res, g, tol=2e-5, gtol=1e-4):
+    for k in ("img_f", "txt_f", "logits", "vis_prompt", "txt_prompt", "base_loss", "alignment_loss"):
+        ref = g[k]
+        got = res[k][: ref.shape[0]] if ref.ndim == 3 else res[k]
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), k
+    for k in GRADS:
+        assert rel_err(res[k], g[k]) <= gtol, (k, rel_err(res[k], g[k]))
+
+
+@pytest.mark.parametrize("name,depth", [("tiny_d1", 1), ("tiny_d2_patched", 2)])
+def test_tiny_train_step(tiny, golden, name, depth):
+    g = golden(name)
+    res = O.train_step(tiny, synth.images(4, 32), g["token_ids"], factors(synth.TINY), depth=depth)
+    check_step(res, g)
+
+
+def test_tiny_depth_changes_result(golden):
+    # the patched fixture must differ from the true-oracle one (otherwise the patch was a no-op)
+    assert np.abs(golden("tiny_d1")["img_f"] - golden("tiny_d2_patched")["img_f"]).max() > 1e-4
+
+
+def test_tiny_task_loss(tiny, golden):
+    g = golden("tiny_task2")
+    allf = [factors(synth.TINY, t) for t in range(2)]
+    res = O.train_step(tiny, synth.images(4, 32), g["token_ids"], allf[1], depth=1, numtask=2,
+                       all_factors_np=allf, task_sim=TASK_SIM)
+    check_step(res, g)
+    assert abs(res["task_loss"] - g["task_loss"]) <= 2e-5 * max(1.0, abs(g["task_loss"]))
+
+
+def test_tiny_eval_interfaces(tiny, golden):
+    g = golden("tiny_eval")
+    cfg = synth.TINY
+    img = torch.from_numpy(synth.images(6, 32, seed=synth.IMAGE_SEED + 7))
+    ids = torch.from_numpy(g["token_ids"])
+    allf = [{k: torch.from_numpy(v) for k, v in factors(cfg, t).items()} for t in range(12)]
+    with torch.no_grad():
+        ev = tiny.extract_vector(img)
+        vi = tiny.visual_interface(img, torch.from_numpy(g["sel_v"]), allf)
+        et = tiny.extract_textual_vector(ids)
+        ti = tiny.textual_interface(ids, torch.from_numpy(g["sel_t"]), allf)
+    assert np.abs(et.numpy() - g["extract_textual_vector"]).max() < 2e-5
+    assert np.abs(ti.numpy() - g["textual_interface"]).max() < 2e-5
+    assert (O.task_id_by_keys(et, torch.from_numpy(g["task_keys"])).numpy() == g["textual_task_id"]).all()
+    with torch.no_grad():
+        pass
+    assert np.abs(ev.numpy() - g["extract_vector"]).max() < 2e-5
+    assert np.abs(vi.numpy() - g["visual_interface"]).max() < 2e-5
+    keys = torch.from_numpy(g["task_keys"])
+    assert (O.task_id_by_keys(ev, keys).numpy() == g["visual_task_id"]).all()
+
+
+def test_itm_eval(golden):
+    g = golden("tiny_eval")
+    s = g["itm_scores"]
+    n_img, n_txt = s.shape
+    fr = O.itm_eval(s, s.T.copy(), {t: t // 2 for t in range(n_txt)}, {i: [2 * i, 2 * i + 1] for i in range(n_img)},
+                    g["itm_cat_i"], g["itm_cat_t"], 3)
+    assert np.allclose([fr["mscoco"]["i2t"][t] for t in range(3)], g["itm_i2t"])
+    assert np.allclose([fr["mscoco"]["t2i"][t] for t in range(3)], g["itm_t2i"])
+
+
+@pytest.mark.parametrize("name,depth", [("vitb16_d1", 1), ("vitb16_d3_patched", 3)])
+def test_vitb16_train_step(golden, name, depth):
+    """BASELINE.json configs[0]: ViT-B/16, bs=8, r=4 on the CPU reference path."""
+    cfg = synth.VIT_B16
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
+    g = golden(name)
+    res = O.train_step(orc, synth.images(8, 224), g["token_ids"], factors(cfg), depth=depth)
+    check_step(res, g, tol=5e-5, gtol=2e-3)
+    # top-k index parity wherever the recorded margin dominates the logit error
+    err = np.abs(res["logits"] - g["logits"]).max()
+    for tag, S in (("i2t", res["logits"]), ("t2i", res["logits"].T)):
+        idx = np.argsort(-S, axis=1, kind="stable")[:, : g[f"top5_{tag}"].shape[1]]
+        safe = g[f"top5_margin_{tag}"] > 10 * err
+        assert (idx[safe] == g[f"top5_{tag}"][safe]).all()
