@@ -1,0 +1,152 @@
+/*
+ * lpi_hip.h — C ABI of liblpi_hip.so: the MI355X (gfx950) kernels behind the LPI retrieval hot path.
+ *
+ * The reference (Kelvin-ywc/LPI, retrieval/) has no FFI of its own: its hot path is stock PyTorch modules
+ * (SURVEY.md section 2d).  Each entry point below replaces the ATen arithmetic under one reference call site;
+ * the citation after "replaces:" is the reference file:line (relative to /root/reference/retrieval/).
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (torch); no hidden allocation, no host sync;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     0 on success, a negative LPI_E* code on a rejected argument, or a positive hipError_t;
+ *   - `dtype` selects the storage type of activations/weights fed to the matrix cores:
+ *       LPI_F32  : f32 in, f32 accumulate (v_mfma_f32_16x16x4_f32)     — parity mode
+ *       LPI_BF16 : bf16 in, f32 accumulate (v_mfma_f32_16x16x32_bf16) — throughput mode
+ *     the residual stream, LayerNorm statistics, losses and prompt factors are always f32;
+ *   - token rows are batch-major: row(b, l) = b * L + l (the reference permutes to [L, B, d] for
+ *     nn.MultiheadAttention, models/clip/model.py:253; the arithmetic is layout independent);
+ *   - matrices handed to lpi_gemm_nt are padded by the caller: M % 128 == 0, N % 128 == 0,
+ *     K % (128 / sizeof(element)) == 0, all leading dimensions 16-byte aligned.
+ */
+#ifndef LPI_HIP_H
+#define LPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPI_F32 0
+#define LPI_BF16 1
+
+#define LPI_EINVAL (-22)   /* bad shape / alignment / null pointer */
+#define LPI_ENOSYS (-38)   /* combination not built */
+
+/* epilogue selectors of lpi_gemm_nt */
+#define LPI_EPI_NONE 0        /* C = alpha*acc (+bias) (+residual)                                     */
+#define LPI_EPI_QUICKGELU 1   /* u = acc+bias; aux = u (if aux); C = u*sigmoid(1.702u)   model.py:163-165 */
+#define LPI_EPI_DQUICKGELU 2  /* C = acc * d/du[u*sigmoid(1.702u)] with u = aux          (backward)     */
+
+int lpi_version(void);
+/* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
+uint64_t lpi_launch_count(void);
+
+/* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
+ * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
+ * replaces: models/clip/model.py:175-177 (c_fc, c_proj), :172,185 (nn.MultiheadAttention in/out proj),
+ *           :215,228 (conv1 as per-patch matmul), :257 (x @ proj); prompt_learner.py:61 (@ text_projection);
+ *           slinet.py:139 (logit_scale * I @ T^T); and their autograd dgrads (B = pre-transposed weight).
+ * A, B: `dtype` elements.  C: `c_dtype` elements.  bias, residual: f32 or NULL.  aux: `dtype` or NULL. */
+int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K,
+                const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                const float* bias, const float* residual, int ldr,
+                int epilogue, void* aux, int ldaux, float alpha, void* stream);
+
+/* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
+ * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x f32 [rows,d] (row stride ldx), y `dtype`.
+ * bwd: dx[r,:] (f32, in/out: residual-stream gradient) += LN'(dy[r,:]); optionally also writes a `dtype`
+ *      copy dx_cast (the next dgrad GEMM's operand).  dy is `dy_dtype`. */
+int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int ldx, const float* gamma, const float* beta,
+                      void* y, int ldy, float* mean, float* rstd, void* stream);
+int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy,
+                      const float* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, int lddx, void* dx_cast, int ldcast, void* stream);
+
+/* ---- a4: prompted multi-head attention, head_dim 64   replaces: models/clip/model.py:183-185 -----------
+ * qkv: [B*L, 3*d] `dtype` (q | k | v, heads contiguous by 64).  ctx: [B*L, d] `dtype`.  lse: [B, H, L] f32.
+ * softmax(q k^T / 8 + causal mask) v; causal != 0 applies the text tower's strict upper-triangular -inf mask
+ * (model.py:347-353).  Backward recomputes P from lse; delta = rowsum(dctx*ctx) is produced into `delta`
+ * ([B,H,L] f32 scratch).  dqkv: [B*L, 3*d] `dtype`. L <= 288. */
+int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                 float* lse, int causal, void* stream);
+int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
+                 const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
+                 int causal, void* stream);
+
+/* ---- a1: DecomposedPrompt                          replaces: models/prompts/prompts.py:38-57 -----------
+ * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout. */
+int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,
+                      float scale, float* out, void* stream);
+int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,
+                      float scale, const float* dout, float* g1, float* g2, float* g3, int accumulate_g1,
+                      void* stream);
+
+/* ---- a3: vision front end                          replaces: models/clip/model.py:227-251 --------------
+ * patchify: image [B,3,R,R] f32 -> cols [B*G*G (padded rows untouched), Kp] `dtype`, Kp >= 3*ps*ps zero padded.
+ * assemble + ln_pre: x0[b] = LN([cls+pos0 ; prompts[b,0] (no pos) ; patch_emb[b]+pos1..]) -> x0 f32 [B*L,d];
+ * prompt0: f32, element (b,p,:) at prompt0 + b*prompt_bstride + p*d (bstride 0 = broadcast, slinet.py:119).
+ * bwd: applies LN' to rows 1..P of dx0 IN PLACE (dx0 is dead afterwards; the other rows' input gradients are
+ *      not needed because the backbone is frozen), then dprompt[p,:] = sum_b dx0[b,1+p,:] (f32 [P,d]; the batch
+ *      sum is the gradient of the training-time stride-0 broadcast, slinet.py:119). */
+int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream);
+int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
+                         const float* pos, const float* prompt0, long prompt_bstride,
+                         const float* gamma, const float* beta, float* x0, float* mean, float* rstd, void* stream);
+int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, const float* prompt0, long prompt_bstride,
+                         const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream);
+
+/* ---- a6/a7: text front end          replaces: models/clip/prompt_learner.py:52-53,128-163 --------------
+ * x0[b,l] = (l in 1..P ? ctx[b,l-1] : tok_emb[ids[b,l]]) + pos[l]      (CLASS_TOKEN_POSITION == "end")
+ * bwd: dctx[p,:] (+)= sum_b dx0[b,1+p,:] */
+int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
+                      const float* ctx, long ctx_bstride, float* x0, void* stream);
+int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate,
+                            void* stream);
+
+/* ---- F1: deep prompts                               replaces: models/clip/model.py:189-193 -------------
+ * x[b, 1..P, :] += prompt_l[b?, p, :]   (in place on the f32 residual stream) */
+int lpi_prompt_add(int B, int L, int P, int d, float* x, const float* prompt_l, long prompt_bstride, void* stream);
+
+/* ---- a3/a7/a2: pooled head     replaces: model.py:255-257, prompt_learner.py:57-61, slinet.py:122,133 --
+ * pool_ln: y[b,:] = LN(x[b*L + idx[b], :]) (idx NULL -> row 0 = CLS; else EOT position) -> y `dtype` [B,d]
+ * pool_ln_bwd: dx (f32 [B*L,d], pre-zeroed) row idx[b] = LN'(dy[b]);
+ * l2norm fwd/bwd on f32 [B,E]:  y = x/||x||. */
+int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, const int32_t* idx, const float* gamma,
+                    const float* beta, void* y, int ldy, float* mean, float* rstd, void* stream);
+int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float* dy, int lddy, const float* x,
+                    const int32_t* idx, const float* gamma, const float* mean, const float* rstd,
+                    float* dx, void* dx_cast, void* stream);
+int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, int ldy, float* inv_norm, void* stream);
+int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int lddy, const float* inv_norm,
+                   float* dx, int lddx, void* stream);
+int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream);   /* ids.argmax(-1), prompt_learner.py:61 */
+
+/* ---- a8: symmetric contrastive loss   replaces: loss/loss.py:75-87 (ClipLoss.forward), slinet.py:139-141
+ * logits f32 [n_rows, n_cols] (ld), rows r0..r0+n_local-1 are this rank's pairs; square global matrix
+ * (n_rows == n_cols == W*B).  loss[0] = (CE(logits,arange)+CE(logits^T,arange))/2 over ALL rows/cols;
+ * dlogits (f32, same shape) = upstream * dloss/dlogits. */
+int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, float* loss, float* dlogits,
+                          int lddl, float* row_lse, float* col_lse, void* stream);
+
+/* ---- a8: alignment loss                                   replaces: models/slinet.py:143-158 ------------
+ * v = mean_d(vis)/temp, t = mean_d(txt)/temp ([Lyr,P]); S = v t^T [Lyr,Lyr]; loss[0] = weight * ClipLoss(S);
+ * dvis [Lyr,P,Dv], dtxt [Lyr,P,Dt] = dense gradients of loss[0] (both NULL: forward only). */
+int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp,
+                           float weight, float* loss, float* dvis, float* dtxt, void* stream);
+
+/* ---- misc ---------------------------------------------------------------------------------------------- */
+int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, void* stream);
+int lpi_transpose(int dtype, int rows, int cols, const void* src, int lds, void* dst, int ldd, void* stream);
+/* per-row descending rank of the best ground-truth column (itm_eval, methods/sprompt.py:558-599):
+ * rank[i] = #{j : s[i,j] > s[i,gt] or (s[i,j] == s[i,gt] and j > gt)} minimised over gt in gt_list row i.
+ * (np.argsort(score)[::-1] places later indices first among ties.) */
+int lpi_retrieval_rank(int n_rows, int n_cols, const float* scores, int ld, const int32_t* gt, int gt_per_row,
+                       int32_t* rank, void* stream);
+int lpi_topk(int n_rows, int n_cols, int k, const float* scores, int ld, int32_t* idx, float* val, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPI_HIP_H */

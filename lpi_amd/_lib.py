@@ -1,0 +1,96 @@
+"""ctypes binding of ``liblpi_hip.so`` (C ABI declared in ``include/lpi_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing, or a call returns an error, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblpi_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU = 0, 1, 2
+
+
+class LpiError(RuntimeError):
+    pass
+
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_long
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); must list EVERY symbol of include/lpi_hip.h
+SIGNATURES = {
+    "lpi_version": [],
+    "lpi_launch_count": [],
+    "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
+    "lpi_layernorm_fwd": [_I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
+    "lpi_layernorm_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
+    "lpi_attn_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "lpi_prompt_cp_fwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P],
+    "lpi_prompt_cp_bwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
+    "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
+    "lpi_patchify": [_I, _I, _I, _I, _P, _P, _I, _P],
+    "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "lpi_vis_assemble_bwd": [_I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
+    "lpi_txt_embed_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P],
+    "lpi_rows_sum_over_batch": [_I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "lpi_prompt_add": [_I, _I, _I, _I, _P, _P, _L, _P],
+    "lpi_pool_ln_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "lpi_pool_ln_bwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "lpi_l2norm_fwd": [_I, _I, _P, _I, _P, _I, _P, _P],
+    "lpi_l2norm_bwd": [_I, _I, _P, _I, _P, _I, _P, _P, _I, _P],
+    "lpi_eot_index": [_I, _I, _P, _P, _P],
+    "lpi_clip_loss_fwd_bwd": [_I, _P, _I, _F, _P, _P, _I, _P, _P, _P],
+    "lpi_cast": [_I, _I, _L, _P, _P, _P],
+    "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],
+    "lpi_retrieval_rank": [_I, _I, _P, _I, _P, _I, _P, _P],
+    "lpi_topk": [_I, _I, _I, _P, _I, _P, _P, _P],
+}
+_RESTYPES = {"lpi_launch_count": c_uint64}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise (never fall back) if it is absent or lacks a declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LpiError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or lpi_amd/csrc/build.sh. "
+            f"There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise LpiError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point with tensors converted to device pointers; raise on error."""
+    fn = getattr(load(), name)
+    conv = [(_ptr(a) if (a is None or hasattr(a, "data_ptr")) else a) for a in args]
+    rc = fn(*conv)
+    if rc != 0:
+        raise LpiError(f"{name} failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+
+
+def launch_count() -> int:
+    return int(load().lpi_launch_count())

@@ -1,0 +1,97 @@
+// Shared device helpers for the LPI gfx950 kernels (wave64, MFMA 16x16 fragments, 16-byte chunks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lpi_hip.h"
+
+typedef unsigned short bf16_t;  // storage type of a bfloat16
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+
+#define WAVE 64
+
+extern "C" void lpi_count_launch();
+#define LPI_LAUNCHED() lpi_count_launch()
+
+#define LPI_CHECK_LAST()                                      \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int DT = LPI_F32;
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // load / store 4 consecutive elements as floats
+    __device__ static __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    __device__ static __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int DT = LPI_BF16;
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    __device__ static __forceinline__ f32x4 ld4(const bf16_t* p) {
+        uint2 u = *reinterpret_cast<const uint2*>(p);
+        f32x4 r;
+        r[0] = __uint_as_float(u.x << 16);
+        r[1] = __uint_as_float(u.x & 0xFFFF0000u);
+        r[2] = __uint_as_float(u.y << 16);
+        r[3] = __uint_as_float(u.y & 0xFFFF0000u);
+        return r;
+    }
+    __device__ static __forceinline__ void st4(bf16_t* p, f32x4 v) {
+        bf16x4 b;
+        b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(p) = b;
+    }
+};
+
+// 16-byte fragment chunk as it sits in a lane's registers
+union Chunk {
+    uint4 u;
+    f32x4 f;
+    bf16x8 h;
+};
+
+// acc += A_chunk (x) B_chunk over the chunk's k values, 16x16 output tile.
+// Lane l supplies row (l & 15) of each operand and k-group (l >> 4); see cdna_hip_programming.md section 3.
+template <typename T> __device__ __forceinline__ void mma_chunk(f32x4& acc, const Chunk& a, const Chunk& b);
+template <> __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const Chunk& a, const Chunk& b) {
+    // k index of element s in k-group g is 4g+s for both operands: any consistent assignment sums the same products
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[0], b.f[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[1], b.f[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[2], b.f[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[3], b.f[3], acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x4& acc, const Chunk& a, const Chunk& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float quick_gelu_grad(float u) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * u));
+    return s * (1.0f + 1.702f * u * (1.0f - s));
+}

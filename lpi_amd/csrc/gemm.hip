@@ -1,0 +1,207 @@
+// NT GEMM on the gfx950 matrix cores:  C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias) + residual
+//
+// replaces: nn.Linear / nn.MultiheadAttention projections / conv1-as-matmul / x @ proj of the reference
+// (retrieval/models/clip/model.py:172-177,185,215,228,257; prompt_learner.py:61) and all their dgrads
+// (the backbone is frozen, so backward is dgrad only and B is then the pre-transposed weight).
+//
+// Design (MI355X first):
+//  * block tile 128x128, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16 tiles (64 accumulator VGPRs);
+//  * both operands are K-contiguous, so one LDS tile row = 128 bytes = 8 x 16-byte chunks for either element
+//    type (bf16: BK=64, f32: BK=32); the same staging/fragment code serves both, only mma_chunk differs;
+//  * global -> LDS by `global_load_lds_dwordx4` (16 B/lane, no VGPR round trip), double buffered, one barrier
+//    per K tile; the LDS image is lane-linear so the bank swizzle chunk ^= (row>>1)&7 is applied to the
+//    per-lane SOURCE address and again on the ds_read_b128 (conflict-free for the 16x16 fragment pattern);
+//  * operands are swapped in the MFMA (weights = "A", activations = "B") so that each lane ends up holding 4
+//    CONSECUTIVE columns of one output row: the epilogue (bias, QuickGELU, gelu', residual) runs on float4s and
+//    stores 16 B (f32) / 8 B (bf16) per lane;
+//  * blockIdx is remapped so that the blocks sharing one XCD's L2 walk neighbouring M tiles of the same N panel.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;              // one staged tile row (BK elements)
+constexpr int TILE_BYTES = BM * ROW_BYTES;  // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+constexpr int NTHREADS = 256;
+
+template <typename T, typename TC, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
+    int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+    TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
+    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = ROW_BYTES / (int)sizeof(T);
+
+    // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
+    // run of the (n-panel major, m minor) tile list so the B panel and neighbouring A tiles stay in its L2.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // group GROUP_M m-tiles per n-tile sweep so one XCD reuses a B panel against several A tiles
+    constexpr int GROUP_M = 8;
+    const int group = bid / (GROUP_M * tiles_n);
+    const int first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int in_group = bid - group * GROUP_M * tiles_n;
+    const int tm = first_m + in_group % gsz;
+    const int tn = in_group / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;   // wave's 64x64 quadrant
+
+    // ---- staging addresses: thread t, instruction i writes LDS byte i*4096 + t*16 of the tile ----------
+    // row = i*32 + t/8, physical chunk = t%8, logical chunk = phys ^ ((row>>1)&7) = phys ^ (4*(wave&1) + lane/16)
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+    const T* a_src = A + (size_t)(m0 + srow) * lda + schunk * EPC;
+    const T* b_src = B + (size_t)(n0 + srow) * ldb + schunk * EPC;
+    const size_t a_step = (size_t)32 * lda, b_step = (size_t)32 * ldb;
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE_BYTES + wave * 1024;
+        const T* ap = a_src + (size_t)kt * BK;
+        const T* bp = b_src + (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap + i * a_step),
+                                             (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + i * b_step),
+                                             (__attribute__((address_space(3))) void*)(base + TILE_BYTES + i * 4096), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets: lane reads row (l&15) of a 16-row sub tile, logical chunk 4*ks + (l>>4) ----
+    const int frow = lane & 15;
+    const int fsw = frow >> 1;                 // (row>>1)&7, sub-tile bases are multiples of 16
+    const int fg = lane >> 4;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * ROW_BYTES + (((ks << 2) | fg) ^ fsw) * 16;
+    const int a_frag_base = (wm * 64) * ROW_BYTES;               // activations: rows of the A tile
+    const int b_frag_base = TILE_BYTES + (wn * 64) * ROW_BYTES;  // weights: rows of the B tile
+
+    f32x4 acc[4][4];  // [n sub tile][m sub tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA of tile kt has landed
+        __syncthreads();                                  // ... and everyone's; buffer (kt+1)&1 is free again
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* buf = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Chunk fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i].u = *reinterpret_cast<const uint4*>(buf + a_frag_base + i * 16 * ROW_BYTES + foff[ks]);
+                fb[i].u = *reinterpret_cast<const uint4*>(buf + b_frag_base + i * 16 * ROW_BYTES + foff[ks]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma_chunk<T>(acc[ni][mi], fb[ni], fa[mi]);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m = .. + (l&15)][n = .. + 4*(l>>4) + 0..3] ------------------------------
+    const int row_base = m0 + wm * 64 + (lane & 15);
+    const int col_base = n0 + wn * 64 + ((lane >> 4) << 2);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = col_base + ni * 16;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = row_base + mi * 16;
+            f32x4 v = acc[ni][mi] * alpha + bv;
+            if constexpr (EPI == LPI_EPI_QUICKGELU) {
+                if (aux) Elem<T>::st4(aux + (size_t)row * ldaux + col, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+            } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
+                f32x4 u = Elem<T>::ld4(aux + (size_t)row * ldaux + col);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
+            }
+            if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
+            Elem<TC>::st4(C + (size_t)row * ldc + col, v);
+        }
+    }
+}
+
+template <typename T, typename TC, int EPI>
+int launch(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+           const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    const int tm = M / BM, tn = N / BN;
+    auto kern = gemm_nt_kernel<T, TC, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
+                       (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+template <typename T, typename TC>
+int dispatch_epi(int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                 const float* bias, const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    switch (epi) {
+    case LPI_EPI_NONE: return launch<T, TC, LPI_EPI_NONE>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    case LPI_EPI_QUICKGELU: return launch<T, TC, LPI_EPI_QUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    case LPI_EPI_DQUICKGELU:
+        if (!aux) return LPI_EINVAL;
+        return launch<T, TC, LPI_EPI_DQUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    }
+    return LPI_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           void* C, int ldc, const float* bias, const float* residual, int ldr, int epilogue, void* aux,
+                           int ldaux, float alpha, void* stream)
+{
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    const int csz = c_dtype == LPI_F32 ? 4 : 2;
+    const int bk = ROW_BYTES / esz;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return LPI_EINVAL;
+    if (M % BM || N % BN || K % bk) return LPI_EINVAL;
+    if ((lda * esz) % 16 || (ldb * esz) % 16 || (ldc * csz) % 8 || lda < K || ldb < K || ldc < N) return LPI_EINVAL;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return LPI_EINVAL;
+    if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
+    if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
+    if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F32 && c_dtype == LPI_F32)
+        return dispatch_epi<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_BF16)
+        return dispatch_epi<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F32)
+        return dispatch_epi<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    return LPI_ENOSYS;
+}

@@ -1,0 +1,335 @@
+// Contrastive loss, DecomposedPrompt (rank-r CP reconstruction) and retrieval ranking kernels.
+//
+// replaces (reference, retrieval/): loss/loss.py:75-87 (ClipLoss.forward: symmetric cross entropy),
+// models/prompts/prompts.py:38-57 (DecomposedPrompt.forward) and its autograd backward,
+// methods/sprompt.py:558-599 (itm_eval's per-row argsort rank search).
+// All f32; all reductions run in a fixed order (no atomics) so results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- ClipLoss
+// row_lse[i] = logsumexp_j logits[i,j]  (one wave per row)
+__global__ __launch_bounds__(256) void row_lse_kernel(int n, const float* __restrict__ x, int ld, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* r = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, r[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += expf(r[j] - m);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = m + logf(s);
+}
+
+// col_lse[j] = logsumexp_i logits[i,j]  (one thread per column, coalesced across columns, online max)
+__global__ __launch_bounds__(256) void col_lse_kernel(int n, const float* __restrict__ x, int ld, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float m = -INFINITY;
+    for (int i = 0; i < n; ++i) m = fmaxf(m, x[(size_t)i * ld + j]);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += expf(x[(size_t)i * ld + j] - m);
+    out[j] = m + logf(s);
+}
+
+// loss = mean_i( (row_lse[i] + col_lse[i]) / 2 - logits[i,i] )   (single block, fixed-order tree)
+__global__ __launch_bounds__(256) void clip_loss_reduce_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
+                                                              const float* __restrict__ cl, float* __restrict__ loss) {
+    __shared__ float part[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += 0.5f * (rl[i] + cl[i]) - x[(size_t)i * ld + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+}
+
+// dlogits[i,j] = up/(2n) * (softmax_row[i,j] + softmax_col[i,j] - 2*delta_ij)
+__global__ __launch_bounds__(256) void clip_loss_grad_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
+                                                            const float* __restrict__ cl, float up, float* __restrict__ dl, int lddl) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    const float v = x[(size_t)i * ld + j];
+    float g = expf(v - rl[i]) + expf(v - cl[j]);
+    if (i == j) g -= 2.f;
+    dl[(size_t)i * lddl + j] = g * (up / (2.f * (float)n));
+}
+
+// ---------------------------------------------------------------------------------------------- CP prompt
+constexpr int MAXR = 16;
+
+__global__ __launch_bounds__(256) void cp_fwd_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                    const float* __restrict__ d3, float sc, float* __restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)Lyr * P * D) return;
+    const int d = (int)(t % D), p = (int)((t / D) % P), l = (int)(t / ((long)D * P));
+    float s = 0.f;
+    for (int k = 0; k < r; ++k) s += d1[l * r + k] * d2[p * r + k] * d3[d * r + k];   // same product order as prompts.py:49
+    out[t] = s * sc;
+}
+
+// g3[d,k] = sc * sum_{l,p} dout[l,p,d] * d1[l,k] * d2[p,k]    (one thread per d, coalesced over d)
+__global__ __launch_bounds__(256) void cp_bwd_g3_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                       float sc, const float* __restrict__ dout, float* __restrict__ g3) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float acc[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
+    for (int l = 0; l < Lyr; ++l)
+        for (int p = 0; p < P; ++p) {
+            const float g = dout[((size_t)l * P + p) * D + d];
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k)
+                if (k < r) acc[k] += g * (d1[l * r + k] * d2[p * r + k]);
+        }
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k)
+        if (k < r) g3[d * r + k] = acc[k] * sc;
+}
+
+// t[l,p,k] = sum_d dout[l,p,d] * d3[d,k]  (one wave per (l,p) row) -> scratch in LDS -> g1, g2   (single block)
+__global__ __launch_bounds__(1024) void cp_bwd_g12_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                         const float* __restrict__ d3, float sc, const float* __restrict__ dout,
+                                                         float* __restrict__ g1, float* __restrict__ g2, int accumulate_g1) {
+    extern __shared__ float tl[];  // [Lyr*P][r]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int row = wave; row < Lyr * P; row += nw) {
+        float acc[MAXR];
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
+        const float* g = dout + (size_t)row * D;
+        for (int d = lane; d < D; d += 64) {
+            const float v = g[d];
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k)
+                if (k < r) acc[k] += v * d3[d * r + k];
+        }
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < r) {
+                const float s = wave_sum(acc[k]);
+                if (lane == 0) tl[row * r + k] = s;
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Lyr * r; i += blockDim.x) {
+        const int l = i / r, k = i % r;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += tl[(l * P + p) * r + k] * d2[p * r + k];
+        s *= sc;
+        g1[i] = accumulate_g1 ? g1[i] + s : s;
+    }
+    for (int i = threadIdx.x; i < P * r; i += blockDim.x) {
+        const int p = i / r, k = i % r;
+        float s = 0.f;
+        for (int l = 0; l < Lyr; ++l) s += tl[(l * P + p) * r + k] * d1[l * r + k];
+        g2[i] = s * sc;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- alignment loss
+// slinet.py:143-158: v = mean_d(vis)/T, t = mean_d(txt)/T ([Lyr,P]); S = v t^T; loss = w * ClipLoss(S).  Single block.
+__global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv, int Dt, const float* __restrict__ vis,
+                                                         const float* __restrict__ txt, float temp, float w, float* __restrict__ loss,
+                                                         float* __restrict__ dvis, float* __restrict__ dtxt) {
+    extern __shared__ float sm[];
+    float* v = sm;                 // [Lyr*P]
+    float* t = v + Lyr * P;        // [Lyr*P]
+    float* Sm = t + Lyr * P;       // [Lyr*Lyr]
+    float* dS = Sm + Lyr * Lyr;    // [Lyr*Lyr]
+    float* rl = dS + Lyr * Lyr;    // [Lyr]
+    float* cl = rl + Lyr;          // [Lyr]
+    float* dv = cl + Lyr;          // [Lyr*P]
+    float* dt = dv + Lyr * P;      // [Lyr*P]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nr = Lyr * P;
+    for (int row = wave; row < 2 * nr; row += nw) {
+        const bool isv = row < nr;
+        const int rr = isv ? row : row - nr;
+        const int D = isv ? Dv : Dt;
+        const float* src = (isv ? vis : txt) + (size_t)rr * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s += src[d];
+        s = wave_sum(s);
+        if (lane == 0) (isv ? v : t)[rr] = s / (float)D / temp;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Lyr * Lyr; i += blockDim.x) {
+        const int a = i / Lyr, b = i % Lyr;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += v[a * P + p] * t[b * P + p];
+        Sm[i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * Lyr) {
+        const bool row = (int)threadIdx.x < Lyr;
+        const int i = row ? threadIdx.x : threadIdx.x - Lyr;
+        float m = -INFINITY;
+        for (int j = 0; j < Lyr; ++j) m = fmaxf(m, row ? Sm[i * Lyr + j] : Sm[j * Lyr + i]);
+        float s = 0.f;
+        for (int j = 0; j < Lyr; ++j) s += expf((row ? Sm[i * Lyr + j] : Sm[j * Lyr + i]) - m);
+        (row ? rl : cl)[i] = m + logf(s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < Lyr; ++i) s += 0.5f * (rl[i] + cl[i]) - Sm[i * Lyr + i];
+        loss[0] = w * s / (float)Lyr;
+    }
+    if (!dvis || !dtxt) return;
+    for (int i = threadIdx.x; i < Lyr * Lyr; i += blockDim.x) {
+        const int a = i / Lyr, b = i % Lyr;
+        float g = expf(Sm[i] - rl[a]) + expf(Sm[i] - cl[b]);
+        if (a == b) g -= 2.f;
+        dS[i] = g * (w / (2.f * (float)Lyr));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * nr; i += blockDim.x) {
+        const bool isv = i < nr;
+        const int rr = isv ? i : i - nr;
+        const int a = rr / P, p = rr % P;
+        float s = 0.f;
+        if (isv) for (int b = 0; b < Lyr; ++b) s += dS[a * Lyr + b] * t[b * P + p];
+        else for (int b = 0; b < Lyr; ++b) s += dS[b * Lyr + a] * v[b * P + p];
+        (isv ? dv : dt)[rr] = s / ((float)(isv ? Dv : Dt) * temp);
+    }
+    __syncthreads();
+    for (long i = threadIdx.x; i < (long)nr * Dv; i += blockDim.x) dvis[i] = dv[i / Dv];
+    for (long i = threadIdx.x; i < (long)nr * Dt; i += blockDim.x) dtxt[i] = dt[i / Dt];
+}
+
+// ---------------------------------------------------------------------------------------------- retrieval
+// rank of the best ground-truth column under np.argsort(score)[::-1] (later index first among equal scores)
+__global__ __launch_bounds__(256) void retrieval_rank_kernel(int n_rows, int n_cols, const float* __restrict__ s, int ld,
+                                                            const int32_t* __restrict__ gt, int gpr, int32_t* __restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* r = s + (size_t)row * ld;
+    int best = 0x7fffffff;
+    for (int t = 0; t < gpr; ++t) {
+        const int gidx = gt[(size_t)row * gpr + t];
+        if (gidx < 0) continue;
+        const float gv = r[gidx];
+        int cnt = 0;
+        for (int j = lane; j < n_cols; j += 64) {
+            const float v = r[j];
+            cnt += (v > gv) || (v == gv && j > gidx);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        best = min(best, cnt);
+    }
+    if (lane == 0) rank[row] = best;
+}
+
+// top-k per row by k rounds of (value desc, index desc) arg-max; k is small (<= 16)
+__global__ __launch_bounds__(256) void topk_kernel(int n_rows, int n_cols, int k, const float* __restrict__ s, int ld,
+                                                  int32_t* __restrict__ idx, float* __restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const float* r = s + (size_t)row * ld;
+    float pv = INFINITY;
+    int pi = 0x7fffffff;
+    for (int t = 0; t < k; ++t) {
+        float bv = -INFINITY;
+        int bi = -1;
+        for (int j = lane; j < n_cols; j += 64) {
+            const float v = r[j];
+            const bool after_prev = (v < pv) || (v == pv && j < pi);       // strictly after the previous pick in the order
+            const bool better = (v > bv) || (v == bv && j > bi);
+            if (after_prev && better) { bv = v; bi = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if ((ov > bv) || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { idx[(size_t)row * k + t] = bi; if (val) val[(size_t)row * k + t] = bv; }
+        pv = bv;
+        pi = bi;
+    }
+}
+
+}  // namespace
+
+#define S(stream) ((hipStream_t)(stream))
+
+extern "C" int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, float* loss, float* dlogits, int lddl,
+                                     float* row_lse, float* col_lse, void* stream) {
+    if (!logits || !loss || !row_lse || !col_lse || n <= 0 || ld < n) return LPI_EINVAL;
+    hipLaunchKernelGGL(row_lse_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, logits, ld, row_lse);
+    LPI_LAUNCHED();
+    hipLaunchKernelGGL(col_lse_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), n, logits, ld, col_lse);
+    LPI_LAUNCHED();
+    hipLaunchKernelGGL(clip_loss_reduce_kernel, dim3(1), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, loss);
+    LPI_LAUNCHED();
+    if (dlogits) {
+        if (lddl < n) return LPI_EINVAL;
+        hipLaunchKernelGGL(clip_loss_grad_kernel, dim3((n + 255) / 256, n), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream,
+                           dlogits, lddl);
+        LPI_LAUNCHED();
+    }
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3, float scale, float* out,
+                                 void* stream) {
+    if (!d1 || !d2 || !d3 || !out || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
+    const long n = (long)Lyr * P * D;
+    hipLaunchKernelGGL(cp_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, d3, scale / (float)r, out);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3, float scale,
+                                 const float* dout, float* g1, float* g2, float* g3, int accumulate_g1, void* stream) {
+    if (!d1 || !d2 || !d3 || !dout || !g1 || !g2 || !g3 || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
+    const size_t lds = (size_t)Lyr * P * r * sizeof(float);
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    const float sc = scale / (float)r;
+    hipLaunchKernelGGL(cp_bwd_g12_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, D, r, d1, d2, d3, sc, dout, g1, g2, accumulate_g1);
+    LPI_LAUNCHED();
+    hipLaunchKernelGGL(cp_bwd_g3_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, sc, dout, g3);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp, float weight,
+                                      float* loss, float* dvis, float* dtxt, void* stream) {
+    if (!vis || !txt || !loss || Lyr <= 0 || P <= 0 || Dv <= 0 || Dt <= 0 || temp <= 0.f) return LPI_EINVAL;
+    const size_t lds = ((size_t)4 * Lyr * P + 2 * Lyr * Lyr + 2 * Lyr) * sizeof(float);
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    hipLaunchKernelGGL(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_retrieval_rank(int n_rows, int n_cols, const float* scores, int ld, const int32_t* gt, int gt_per_row, int32_t* rank,
+                                  void* stream) {
+    if (!scores || !gt || !rank || n_rows <= 0 || n_cols <= 0 || gt_per_row <= 0 || ld < n_cols) return LPI_EINVAL;
+    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, scores, ld, gt, gt_per_row, rank);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_topk(int n_rows, int n_cols, int k, const float* scores, int ld, int32_t* idx, float* val, void* stream) {
+    if (!scores || !idx || n_rows <= 0 || n_cols <= 0 || k <= 0 || k > n_cols || ld < n_cols) return LPI_EINVAL;
+    hipLaunchKernelGGL(topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, k, scores, ld, idx, val);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}

@@ -1,0 +1,533 @@
+// Row-wise, HBM-bound kernels of the LPI hot path: LayerNorm forward/backward (fp32 statistics), the vision
+// and text front ends (class token / positional embedding / prompt insertion / ln_pre), deep-prompt add, pooled
+// heads (CLS / EOT gather + LayerNorm), L2 normalisation and small utilities.
+//
+// replaces (reference, retrieval/): models/clip/model.py:154-160 (LayerNorm), :227-251 (VisionTransformer
+// front end), :189-193 (deep prompt add), :255 (ln_post on CLS); models/clip/prompt_learner.py:52-61,128-163
+// (TextEncoder front end / EOT gather), models/slinet.py:122,133 (L2 normalise).
+//
+// One 64-lane wave owns one row of d floats and keeps it in registers (float4 per lane per 256 columns), so each
+// row is read once and written once; reductions are wave shuffles; 4 rows per 256-thread block; every access is a
+// 16-byte coalesced load/store.  These kernels are bounded by HBM bandwidth, not by the matrix cores.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int MAXC = 8;  // float4 chunks per lane: d <= 2048
+
+struct Row {
+    f32x4 v[MAXC];
+};
+
+template <typename F> __device__ __forceinline__ void for_chunks(int d, int lane, F f) {
+    const int nch = d >> 2;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + (i << 6);
+        if (c < nch) f(i, c << 2);
+    }
+}
+
+__device__ __forceinline__ float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// mean / rstd of the row held in r (two-pass, like ATen's CPU LayerNorm in effect)
+__device__ __forceinline__ void row_stats(const Row& r, int d, int lane, float& mu, float& rs) {
+    float s = 0.f;
+    for_chunks(d, lane, [&](int i, int) { s += hsum(r.v[i]); });
+    mu = wave_sum(s) / (float)d;
+    float ss = 0.f;
+    for_chunks(d, lane, [&](int i, int) { f32x4 c = r.v[i] - mu; ss += hsum(c * c); });
+    const float var = wave_sum(ss) / (float)d;
+    rs = 1.0f / sqrtf(var + LN_EPS);
+}
+
+// y = LN(r)
+template <typename TY>
+__device__ __forceinline__ void ln_apply_store(const Row& r, int d, int lane, float mu, float rs, const float* gamma,
+                                               const float* beta, TY* y) {
+    for_chunks(d, lane, [&](int i, int col) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+        f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+        Elem<TY>::st4(y + col, (r.v[i] - mu) * rs * g + b);
+    });
+}
+
+// dxn = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); x row in `x`, dy row in `dy`; result left in dy
+__device__ __forceinline__ void ln_bwd_row(Row& dy, const Row& x, int d, int lane, float mu, float rs, const float* gamma) {
+    float s1 = 0.f, s2 = 0.f;
+    for_chunks(d, lane, [&](int i, int col) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+        f32x4 gdy = g * dy.v[i];
+        f32x4 xh = (x.v[i] - mu) * rs;
+        dy.v[i] = gdy;
+        s1 += hsum(gdy);
+        s2 += hsum(gdy * xh);
+    });
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+    for_chunks(d, lane, [&](int i, int) {
+        f32x4 xh = (x.v[i] - mu) * rs;
+        dy.v[i] = (dy.v[i] - c1 - xh * c2) * rs;
+    });
+}
+
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    TY* __restrict__ y, int ldy, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row r;
+    const float* xr = x + (size_t)row * ldx;
+    for_chunks(d, lane, [&](int i, int col) { r.v[i] = *reinterpret_cast<const f32x4*>(xr + col); });
+    float mu, rs;
+    row_stats(r, d, lane, mu, rs);
+    ln_apply_store<TY>(r, d, lane, mu, rs, gamma, beta, y + (size_t)row * ldy);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <typename TDY, typename TCAST>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
+                                                    const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    Row g, xr;
+    const TDY* dyr = dy + (size_t)row * lddy;
+    const float* xp = x + (size_t)row * ldx;
+    for_chunks(d, lane, [&](int i, int col) {
+        g.v[i] = Elem<TDY>::ld4(dyr + col);
+        xr.v[i] = *reinterpret_cast<const f32x4*>(xp + col);
+    });
+    ln_bwd_row(g, xr, d, lane, mean[row], rstd[row], gamma);
+    float* dxr = dx + (size_t)row * lddx;
+    for_chunks(d, lane, [&](int i, int col) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(dxr + col) + g.v[i];
+        *reinterpret_cast<f32x4*>(dxr + col) = t;
+        if (dx_cast) Elem<TCAST>::st4(dx_cast + (size_t)row * ldcast + col, t);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vision front end
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(int B, int R, int ps, int G, int Kp, const float* __restrict__ img,
+                                                      T* __restrict__ cols, int ldcols) {
+    // one thread per 4 consecutive k of one patch row; k = c*ps*ps + dy*ps + dx (conv weight [d,3,ps,ps] flattened)
+    const int K = 3 * ps * ps;
+    const long total = (long)B * G * G * (Kp >> 2);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int k4 = (int)(t % (Kp >> 2)) << 2;
+    const long patch = t / (Kp >> 2);
+    const int b = (int)(patch / (G * G)), gy = (int)(patch % (G * G)) / G, gx = (int)(patch % G);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k4 + j;
+        if (k < K) {
+            const int c = k / (ps * ps), rem = k % (ps * ps), dy = rem / ps, dx = rem % ps;
+            v[j] = img[(((size_t)b * 3 + c) * R + gy * ps + dy) * R + gx * ps + dx];
+        }
+    }
+    Elem<T>::st4(cols + (size_t)patch * ldcols + k4, v);
+}
+
+__device__ __forceinline__ void vis_pre_row(Row& r, int b, int l, int G2, int P, int d, int lane, const float* patch_emb,
+                                            int ldpe, const float* cls, const float* pos, const float* prompt0, long pbs) {
+    if (l == 0) {
+        for_chunks(d, lane, [&](int i, int col) {
+            r.v[i] = *reinterpret_cast<const f32x4*>(cls + col) + *reinterpret_cast<const f32x4*>(pos + col);
+        });
+    } else if (l <= P) {
+        const float* p = prompt0 + (size_t)b * pbs + (size_t)(l - 1) * d;
+        for_chunks(d, lane, [&](int i, int col) { r.v[i] = *reinterpret_cast<const f32x4*>(p + col); });
+    } else {
+        const int g = l - 1 - P;
+        const float* pe = patch_emb + ((size_t)b * G2 + g) * ldpe;
+        const float* pp = pos + (size_t)(g + 1) * d;
+        for_chunks(d, lane, [&](int i, int col) {
+            r.v[i] = *reinterpret_cast<const f32x4*>(pe + col) + *reinterpret_cast<const f32x4*>(pp + col);
+        });
+    }
+}
+
+__global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, int P, int d, const float* __restrict__ patch_emb,
+                                                              int ldpe, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                              const float* __restrict__ prompt0, long pbs,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int L = 1 + P + G2;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, l = row % L;
+    Row r;
+    vis_pre_row(r, b, l, G2, P, d, lane, patch_emb, ldpe, cls, pos, prompt0, pbs);
+    float mu, rs;
+    row_stats(r, d, lane, mu, rs);
+    ln_apply_store<float>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// LN' on the prompt rows only, in place on dx0 (the other rows' input gradients are not needed: frozen weights)
+__global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, int P, int d, float* __restrict__ dx0,
+                                                                 const float* __restrict__ prompt0, long pbs,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= B * P) return;
+    const int b = w / P, p = w % P;
+    const int row = b * L + 1 + p;
+    Row g, x;
+    float* dxr = dx0 + (size_t)row * d;
+    const float* pr = prompt0 + (size_t)b * pbs + (size_t)p * d;
+    for_chunks(d, lane, [&](int i, int col) {
+        g.v[i] = *reinterpret_cast<const f32x4*>(dxr + col);
+        x.v[i] = *reinterpret_cast<const f32x4*>(pr + col);
+    });
+    ln_bwd_row(g, x, d, lane, mean[row], rstd[row], gamma);
+    for_chunks(d, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(dxr + col) = g.v[i]; });
+}
+
+// out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic (fixed order over b), one float4 column per thread
+__global__ __launch_bounds__(256) void rows_sum_kernel(int B, int L, int row0, int P, int d, const float* __restrict__ dx,
+                                                      float* __restrict__ out, int accumulate) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = d >> 2;
+    if (t >= P * nch) return;
+    const int p = t / nch, col = (t % nch) << 2;
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* src = dx + (size_t)(row0 + p) * d + col;
+    for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(src + (size_t)b * L * d);
+    float* o = out + (size_t)p * d + col;
+    if (accumulate) s += *reinterpret_cast<const f32x4*>(o);
+    *reinterpret_cast<f32x4*>(o) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// text front end
+__global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, int P, int d, const int64_t* __restrict__ ids,
+                                                       const float* __restrict__ tok, const float* __restrict__ pos,
+                                                       const float* __restrict__ ctx, long cbs, float* __restrict__ x0) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * L) return;
+    const int b = row / L, l = row % L;
+    const float* src = (ctx && l >= 1 && l <= P) ? ctx + (size_t)b * cbs + (size_t)(l - 1) * d
+                                                 : tok + (size_t)ids[row] * d;
+    const float* pp = pos + (size_t)l * d;
+    float* o = x0 + (size_t)row * d;
+    for_chunks(d, lane, [&](int, int col) {
+        *reinterpret_cast<f32x4*>(o + col) = *reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col);
+    });
+}
+
+__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, int P, int d, float* __restrict__ x,
+                                                        const float* __restrict__ pr, long pbs) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= B * P) return;
+    const int b = w / P, p = w % P;
+    float* xr = x + ((size_t)b * L + 1 + p) * d;
+    const float* s = pr + (size_t)b * pbs + (size_t)p * d;
+    for_chunks(d, lane, [&](int, int col) {
+        *reinterpret_cast<f32x4*>(xr + col) = *reinterpret_cast<const f32x4*>(xr + col) + *reinterpret_cast<const f32x4*>(s + col);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pooled heads
+template <typename TY>
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, const float* __restrict__ x,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, TY* __restrict__ y, int ldy,
+                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
+    Row r;
+    for_chunks(d, lane, [&](int i, int col) { r.v[i] = *reinterpret_cast<const f32x4*>(x + row * d + col); });
+    float mu, rs;
+    row_stats(r, d, lane, mu, rs);
+    ln_apply_store<TY>(r, d, lane, mu, rs, gamma, beta, y + (size_t)b * ldy);
+    if (lane == 0) { mean[b] = mu; rstd[b] = rs; }
+}
+
+template <typename TCAST>
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, const float* __restrict__ dy, int lddy,
+                                                         const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dx,
+                                                         TCAST* __restrict__ dx_cast) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
+    Row g, xr;
+    for_chunks(d, lane, [&](int i, int col) {
+        g.v[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)b * lddy + col);
+        xr.v[i] = *reinterpret_cast<const f32x4*>(x + row * d + col);
+    });
+    ln_bwd_row(g, xr, d, lane, mean[b], rstd[b], gamma);
+    for_chunks(d, lane, [&](int i, int col) {
+        *reinterpret_cast<f32x4*>(dx + row * d + col) = g.v[i];
+        if (dx_cast) Elem<TCAST>::st4(dx_cast + row * d + col, g.v[i]);
+    });
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int B, int E, const float* __restrict__ x, int ldx,
+                                                        float* __restrict__ y, int ldy, float* __restrict__ inv_norm) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    Row r;
+    float ss = 0.f;
+    for_chunks(E, lane, [&](int i, int col) {
+        r.v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)b * ldx + col);
+        ss += hsum(r.v[i] * r.v[i]);
+    });
+    const float inv = 1.0f / sqrtf(wave_sum(ss));
+    for_chunks(E, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(y + (size_t)b * ldy + col) = r.v[i] * inv; });
+    if (lane == 0) inv_norm[b] = inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int B, int E, const float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ dy, int lddy, const float* __restrict__ inv_norm,
+                                                        float* __restrict__ dx, int lddx) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    Row yr, g;
+    float dot = 0.f;
+    for_chunks(E, lane, [&](int i, int col) {
+        yr.v[i] = *reinterpret_cast<const f32x4*>(y + (size_t)b * ldy + col);
+        g.v[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)b * lddy + col);
+        dot += hsum(yr.v[i] * g.v[i]);
+    });
+    dot = wave_sum(dot);
+    const float inv = inv_norm[b];
+    for_chunks(E, lane, [&](int i, int col) {
+        *reinterpret_cast<f32x4*>(dx + (size_t)b * lddx + col) = (g.v[i] - yr.v[i] * dot) * inv;
+    });
+}
+
+__global__ void eot_index_kernel(int B, int L, const int64_t* __restrict__ ids, int32_t* __restrict__ idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t best = ids[(size_t)b * L];
+    int bi = 0;
+    for (int l = 1; l < L; ++l) {
+        const int64_t v = ids[(size_t)b * L + l];
+        if (v > best) { best = v; bi = l; }   // first maximum, as torch.argmax
+    }
+    idx[b] = bi;
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(long n4, const TS* __restrict__ s, TD* __restrict__ dst) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        Elem<TD>::st4(dst + (i << 2), Elem<TS>::ld4(s + (i << 2)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T* __restrict__ s, int lds, T* __restrict__ dst, int ldd) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < rows && c < cols) tile[j][tx] = s[(size_t)r * lds + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + j, c = by + tx;  // dst is [cols, rows]
+        if (r < cols && c < rows) dst[(size_t)r * ldd + c] = tile[tx][j];
+    }
+}
+
+inline bool bad_row_dim(int d) { return d <= 0 || (d & 3) || d > MAXC * 256; }
+inline int rows_grid(long rows) { return (int)((rows + 3) / 4); }
+
+}  // namespace
+
+#define S(stream) ((hipStream_t)(stream))
+
+extern "C" int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int ldx, const float* gamma, const float* beta,
+                                 void* y, int ldy, float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || bad_row_dim(d) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
+    if (dtype == LPI_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd);
+    else if (dtype == LPI_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    else
+        return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy, const float* x, int ldx,
+                                 const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
+                                 int ldcast, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
+        return LPI_EINVAL;
+    dim3 g(rows_grid(rows)), b(256);
+#define LNB(TDY, TC) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
+    if (dy_dtype == LPI_F32 && cast_dtype == LPI_F32) LNB(float, float);
+    else if (dy_dtype == LPI_F32 && cast_dtype == LPI_BF16) LNB(float, bf16_t);
+    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16) LNB(bf16_t, bf16_t);
+    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_F32) LNB(bf16_t, float);
+    else return LPI_EINVAL;
+#undef LNB
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream) {
+    if (!image || !cols || B <= 0 || ps <= 0 || R % ps) return LPI_EINVAL;
+    const int G = R / ps, K = 3 * ps * ps;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    const int bk = 128 / esz;
+    const int Kp = (K + bk - 1) / bk * bk;
+    if (ldcols < Kp || (ldcols & 3)) return LPI_EINVAL;
+    const long total = (long)B * G * G * (Kp >> 2);
+    dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (dtype == LPI_F32) hipLaunchKernelGGL(patchify_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (float*)cols, ldcols);
+    else if (dtype == LPI_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (bf16_t*)cols, ldcols);
+    else return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls, const float* pos,
+                                    const float* prompt0, long prompt_bstride, const float* gamma, const float* beta, float* x0,
+                                    float* mean, float* rstd, void* stream) {
+    if (!patch_emb || !cls || !pos || !gamma || !beta || !x0 || !mean || !rstd || B <= 0 || G2 <= 0 || P < 0 || bad_row_dim(d) || (ldpe & 3))
+        return LPI_EINVAL;
+    if (P > 0 && (!prompt0 || (prompt_bstride & 3))) return LPI_EINVAL;
+    const long rows = (long)B * (1 + P + G2);
+    hipLaunchKernelGGL(vis_assemble_fwd_kernel, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
+                       prompt0, prompt_bstride, gamma, beta, x0, mean, rstd);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate, void* stream) {
+    if (!dx || !out || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || bad_row_dim(d)) return LPI_EINVAL;
+    const int n = P * (d >> 2);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, const float* prompt0, long prompt_bstride,
+                                    const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream) {
+    if (!dx0 || !prompt0 || !gamma || !mean || !rstd || !dprompt || B <= 0 || P <= 0 || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
+    const int L = 1 + P + G2;
+    hipLaunchKernelGGL(vis_prompt_rows_bwd_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, dx0, prompt0,
+                       prompt_bstride, gamma, mean, rstd);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return lpi_rows_sum_over_batch(B, L, 1, P, d, dx0, dprompt, 0, stream);
+}
+
+extern "C" int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
+                                 long ctx_bstride, float* x0, void* stream) {
+    if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
+    hipLaunchKernelGGL(txt_embed_kernel, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_prompt_add(int B, int L, int P, int d, float* x, const float* prompt_l, long prompt_bstride, void* stream) {
+    if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
+    hipLaunchKernelGGL(prompt_add_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, x, prompt_l, prompt_bstride);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, const int32_t* idx, const float* gamma, const float* beta,
+                               void* y, int ldy, float* mean, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || L <= 0 || bad_row_dim(d) || (ldy & 3)) return LPI_EINVAL;
+    dim3 g(rows_grid(B)), b(256);
+    if (dtype == LPI_F32) hipLaunchKernelGGL(pool_ln_fwd_kernel<float>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
+    else if (dtype == LPI_BF16) hipLaunchKernelGGL(pool_ln_fwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    else return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float* dy, int lddy, const float* x, const int32_t* idx,
+                               const float* gamma, const float* mean, const float* rstd, float* dx, void* dx_cast, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || B <= 0 || bad_row_dim(d) || (lddy & 3)) return LPI_EINVAL;
+    dim3 g(rows_grid(B)), b(256);
+    if (cast_dtype == LPI_F32) hipLaunchKernelGGL(pool_ln_bwd_kernel<float>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (float*)dx_cast);
+    else if (cast_dtype == LPI_BF16) hipLaunchKernelGGL(pool_ln_bwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (bf16_t*)dx_cast);
+    else return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, int ldy, float* inv_norm, void* stream) {
+    if (!x || !y || !inv_norm || B <= 0 || bad_row_dim(E) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, x, ldx, y, ldy, inv_norm);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int lddy, const float* inv_norm, float* dx, int lddx,
+                              void* stream) {
+    if (!y || !dy || !inv_norm || !dx || B <= 0 || bad_row_dim(E) || (ldy & 3) || (lddy & 3) || (lddx & 3)) return LPI_EINVAL;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, y, ldy, dy, lddy, inv_norm, dx, lddx);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream) {
+    if (!ids || !idx || B <= 0 || L <= 0) return LPI_EINVAL;
+    hipLaunchKernelGGL(eot_index_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), B, L, ids, idx);
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, void* stream) {
+    if (!src || !dst || n <= 0 || (n & 3)) return LPI_EINVAL;
+    const long n4 = n >> 2;
+    dim3 g((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), b(256);
+    if (src_dtype == LPI_F32 && dst_dtype == LPI_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, S(stream), n4, (const float*)src, (bf16_t*)dst);
+    else if (src_dtype == LPI_BF16 && dst_dtype == LPI_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, S(stream), n4, (const bf16_t*)src, (float*)dst);
+    else if (src_dtype == LPI_F32 && dst_dtype == LPI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, S(stream), n4, (const float*)src, (float*)dst);
+    else return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_transpose(int dtype, int rows, int cols, const void* src, int lds, void* dst, int ldd, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < rows) return LPI_EINVAL;
+    dim3 g((cols + 31) / 32, (rows + 31) / 32), b(256);
+    if (dtype == LPI_F32) hipLaunchKernelGGL(transpose_kernel<float>, g, b, 0, S(stream), rows, cols, (const float*)src, lds, (float*)dst, ldd);
+    else if (dtype == LPI_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, b, 0, S(stream), rows, cols, (const bf16_t*)src, lds, (bf16_t*)dst, ldd);
+    else return LPI_EINVAL;
+    LPI_LAUNCHED();
+    LPI_CHECK_LAST();
+    return 0;
+}

@@ -1,0 +1,418 @@
+"""Host-side engine of the MI355X LPI hot path: owns the frozen CLIP weights (pre-converted and pre-transposed
+for the matrix cores), a workspace arena sized for 288 GB of HBM, and sequences the HIP kernels of
+``liblpi_hip.so`` for the prompted dual-encoder forward and its dgrad-only backward.
+
+What it stands in for in the reference (paths relative to /root/reference/retrieval/):
+  * ``VisionTransformer.forward``                    models/clip/model.py:227-259
+  * ``TextEncoder.forward`` + ``PromptLearner.forward``  models/clip/prompt_learner.py:52-63, 128-163
+  * ``Transformer`` / ``ResidualAttentionBlock``     models/clip/model.py:168-207
+  * their autograd backward w.r.t. the prompt tensors (the backbone is frozen: sprompt.py:230-237)
+
+PyTorch is used for device memory, streams and (in ``dp.py``) torch.distributed only; all arithmetic on the
+path runs in the HIP kernels.  There is no CPU / eager fallback: without the library or a GPU this raises.
+
+Layout: token rows are batch-major (row = b*L + l), padded to a multiple of 128 rows for the 128x128 GEMM
+tiles; the residual stream, LN statistics and every reduction are f32; ``dtype`` ('f32' | 'bf16') selects the
+matrix-core operand type (see include/lpi_hip.h).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_DQUICKGELU, EPI_NONE, EPI_QUICKGELU, F32, call
+from .synth import ClipConfig
+
+_DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def _pad(n: int, m: int = 128) -> int:
+    return (n + m - 1) // m * m
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(device):
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.LpiError("lpi_amd runs on an MI355X only (device must be cuda:N); there is no CPU fallback")
+
+
+class Linear:
+    """A frozen nn.Linear prepared for the NT GEMM: W [out,in] and W^T [in,out] in the operand dtype, f32 bias."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], dt: int, device, k_pad: Optional[int] = None):
+        w = w.to(device=device, dtype=torch.float32)
+        if k_pad is not None and k_pad != w.shape[1]:
+            w = torch.nn.functional.pad(w, (0, k_pad - w.shape[1]))
+        self.out_features, self.in_features = w.shape
+        self.w = w.to(_TORCH_DT[dt]).contiguous()
+        self.wt = w.t().contiguous().to(_TORCH_DT[dt]).contiguous()
+        self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
+
+
+def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0):
+    """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows)."""
+    cdt = F32 if c.dtype == torch.float32 else BF16
+    call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
+         residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
+         float(alpha), _stream())
+
+
+@dataclass
+class TowerSpec:
+    width: int
+    heads: int
+    layers: int
+    causal: bool
+
+
+class Tower:
+    """One transformer tower (vision or text): weights + forward/backward over a [B*L, d] residual stream."""
+
+    def __init__(self, sd: dict, prefix: str, spec: TowerSpec, dt: int, device):
+        self.spec, self.dt, self.device = spec, dt, device
+        self.blocks = []
+        f = lambda k: torch.as_tensor(np.asarray(sd[k])) if not torch.is_tensor(sd[k]) else sd[k]  # noqa: E731
+        for i in range(spec.layers):
+            p = f"{prefix}resblocks.{i}."
+            blk = {
+                "qkv": Linear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), dt, device),
+                "out": Linear(f(p + "attn.out_proj.weight"), f(p + "attn.out_proj.bias"), dt, device),
+                "fc": Linear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), dt, device),
+                "proj": Linear(f(p + "mlp.c_proj.weight"), f(p + "mlp.c_proj.bias"), dt, device),
+            }
+            for nm in ("ln_1", "ln_2"):
+                blk[nm + ".w"] = f(p + nm + ".weight").to(device=device, dtype=torch.float32).contiguous()
+                blk[nm + ".b"] = f(p + nm + ".bias").to(device=device, dtype=torch.float32).contiguous()
+            self.blocks.append(blk)
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B: int, L: int, train: bool):
+        key = (B, L, train)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        self._ws.clear()   # one live shape per tower: the arena is large
+        d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
+        Mp = _pad(B * L)
+        T = _TORCH_DT[self.dt]
+        dev = self.device
+        z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        keep = nl if train else 1
+        ws = {
+            "B": B, "L": L, "Mp": Mp,
+            "x": [z(Mp, d) for _ in range(nl + 1 if train else 2)],
+            "xmid": [z(Mp, d) for _ in range(keep)],
+            "qkv": [z(Mp, 3 * d, dtype=T) for _ in range(keep)],
+            "ctx": [z(Mp, d, dtype=T) for _ in range(keep)],
+            "lse": [z(B, H, L) for _ in range(keep)],
+            "u": [z(Mp, 4 * d, dtype=T) for _ in range(keep)] if train else [None],
+            "stat": [z(4, Mp) for _ in range(keep)],      # ln1 mean, ln1 rstd, ln2 mean, ln2 rstd
+            "h": z(Mp, d, dtype=T),
+            "g": z(Mp, 4 * d, dtype=T),
+        }
+        if train:
+            ws.update({
+                "dx": z(Mp, d), "dh": z(Mp, d), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
+                "delta": z(B, H, L),
+                "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
+            })
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True):
+        """Runs the blocks over ws['x'][0]; returns the output residual stream tensor [Mp, d] (f32).
+
+        prompts: f32 tensor whose element (b, layer, p, :) sits at  b*prompt_bstride + (layer*P + p)*d."""
+        sp, dt, s = self.spec, self.dt, _stream()
+        d, H = sp.width, sp.heads
+        B, L, Mp = ws["B"], ws["L"], ws["Mp"]
+        M = B * L
+        P = prompts.shape[-2] if prompts is not None else 0
+        for i, blk in enumerate(self.blocks):
+            k = i if train else 0
+            x_in = ws["x"][i if train else i % 2]
+            x_out = ws["x"][i + 1 if train else (i + 1) % 2]
+            xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][k]
+            if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
+                call("lpi_prompt_add", B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
+            call("lpi_layernorm_fwd", dt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
+            gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b)
+            call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
+            gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in)
+            call("lpi_layernorm_fwd", dt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
+            gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u)
+            gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid)
+        return ws["x"][len(self.blocks) if train else len(self.blocks) % 2]
+
+    # ------------------------------------------------------------------ backward (dgrad only)
+    def backward(self, ws, prompts=None, depth=1, dprompts=None):
+        """ws['dx'] (f32) [and ws['dxT']] hold dL/dx_out on entry and dL/dx_0 on exit.
+        dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
+        sp, dt, s = self.spec, self.dt, _stream()
+        d, H = sp.width, sp.heads
+        B, L, Mp = ws["B"], ws["L"], ws["Mp"]
+        M = B * L
+        dx, dh, dctx, dqkv = ws["dx"], ws["dh"], ws["dctx"], ws["dqkv"]
+        dxT = ws["dxT"] if dt != F32 else dx
+        P = prompts.shape[-2] if prompts is not None else 0
+        for i in reversed(range(len(self.blocks))):
+            blk = self.blocks[i]
+            x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
+            du = ws["g"]
+            gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u)          # d c_proj, * gelu'
+            gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d)                                         # d c_fc
+            call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
+                 None if dt == F32 else dxT, d, s)
+            gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d)                                         # d out_proj
+            call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
+            gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d)                                      # d in_proj
+            call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                 None if dt == F32 else dxT, d, s)
+            if prompts is not None and dprompts is not None and 0 < i < depth:
+                call("lpi_rows_sum_over_batch", B, L, 1, P, d, dx, dprompts[i], 0, s)
+        return dx
+
+
+class DualEncoder:
+    """CLIP ViT + text transformer with prompt side inputs, forward and dgrad backward, on one MI355X."""
+
+    def __init__(self, cfg: ClipConfig, state_dict: dict, dtype: str = "f32", device="cuda:0", n_ctx: int = 16):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        _require_gpu(self.device)
+        _lib.load()
+        self.dt = _DT[dtype]
+        self.dtype_name = "f32" if self.dt == F32 else "bf16"
+        self.n_ctx = n_ctx
+        dev, dt = self.device, self.dt
+        t = lambda k: (state_dict[k] if torch.is_tensor(state_dict[k]) else torch.as_tensor(np.asarray(state_dict[k]))).to(  # noqa: E731
+            device=dev, dtype=torch.float32).contiguous()
+        self.vis = Tower(state_dict, "visual.transformer.", TowerSpec(cfg.vision_width, cfg.vision_heads, cfg.vision_layers, False), dt, dev)
+        self.txt = Tower(state_dict, "transformer.", TowerSpec(cfg.transformer_width, cfg.transformer_heads, cfg.transformer_layers, True), dt, dev)
+        ps = cfg.vision_patch_size
+        self.kp = _pad(3 * ps * ps, 32 if dt == F32 else 64)
+        self.conv = Linear(t("visual.conv1.weight").reshape(cfg.vision_width, -1), None, dt, dev, k_pad=self.kp)
+        self.cls = t("visual.class_embedding")
+        self.vpos = t("visual.positional_embedding")
+        self.ln_pre = (t("visual.ln_pre.weight"), t("visual.ln_pre.bias"))
+        self.ln_post = (t("visual.ln_post.weight"), t("visual.ln_post.bias"))
+        self.vproj = Linear(t("visual.proj").t().contiguous(), None, dt, dev)        # Linear weight [E, d]
+        self.tok = t("token_embedding.weight")
+        self.tpos = t("positional_embedding")
+        self.ln_final = (t("ln_final.weight"), t("ln_final.bias"))
+        self.tproj = Linear(t("text_projection").t().contiguous(), None, dt, dev)
+        self.logit_scale = t("logit_scale")
+        self.logit_scale_exp = float(math.exp(float(np.asarray(state_dict["logit_scale"] if not torch.is_tensor(state_dict["logit_scale"]) else state_dict["logit_scale"].cpu()))))
+        self._head_ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _head(self, tag, B, d):
+        key = (tag, B)
+        hw = self._head_ws.get(key)
+        if hw is None:
+            Bp, E, dev, T = _pad(B), self.cfg.embed_dim, self.device, _TORCH_DT[self.dt]
+            z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+            hw = {"pooled": z(Bp, d, dtype=T), "stat": z(2, Bp), "feat": z(Bp, E), "inv": z(Bp),
+                  "dfeat": z(Bp, E), "dfeatT": z(Bp, E, dtype=T) if self.dt != F32 else None, "dpooled": z(Bp, d),
+                  "idx": torch.zeros(Bp, dtype=torch.int32, device=dev)}
+            self._head_ws[key] = hw
+        return hw
+
+    @staticmethod
+    def _prompt_args(prompts, B):
+        """prompts: None | [Lyr,P,d] (broadcast over the batch, slinet.py:119) | [B,Lyr,P,d] (per sample, slinet.py:215)."""
+        if prompts is None:
+            return None, 0, 0
+        if prompts.dim() == 4 and prompts.stride(0) == 0:
+            prompts = prompts[0]
+        if prompts.dim() == 3:
+            return prompts.contiguous().float(), 0, prompts.shape[-2]
+        if prompts.shape[0] != B:
+            raise ValueError("per-sample prompts must have batch dimension B")
+        p = prompts.contiguous().float()
+        return p, p.stride(0), p.shape[-2]
+
+    # ------------------------------------------------------------------ vision
+    def encode_image(self, image, prompts=None, depth=1, train=False, normalise=True):
+        """image [B,3,R,R] f32 (device) -> features [B,E] f32 (L2-normalised like slinet.py:122 unless normalise=False)."""
+        cfg, dt, s = self.cfg, self.dt, _stream()
+        B = image.shape[0]
+        image = image.to(device=self.device, dtype=torch.float32).contiguous()
+        pr, pbs, P = self._prompt_args(prompts, B)
+        G2, d = cfg.n_patches, cfg.vision_width
+        L = 1 + P + G2
+        ws = self.vis.workspace(B, L, train)
+        fe = ws.get("front")
+        if fe is None:
+            rows = _pad(B * G2)
+            fe = {"cols": torch.zeros(rows, self.kp, dtype=_TORCH_DT[dt], device=self.device),
+                  "pe": torch.zeros(rows, d, device=self.device), "stat": torch.zeros(2, ws["Mp"], device=self.device)}
+            ws["front"] = fe
+        call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
+        gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp)
+        call("lpi_vis_assemble_fwd", B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
+             ws["x"][0], fe["stat"][0], fe["stat"][1], s)
+        xo = self.vis.forward(ws, pr, pbs, depth, train)
+        hw = self._head("v", B, d)
+        call("lpi_pool_ln_fwd", dt, B, L, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        gemm(dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        out = torch.empty(B, cfg.embed_dim, device=self.device)
+        if normalise:
+            call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
+        else:
+            out.copy_(hw["feat"][:B])
+        self._vis_ctx = (ws, pr, pbs, P, depth, B, L, out)
+        return out
+
+    def encode_image_backward(self, dout):
+        """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch."""
+        cfg, dt, s = self.cfg, self.dt, _stream()
+        ws, pr, pbs, P, depth, B, L, out = self._vis_ctx
+        d, E = cfg.vision_width, cfg.embed_dim
+        hw = self._head("v", B, d)
+        dout = dout.contiguous().float()
+        call("lpi_l2norm_bwd", B, E, out, E, dout, E, hw["inv"], hw["dfeat"], E, s)
+        dfe = hw["dfeat"]
+        if dt != F32:
+            call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
+            dfe = hw["dfeatT"]
+        gemm(dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        ws["dx"].zero_()
+        if dt != F32:
+            ws["dxT"].zero_()
+        xo = ws["x"][len(self.vis.blocks)]
+        call("lpi_pool_ln_bwd", dt, B, L, d, hw["dpooled"], d, xo, None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
+             ws["dx"], None if dt == F32 else ws["dxT"], s)
+        if pr is None:
+            return None
+        Lyr = pr.shape[-3]
+        dpr = torch.zeros(Lyr, P, d, device=self.device)
+        self.vis.backward(ws, pr, depth, dpr)
+        call("lpi_vis_assemble_bwd", B, cfg.n_patches, P, d, ws["dx"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
+             ws["front"]["stat"][1], dpr[0], s)
+        return dpr
+
+    # ------------------------------------------------------------------ text
+    def encode_text(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True):
+        """ids [B,77] int64 (device).  prompts as in encode_image; row 0 of the prompt stack is the ctx spliced over
+        positions 1..n_ctx (slinet.py:130, prompt_learner.py:155-163); use_ctx=False = extract_vector (:118-126)."""
+        cfg, dt, s = self.cfg, self.dt, _stream()
+        B, L = ids.shape
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        pr, pbs, P = self._prompt_args(prompts, B)
+        if pr is not None and P != self.n_ctx:
+            raise ValueError("prompt length must equal n_ctx")
+        d = cfg.transformer_width
+        ws = self.txt.workspace(B, L, train)
+        hw = self._head("t", B, d)
+        call("lpi_eot_index", B, L, ids, hw["idx"], s)
+        ctx = pr if (pr is not None and use_ctx) else None
+        call("lpi_txt_embed_fwd", B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
+        xo = self.txt.forward(ws, pr, pbs, depth, train)
+        call("lpi_pool_ln_fwd", dt, B, L, d, xo, hw["idx"], self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        gemm(dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        out = torch.empty(B, cfg.embed_dim, device=self.device)
+        if normalise:
+            call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
+        else:
+            out.copy_(hw["feat"][:B])
+        self._txt_ctx = (ws, pr, pbs, P, depth, B, L, out)
+        return out
+
+    def encode_text_backward(self, dout):
+        cfg, dt, s = self.cfg, self.dt, _stream()
+        ws, pr, pbs, P, depth, B, L, out = self._txt_ctx
+        d, E = cfg.transformer_width, cfg.embed_dim
+        hw = self._head("t", B, d)
+        dout = dout.contiguous().float()
+        call("lpi_l2norm_bwd", B, E, out, E, dout, E, hw["inv"], hw["dfeat"], E, s)
+        dfe = hw["dfeat"]
+        if dt != F32:
+            call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
+            dfe = hw["dfeatT"]
+        gemm(dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        ws["dx"].zero_()
+        if dt != F32:
+            ws["dxT"].zero_()
+        xo = ws["x"][len(self.txt.blocks)]
+        call("lpi_pool_ln_bwd", dt, B, L, d, hw["dpooled"], d, xo, hw["idx"], self.ln_final[0], hw["stat"][0], hw["stat"][1],
+             ws["dx"], None if dt == F32 else ws["dxT"], s)
+        if pr is None:
+            return None
+        Lyr = pr.shape[-3]
+        dpr = torch.zeros(Lyr, P, d, device=self.device)
+        self.txt.backward(ws, pr, depth, dpr)
+        call("lpi_rows_sum_over_batch", B, L, 1, P, d, ws["dx"], dpr[0], 0, s)
+        return dpr
+
+
+# ---------------------------------------------------------------------------------------------- loss / prompt ops
+def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True):
+    """Symmetric CE over the (global) n x n logits (loss/loss.py:75-87, slinet.py:139-141).
+    img_all/txt_all: f32 [n, E] on device.  Returns (loss[1], logits[n,n] view, dimg[n,E], dtxt[n,E])."""
+    n, E = img_all.shape
+    dev = img_all.device
+    npad = _pad(n)
+    s = _stream()
+    A = torch.zeros(npad, E, device=dev)
+    Bm = torch.zeros(npad, E, device=dev)
+    A[:n].copy_(img_all)
+    Bm[:n].copy_(txt_all)
+    logits = torch.zeros(npad, npad, device=dev)
+    gemm(F32, A, Bm, logits, npad, npad, E, alpha=scale)
+    loss = torch.zeros(1, device=dev)
+    lse = torch.zeros(2, npad, device=dev)
+    dlog = torch.zeros(npad, npad, device=dev) if need_grad else None
+    call("lpi_clip_loss_fwd_bwd", n, logits, npad, 1.0, loss, dlog, npad, lse[0], lse[1], s)
+    if not need_grad:
+        return loss, logits[:n, :n], None, None
+    # dI = scale * dlogits @ T ; dT = scale * dlogits^T @ I   (NT form: B operand = T^T / I^T)
+    At = torch.zeros(E, npad, device=dev)
+    Bt = torch.zeros(E, npad, device=dev)
+    call("lpi_transpose", F32, npad, E, A, E, At, npad, s)
+    call("lpi_transpose", F32, npad, E, Bm, E, Bt, npad, s)
+    dlt = torch.zeros(npad, npad, device=dev)
+    call("lpi_transpose", F32, npad, npad, dlog, npad, dlt, npad, s)
+    dI = torch.zeros(npad, E, device=dev)
+    dT = torch.zeros(npad, E, device=dev)
+    gemm(F32, dlog, Bt, dI, npad, E, npad, alpha=scale)
+    gemm(F32, dlt, At, dT, npad, E, npad, alpha=scale)
+    return loss, logits[:n, :n], dI[:n], dT[:n]
+
+
+def prompt_cp_fwd(d1, d2, d3, scale=1.0):
+    Lyr, r = d1.shape
+    P, D = d2.shape[0], d3.shape[0]
+    out = torch.empty(Lyr, P, D, device=d1.device)
+    call("lpi_prompt_cp_fwd", Lyr, P, D, r, d1, d2, d3, float(scale), out, _stream())
+    return out
+
+
+def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0):
+    Lyr, r = d1.shape
+    P, D = d2.shape[0], d3.shape[0]
+    g2 = torch.empty_like(d2)
+    g3 = torch.empty_like(d3)
+    call("lpi_prompt_cp_bwd", Lyr, P, D, r, d1, d2, d3, float(scale), dout.contiguous(), g1, g2, g3, int(accumulate_g1), _stream())
+    return g2, g3
+
+
+def align_loss_fwd_bwd(vis, txt, temp=0.01, weight=0.1, need_grad=True):
+    Lyr, P, Dv = vis.shape
+    Dt = txt.shape[-1]
+    loss = torch.zeros(1, device=vis.device)
+    dv = torch.empty_like(vis) if need_grad else None
+    dtx = torch.empty_like(txt) if need_grad else None
+    call("lpi_align_loss_fwd_bwd", Lyr, P, Dv, Dt, vis.contiguous(), txt.contiguous(), float(temp), float(weight), loss, dv, dtx, _stream())
+    return loss, dv, dtx

@@ -1,0 +1,108 @@
+"""torch.autograd glue over the HIP engine: each Function's forward/backward only enqueues kernels of
+``liblpi_hip.so`` (via ``engine``), so ``loss.backward()`` in the reference's training loop
+(methods/sprompt.py:308-311) drives the hand-written backward.  No arithmetic of the path runs in ATen.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine as E
+
+
+class DecomposedPromptFn(torch.autograd.Function):
+    """DecomposedPrompt.forward (models/prompts/prompts.py:38-57): (vis [Lyr,P,Dv], txt [Lyr,P,Dt])."""
+
+    @staticmethod
+    def forward(ctx, d1, d2v, d2t, d3v, d3t, scale=1.0):
+        args = [t.detach().contiguous().float() for t in (d1, d2v, d2t, d3v, d3t)]
+        ctx.save_for_backward(*args)
+        ctx.scale = scale
+        return E.prompt_cp_fwd(args[0], args[1], args[3], scale), E.prompt_cp_fwd(args[0], args[2], args[4], scale)
+
+    @staticmethod
+    def backward(ctx, gvis, gtxt):
+        d1, d2v, d2t, d3v, d3t = ctx.saved_tensors
+        g1 = torch.zeros_like(d1)
+        g2v, g3v = E.prompt_cp_bwd(d1, d2v, d3v, gvis.contiguous().float(), g1, False, ctx.scale)
+        g2t, g3t = E.prompt_cp_bwd(d1, d2t, d3t, gtxt.contiguous().float(), g1, True, ctx.scale)   # shared dim_1_share
+        return g1, g2v, g2t, g3v, g3t, None
+
+
+class EncodeImageFn(torch.autograd.Function):
+    """image_encoder(image, prompts) followed by the L2 normalisation of slinet.py:121-122."""
+
+    @staticmethod
+    def forward(ctx, enc, image, prompts, depth):
+        ctx.enc = enc
+        ctx.pshape = prompts.shape
+        train = prompts.requires_grad
+        return enc.encode_image(image, prompts.detach(), depth, train=train)
+
+    @staticmethod
+    def backward(ctx, g):
+        dpr = ctx.enc.encode_image_backward(g)
+        if len(ctx.pshape) == 4:     # stride-0 expanded [B,Lyr,P,d] view: autograd sums the broadcast itself
+            full = torch.zeros(ctx.pshape, device=dpr.device)
+            full[0] = dpr
+            dpr = full
+        return None, None, dpr, None
+
+
+class EncodeTextFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, ids, prompts, depth):
+        ctx.enc = enc
+        ctx.pshape = prompts.shape
+        train = prompts.requires_grad
+        return enc.encode_text(ids, prompts.detach(), depth, train=train)
+
+    @staticmethod
+    def backward(ctx, g):
+        dpr = ctx.enc.encode_text_backward(g)
+        if len(ctx.pshape) == 4:
+            full = torch.zeros(ctx.pshape, device=dpr.device)
+            full[0] = dpr
+            dpr = full
+        return None, None, dpr, None
+
+
+class ClipLossFn(torch.autograd.Function):
+    """logit_scale * I @ T^T then ClipLoss (slinet.py:138-141, loss/loss.py:75-87).  With a process group the
+    features are all-gathered first (dp.py) and every rank evaluates the full global loss (``local_loss=False``
+    semantics of the reference's dead ``gather_features``, sprompt.py:38-82)."""
+
+    @staticmethod
+    def forward(ctx, img_f, txt_f, scale, gather=None):
+        if gather is not None:
+            img_all, txt_all, r0 = gather(img_f.detach(), txt_f.detach())
+        else:
+            img_all, txt_all, r0 = img_f.detach().contiguous(), txt_f.detach().contiguous(), 0
+        need = img_f.requires_grad or txt_f.requires_grad
+        loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need)
+        n = img_f.shape[0]
+        if need:
+            ctx.save_for_backward(dI[r0:r0 + n], dT[r0:r0 + n])
+        ctx.logits = logits
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dI, dT = ctx.saved_tensors
+        return dI * g, dT * g, None, None
+
+
+class AlignLossFn(torch.autograd.Function):
+    """0.1 * ClipLoss((mean_d vis / 0.01) @ (mean_d txt / 0.01)^T)   (slinet.py:143-158)."""
+
+    @staticmethod
+    def forward(ctx, vis, txt, temp, weight):
+        need = vis.requires_grad or txt.requires_grad
+        loss, dv, dt = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), temp, weight, need)
+        if need:
+            ctx.save_for_backward(dv, dt)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt = ctx.saved_tensors
+        return dv * g, dt * g, None, None

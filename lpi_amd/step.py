@@ -1,0 +1,35 @@
+"""One training step of the LPI hot path on the HIP engine, written the way the reference's hot loop runs it
+(methods/sprompt.py:297-311: forward -> cal_loss -> sum of losses -> backward), minus the optimiser.
+
+Used by bench.py, __graft_entry__.smoke() and the parity tests; the plugin surface (lpi_amd/retrieval) reaches the
+same Functions through SliNet.forward / SliNet.cal_loss.
+"""
+from __future__ import annotations
+
+import torch
+
+from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeImageFn, EncodeTextFn
+from .synth import PROMPT_NAMES
+
+
+def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1):
+    """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
+    Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits)."""
+    vis, txt = DecomposedPromptFn.apply(*[factors[k] for k in ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")])
+    img_f = EncodeImageFn.apply(enc, images, vis, depth)
+    txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
+    fn = ClipLossFn
+    base = fn.apply(img_f, txt_f, enc.logit_scale_exp, gather)
+    losses = {"base_loss": base, "alignment_loss": AlignLossFn.apply(vis, txt, 0.01, align_weight)}
+    return losses, img_f, txt_f, vis, txt
+
+
+def train_step(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1):
+    """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs."""
+    for k in PROMPT_NAMES:
+        factors[k].grad = None
+    losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight)
+    total = losses["base_loss"] + losses["alignment_loss"]
+    total.backward()
+    return {"img_f": img_f.detach(), "txt_f": txt_f.detach(), "vis_prompt": vis.detach(), "txt_prompt": txt.detach(),
+            "base_loss": losses["base_loss"].detach(), "alignment_loss": losses["alignment_loss"].detach()}

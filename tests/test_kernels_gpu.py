@@ -1,0 +1,218 @@
+"""Per-kernel parity on a real MI355X: every C-ABI kernel vs a plain PyTorch reference of the same op computed on
+the CPU in float64 from the same (rounded) inputs.  f32 mode is held to f32 round-off; bf16 mode to bf16 round-off.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lpi_amd import _lib, engine as E  # noqa: E402
+from lpi_amd._lib import BF16, F32, call  # noqa: E402
+
+DEV = "cuda:0"
+TD = {F32: torch.float32, BF16: torch.bfloat16}
+TOL = {F32: 2e-5, BF16: 2e-2}
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def relerr(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_library_loaded_and_counts():
+    n0 = _lib.launch_count()
+    a = torch.zeros(128, 32, device=DEV)
+    c = torch.zeros(128, 128, device=DEV)
+    E.gemm(F32, a, torch.zeros(128, 32, device=DEV), c, 128, 128, 32)
+    torch.cuda.synchronize()
+    assert _lib.launch_count() == n0 + 1
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (384, 128, 3072), (1792, 2304, 768)])
+def test_gemm_plain(dt, M, N, K):
+    a = rnd(M, K, seed=1).to(TD[dt])
+    b = rnd(N, K, seed=2).to(TD[dt])
+    bias = rnd(N, seed=3)
+    c = torch.zeros(M, N, device=DEV, dtype=TD[dt])
+    E.gemm(dt, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), alpha=0.5)
+    ref = 0.5 * (a.double() @ b.double().t()) + bias.double()
+    assert relerr(c, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_gemm_epilogues(dt):
+    M, N, K = 256, 512, 128
+    a = rnd(M, K, seed=1).to(TD[dt])
+    b = rnd(N, K, seed=2, scale=0.1).to(TD[dt])
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, seed=4)
+    # residual (f32 out)
+    c = torch.zeros(M, N, device=DEV)
+    E.gemm(dt, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), residual=res.to(DEV))
+    ref = a.double() @ b.double().t() + bias.double() + res.double()
+    assert relerr(c, ref) < TOL[dt]
+    # QuickGELU with saved pre-activation
+    g = torch.zeros(M, N, device=DEV, dtype=TD[dt])
+    u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
+    E.gemm(dt, a.to(DEV), b.to(DEV), g, M, N, K, bias=bias.to(DEV), epi=E.EPI_QUICKGELU, aux=u)
+    uref = a.double() @ b.double().t() + bias.double()
+    assert relerr(u, uref) < TOL[dt]
+    assert relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
+    # gelu' epilogue reads the (rounded) saved u
+    du = torch.zeros(M, N, device=DEV, dtype=TD[dt])
+    E.gemm(dt, a.to(DEV), b.to(DEV), du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u)
+    ud = u.double().cpu()
+    sg = torch.sigmoid(1.702 * ud)
+    ref = (a.double() @ b.double().t()) * (sg * (1 + 1.702 * ud * (1 - sg)))
+    assert relerr(du, ref) < TOL[dt]
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(100, 32, device=DEV)
+    with pytest.raises(_lib.LpiError):
+        E.gemm(F32, a, a, torch.zeros(100, 100, device=DEV), 100, 100, 32)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("d", [128, 512, 768, 1024])
+def test_layernorm_fwd_bwd(dt, d):
+    rows = 203
+    x = rnd(rows, d, seed=5) * 2 + 0.3
+    gam, bet = 1 + 0.1 * rnd(d, seed=6), 0.05 * rnd(d, seed=7)
+    dy = rnd(rows, d, seed=8).to(TD[dt])
+    dx0 = rnd(rows, d, seed=9)
+    y = torch.zeros(rows, d, device=DEV, dtype=TD[dt])
+    st = torch.zeros(2, rows, device=DEV)
+    xd = x.to(DEV)
+    call("lpi_layernorm_fwd", dt, rows, d, xd, d, gam.to(DEV), bet.to(DEV), y, d, st[0], st[1], stream())
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gam.double(), bet.double(), 1e-5)
+    assert relerr(y, yr.detach()) < TOL[dt]
+    yr.backward(dy.double())
+    dx = dx0.clone().to(DEV)
+    cast = torch.zeros(rows, d, device=DEV, dtype=TD[dt])
+    call("lpi_layernorm_bwd", dt, dt, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, cast, d, stream())
+    ref = dx0.double() + xr.grad
+    assert relerr(dx, ref) < 2e-5
+    assert relerr(cast, ref) < TOL[dt]
+
+
+def attn_ref(qkv, B, L, H, causal):
+    d = H * 64
+    q, k, v = qkv.double().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * 0.125) @ k.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((L, L), float("-inf"), dtype=torch.float64).triu_(1)
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B * L, d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("B,L,H,causal", [(2, 213, 3, 0), (3, 77, 2, 1), (2, 21, 2, 0), (1, 197, 1, 0), (1, 273, 2, 0), (2, 32, 1, 1)])
+def test_attention_fwd_bwd(dt, B, L, H, causal):
+    d = H * 64
+    qkv = rnd(B * L, 3 * d, seed=11).to(TD[dt])
+    dctx = rnd(B * L, d, seed=12).to(TD[dt])
+    qd = qkv.to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=TD[dt])
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, causal, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = attn_ref(qr, B, L, H, causal)
+    assert relerr(ctx, oref.detach()) < TOL[dt]
+    assert relerr(lse, lref.detach()) < (1e-5 if dt == F32 else 2e-2)
+    oref.backward(dctx.double())
+    dqkv = torch.zeros(B * L, 3 * d, device=DEV, dtype=TD[dt])
+    delta = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_bwd", dt, B, L, H, qd, 3 * d, ctx, d, dctx.to(DEV), d, lse, delta, dqkv, 3 * d, causal, stream())
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        e = relerr(dqkv[:, sl], qr.grad[:, sl])
+        assert e < (5e-5 if dt == F32 else 4e-2), (name, e)
+
+
+def test_attention_large_scores_online_softmax():
+    """Force the running-max rescale: one key dominates late in the sequence (cdna guide rule 26)."""
+    B, L, H = 1, 213, 1
+    qkv = rnd(B * L, 192, seed=13)
+    qkv[:, :64] *= 4
+    qkv[200, 64:128] = qkv[5, :64] * 3          # key 200 matches query 5 strongly
+    ctx = torch.zeros(L, 64, device=DEV)
+    lse = torch.zeros(1, 1, L, device=DEV)
+    call("lpi_attn_fwd", F32, B, L, H, qkv.to(DEV), 192, ctx, 64, lse, 0, stream())
+    oref, lref = attn_ref(qkv, B, L, H, 0)
+    assert relerr(ctx, oref) < 2e-5 and relerr(lse, lref) < 1e-5
+
+
+def test_prompt_cp_fwd_bwd():
+    Lyr, P, D, r = 9, 16, 768, 4
+    d1, d2, d3 = rnd(Lyr, r, seed=1) * .5, rnd(P, r, seed=2) * .5, rnd(D, r, seed=3) * .5
+    dout = rnd(Lyr, P, D, seed=4)
+    out = E.prompt_cp_fwd(d1.to(DEV), d2.to(DEV), d3.to(DEV))
+    a, b, c = d1.double().requires_grad_(True), d2.double().requires_grad_(True), d3.double().requires_grad_(True)
+    ref = torch.einsum("lr,pr,dr->lpd", a, b, c) / r
+    assert relerr(out, ref.detach()) < 1e-6
+    ref.backward(dout.double())
+    g1 = torch.zeros(Lyr, r, device=DEV)
+    g2, g3 = E.prompt_cp_bwd(d1.to(DEV), d2.to(DEV), d3.to(DEV), dout.to(DEV), g1, False)
+    assert relerr(g1, a.grad) < 1e-5 and relerr(g2, b.grad) < 1e-5 and relerr(g3, c.grad) < 1e-5
+    E.prompt_cp_bwd(d1.to(DEV), d2.to(DEV), d3.to(DEV), dout.to(DEV), g1, True)      # accumulate into g1
+    assert relerr(g1, 2 * a.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n", [4, 8, 256, 300])
+def test_clip_loss(n):
+    Ed = 512
+    i = torch.nn.functional.normalize(rnd(n, Ed, seed=1), dim=-1)
+    t = torch.nn.functional.normalize(rnd(n, Ed, seed=2), dim=-1)
+    scale = 1 / 0.07
+    loss, logits, dI, dT = E.clip_loss_fwd_bwd(i.to(DEV), t.to(DEV), scale)
+    ir, tr = i.double().requires_grad_(True), t.double().requires_grad_(True)
+    lg = scale * ir @ tr.t()
+    lab = torch.arange(n)
+    ref = (torch.nn.functional.cross_entropy(lg, lab) + torch.nn.functional.cross_entropy(lg.t(), lab)) / 2
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    assert relerr(logits, lg.detach()) < 1e-5
+    assert relerr(dI, ir.grad) < 5e-5 and relerr(dT, tr.grad) < 5e-5
+
+
+def test_align_loss():
+    vis, txt = rnd(9, 16, 768, seed=1) * 0.1, rnd(9, 16, 512, seed=2) * 0.1
+    loss, dv, dt = E.align_loss_fwd_bwd(vis.to(DEV), txt.to(DEV))
+    v, t = vis.double().requires_grad_(True), txt.double().requires_grad_(True)
+    S = (v.mean(-1) / 0.01) @ (t.mean(-1) / 0.01).t()
+    lab = torch.arange(9)
+    ref = 0.1 * (torch.nn.functional.cross_entropy(S, lab) + torch.nn.functional.cross_entropy(S.t(), lab)) / 2
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1, abs(ref.item()))
+    assert relerr(dv, v.grad) < 5e-5 and relerr(dt, t.grad) < 5e-5
+
+
+def test_retrieval_rank_and_topk():
+    n_img, n_txt = 37, 91
+    s = rnd(n_img, n_txt, seed=3)
+    s[3, 10] = s[3, 20]                      # a tie: np.argsort(...)[::-1] puts the LATER index first
+    gt = torch.stack([torch.arange(n_img) * 2, torch.arange(n_img) * 2 + 1], 1).int()
+    rank = torch.zeros(n_img, dtype=torch.int32, device=DEV)
+    call("lpi_retrieval_rank", n_img, n_txt, s.to(DEV), n_txt, gt.to(DEV), 2, rank, stream())
+    ref = []
+    for i in range(n_img):
+        inds = np.argsort(s[i].numpy(), kind="stable")[::-1]
+        ref.append(min(np.where(inds == j)[0][0] for j in gt[i].tolist()))
+    assert rank.cpu().tolist() == ref
+    idx = torch.zeros(n_img, 5, dtype=torch.int32, device=DEV)
+    val = torch.zeros(n_img, 5, device=DEV)
+    call("lpi_topk", n_img, n_txt, 5, s.to(DEV), n_txt, idx, val, stream())
+    refi = np.stack([np.argsort(s[i].numpy(), kind="stable")[::-1][:5] for i in range(n_img)])
+    assert (idx.cpu().numpy() == refi).all()
