@@ -60,6 +60,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): import it first so that this library binds to the
+    # HIP runtime instance that owns torch's device context and streams, whichever module the process imported first.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise LpiError(
             f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run "

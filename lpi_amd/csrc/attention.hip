@@ -355,13 +355,12 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
     if (causal) {
         int e = set_lds(attn_fwd_kernel<T, true>, lds);
         if (e) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, true>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+        LPI_LAUNCH((attn_fwd_kernel<T, true>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
     } else {
         int e = set_lds(attn_fwd_kernel<T, false>, lds);
         if (e) return e;
-        hipLaunchKernelGGL((attn_fwd_kernel<T, false>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+        LPI_LAUNCH((attn_fwd_kernel<T, false>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
     }
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -377,13 +376,11 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     if (e) return e;
     e = set_lds(attn_bwd_dkv_kernel<T, CAUSAL>, ldsB);
     if (e) return e;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
                        (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
+    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
                        lse, delta, (T*)dqkv, lddqkv);
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }

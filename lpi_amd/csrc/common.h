@@ -13,7 +13,14 @@ typedef __attribute__((ext_vector_type(4))) short short4v;
 #define WAVE 64
 
 extern "C" void lpi_count_launch();
-#define LPI_LAUNCHED() lpi_count_launch()
+// Launch + count.  The sticky HIP error state is cleared first so that LPI_CHECK_LAST reports only THIS launch's error
+// (the host framework's own runtime calls can leave a stale code behind).
+#define LPI_LAUNCH(...)                     \
+    do {                                    \
+        (void)hipGetLastError();            \
+        hipLaunchKernelGGL(__VA_ARGS__);    \
+        lpi_count_launch();                 \
+    } while (0)
 
 #define LPI_CHECK_LAST()                                      \
     do {                                                      \

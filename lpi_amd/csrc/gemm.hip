@@ -159,9 +159,8 @@ int launch(int M, int N, int K, const void* A, int lda, const void* B, int ldb, 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
+    LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
                        (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn);
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }

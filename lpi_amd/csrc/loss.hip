@@ -266,17 +266,13 @@ __global__ __launch_bounds__(256) void topk_kernel(int n_rows, int n_cols, int k
 extern "C" int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, float* loss, float* dlogits, int lddl,
                                      float* row_lse, float* col_lse, void* stream) {
     if (!logits || !loss || !row_lse || !col_lse || n <= 0 || ld < n) return LPI_EINVAL;
-    hipLaunchKernelGGL(row_lse_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, logits, ld, row_lse);
-    LPI_LAUNCHED();
-    hipLaunchKernelGGL(col_lse_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), n, logits, ld, col_lse);
-    LPI_LAUNCHED();
-    hipLaunchKernelGGL(clip_loss_reduce_kernel, dim3(1), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, loss);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(row_lse_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, logits, ld, row_lse);
+    LPI_LAUNCH(col_lse_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), n, logits, ld, col_lse);
+    LPI_LAUNCH(clip_loss_reduce_kernel, dim3(1), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, loss);
     if (dlogits) {
         if (lddl < n) return LPI_EINVAL;
-        hipLaunchKernelGGL(clip_loss_grad_kernel, dim3((n + 255) / 256, n), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream,
+        LPI_LAUNCH(clip_loss_grad_kernel, dim3((n + 255) / 256, n), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream,
                            dlogits, lddl);
-        LPI_LAUNCHED();
     }
     LPI_CHECK_LAST();
     return 0;
@@ -286,8 +282,7 @@ extern "C" int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, 
                                  void* stream) {
     if (!d1 || !d2 || !d3 || !out || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
     const long n = (long)Lyr * P * D;
-    hipLaunchKernelGGL(cp_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, d3, scale / (float)r, out);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(cp_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, d3, scale / (float)r, out);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -298,10 +293,8 @@ extern "C" int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, 
     const size_t lds = (size_t)Lyr * P * r * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
     const float sc = scale / (float)r;
-    hipLaunchKernelGGL(cp_bwd_g12_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, D, r, d1, d2, d3, sc, dout, g1, g2, accumulate_g1);
-    LPI_LAUNCHED();
-    hipLaunchKernelGGL(cp_bwd_g3_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, sc, dout, g3);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(cp_bwd_g12_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, D, r, d1, d2, d3, sc, dout, g1, g2, accumulate_g1);
+    LPI_LAUNCH(cp_bwd_g3_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, sc, dout, g3);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -311,8 +304,7 @@ extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const floa
     if (!vis || !txt || !loss || Lyr <= 0 || P <= 0 || Dv <= 0 || Dt <= 0 || temp <= 0.f) return LPI_EINVAL;
     const size_t lds = ((size_t)4 * Lyr * P + 2 * Lyr * Lyr + 2 * Lyr) * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
-    hipLaunchKernelGGL(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -320,16 +312,14 @@ extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const floa
 extern "C" int lpi_retrieval_rank(int n_rows, int n_cols, const float* scores, int ld, const int32_t* gt, int gt_per_row, int32_t* rank,
                                   void* stream) {
     if (!scores || !gt || !rank || n_rows <= 0 || n_cols <= 0 || gt_per_row <= 0 || ld < n_cols) return LPI_EINVAL;
-    hipLaunchKernelGGL(retrieval_rank_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, scores, ld, gt, gt_per_row, rank);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(retrieval_rank_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, scores, ld, gt, gt_per_row, rank);
     LPI_CHECK_LAST();
     return 0;
 }
 
 extern "C" int lpi_topk(int n_rows, int n_cols, int k, const float* scores, int ld, int32_t* idx, float* val, void* stream) {
     if (!scores || !idx || n_rows <= 0 || n_cols <= 0 || k <= 0 || k > n_cols || ld < n_cols) return LPI_EINVAL;
-    hipLaunchKernelGGL(topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, k, scores, ld, idx, val);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(topk_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, S(stream), n_rows, n_cols, k, scores, ld, idx, val);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -363,12 +363,11 @@ extern "C" int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int
                                  void* y, int ldy, float* mean, float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || bad_row_dim(d) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
     if (dtype == LPI_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd);
+        LPI_LAUNCH(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd);
     else if (dtype == LPI_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+        LPI_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
     else
         return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -379,14 +378,13 @@ extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, 
     if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
-#define LNB(TDY, TC) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
+#define LNB(TDY, TC) LPI_LAUNCH((ln_bwd_kernel<TDY, TC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
     if (dy_dtype == LPI_F32 && cast_dtype == LPI_F32) LNB(float, float);
     else if (dy_dtype == LPI_F32 && cast_dtype == LPI_BF16) LNB(float, bf16_t);
     else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16) LNB(bf16_t, bf16_t);
     else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_F32) LNB(bf16_t, float);
     else return LPI_EINVAL;
 #undef LNB
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -400,10 +398,9 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
     if (ldcols < Kp || (ldcols & 3)) return LPI_EINVAL;
     const long total = (long)B * G * G * (Kp >> 2);
     dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (dtype == LPI_F32) hipLaunchKernelGGL(patchify_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (float*)cols, ldcols);
-    else if (dtype == LPI_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (bf16_t*)cols, ldcols);
+    if (dtype == LPI_F32) LPI_LAUNCH(patchify_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (float*)cols, ldcols);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(patchify_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (bf16_t*)cols, ldcols);
     else return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -415,9 +412,8 @@ extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* pa
         return LPI_EINVAL;
     if (P > 0 && (!prompt0 || (prompt_bstride & 3))) return LPI_EINVAL;
     const long rows = (long)B * (1 + P + G2);
-    hipLaunchKernelGGL(vis_assemble_fwd_kernel, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
+    LPI_LAUNCH(vis_assemble_fwd_kernel, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
                        prompt0, prompt_bstride, gamma, beta, x0, mean, rstd);
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -425,8 +421,7 @@ extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* pa
 extern "C" int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate, void* stream) {
     if (!dx || !out || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || bad_row_dim(d)) return LPI_EINVAL;
     const int n = P * (d >> 2);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(rows_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -435,9 +430,8 @@ extern "C" int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, con
                                     const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream) {
     if (!dx0 || !prompt0 || !gamma || !mean || !rstd || !dprompt || B <= 0 || P <= 0 || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
     const int L = 1 + P + G2;
-    hipLaunchKernelGGL(vis_prompt_rows_bwd_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, dx0, prompt0,
+    LPI_LAUNCH(vis_prompt_rows_bwd_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, dx0, prompt0,
                        prompt_bstride, gamma, mean, rstd);
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return lpi_rows_sum_over_batch(B, L, 1, P, d, dx0, dprompt, 0, stream);
 }
@@ -445,16 +439,14 @@ extern "C" int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, con
 extern "C" int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
                                  long ctx_bstride, float* x0, void* stream) {
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
-    hipLaunchKernelGGL(txt_embed_kernel, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(txt_embed_kernel, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0);
     LPI_CHECK_LAST();
     return 0;
 }
 
 extern "C" int lpi_prompt_add(int B, int L, int P, int d, float* x, const float* prompt_l, long prompt_bstride, void* stream) {
     if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
-    hipLaunchKernelGGL(prompt_add_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, x, prompt_l, prompt_bstride);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(prompt_add_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, x, prompt_l, prompt_bstride);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -463,10 +455,9 @@ extern "C" int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, c
                                void* y, int ldy, float* mean, float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || L <= 0 || bad_row_dim(d) || (ldy & 3)) return LPI_EINVAL;
     dim3 g(rows_grid(B)), b(256);
-    if (dtype == LPI_F32) hipLaunchKernelGGL(pool_ln_fwd_kernel<float>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
-    else if (dtype == LPI_BF16) hipLaunchKernelGGL(pool_ln_fwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    if (dtype == LPI_F32) LPI_LAUNCH(pool_ln_fwd_kernel<float>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(pool_ln_fwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
     else return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -475,18 +466,16 @@ extern "C" int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float*
                                const float* gamma, const float* mean, const float* rstd, float* dx, void* dx_cast, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || B <= 0 || bad_row_dim(d) || (lddy & 3)) return LPI_EINVAL;
     dim3 g(rows_grid(B)), b(256);
-    if (cast_dtype == LPI_F32) hipLaunchKernelGGL(pool_ln_bwd_kernel<float>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (float*)dx_cast);
-    else if (cast_dtype == LPI_BF16) hipLaunchKernelGGL(pool_ln_bwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (bf16_t*)dx_cast);
+    if (cast_dtype == LPI_F32) LPI_LAUNCH(pool_ln_bwd_kernel<float>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (float*)dx_cast);
+    else if (cast_dtype == LPI_BF16) LPI_LAUNCH(pool_ln_bwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (bf16_t*)dx_cast);
     else return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
 
 extern "C" int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, int ldy, float* inv_norm, void* stream) {
     if (!x || !y || !inv_norm || B <= 0 || bad_row_dim(E) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, x, ldx, y, ldy, inv_norm);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(l2norm_fwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, x, ldx, y, ldy, inv_norm);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -494,16 +483,14 @@ extern "C" int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, i
 extern "C" int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int lddy, const float* inv_norm, float* dx, int lddx,
                               void* stream) {
     if (!y || !dy || !inv_norm || !dx || B <= 0 || bad_row_dim(E) || (ldy & 3) || (lddy & 3) || (lddx & 3)) return LPI_EINVAL;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, y, ldy, dy, lddy, inv_norm, dx, lddx);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(l2norm_bwd_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, E, y, ldy, dy, lddy, inv_norm, dx, lddx);
     LPI_CHECK_LAST();
     return 0;
 }
 
 extern "C" int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream) {
     if (!ids || !idx || B <= 0 || L <= 0) return LPI_EINVAL;
-    hipLaunchKernelGGL(eot_index_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), B, L, ids, idx);
-    LPI_LAUNCHED();
+    LPI_LAUNCH(eot_index_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), B, L, ids, idx);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -512,11 +499,10 @@ extern "C" int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, v
     if (!src || !dst || n <= 0 || (n & 3)) return LPI_EINVAL;
     const long n4 = n >> 2;
     dim3 g((unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256)), b(256);
-    if (src_dtype == LPI_F32 && dst_dtype == LPI_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, S(stream), n4, (const float*)src, (bf16_t*)dst);
-    else if (src_dtype == LPI_BF16 && dst_dtype == LPI_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, S(stream), n4, (const bf16_t*)src, (float*)dst);
-    else if (src_dtype == LPI_F32 && dst_dtype == LPI_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, S(stream), n4, (const float*)src, (float*)dst);
+    if (src_dtype == LPI_F32 && dst_dtype == LPI_BF16) LPI_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, S(stream), n4, (const float*)src, (bf16_t*)dst);
+    else if (src_dtype == LPI_BF16 && dst_dtype == LPI_F32) LPI_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, S(stream), n4, (const bf16_t*)src, (float*)dst);
+    else if (src_dtype == LPI_F32 && dst_dtype == LPI_F32) LPI_LAUNCH((cast_kernel<float, float>), g, b, 0, S(stream), n4, (const float*)src, (float*)dst);
     else return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }
@@ -524,10 +510,9 @@ extern "C" int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, v
 extern "C" int lpi_transpose(int dtype, int rows, int cols, const void* src, int lds, void* dst, int ldd, void* stream) {
     if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < rows) return LPI_EINVAL;
     dim3 g((cols + 31) / 32, (rows + 31) / 32), b(256);
-    if (dtype == LPI_F32) hipLaunchKernelGGL(transpose_kernel<float>, g, b, 0, S(stream), rows, cols, (const float*)src, lds, (float*)dst, ldd);
-    else if (dtype == LPI_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, g, b, 0, S(stream), rows, cols, (const bf16_t*)src, lds, (bf16_t*)dst, ldd);
+    if (dtype == LPI_F32) LPI_LAUNCH(transpose_kernel<float>, g, b, 0, S(stream), rows, cols, (const float*)src, lds, (float*)dst, ldd);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(transpose_kernel<bf16_t>, g, b, 0, S(stream), rows, cols, (const bf16_t*)src, lds, (bf16_t*)dst, ldd);
     else return LPI_EINVAL;
-    LPI_LAUNCHED();
     LPI_CHECK_LAST();
     return 0;
 }

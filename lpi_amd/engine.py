@@ -58,12 +58,25 @@ class Linear:
         self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
 
 
-def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0):
-    """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows)."""
+# When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
+# (start, end, algorithmic_flops) is appended: bench.py's live roofline measurement of the dominant kernel.
+GEMM_PROFILE = None
+
+
+def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None):
+    """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows).
+    m_real: un-padded row count, used only for algorithmic-FLOP accounting."""
     cdt = F32 if c.dtype == torch.float32 else BF16
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
          residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
          float(alpha), _stream())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * (m_real or M) * N * K))
 
 
 @dataclass
@@ -147,12 +160,12 @@ class Tower:
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
                 call("lpi_prompt_add", B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
             call("lpi_layernorm_fwd", dt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
-            gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b)
+            gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
-            gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in)
+            gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             call("lpi_layernorm_fwd", dt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
-            gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u)
-            gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid)
+            gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
+            gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         return ws["x"][len(self.blocks) if train else len(self.blocks) % 2]
 
     # ------------------------------------------------------------------ backward (dgrad only)
@@ -170,13 +183,13 @@ class Tower:
             blk = self.blocks[i]
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
             du = ws["g"]
-            gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u)          # d c_proj, * gelu'
-            gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d)                                         # d c_fc
+            gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
+            gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
             call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                  None if dt == F32 else dxT, d, s)
-            gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d)                                         # d out_proj
+            gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
-            gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d)                                      # d in_proj
+            gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
@@ -260,7 +273,7 @@ class DualEncoder:
                   "pe": torch.zeros(rows, d, device=self.device), "stat": torch.zeros(2, ws["Mp"], device=self.device)}
             ws["front"] = fe
         call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
-        gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp)
+        gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
         call("lpi_vis_assemble_fwd", B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
              ws["x"][0], fe["stat"][0], fe["stat"][1], s)
         xo = self.vis.forward(ws, pr, pbs, depth, train)

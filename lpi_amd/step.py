@@ -24,12 +24,19 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
     return losses, img_f, txt_f, vis, txt
 
 
-def train_step(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1):
-    """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs."""
+def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1):
+    """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
+
+    exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
+    gradients SUM all-reduced; the data-independent alignment term is scaled by 1/W so that it counts once)."""
     for k in PROMPT_NAMES:
         factors[k].grad = None
+    gather = exchange.gather if exchange is not None else None
     losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight)
-    total = losses["base_loss"] + losses["alignment_loss"]
+    world = exchange.world if exchange is not None else 1
+    total = losses["base_loss"] + losses["alignment_loss"] / world
     total.backward()
+    if exchange is not None:
+        exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES])
     return {"img_f": img_f.detach(), "txt_f": txt_f.detach(), "vis_prompt": vis.detach(), "txt_prompt": txt.detach(),
             "base_loss": losses["base_loss"].detach(), "alignment_loss": losses["alignment_loss"].detach()}
