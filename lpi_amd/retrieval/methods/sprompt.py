@@ -1,0 +1,253 @@
+"""SPrompts — the continual-learning driver plugin surface of the reference (methods/sprompt.py:104-694) over the HIP
+network.  Same constructor argument, same public attributes/methods the trainer uses (``_network``,
+``incremental_train()``, ``after_task()``), same hot loop (forward -> cal_loss -> sum -> backward -> SGD step), same
+trainable-parameter filter, optimiser and scheduler, same evaluation protocol and ``final_res`` structure.
+
+What changed, and why:
+  * device handling is explicit (no hard ``.cuda()``): everything follows ``args['device'][0]``;
+  * data parallelism actually works: with torch.distributed initialised (one process per GPU, RCCL), the features are
+    all-gathered for the global contrastive matrix and the prompt-factor gradients are SUM all-reduced (lpi_amd/dp.py) —
+    the reference's multi-GPU path is dead code (README.md:13);
+  * the per-row ``np.argsort`` rank search of ``itm_eval`` (sprompt.py:558-599) runs on the GPU (lpi_retrieval_rank);
+  * datasets: COCO is not available offline; ``args['dataset_impl'] == 'synthetic'`` (default when image_root is missing)
+    builds synthetic loaders with the same item structure.  KMeans task keys stay on the host (sklearn), as in the reference.
+"""
+import collections
+import json
+import logging
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+from torch import optim
+from torch.utils.data import DataLoader
+
+from lpi_amd import _lib
+from lpi_amd.retrieval.loss.loss import ClipLoss
+from lpi_amd.retrieval.methods.base import BaseLearner
+from lpi_amd.retrieval.models.slinet import SliNet
+from lpi_amd.retrieval.utils.data import SyntheticCoco, SyntheticCocoEval
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def _dist_world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class SPrompts(BaseLearner):
+    def __init__(self, args):
+        super().__init__(args)
+        if args["net_type"] == "slip":
+            self._network = SliNet(args)
+        else:
+            raise ValueError('Unknown net: {}.'.format(args["net_type"]))       # sprompt.py:118
+        self.args = args
+        self.EPSILON = args["EPSILON"]
+        self.epochs = args["epochs"]
+        self.lrate = args["lrate"]
+        self.batch_size = args["batch_size"]
+        self.weight_decay = args["weight_decay"]
+        self.num_workers = args["num_workers"]
+        self.num_tasks = int(args.get("num_tasks", 12))
+        self.topk = 2
+        self.class_num = self._network.class_num
+        self.all_keys = []
+        self.textual_all_keys = []
+        self.loss = ClipLoss()
+        self.cur_id = 0
+        self.final_res = None
+
+    # ------------------------------------------------------------------ sprompt.py:145-195
+    def after_task(self):
+        self._old_network = self._network.copy().freeze()
+        self._known_classes = self._total_classes
+        logging.info('Exemplar size: {}'.format(self.exemplar_size))
+
+    def _datasets(self, i):
+        impl = self.args.get("dataset_impl")
+        if impl is None:
+            impl = "coco" if os.path.isdir(str(self.args.get("image_root", ""))) else "synthetic"
+        if impl != "synthetic":
+            raise NotImplementedError("COCO loading needs torchvision/PIL pipelines that are outside the hot path; pass your own "
+                                      "loaders to _train(train_loader, test_loader) or use dataset_impl='synthetic'")
+        res = self._network.clip_cfg.image_resolution
+        n_train = int(self.args.get("synthetic_train_size", 4 * self.batch_size))
+        n_eval = int(self.args.get("synthetic_eval_images_per_task", 16))
+        return (SyntheticCoco(n_train, [i], res, seed=i), SyntheticCocoEval(n_eval, np.arange(0, i + 1), 2, res, seed=i))
+
+    def incremental_train(self):
+        final_res = {}
+        for i in range(self.num_tasks):
+            self._cur_task = [i]
+            self.cur_id = i
+            self._network.update_fc(self._total_classes)
+            train_dataset, test_dataset = self._datasets(i)
+            sampler = None
+            if _dist_world() > 1:
+                from torch.utils.data.distributed import DistributedSampler
+                sampler = DistributedSampler(train_dataset, shuffle=True, drop_last=True)
+            self.train_loader = DataLoader(train_dataset, batch_size=self.batch_size, shuffle=sampler is None, sampler=sampler,
+                                           num_workers=self.num_workers, drop_last=sampler is not None)
+            self.test_loader = DataLoader(test_dataset, batch_size=128, shuffle=False, num_workers=self.num_workers)
+            final_res[i] = self._train(self.train_loader, self.test_loader)
+        self.final_res = final_res
+        os.makedirs('./res', exist_ok=True)
+        self.save_dict(final_res, f'./res/{datetime.now()}.json')
+
+    def save_dict(self, dictionary, file_path):
+        with open(file_path, 'w') as file:
+            json.dump(dictionary, file)
+
+    # ------------------------------------------------------------------ sprompt.py:197-256
+    def _train(self, train_loader, test_loader):
+        self._network.to(self._device)
+        if _dist_world() > 1 and self._network.exchange is None:
+            from lpi_amd.dp import Exchange
+            self._network.exchange = Exchange()
+        network = self._network
+        for name, param in network.named_parameters():
+            param.requires_grad_(False)
+            if "prompts" + "." + str(network.numtask - 1) + "." in name:           # sprompt.py:235
+                param.requires_grad_(True)
+        enabled = {n for n, p in network.named_parameters() if p.requires_grad}
+        print(f"Parameters to be updated: {enabled}")
+        optimizer = optim.SGD(network.parameters(), momentum=0.9, lr=self.lrate, weight_decay=self.weight_decay)
+        scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer=optimizer, T_max=self.epochs)
+        self.run_epoch = self.epochs
+        return self.train_function(train_loader, test_loader, optimizer, scheduler)
+
+    # ------------------------------------------------------------------ sprompt.py:290-334 (hot loop)
+    def train_function(self, train_loader, test_loader, optimizer, scheduler):
+        loss_meter = collections.defaultdict(AverageMeter)
+        net = self._network
+        for epoch in range(self.run_epoch):
+            net.train()
+            for i, (images, captions, _, _) in enumerate(train_loader):
+                images = images.to(self._device, non_blocking=True)
+                captions = captions if torch.is_tensor(captions) else list(captions)
+                image_features, text_features, visual_prompt, textual_prompt = net(images, captions)
+                model_out = net.cal_loss(image_features, text_features, visual_prompt, textual_prompt)
+                world = net.exchange.world if net.exchange is not None else 1
+                # data-independent terms are identical on every rank: count them once under the SUM all-reduce
+                loss = sum(v if k == "base_loss" else v / world for k, v in model_out['loss'].items())
+                optimizer.zero_grad()
+                loss.backward()
+                if net.exchange is not None:
+                    net.exchange.allreduce_grads([p for p in net.parameters() if p.requires_grad])
+                optimizer.step()
+                for k, v in model_out['loss'].items():
+                    loss_meter[k].update(v.detach())
+                if i % 50 == 0:
+                    info = 'Task {}, Epoch {}/{}, Batch {}, lr {:.4f} =>, '.format(
+                        self.cur_id, epoch + 1, self.run_epoch, i, optimizer.param_groups[0]["lr"])
+                    for k, v in loss_meter.items():
+                        info += '{} = {:.4f}, '.format(k, float(v.avg))
+                        v.reset()
+                    logging.info(info)
+            scheduler.step()
+        self.clustering(dataloader=train_loader)
+        _, _, final_res = self._evaluate_retrieval(test_loader)
+        return final_res
+
+    # ------------------------------------------------------------------ sprompt.py:336-397
+    def _task_id(self, feature, all_keys):
+        sel = []
+        for task_centers in all_keys:
+            d = (feature[:, None, :] - task_centers[None].to(feature.device)).abs().sum(-1)      # ((f-c)**2)**0.5 summed
+            sel.append(d.min(1)[0])
+        return torch.vstack(sel).min(0)[1]
+
+    def get_visual_task_id(self, inputs):
+        with torch.no_grad():
+            return self._task_id(self._network.extract_vector(inputs), self.all_keys)
+
+    def get_textual_task_id(self, inputs):
+        with torch.no_grad():
+            return self._task_id(self._network.extract_textual_vector(inputs), self.textual_all_keys)
+
+    def clustering(self, dataloader):
+        from sklearn.cluster import KMeans
+        vf, tf = [], []
+        for inputs, captions, _, _ in dataloader:
+            with torch.no_grad():
+                v = self._network.extract_vector(inputs.to(self._device))
+                t = self._network.extract_textual_vector(captions if torch.is_tensor(captions) else list(captions))
+            vf.append(v / v.norm(dim=-1, keepdim=True))
+            tf.append(t / t.norm(dim=-1, keepdim=True))
+        vf = torch.cat(vf, 0).cpu().numpy()
+        tf = torch.cat(tf, 0).cpu().numpy()
+        vc = KMeans(n_clusters=5, random_state=0).fit(vf)
+        tc = KMeans(n_clusters=5, random_state=0).fit(tf)
+        self.all_keys.append(torch.tensor(vc.cluster_centers_).to(self._device))
+        self.textual_all_keys.append(torch.tensor(tc.cluster_centers_).to(self._device))
+
+    # ------------------------------------------------------------------ sprompt.py:433-548
+    @torch.no_grad()
+    def _evaluate_retrieval(self, data_loader):
+        self._network.eval()
+        ds = data_loader.dataset
+        texts, texts_cat = ds.text, torch.tensor(ds.text_cat)
+        num_text = len(texts)
+        text_bs = 256
+        image_feats, category_i = [], []
+        for image, img_id, category in data_loader:
+            image = image.to(self._device)
+            selection = self.get_visual_task_id(image)
+            image_feats.append(self._network.visual_interface(image, selection))
+            category_i.extend(int(z) for z in category)
+        text_feats = []
+        for i in range(0, num_text, text_bs):
+            text = texts[i: min(num_text, i + text_bs)]
+            sel = self.get_textual_task_id(text)
+            text_feats.append(self._network.textual_interface(text, sel))
+        image_feats, text_feats = torch.cat(image_feats), torch.cat(text_feats)
+        score_t2i = (image_feats @ text_feats.t()).t().contiguous()      # sprompt.py:509
+        score_i2t = score_t2i.t().contiguous()
+        final_res = self.itm_eval(score_i2t, score_t2i, ds.txt2img, ds.img2txt, category_i, texts_cat)
+        return score_i2t.cpu().numpy(), score_t2i.cpu().numpy(), final_res
+
+    # ------------------------------------------------------------------ sprompt.py:550-646
+    @torch.no_grad()
+    def itm_eval(self, scores_i2t, scores_t2i, txt2img, img2txt, category_i, category_t):
+        dev = self._device if torch.device(self._device).type == "cuda" else "cuda:0"
+        s_i2t = torch.as_tensor(scores_i2t, dtype=torch.float32, device=dev).contiguous()
+        s_t2i = torch.as_tensor(scores_t2i, dtype=torch.float32, device=dev).contiguous()
+        n_img, n_txt = s_i2t.shape
+        gmax = max(len(v) for v in img2txt.values())
+        gt_i = torch.full((n_img, gmax), -1, dtype=torch.int32)
+        for i in range(n_img):
+            gt_i[i, :len(img2txt[i])] = torch.tensor(img2txt[i], dtype=torch.int32)
+        gt_t = torch.tensor([txt2img[t] for t in range(n_txt)], dtype=torch.int32).view(-1, 1)
+        r_i = torch.zeros(n_img, dtype=torch.int32, device=dev)
+        r_t = torch.zeros(n_txt, dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.call("lpi_retrieval_rank", n_img, n_txt, s_i2t, n_txt, gt_i.to(dev), gmax, r_i, s)
+        _lib.call("lpi_retrieval_rank", n_txt, n_img, s_t2i, n_img, gt_t.to(dev), 1, r_t, s)
+        ranks_i, ranks_t = r_i.cpu().numpy(), r_t.cpu().numpy()
+        category_i = np.asarray(category_i)
+        category_t = np.asarray(category_t)
+        task_num = self.cur_id + 1
+        i2t_res, t2i_res = {}, {}
+        for task in range(task_num):
+            r = ranks_i[category_i == task]
+            i2t_res[task] = [100.0 * float((r < k).sum()) / len(r) for k in (1, 5, 10)]
+            r = ranks_t[category_t == task]
+            t2i_res[task] = [100.0 * float((r < k).sum()) / len(r) for k in (1, 5, 10)]
+        final_res = {'mscoco': {'i2t': i2t_res, 't2i': t2i_res}}
+        logging.info(final_res)
+        return final_res

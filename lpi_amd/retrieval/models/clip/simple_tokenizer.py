@@ -1,0 +1,127 @@
+"""Byte-level BPE tokenizer producing CLIP token ids — own implementation of the published CLIP BPE scheme, validated
+against ids captured from the reference's ``SimpleTokenizer`` (models/clip/simple_tokenizer.py:62-132) and
+``clip.tokenize`` (models/clip/clip.py:185-221); see tests/test_tokenizer.py.
+
+The merge table ``bpe_simple_vocab_16e6.txt.gz`` is third-party data (OpenAI CLIP) that is NOT shipped here; it is looked up
+at run time: $LPI_BPE_VOCAB, then ./models/clip/ (the reference checkout the plugin is dropped into), then next to this
+file.  Callers that already hold token ids (bench, tests) never need it.
+"""
+from __future__ import annotations
+
+import gzip
+import html
+import os
+from functools import lru_cache
+
+import regex
+
+VOCAB_FILE = "bpe_simple_vocab_16e6.txt.gz"
+SOT_TEXT, EOT_TEXT = "<|startoftext|>", "<|endoftext|>"
+N_MERGES = 49152 - 256 - 2      # merges used by CLIP (simple_tokenizer.py:66)
+_WORD_END = "</w>"
+_SPLIT = regex.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
+_WS = regex.compile(r"\s+")
+
+
+def find_vocab(path: str | None = None) -> str:
+    cands = [path, os.environ.get("LPI_BPE_VOCAB"), os.path.join(os.getcwd(), "models", "clip", VOCAB_FILE),
+             os.path.join(os.path.dirname(os.path.abspath(__file__)), VOCAB_FILE)]
+    for c in cands:
+        if c and os.path.isfile(c):
+            return c
+    raise FileNotFoundError(f"{VOCAB_FILE} not found; set LPI_BPE_VOCAB or pass token ids instead of strings")
+
+
+@lru_cache()
+def byte_alphabet():
+    """256 printable stand-ins, one per byte: printable latin-1 bytes map to themselves, the rest to U+0100.. in order."""
+    keep = set(range(0x21, 0x7F)) | set(range(0xA1, 0xAD)) | set(range(0xAE, 0x100))
+    table, extra = {}, 0
+    for b in range(256):
+        if b in keep:
+            table[b] = chr(b)
+    for b in range(256):
+        if b not in keep:
+            table[b] = chr(256 + extra)
+            extra += 1
+    return table
+
+
+def _clean(text: str) -> str:
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:     # ftfy only repairs mojibake; plain text is unchanged by it
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    return _WS.sub(" ", text).strip().lower()
+
+
+class SimpleTokenizer:
+    def __init__(self, bpe_path: str | None = None):
+        lines = gzip.open(find_vocab(bpe_path)).read().decode("utf-8").split("\n")
+        merges = [tuple(l.split()) for l in lines[1:N_MERGES + 1]]
+        alpha = byte_alphabet()
+        # vocabulary order of CLIP: 256 byte symbols in the order printable-first (as bytes_to_unicode enumerates them),
+        # the same with the word-end marker, one entry per merge, then the two specials
+        ordered = [alpha[b] for b in list(range(0x21, 0x7F)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))]
+        ordered += [alpha[b] for b in range(256) if alpha[b] not in set(ordered)]
+        symbols = ordered + [s + _WORD_END for s in ordered] + ["".join(m) for m in merges] + [SOT_TEXT, EOT_TEXT]
+        self.encoder = {s: i for i, s in enumerate(symbols)}
+        self.rank = {m: i for i, m in enumerate(merges)}
+        self.alpha = alpha
+        self._memo = {}
+
+    def _merge_word(self, word: str):
+        """Greedy lowest-rank-first pair merging of one pre-token (already mapped to the byte alphabet)."""
+        got = self._memo.get(word)
+        if got is not None:
+            return got
+        parts = list(word[:-1]) + [word[-1] + _WORD_END]
+        while len(parts) > 1:
+            best, where = None, None
+            for i in range(len(parts) - 1):
+                r = self.rank.get((parts[i], parts[i + 1]))
+                if r is not None and (best is None or r < best):
+                    best, where = r, (parts[i], parts[i + 1])
+            if best is None:
+                break
+            merged, i = [], 0
+            while i < len(parts):
+                if i + 1 < len(parts) and parts[i] == where[0] and parts[i + 1] == where[1]:
+                    merged.append(parts[i] + parts[i + 1])
+                    i += 2
+                else:
+                    merged.append(parts[i])
+                    i += 1
+            parts = merged
+        ids = [self.encoder[p] for p in parts]
+        self._memo[word] = ids
+        return ids
+
+    def encode(self, text: str):
+        out = []
+        for tok in _SPLIT.findall(_clean(text)):
+            if tok in (SOT_TEXT, EOT_TEXT):
+                out.append(self.encoder[tok])
+                continue
+            out.extend(self._merge_word("".join(self.alpha[b] for b in tok.encode("utf-8"))))
+        return out
+
+
+def tokenize(tokenizer: SimpleTokenizer, texts, context_length: int = 77, truncate: bool = False):
+    """[SOT] + ids + [EOT], zero padded to context_length; RuntimeError when too long (clip.py:205-219)."""
+    import torch
+    if isinstance(texts, str):
+        texts = [texts]
+    sot, eot = tokenizer.encoder[SOT_TEXT], tokenizer.encoder[EOT_TEXT]
+    out = torch.zeros(len(texts), context_length, dtype=torch.long)
+    for i, t in enumerate(texts):
+        ids = [sot] + tokenizer.encode(t) + [eot]
+        if len(ids) > context_length:
+            if not truncate:
+                raise RuntimeError(f"Input {t} is too long for context length {context_length}")
+            ids = ids[:context_length]
+            ids[-1] = eot
+        out[i, :len(ids)] = torch.tensor(ids)
+    return out

@@ -257,6 +257,14 @@ def main():
     meta["_generator"] = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(),
                           "reference": "Kelvin-ywc/LPI @ 2024-12-23, retrieval/", "dtype": "float32 (CPU)"}
 
+    if a.only in (None, "tokenizer"):
+        from models.clip.clip import tokenize
+        texts = ["A photo of a cat.", "two  dogs,   running!", "it's the man's 3rd try -- isn't it?", "caf\u00e9 na\u00efve r\u00e9sum\u00e9",
+                 "12345 67 890", "hello<|endoftext|>world", "UPPER lower MiXeD", "a/b c-d e_f (g) [h] {i}", "\u4f60\u597d \u4e16\u754c",
+                 "emoji \U0001F600 test", "x" * 40, "the quick brown fox jumps over the lazy dog " * 3, "&amp; &lt;tag&gt; &quot;q&quot;",
+                 " ".join(["X"] * 16) + " a man riding a wave on top of a surfboard."]
+        save("tokenizer", {"texts": np.array(texts), "ids": tokenize(texts).numpy()}, meta)
+
     if a.only in (None, "tiny"):
         cfg = synth.TINY
         net = build_slinet(cfg)

@@ -1,0 +1,74 @@
+"""Data-parallel exchange (lpi_amd/dp.py) with world_size 2 on CPU (gloo): W-rank result == single-process result on the
+concatenated global batch.  The per-rank arithmetic is done by the ORACLE here (no GPU in this container); what is under test
+is the exchange protocol: fused feature all-gather, local-rows-only gradient flow (``local_loss=False`` semantics of the
+reference's gather_features, sprompt.py:38-82), 1/W scaling of data-independent terms, SUM all-reduce of factor grads."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lpi_amd import synth
+
+W, B = 2, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from lpi_amd.dp import Exchange
+    from oracle import lpi_oracle as O
+    cfg = synth.TINY
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
+    fac = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+    img = torch.from_numpy(synth.images(W * B, 32))[rank * B:(rank + 1) * B]
+    ids = torch.from_numpy(synth.token_ids(W * B))[rank * B:(rank + 1) * B]
+    ex = Exchange()
+    img_f, txt_f, vp, tp = orc.forward(img, ids, fac, depth=2)
+    ia, ta, r0 = ex.gather(img_f.detach(), txt_f.detach())
+    assert r0 == rank * B and ia.shape == (W * B, cfg.embed_dim)
+    ia = torch.cat([ia[:r0], img_f, ia[r0 + B:]])          # only this rank's rows carry gradient
+    ta = torch.cat([ta[:r0], txt_f, ta[r0 + B:]])
+    losses, _ = orc.cal_loss(ia, ta, vp, tp)
+    (losses["base_loss"] + losses["alignment_loss"] / ex.world).backward()
+    n = ex.allreduce_grads(list(fac.values()))
+    assert n == sum(v.numel() for v in fac.values())
+    q.put((rank, float(losses["base_loss"]), {k: v.grad.numpy().copy() for k, v in fac.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_global_batch():
+    from oracle import lpi_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(W)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    cfg = synth.TINY
+    ref = O.train_step(O.Oracle(cfg, synth.clip_state_dict(cfg)), synth.images(W * B, 32), synth.token_ids(W * B),
+                       synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width), depth=2)
+    for rank, base, grads in res:
+        assert abs(base - float(ref["base_loss"])) < 1e-5          # every rank evaluates the full global loss
+        for k, g in grads.items():
+            r = ref["grad." + k]
+            assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-7, (rank, k)
+    # and the two ranks end up with identical gradients
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k])

@@ -1,0 +1,122 @@
+"""The plugin surface (SliNet / SPrompts / factory) driving the HIP engine on a real MI355X, checked against the fixtures
+captured from the reference (same API calls the reference's hot loop makes: net(images, captions) -> cal_loss -> backward)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lpi_amd import _lib, synth  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RET = os.path.join(REPO, "lpi_amd", "retrieval")
+DEV = torch.device("cuda:0")
+
+
+def tiny_args(**over):
+    args = json.load(open(os.path.join(RET, "configs", "lpi", "coco_lpi.json")))
+    args.update(backbonename="tiny", visual_dim=128, textual_dim=128, device=[DEV], compute_dtype="f32", batch_size=4,
+                epochs=1, num_workers=0)
+    args.update(over)
+    return args
+
+
+def set_factors(net):
+    for t in range(len(net.prompts)):
+        for k, v in synth.prompt_factors(9, 16, 128, 128, task=t).items():
+            getattr(net.prompts[t], k).data = torch.from_numpy(v.copy()).to(DEV)
+
+
+def run_step(net, numtask, ids):
+    net.numtask = numtask
+    net.train()
+    for name, p in net.named_parameters():
+        p.requires_grad_("prompts." + str(numtask - 1) + "." in name)
+        p.grad = None
+    img = torch.from_numpy(synth.images(4, 32)).to(DEV)
+    n0 = _lib.launch_count()
+    img_f, txt_f, vp, tp = net(img, torch.from_numpy(ids))
+    out = net.cal_loss(img_f, txt_f, vp, tp)
+    loss = sum(v for v in out["loss"].values())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _lib.launch_count() - n0 > 30
+    return img_f, txt_f, vp, tp, out["loss"]
+
+
+@pytest.mark.parametrize("name,numtask", [("tiny_d1", 1), ("tiny_task2", 2)])
+def test_slinet_train_step_matches_reference(golden, name, numtask):
+    from lpi_amd.retrieval.models.slinet import SliNet
+    g = golden(name)
+    net = SliNet(tiny_args()).to(DEV)
+    set_factors(net)
+    img_f, txt_f, vp, tp, losses = run_step(net, numtask, g["token_ids"])
+    assert vp.shape == (4, 9, 16, 128) and vp.stride(0) == 0            # stride-0 batch broadcast like slinet.py:119
+    assert np.abs(img_f.detach().cpu().numpy() - g["img_f"]).max() < 1e-4
+    assert np.abs(txt_f.detach().cpu().numpy() - g["txt_f"]).max() < 1e-4
+    assert set(losses) == ({"base_loss", "alignment_loss"} | ({"task_loss"} if numtask != 1 else set()))
+    for k in losses:
+        assert abs(float(losses[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    for k in synth.PROMPT_NAMES:
+        got = getattr(net.prompts[numtask - 1], k).grad.cpu().numpy()
+        ref = g["grad." + k]
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-5, k
+
+
+def test_eval_interfaces_and_task_ids(golden):
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    g = golden("tiny_eval")
+    m = SPrompts(tiny_args())
+    net = m._network.to(DEV)
+    set_factors(net)
+    net.numtask = 3
+    net.eval()
+    img = torch.from_numpy(synth.images(6, 32, seed=synth.IMAGE_SEED + 7)).to(DEV)
+    ids = torch.from_numpy(g["token_ids"])
+    with torch.no_grad():
+        assert np.abs(net.extract_vector(img).cpu().numpy() - g["extract_vector"]).max() < 1e-4
+        assert np.abs(net.extract_textual_vector(ids).cpu().numpy() - g["extract_textual_vector"]).max() < 1e-4
+        vi = net.visual_interface(img, torch.from_numpy(g["sel_v"]))
+        ti = net.textual_interface(ids, torch.from_numpy(g["sel_t"]))
+    assert np.abs(vi.cpu().numpy() - g["visual_interface"]).max() < 1e-4
+    assert np.abs(ti.cpu().numpy() - g["textual_interface"]).max() < 1e-4
+    m.all_keys = m.textual_all_keys = [torch.from_numpy(k).to(DEV) for k in g["task_keys"]]
+    assert (m.get_visual_task_id(img).cpu().numpy() == g["visual_task_id"]).all()
+    assert (m.get_textual_task_id(ids).cpu().numpy() == g["textual_task_id"]).all()
+
+
+def test_itm_eval_matches_reference(golden):
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    g = golden("tiny_eval")
+    m = SPrompts(tiny_args())
+    m.cur_id = 2
+    s = g["itm_scores"]
+    n_img, n_txt = s.shape
+    fr = m.itm_eval(s, s.T.copy(), {t: t // 2 for t in range(n_txt)}, {i: [2 * i, 2 * i + 1] for i in range(n_img)},
+                    list(g["itm_cat_i"]), torch.tensor(g["itm_cat_t"]))
+    assert np.allclose([fr["mscoco"]["i2t"][t] for t in range(3)], g["itm_i2t"])
+    assert np.allclose([fr["mscoco"]["t2i"][t] for t in range(3)], g["itm_t2i"])
+
+
+def test_incremental_train_two_tasks_end_to_end(tmp_path, monkeypatch):
+    """trainer -> factory -> SPrompts.incremental_train over synthetic loaders: the whole continual loop incl. task_loss,
+    KMeans task keys, retrieval eval and the final_res JSON (sprompt.py:150-187, 638-646)."""
+    monkeypatch.chdir(tmp_path)
+    from lpi_amd.retrieval import trainer
+    args = tiny_args(num_tasks=2, synthetic_train_size=8, synthetic_eval_images_per_task=6, seed=[1993], device=["0"])
+    before = None
+    model = trainer._train(args)
+    net = model._network
+    assert net.numtask == 2 and len(model.all_keys) == 2 and model.all_keys[0].shape == (5, 128)
+    fr = model.final_res
+    assert set(fr) == {0, 1} and set(fr[1]["mscoco"]) == {"i2t", "t2i"} and set(fr[1]["mscoco"]["i2t"]) == {0, 1}
+    assert all(len(v) == 3 and 0 <= v[0] <= v[1] <= v[2] <= 100 for v in fr[1]["mscoco"]["t2i"].values())
+    assert len(list((tmp_path / "res").glob("*.json"))) == 1
+    ref0 = synth.prompt_factors(9, 16, 128, 128, task=0)["dim_1_share"]
+    assert model._old_network is not None and model._old_network.engine is net.engine
+    # task-1 prompts moved (trained), task-5 prompts did not
+    p5 = net.prompts[5].dim_1_share.detach().clone()
+    assert net.prompts[1].dim_1_share.grad is not None and net.prompts[5].dim_1_share.grad is None

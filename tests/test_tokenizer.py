@@ -1,0 +1,54 @@
+"""Own BPE tokenizer vs ids captured from the reference's SimpleTokenizer / clip.tokenize.  Needs the third-party merge
+table (not shipped); skipped where it is absent (e.g. on the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+
+from lpi_amd.retrieval.models.clip import simple_tokenizer as T
+
+CANDS = [os.environ.get("LPI_BPE_VOCAB"), "/root/reference/retrieval/models/clip/" + T.VOCAB_FILE]
+VOCAB = next((c for c in CANDS if c and os.path.isfile(c)), None)
+needs_vocab = pytest.mark.skipif(VOCAB is None, reason="bpe_simple_vocab_16e6.txt.gz not available")
+
+
+@needs_vocab
+def test_ids_match_reference(golden):
+    tk = T.SimpleTokenizer(VOCAB)
+    g = golden("tokenizer")
+    ids = T.tokenize(tk, [str(t) for t in g["texts"]]).numpy()
+    assert (ids == g["ids"]).all()
+    assert tk.encoder[T.SOT_TEXT] == 49406 and tk.encoder[T.EOT_TEXT] == 49407 and tk.encoder["x</w>"] == 343
+
+
+@needs_vocab
+def test_prompt_learner_ids(golden):
+    from lpi_amd.retrieval.models.clip import prompt_learner as PL
+    PL._tokenizer = T.SimpleTokenizer(VOCAB)
+    g = golden("tiny_eval")
+    pl = PL.PromptLearner(PL.cfgc())
+    assert (pl([str(c) for c in g["captions"]]).numpy() == g["token_ids"]).all()
+
+
+@needs_vocab
+def test_too_long_raises():
+    tk = T.SimpleTokenizer(VOCAB)
+    with pytest.raises(RuntimeError):
+        T.tokenize(tk, ["word " * 100])
+    assert T.tokenize(tk, ["word " * 100], truncate=True)[0, -1] == 49407
+
+
+def test_missing_vocab_is_loud(tmp_path, monkeypatch):
+    monkeypatch.delenv("LPI_BPE_VOCAB", raising=False)
+    monkeypatch.chdir(tmp_path)
+    if os.path.isfile(os.path.join(os.path.dirname(T.__file__), T.VOCAB_FILE)):
+        pytest.skip("vocab shipped next to the module")
+    with pytest.raises(FileNotFoundError):
+        T.find_vocab(None)
+
+
+def test_synthetic_ids_shape():
+    from lpi_amd import synth
+    ids = synth.token_ids(5)
+    assert ids.shape == (5, 77) and (ids[:, 0] == 49406).all() and (ids[:, 1:17] == 343).all()
+    assert (ids.max(1) == 49407).all() and (np.argmax(ids, 1) >= 23).all()
