@@ -43,6 +43,10 @@ int lpi_version(void);
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
 uint64_t lpi_launch_count(void);
 
+/* tuning knobs (speed only, never results): keys 0 / 1 = minimum number of 256x256 tiles for which lpi_gemm_nt uses
+ * the 8-phase 256x256 kernel instead of the 128x128 one, for bf16 / f32 operands (defaults 160 / 1500; INT_MAX disables it). */
+int lpi_set_tuning(int key, int value);
+
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
  * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
  * replaces: models/clip/model.py:175-177 (c_fc, c_proj), :172,185 (nn.MultiheadAttention in/out proj),

@@ -25,6 +25,7 @@ _P, _I, _F, _L = c_void_p, c_int, c_float, c_long
 SIGNATURES = {
     "lpi_version": [],
     "lpi_launch_count": [],
+    "lpi_set_tuning": [_I, _I],
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],

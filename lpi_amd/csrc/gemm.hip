@@ -16,6 +16,7 @@
 //    stores 16 B (f32) / 8 B (bf16) per lane;
 //  * blockIdx is remapped so that the blocks sharing one XCD's L2 walk neighbouring M tiles of the same N panel.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -25,7 +26,7 @@ constexpr int TILE_BYTES = BM * ROW_BYTES;  // 16 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
 constexpr int NTHREADS = 256;
 
-template <typename T, typename TC, int EPI>
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
@@ -123,36 +124,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
     // ---- epilogue: lane holds C[m = .. + (l&15)][n = .. + 4*(l>>4) + 0..3] ------------------------------
     const int row_base = m0 + wm * 64 + (lane & 15);
     const int col_base = n0 + wn * 64 + ((lane >> 4) << 2);
+    f32x4 bvs[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bvs[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) {   // ONE branch for all bias loads
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bvs[ni] = *reinterpret_cast<const f32x4*>(bias + col_base + ni * 16);
+    }
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         const int col = col_base + ni * 16;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int row = row_base + mi * 16;
-            f32x4 v = acc[ni][mi] * alpha + bv;
-            if constexpr (EPI == LPI_EPI_QUICKGELU) {
-                if (aux) Elem<T>::st4(aux + (size_t)row * ldaux + col, v);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
-            } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
-                f32x4 u = Elem<T>::ld4(aux + (size_t)row * ldaux + col);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
-            }
-            if (residual) v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
-            Elem<TC>::st4(C + (size_t)row * ldc + col, v);
-        }
+        for (int mi = 0; mi < 4; ++mi)
+            gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(acc[ni][mi], row_base + mi * 16, col, C, ldc, bvs[ni], alpha, residual, ldr, aux, ldaux);
     }
 }
 
-template <typename T, typename TC, int EPI>
-int launch(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
+int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
            const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
 {
     const int tm = M / BM, tn = N / BN;
-    auto kern = gemm_nt_kernel<T, TC, EPI>;
+    auto kern = gemm_nt_kernel<T, TC, EPI, RES, SAVE_U>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -163,6 +156,26 @@ int launch(int M, int N, int K, const void* A, int lda, const void* B, int ldb, 
                        (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn);
     LPI_CHECK_LAST();
     return 0;
+}
+
+// run-time pointer presence -> compile-time epilogue flags (residual only with EPI_NONE, save-u only with QUICKGELU)
+template <typename T, typename TC, int EPI>
+int launch(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+           const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    if constexpr (EPI == LPI_EPI_NONE) {
+        if (residual) return launch_impl<T, TC, EPI, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        return launch_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    } else {
+        if (residual) return LPI_ENOSYS;
+        if constexpr (EPI == LPI_EPI_QUICKGELU) {
+            if (aux) return launch_impl<T, TC, EPI, false, true>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+            return launch_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        } else {
+            if (!aux) return LPI_EINVAL;
+            return launch_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        }
+    }
 }
 
 template <typename T, typename TC>
@@ -181,6 +194,11 @@ int dispatch_epi(int epi, int M, int N, int K, const void* A, int lda, const voi
 
 }  // namespace
 
+bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
+int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                       const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
+extern int g_lpi_tuning[8];
+
 extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
                            void* C, int ldc, const float* bias, const float* residual, int ldr, int epilogue, void* aux,
                            int ldaux, float alpha, void* stream)
@@ -196,6 +214,10 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
     if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (epilogue == LPI_EPI_DQUICKGELU && !aux) return LPI_EINVAL;
+    // 256x256 8-phase kernel when the shape gives it enough tiles to fill the chip (tuning keys 0 / 1 = minimum tile count for bf16 / f32)
+    if (lpi_gemm256_eligible(dtype, M, N, K) && (M / 256) * (N / 256) >= g_lpi_tuning[dtype == LPI_F32 ? 1 : 0])
+        return lpi_gemm256_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
     if (dtype == LPI_F32 && c_dtype == LPI_F32)
         return dispatch_epi<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_BF16)

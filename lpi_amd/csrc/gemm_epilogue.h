@@ -1,0 +1,23 @@
+// Fused GEMM epilogue shared by the 128x128 and 256x256 kernels: the lane holds 4 consecutive output columns of one row.
+#pragma once
+#include "common.h"
+
+// RES (residual present) and SAVE_U (QuickGELU pre-activation wanted) are COMPILE-TIME: a run-time "pointer or not" test per
+// element makes hipcc branch around every load and wait vmcnt(0) each time — 32 serial HBM round trips per lane
+// (cdna_hip_programming.md, "Three .s-level traps" (c)).  Without branches the unrolled loads are batched.
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true>
+__device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
+                                                    const float* __restrict__ residual, int ldr, T* __restrict__ aux, int ldaux) {
+    f32x4 v = acc * alpha + bv;
+    if constexpr (EPI == LPI_EPI_QUICKGELU) {
+        if constexpr (SAVE_U) Elem<T>::st4(aux + (size_t)row * ldaux + col, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+    } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
+        f32x4 u = Elem<T>::ld4(aux + (size_t)row * ldaux + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
+    }
+    if constexpr (RES) v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
+    Elem<TC>::st4(C + (size_t)row * ldc + col, v);
+}

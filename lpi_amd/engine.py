@@ -116,7 +116,7 @@ class Tower:
             return ws
         self._ws.clear()   # one live shape per tower: the arena is large
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
-        Mp = _pad(B * L)
+        Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         T = _TORCH_DT[self.dt]
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
@@ -268,7 +268,7 @@ class DualEncoder:
         ws = self.vis.workspace(B, L, train)
         fe = ws.get("front")
         if fe is None:
-            rows = _pad(B * G2)
+            rows = _pad(B * G2, 256)
             fe = {"cols": torch.zeros(rows, self.kp, dtype=_TORCH_DT[dt], device=self.device),
                   "pe": torch.zeros(rows, d, device=self.device), "stat": torch.zeros(2, ws["Mp"], device=self.device)}
             ws["front"] = fe
