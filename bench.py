@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="BASELINE.json configs[1]: encoder forward + cosine matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the two towers on one stream")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -101,9 +102,9 @@ def main():
     def step():
         if a.fwd_only:
             with torch.no_grad():
-                forward_loss(enc, images, ids, fac, a.depth, exchange.gather if exchange else None)
+                forward_loss(enc, images, ids, fac, a.depth, exchange.gather if exchange else None, overlap_towers=not a.no_overlap)
         else:
-            train_step(enc, images, ids, fac, a.depth, exchange)
+            train_step(enc, images, ids, fac, a.depth, exchange, overlap_towers=not a.no_overlap)
             opt.step()
 
     def sync():

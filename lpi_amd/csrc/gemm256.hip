@@ -20,6 +20,8 @@
 #include "common.h"
 #include "gemm_epilogue.h"
 
+extern int g_lpi_tuning[8];
+
 namespace {
 
 constexpr int T256 = 256;
@@ -27,18 +29,25 @@ constexpr int ROWB = 128;                 // bytes per staged row
 constexpr int HALF_BYTES = 128 * ROWB;    // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES; // 64 KiB per K-tile
 constexpr int NTHR = 512;
+constexpr int LDS_BYTES = 128 * 1040;      // max(2 K-tile buffers = 131072, epilogue staging 128 rows x 1040 B = 133120)
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n)
+    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int stagger)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);
 
+    // One workgroup per CU and identical tiles keep the CUs in lockstep: all stream HBM (epilogue) together, then all run the
+    // matrix cores together.  Delaying every other first-round workgroup once makes the two halves of the chip alternate, so one
+    // half's epilogue gets the whole HBM bandwidth while the other half computes (later workgroups inherit their CU's phase).
+    if (stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
     {   // bijective XCD remap: blocks that share an XCD (bid % 8) get a contiguous run of tiles
@@ -181,33 +190,34 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
 #undef PHASE_SYNC_IN
 #undef PHASE_SYNC_OUT
 
-    // ---- epilogue --------------------------------------------------------------------------------------------------
+    // ---- epilogue: through LDS, so that every global access is a whole contiguous tile row ----------------------------
+    // Straight from the accumulators a store instruction would touch 16 rows x 64 B (half cache lines, 16 lines per
+    // instruction): measured ~3 B/clk/CU, several times slower than the main loop for K = 768.  Instead the tile goes through
+    // LDS in two passes of 128 rows (f32, row stride 1040 B = conflict-free ds_write_b128); each wave then owns 16 whole rows
+    // per pass: one ds_read_b128 + one 1 KiB-contiguous residual/aux load + one contiguous store per row, bias held in registers.
+    constexpr int ERS = 1040;   // epilogue LDS row stride in bytes: 256 f32 + 16 B pad
     const int lrow = lane & 15, lcol = (lane >> 4) << 2;
-    f32x4 bvs[2][2];
+    const int ecol = n0 + lane * 4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bvs[nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias) {   // ONE branch for all bias loads
+    for (int mh = 0; mh < 2; ++mh) {
+        if (mh) __builtin_amdgcn_s_barrier();   // pass 0's reads are done before pass 1 overwrites the staging area
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bvs[nh][ni] = *reinterpret_cast<const f32x4*>(bias + n0 + nh * 128 + wn * 32 + ni * 16 + lcol);
-    }
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + nh * 128 + wn * 32 + ni * 16 + lcol;
-            const f32x4 bv = bvs[nh][ni];
-#pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    const int row = m0 + mh * 128 + wm * 64 + mi * 16 + lrow;
-                    gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(acc[nh][ni][mh][mi], row, col, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
-                }
+                for (int mi = 0; mi < 4; ++mi)
+                    *reinterpret_cast<f32x4*>(smem + (wm * 64 + mi * 16 + lrow) * ERS + (nh * 128 + wn * 32 + ni * 16 + lcol) * 4) = acc[nh][ni][mh][mi];
+        __syncthreads();
+        const int r0 = wave * 16;
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + (r0 + rr) * ERS + lane * 16);
+            gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + mh * 128 + r0 + rr, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
         }
+    }
 }
 
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
@@ -218,12 +228,12 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
     auto kern = gemm256_kernel<T, TC, EPI, RES, SAVE_U>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), 2 * BUF_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-               ldr, (T*)aux, ldaux, alpha, tm, tn);
+    LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
+               ldr, (T*)aux, ldaux, alpha, tm, tn, g_lpi_tuning[2]);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -106,7 +106,7 @@ def test_gemm256_kernel(dt, M, N, K):
         sg = torch.sigmoid(1.702 * ud)
         assert relerr(du, ab * (sg * (1 + 1.702 * ud * (1 - sg)))) < TOL[dt]
     finally:
-        call("lpi_set_tuning", 0, 160)
+        call("lpi_set_tuning", 0, 1)
         call("lpi_set_tuning", 1, 1500)
 
 

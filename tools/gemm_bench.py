@@ -46,4 +46,4 @@ for name, M, N, K, f32out, epi, res in shapes:
     fl = 2.0 * M * N * K
     u1, u2 = min(t["128"]), min(t["256"])
     print(f"{name:16s} {M:6d} {N:5d} {K:5d} | {u1:8.1f} {fl / u1 / 1e6:7.1f} | {u2:8.1f} {fl / u2 / 1e6:7.1f}")
-call("lpi_set_tuning", 0, 160)
+call("lpi_set_tuning", 0, 1)
