@@ -132,9 +132,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
                 for (int mi = 0; mi < 4; ++mi) mma_chunk<T>(c[nh][ni][mh][mi], fb[ni][ks], fa[mi][ks]);
         __builtin_amdgcn_s_setprio(0);
     };
+// lgkmcnt(0) BEFORE the barrier: with the two wave groups staggered by one barrier (below), the other group restages a half
+// tile right after this barrier, so this group's ds_reads of it must already have completed (WAR).
 #define PHASE_SYNC_IN()                                   \
-    __builtin_amdgcn_s_barrier();                         \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                         \
     __builtin_amdgcn_sched_barrier(0)
 #define PHASE_SYNC_OUT()                                  \
     __builtin_amdgcn_sched_barrier(0);                    \
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     stage_A(1, 0, 1); stage_B(1, 0, 1); stage_B(1, 1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // Stagger: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that while one group issues its
+    // ds_reads / LDS-DMA the other group's MFMAs own the matrix pipe (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+    // Every wave must execute the same number of barriers: group 0 pays its extra one after the loop.
+    if (wm == 1) __builtin_amdgcn_s_barrier();
 
     // one K-tile = 4 phases; BUF is a compile-time constant so every LDS address folds to base + immediate
     auto ktile = [&](int kt, const int BUF) {
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     }
 #undef PHASE_SYNC_IN
 #undef PHASE_SYNC_OUT
+    if (wm == 0) __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: through LDS, so that every global access is a whole contiguous tile row ----------------------------
     // Straight from the accumulators a store instruction would touch 16 rows x 64 B (half cache lines, 16 lines per
