@@ -84,8 +84,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     exchange = None
-    if world > 1:
+    if world > 1 or os.environ.get("LPI_FORCE_DIST") == "1":       # LPI_FORCE_DIST: exercise the RCCL path on a 1-GPU box
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         from lpi_amd.dp import Exchange
         exchange = Exchange()
@@ -108,7 +111,7 @@ def main():
             opt.step()
 
     def sync():
-        if world > 1:
+        if exchange is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -120,7 +123,7 @@ def main():
         step()
     sync()
     el = time.perf_counter() - t0
-    if world > 1:
+    if exchange is not None:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -163,7 +166,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchange is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -8,21 +8,26 @@
 // Design (MI355X first).  Sequences are short (L <= 288), so ONE workgroup owns one (sample, head) and keeps the
 // whole K and V (forward, dQ pass) or Q and dO (dK/dV pass) of that head in LDS, row-major with a padded row
 // stride; nothing N x N ever touches HBM.  Scores are computed TRANSPOSED (mfma(K, Q)) so that a lane holds one
-// query column: the online softmax needs only two 16-lane shuffles, and the probability tile sitting in the
-// accumulator registers is directly the B operand of the following P.V product (no LDS round trip).  The
+// query column: the online softmax needs only two lane swaps (v_permlane16/32_swap, no LDS round trip), and the
+// probability tile sitting in the accumulator registers is directly the B operand of the following P.V product.  The
 // transposed operand of that product (V^T, K^T, dO^T, Q^T) is read straight from the row-major LDS image with
 // ds_read_b64_tr_b16 (bf16) or 4-byte strided reads (f32): no transposed copy is ever staged.
+// A wave works on NB = 2 independent 16-row blocks at once: they share every LDS operand read and give the scheduler
+// two independent MFMA -> softmax -> MFMA chains to interleave (one chain alone is latency bound: ~1000 cycles per
+// 32-key tile with ~250 cycles of issue).
 // Backward recomputes P from the saved log-sum-exp and runs as two kernels so that every accumulator stays in
 // one wave's registers (no atomics, bitwise reproducible):
-//   pass A (a wave owns 16 queries): delta = rowsum(dO*O);  dQ = scale * dS K
-//   pass B (a wave owns 16 keys)   : dV = P^T dO;           dK = scale * dS^T Q
+//   pass A (a wave owns 2x16 queries): delta = rowsum(dO*O);  dQ = scale * dS K
+//   pass B (a wave owns 2x16 keys)   : dV = P^T dO;           dK = scale * dS^T Q
 // Fragment conventions (cdna_hip_programming.md section 3): 16x16 MFMA tiles, lane l supplies row (l & 15) and
 // k-group g = l >> 4 of each operand as one 16-byte chunk; it receives column (l & 15), rows 4g..4g+3.
+#include <type_traits>
 #include "common.h"
 
 namespace {
 
 constexpr int HD = 64;  // head_dim of every CLIP tower (width / 64 heads, model.py:292)
+constexpr int NB = 2;   // 16-row blocks a wave processes together
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float SCALE = 0.125f;  // HD ** -0.5
@@ -37,15 +42,33 @@ template <> struct AT<bf16_t> {
     static constexpr int RS = 144;      // 64 bf16 + 16 B pad
 };
 
-// stage rows [0, L) x 64 elements of a head (global row stride ld elements) into LDS, zero rows [L, Lp)
+// stage rows [0, L) x 64 elements of two matrices (global row strides ld0/ld1 elements) into two LDS images, zero rows
+// [L, Lp).  8 independent 16-byte loads are kept in flight per thread before any LDS write: the loop is latency bound
+// (the qkv buffer is far larger than the caches), and a one-load-at-a-time loop costs a full HBM round trip per iteration.
 template <typename T>
-__device__ __forceinline__ void stage_rows(char* lds, const T* g, int ld, int L, int Lp) {
+__device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1, const T* g1, int ld0, int ld1, int L, int Lp) {
     constexpr int NCH = HD * (int)sizeof(T) / 16;
-    for (int i = threadIdx.x; i < Lp * NCH; i += blockDim.x) {
-        const int row = i / NCH, c = i % NCH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < L) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + c * Elem<T>::EPC);
-        *reinterpret_cast<uint4*>(lds + row * AT<T>::RS + c * 16) = v;
+    const int n = Lp * NCH, nt = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += 4 * nt) {
+        uint4 v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * nt, row = i / NCH, c = i % NCH;
+            v0[j] = make_uint4(0, 0, 0, 0);
+            v1[j] = make_uint4(0, 0, 0, 0);
+            if (i < n && row < L) {
+                v0[j] = *reinterpret_cast<const uint4*>(g0 + (size_t)row * ld0 + c * Elem<T>::EPC);
+                v1[j] = *reinterpret_cast<const uint4*>(g1 + (size_t)row * ld1 + c * Elem<T>::EPC);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * nt, row = i / NCH, c = i % NCH;
+            if (i < n) {
+                *reinterpret_cast<uint4*>(lds0 + row * AT<T>::RS + c * 16) = v0[j];
+                *reinterpret_cast<uint4*>(lds1 + row * AT<T>::RS + c * 16) = v1[j];
+            }
+        }
     }
 }
 
@@ -59,48 +82,54 @@ __device__ __forceinline__ void load_row_chunks(Chunk (&q)[AT<T>::KS], const T* 
     }
 }
 
-// acc(16 rows of LDS matrix starting at r0) x (register operand rows)^T : acc[col = reg operand row][rows = lds rows]
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));   // one v_cvt_pk_bf16_f32
+}
+
+// 16 LDS rows x (NB register operands)^T, the LDS chunk read once.  p = this lane's row pointer:
+// lds + (r0 + (lane & 15)) * RS + (lane >> 4) * 16.  acc[j]: column = operand j's row (lane & 15), rows = LDS rows r0+4g+0..3.
 template <typename T>
-__device__ __forceinline__ f32x4 mma_lds_rows(const char* lds, int r0, int lane, const Chunk (&b)[AT<T>::KS], bool lds_is_A) {
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* p = lds + (r0 + (lane & 15)) * AT<T>::RS + (lane >> 4) * 16;
+__device__ __forceinline__ void mma_lds_rows(f32x4 (&acc)[NB], const char* p, const Chunk (&b)[NB][AT<T>::KS]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < AT<T>::KS; ++ks) {
         Chunk a;
         a.u = *reinterpret_cast<const uint4*>(p + ks * 64);
-        if (lds_is_A) mma_chunk<T>(acc, a, b[ks]);
-        else mma_chunk<T>(acc, b[ks], a);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mma_chunk<T>(acc[j], a, b[j][ks]);
     }
-    return acc;
 }
 
-// acc[dt] += X^T[d = 16dt + .., k = r0 .. r0+31] . Preg[k][col], k running over 32 consecutive LDS rows of X.
-// p0/p1: the two 16-row accumulator tiles (rows 4g..4g+3 of rows r0.. and r0+16..) holding the B operand.
+// acc[j][dt] += X^T[d = 16dt + .., k] . P_j[k][col], k = 32 consecutive LDS rows of X; p0[j]/p1[j] = the two 16-row accumulator
+// tiles (this lane: rows 4g..4g+3 of each) holding operand j.  The transposed X fragment is read once for all j.
+// tp = this lane's transposed-read pointer:
+//   bf16: lds + (r0 + 4g + ((lane & 15) >> 2)) * RS + (lane & 3) * 8    (ds_read_b64_tr_b16: lane i = 4q+p of a 16-lane group
+//         addresses row q, columns 4p..4p+3 of a 4 x 16 block and receives column i of its 4 rows)
+//   f32 : lds + (r0 + 4g) * RS + (lane & 15) * 4
 template <typename T>
-__device__ __forceinline__ void mma_transposed(f32x4 (&acc)[4], const char* lds, int r0, int lane, f32x4 p0, f32x4 p1) {
-    const int g = lane >> 4;
+__device__ __forceinline__ void mma_transposed(f32x4 (&acc)[NB][4], const char* tp, const f32x4 (&p0)[NB], const f32x4 (&p1)[NB]) {
     if constexpr (sizeof(T) == 2) {
-        Chunk b;
-        b.h[0] = (__bf16)p0[0]; b.h[1] = (__bf16)p0[1]; b.h[2] = (__bf16)p0[2]; b.h[3] = (__bf16)p0[3];
-        b.h[4] = (__bf16)p1[0]; b.h[5] = (__bf16)p1[1]; b.h[6] = (__bf16)p1[2]; b.h[7] = (__bf16)p1[3];
-        // ds_read_b64_tr_b16: lane i = 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block
-        // and receives column i of its 4 rows.  Block rows = LDS rows r0 + 4g (+16), block columns = d 16dt..16dt+15.
-        const int i = lane & 15;
-        const char* base = lds + (r0 + 4 * g + (i >> 2)) * AT<T>::RS + (i & 3) * 8;
+        Chunk b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            b[j].u = make_uint4(pack_bf16(p0[j][0], p0[j][1]), pack_bf16(p0[j][2], p0[j][3]), pack_bf16(p1[j][0], p1[j][1]), pack_bf16(p1[j][2], p1[j][3]));
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + dt * 32));
-            short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + 16 * AT<T>::RS + dt * 32));
+            short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tp + dt * 32));
+            short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tp + 16 * AT<T>::RS + dt * 32));
             Chunk a;
             const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
             a.u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
-            mma_chunk<T>(acc[dt], a, b);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) mma_chunk<T>(acc[j][dt], a, b[j]);
         }
     } else {
-        Chunk b0, b1;
-        b0.f = p0;
-        b1.f = p1;
-        const float* base = reinterpret_cast<const float*>(lds + (r0 + 4 * g) * AT<T>::RS) + (lane & 15);
+        const float* base = reinterpret_cast<const float*>(tp);
         constexpr int RSF = AT<T>::RS / 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -110,19 +139,38 @@ __device__ __forceinline__ void mma_transposed(f32x4 (&acc)[4], const char* lds,
                 a0.f[s] = base[s * RSF + dt * 16];
                 a1.f[s] = base[(16 + s) * RSF + dt * 16];
             }
-            mma_chunk<T>(acc[dt], a0, b0);
-            mma_chunk<T>(acc[dt], a1, b1);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                Chunk b0, b1;
+                b0.f = p0[j];
+                b1.f = p1[j];
+                mma_chunk<T>(acc[j][dt], a0, b0);
+                mma_chunk<T>(acc[j][dt], a1, b1);
+            }
         }
     }
 }
 
-__device__ __forceinline__ float group_max(float v) {  // over the 4 lanes sharing (lane & 15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
+template <typename T> __device__ __forceinline__ int row_ptr_off(int lane) { return (lane & 15) * AT<T>::RS + (lane >> 4) * 16; }
+template <typename T> __device__ __forceinline__ int tr_ptr_off(int lane) {
+    if constexpr (sizeof(T) == 2) return (4 * (lane >> 4) + ((lane & 15) >> 2)) * AT<T>::RS + (lane & 3) * 8;
+    else return 4 * (lane >> 4) * AT<T>::RS + (lane & 15) * 4;
+}
+
+// reductions over the 4 lanes sharing (lane & 15): lane ^ 16 by v_permlane16_swap (odd rows of vdst <-> even rows of src),
+// lane ^ 32 by v_permlane32_swap (upper half of vdst <-> lower half of src).  With vdst = src = v, one instruction leaves
+// {own, partner} in its two results for every lane.
+__device__ __forceinline__ float group_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -135,57 +183,92 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
     const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
-    stage_rows<T>(k_lds, qg + dm, ldqkv, L, Lp);
-    stage_rows<T>(v_lds, qg + 2 * dm, ldqkv, L, Lp);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int g = lane >> 4;
+    // the wave's first query blocks are fetched before the staging so that their HBM latency hides under it
+    Chunk q[NB][AT<T>::KS];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int qr = (wave * NB + j) * 16 + (lane & 15);
+        load_row_chunks<T>(q[j], qg, qr, ldqkv, g, qr < L);
+    }
+    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    __syncthreads();
+
     const float c = SCALE * LOG2E;
-    for (int q0 = wave * 16; q0 < L; q0 += nw * 16) {
-        const int qrow = q0 + (lane & 15);
-        Chunk q[AT<T>::KS];
-        load_row_chunks<T>(q, qg, qrow, ldqkv, g, qrow < L);
-        float m = -INFINITY, lsum = 0.f;
-        f32x4 o[4];
+    const char* const kp0 = k_lds + row_ptr_off<T>(lane);
+    const char* const vt0 = v_lds + tr_ptr_off<T>(lane);
+    for (int q0 = wave * 16 * NB; q0 < L; q0 += nw * 16 * NB) {
+        int qrow[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int kend = CAUSAL ? min(Lp, ((q0 + 15) / 32 + 1) * 32) : Lp;
-        for (int kb = 0; kb < kend; kb += 32) {
-            f32x4 s0 = mma_lds_rows<T>(k_lds, kb, lane, q, true);
-            f32x4 s1 = mma_lds_rows<T>(k_lds, kb + 16, lane, q, true);
-            float mt = -INFINITY;
+        for (int j = 0; j < NB; ++j) qrow[j] = q0 + 16 * j + (lane & 15);
+        if (q0 != wave * 16 * NB) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                s0[r] = (k0 < L && (!CAUSAL || k0 <= qrow)) ? s0[r] * c : -INFINITY;
-                s1[r] = (k1 < L && (!CAUSAL || k1 <= qrow)) ? s1[r] * c : -INFINITY;
-                mt = fmaxf(mt, fmaxf(s0[r], s1[r]));
-            }
-            mt = group_max(mt);
-            const float mn = fmaxf(m, mt);
-            const float msafe = (mn == -INFINITY) ? 0.f : mn;  // fully masked so far (padded query rows only)
-            const float alpha = exp2f(m - msafe);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s0[r] = exp2f(s0[r] - msafe);
-                s1[r] = exp2f(s1[r] - msafe);
-                ps += s0[r] + s1[r];
-            }
-            lsum = lsum * alpha + ps;
-            m = mn;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] *= alpha;
-            mma_transposed<T>(o, v_lds, kb, lane, s0, s1);
+            for (int j = 0; j < NB; ++j) load_row_chunks<T>(q[j], qg, qrow[j], ldqkv, g, qrow[j] < L);
         }
-        const float ltot = group_sum(lsum);
-        const float inv = 1.0f / ltot;
-        if (qrow < L) {
-            T* dst = ctx + ((size_t)b * L + qrow) * ldctx + h * HD + 4 * g;
+        float m[NB], lsum[NB];    // m in the scaled log2 domain
+        f32x4 o[NB][4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, o[dt] * inv);
-            if (g == 0) lse[((size_t)b * H + h) * L + qrow] = (m + log2f(ltot)) * LN2;
+        for (int j = 0; j < NB; ++j) {
+            m[j] = -INFINITY;
+            lsum[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // one 32-key tile; MASKED only for tiles that can contain padded keys (last tile) or the causal diagonal
+        auto tile = [&](int kb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const char* kp = kp0 + kb * AT<T>::RS;
+            f32x4 s0[NB], s1[NB];
+            mma_lds_rows<T>(s0, kp, q);
+            mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k0 = kb + 4 * g + r, k1 = k0 + 16;
+                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) s0[j][r] = -INFINITY;
+                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) s1[j][r] = -INFINITY;
+                    }
+                }
+                float mt = fmaxf(fmaxf(fmaxf(s0[j][0], s0[j][1]), fmaxf(s0[j][2], s0[j][3])),
+                                 fmaxf(fmaxf(s1[j][0], s1[j][1]), fmaxf(s1[j][2], s1[j][3])));
+                mt = group_max(mt) * c;
+                const float mn = fmaxf(m[j], mt);
+                const float msafe = (MASKED && mn == -INFINITY) ? 0.f : mn;   // fully masked so far (padded / causal-early rows)
+                const float alpha = fast_exp2(m[j] - msafe);
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s0[j][r] = fast_exp2(fmaf(s0[j][r], c, -msafe));
+                    s1[j][r] = fast_exp2(fmaf(s1[j][r], c, -msafe));
+                    ps += s0[j][r] + s1[j][r];
+                }
+                lsum[j] = fmaf(lsum[j], alpha, ps);
+                m[j] = mn;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[j][i] *= alpha;
+            }
+            mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
+        };
+        const int qlast = q0 + 16 * NB - 1;
+        const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
+        // unmasked tiles: every key < L and (causal) every key <= the smallest query of the blocks
+        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        int kb = 0;
+        for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
+        for (; kb < kend; kb += 32) tile(kb, std::true_type{});
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float ltot = group_sum(lsum[j]);
+            const float inv = 1.0f / ltot;
+            if (qrow[j] < L) {
+                T* dst = ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, o[j][dt] * inv);
+                if (g == 0) lse[((size_t)b * H + h) * L + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
+            }
         }
     }
 }
@@ -202,62 +285,85 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
     const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
-    stage_rows<T>(k_lds, qg + dm, ldqkv, L, Lp);
-    stage_rows<T>(v_lds, qg + 2 * dm, ldqkv, L, Lp);
+    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int g = lane >> 4;
     const float c = SCALE * LOG2E;
-    for (int q0 = wave * 16; q0 < L; q0 += nw * 16) {
-        const int qrow = q0 + (lane & 15);
-        const bool valid = qrow < L;
-        const size_t grow = (size_t)b * L + qrow;
-        Chunk q[AT<T>::KS], dO[AT<T>::KS];
-        load_row_chunks<T>(q, qg, qrow, ldqkv, g, valid);
-        load_row_chunks<T>(dO, dctx + h * HD, grow, lddctx, g, valid);
-        float dl = 0.f;
-        {
+    const char* const kp0 = k_lds + row_ptr_off<T>(lane);
+    const char* const vp0 = v_lds + row_ptr_off<T>(lane);
+    const char* const kt0 = k_lds + tr_ptr_off<T>(lane);
+    for (int q0 = wave * 16 * NB; q0 < L; q0 += nw * 16 * NB) {
+        int qrow[NB];
+        Chunk q[NB][AT<T>::KS], dO[NB][AT<T>::KS];
+        float dls[NB], lq[NB];
+        f32x4 dq[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            qrow[j] = q0 + 16 * j + (lane & 15);
+            const bool valid = qrow[j] < L;
+            const size_t grow = (size_t)b * L + qrow[j];
+            load_row_chunks<T>(q[j], qg, qrow[j], ldqkv, g, valid);
+            load_row_chunks<T>(dO[j], dctx + h * HD, grow, lddctx, g, valid);
             Chunk oc[AT<T>::KS];
             load_row_chunks<T>(oc, ctx + h * HD, grow, ldctx, g, valid);
+            float dl = 0.f;
 #pragma unroll
             for (int ks = 0; ks < AT<T>::KS; ++ks) {
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dl += oc[ks].f[j] * dO[ks].f[j];
+                    for (int e = 0; e < 4; ++e) dl += oc[ks].f[e] * dO[j][ks].f[e];
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dl += (float)oc[ks].h[j] * (float)dO[ks].h[j];
+                    for (int e = 0; e < 8; ++e) dl += (float)oc[ks].h[e] * (float)dO[j][ks].h[e];
                 }
             }
+            dl = group_sum(dl);
+            lq[j] = valid ? lse[((size_t)b * H + h) * L + qrow[j]] * LOG2E : INFINITY;     // padded queries -> P = 0
+            if (valid && g == 0) delta[((size_t)b * H + h) * L + qrow[j]] = dl;
+            dls[j] = dl * SCALE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        dl = group_sum(dl);
-        const float lq = valid ? lse[((size_t)b * H + h) * L + qrow] * LOG2E : INFINITY;
-        if (valid && g == 0) delta[((size_t)b * H + h) * L + qrow] = dl;
-        f32x4 dq[4];
+        auto tile = [&](int kb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            const char* kp = kp0 + kb * AT<T>::RS;
+            const char* vp = vp0 + kb * AT<T>::RS;
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
+            mma_lds_rows<T>(s0, kp, q);
+            mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
+            mma_lds_rows<T>(p0, vp, dO);
+            mma_lds_rows<T>(p1, vp + 16 * AT<T>::RS, dO);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int kend = CAUSAL ? min(Lp, ((q0 + 15) / 32 + 1) * 32) : Lp;
-        for (int kb = 0; kb < kend; kb += 32) {
-            f32x4 s0 = mma_lds_rows<T>(k_lds, kb, lane, q, true);
-            f32x4 s1 = mma_lds_rows<T>(k_lds, kb + 16, lane, q, true);
-            f32x4 p0 = mma_lds_rows<T>(v_lds, kb, lane, dO, true);
-            f32x4 p1 = mma_lds_rows<T>(v_lds, kb + 16, lane, dO, true);
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                const float e0 = (k0 < L && (!CAUSAL || k0 <= qrow)) ? exp2f(s0[r] * c - lq) : 0.f;
-                const float e1 = (k1 < L && (!CAUSAL || k1 <= qrow)) ? exp2f(s1[r] * c - lq) : 0.f;
-                s0[r] = e0 * (p0[r] - dl) * SCALE;
-                s1[r] = e1 * (p1[r] - dl) * SCALE;
+                for (int r = 0; r < 4; ++r) {
+                    float e0 = fast_exp2(fmaf(s0[j][r], c, -lq[j]));
+                    float e1 = fast_exp2(fmaf(s1[j][r], c, -lq[j]));
+                    if constexpr (MASKED) {
+                        const int k0 = kb + 4 * g + r, k1 = k0 + 16;
+                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) e0 = 0.f;
+                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) e1 = 0.f;
+                    }
+                    s0[j][r] = e0 * fmaf(p0[j][r], SCALE, -dls[j]);       // P * (dP - delta) * scale
+                    s1[j][r] = e1 * fmaf(p1[j][r], SCALE, -dls[j]);
+                }
+            mma_transposed<T>(dq, kt0 + kb * AT<T>::RS, s0, s1);
+        };
+        const int qlast = q0 + 16 * NB - 1;
+        const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
+        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        int kb = 0;
+        for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
+        for (; kb < kend; kb += 32) tile(kb, std::true_type{});
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (qrow[j] < L) {
+                T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
-            mma_transposed<T>(dq, k_lds, kb, lane, s0, s1);
-        }
-        if (valid) {
-            T* dst = dqkv + grow * lddqkv + h * HD + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[dt]);
-        }
     }
 }
 
@@ -274,93 +380,122 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
     char* do_lds = smem + Lp * AT<T>::RS;
     float* lse_lds = reinterpret_cast<float*>(smem + 2 * Lp * AT<T>::RS);
     float* dl_lds = lse_lds + Lp;
-    stage_rows<T>(q_lds, qg, ldqkv, L, Lp);
-    stage_rows<T>(do_lds, dctx + (size_t)b * L * lddctx + h * HD, lddctx, L, Lp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4;
+    Chunk kk[NB][AT<T>::KS], vv[NB][AT<T>::KS];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {          // first key blocks: fetched ahead of the staging
+        const int kr = (wave * NB + j) * 16 + (lane & 15);
+        load_row_chunks<T>(kk[j], qg + dm, kr, ldqkv, g, kr < L);
+        load_row_chunks<T>(vv[j], qg + 2 * dm, kr, ldqkv, g, kr < L);
+    }
+    stage_rows2<T>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
         lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;  // padded queries -> P = 0
-        dl_lds[i] = i < L ? delta[((size_t)b * H + h) * L + i] : 0.f;
+        dl_lds[i] = i < L ? delta[((size_t)b * H + h) * L + i] * SCALE : 0.f;
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int g = lane >> 4;
     const float c = SCALE * LOG2E;
-    for (int k0 = wave * 16; k0 < L; k0 += nw * 16) {
-        const int krow = k0 + (lane & 15);
-        const bool valid = krow < L;
-        Chunk kk[AT<T>::KS], vv[AT<T>::KS];
-        load_row_chunks<T>(kk, qg + dm, krow, ldqkv, g, valid);
-        load_row_chunks<T>(vv, qg + 2 * dm, krow, ldqkv, g, valid);
-        f32x4 dk[4], dv[4];
+    const char* const qp0 = q_lds + row_ptr_off<T>(lane);
+    const char* const dp0 = do_lds + row_ptr_off<T>(lane);
+    const char* const qt0 = q_lds + tr_ptr_off<T>(lane);
+    const char* const dt0 = do_lds + tr_ptr_off<T>(lane);
+    for (int k0 = wave * 16 * NB; k0 < L; k0 += nw * 16 * NB) {
+        int krow[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const int qstart = CAUSAL ? (k0 / 32) * 32 : 0;
-        for (int qb = qstart; qb < Lp; qb += 32) {
+        for (int j = 0; j < NB; ++j) krow[j] = k0 + 16 * j + (lane & 15);
+        if (k0 != wave * 16 * NB) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                load_row_chunks<T>(kk[j], qg + dm, krow[j], ldqkv, g, krow[j] < L);
+                load_row_chunks<T>(vv[j], qg + 2 * dm, krow[j], ldqkv, g, krow[j] < L);
+            }
+        }
+        f32x4 dk[NB][4], dv[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dk[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // padded queries need no mask: their lse is +inf in LDS, so P = exp2(-inf) = 0; padded KEY rows are never stored.
+        auto tile = [&](int qb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;       // only the causal diagonal tiles
+            const char* qp = qp0 + qb * AT<T>::RS;
+            const char* dp = dp0 + qb * AT<T>::RS;
             // S[q][key]: rows q = qb + 16t + 4g + r, column key = krow
-            f32x4 s0 = mma_lds_rows<T>(q_lds, qb, lane, kk, true);
-            f32x4 s1 = mma_lds_rows<T>(q_lds, qb + 16, lane, kk, true);
-            f32x4 p0 = mma_lds_rows<T>(do_lds, qb, lane, vv, true);
-            f32x4 p1 = mma_lds_rows<T>(do_lds, qb + 16, lane, vv, true);
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB], e0[NB], e1[NB];
+            mma_lds_rows<T>(s0, qp, kk);
+            mma_lds_rows<T>(s1, qp + 16 * AT<T>::RS, kk);
+            mma_lds_rows<T>(p0, dp, vv);
+            mma_lds_rows<T>(p1, dp + 16 * AT<T>::RS, vv);
             const f32x4 l0 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 4 * g);
             const f32x4 l1 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 16 + 4 * g);
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 4 * g);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 4 * g);     // delta * scale
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 16 + 4 * g);
-            f32x4 e0, e1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qa = qb + 4 * g + r, qc = qa + 16;
-                e0[r] = (valid && (!CAUSAL || krow <= qa)) ? exp2f(s0[r] * c - l0[r]) : 0.f;
-                e1[r] = (valid && (!CAUSAL || krow <= qc)) ? exp2f(s1[r] * c - l1[r]) : 0.f;
-                s0[r] = e0[r] * (p0[r] - d0[r]) * SCALE;
-                s1[r] = e1[r] * (p1[r] - d1[r]) * SCALE;
-            }
-            mma_transposed<T>(dv, do_lds, qb, lane, e0, e1);
-            mma_transposed<T>(dk, q_lds, qb, lane, s0, s1);
-        }
-        if (valid) {
-            T* dst = dqkv + ((size_t)b * L + krow) * lddqkv + h * HD + 4 * g;
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                Elem<T>::st4(dst + dm + dt * 16, dk[dt]);
-                Elem<T>::st4(dst + 2 * dm + dt * 16, dv[dt]);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    e0[j][r] = fast_exp2(fmaf(s0[j][r], c, -l0[r]));
+                    e1[j][r] = fast_exp2(fmaf(s1[j][r], c, -l1[r]));
+                    if constexpr (MASKED) {
+                        const int qa = qb + 4 * g + r, qc = qa + 16;
+                        if (krow[j] > qa) e0[j][r] = 0.f;
+                        if (krow[j] > qc) e1[j][r] = 0.f;
+                    }
+                    s0[j][r] = e0[j][r] * fmaf(p0[j][r], SCALE, -d0[r]);
+                    s1[j][r] = e1[j][r] * fmaf(p1[j][r], SCALE, -d1[r]);
+                }
+            mma_transposed<T>(dv, dt0 + qb * AT<T>::RS, e0, e1);
+            mma_transposed<T>(dk, qt0 + qb * AT<T>::RS, s0, s1);
+        };
+        int qb = CAUSAL ? (k0 / 32) * 32 : 0;
+        if constexpr (CAUSAL) {
+            const int qdiag = min(Lp, ((k0 + 16 * NB - 1) / 32 + 1) * 32);      // tiles that can hold q < key
+            for (; qb < qdiag; qb += 32) tile(qb, std::true_type{});
         }
+        for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (krow[j] < L) {
+                T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
+                    Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
+                }
+            }
     }
 }
 
+// waves per workgroup: each wave owns NB 16-row blocks per round; balance the rounds
 inline int pick_waves(int L) {
-    const int nqb = (L + 15) / 16;
+    const int nqb = (L + 16 * NB - 1) / (16 * NB);
     const int rounds = (nqb + 7) / 8;
     return (nqb + rounds - 1) / rounds;
 }
 
-// allow the full 160 KiB of a CU's LDS for this kernel (once per kernel instance)
-template <typename K> int set_lds(K kern, size_t bytes) {
+// allow the full 160 KiB of a CU's LDS for a kernel (once per kernel function)
+int set_lds(const void* kern, size_t bytes) {
     if (bytes > 160 * 1024) return LPI_EINVAL;
-    static bool done = false;   // one static per instantiation (K is a distinct function-pointer VALUE, so key on it)
-    static const void* last = nullptr;
-    if (done && last == (const void*)kern) return 0;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static const void* done[16];
+    static int ndone = 0;
+    for (int i = 0; i < ndone; ++i)
+        if (done[i] == kern) return 0;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    done = true;
-    last = (const void*)kern;
+    if (ndone < 16) done[ndone++] = kern;
     return 0;
 }
 
-template <typename T>
-int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal, hipStream_t s) {
+template <typename T, bool CAUSAL>
+int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)2 * Lp * AT<T>::RS;
     const int thr = 64 * pick_waves(L);
-    if (causal) {
-        int e = set_lds(attn_fwd_kernel<T, true>, lds);
-        if (e) return e;
-        LPI_LAUNCH((attn_fwd_kernel<T, true>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
-    } else {
-        int e = set_lds(attn_fwd_kernel<T, false>, lds);
-        if (e) return e;
-        LPI_LAUNCH((attn_fwd_kernel<T, false>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
-    }
+    int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL>, lds);
+    if (e) return e;
+    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -372,15 +507,15 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
     const int thr = 64 * pick_waves(L);
-    int e = set_lds(attn_bwd_dq_kernel<T, CAUSAL>, ldsA);
+    int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL>, ldsA);
     if (e) return e;
-    e = set_lds(attn_bwd_dkv_kernel<T, CAUSAL>, ldsB);
+    e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL>, ldsB);
     if (e) return e;
     LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-                       (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
+               (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
     LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
-                       lse, delta, (T*)dqkv, lddqkv);
+               lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -396,8 +531,11 @@ extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int
                             void* stream) {
     if (!qkv || !ctx || !lse || bad_attn(dtype, B, L, H, ldqkv) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return LPI_EINVAL;
-    if (dtype == LPI_F32) return fwd_launch<float>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, (hipStream_t)stream);
-    if (dtype == LPI_BF16) return fwd_launch<bf16_t>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F32)
+        return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+    if (dtype == LPI_BF16)
+        return causal ? fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
     return LPI_EINVAL;
 }
 

@@ -135,7 +135,7 @@ class Tower:
         }
         if train:
             ws.update({
-                "dx": z(Mp, d), "dh": z(Mp, d), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
+                "dx": z(Mp, d), "dh": z(Mp, d, dtype=T), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
                 "delta": z(B, H, L),
                 "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
             })
@@ -185,12 +185,12 @@ class Tower:
             du = ws["g"]
             gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
             gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
-            call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
+            call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                  None if dt == F32 else dxT, d, s)
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
-            call("lpi_layernorm_bwd", F32, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+            call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
                 call("lpi_rows_sum_over_batch", B, L, 1, P, d, dx, dprompts[i], 0, s)
