@@ -133,18 +133,30 @@ def main():
     if not a.no_roofline:
         engine.GEMM_PROFILE = []
         nprof = 2
+        overlap_saved, a.no_overlap = a.no_overlap, True     # time each kernel alone: no second stream sharing the GPU
         for _ in range(nprof):
             step()
+        a.no_overlap = overlap_saved
         torch.cuda.synchronize()
         ev = engine.GEMM_PROFILE
         engine.GEMM_PROFILE = None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
-        fl = sum(f for _, _, f in ev)
+        ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+        fl = sum(e[2] for e in ev)
+        by = sum(e[3] for e in ev)
         ach = fl / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": round(ach, 2), "peak": PEAK_TF[a.dtype],
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[a.dtype], 4), "traffic": None,
+        traffic, tsrc = None, None
+        pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if a.dtype == "bf16" and os.path.exists(pmc):      # measured by separate rocprofv3 --pmc passes (tools/pmc_summary.py)
+            k = json.load(open(pmc))["kernels"].get("gemm256_kernel")
+            if k:
+                traffic, tsrc = round(k["hbm_mb_per_launch"] * 1e6), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
+        roofline = {"bound": "mfma", "kernel": "gemm256_kernel (+ gemm_nt_kernel for small shapes)", "achieved": round(ach, 2),
+                    "peak": PEAK_TF[a.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[a.dtype], 4),
+                    "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tsrc,
+                    "algorithmic_bytes_per_launch": round(by / len(ev)),
                     "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
-                    "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1)}
+                    "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
+                    "measured": "HIP events around every GEMM launch of 2 extra steps, towers on one stream (kernel alone on the GPU)"}
 
     if rank == 0:
         gf = GFLOP_PER_PAIR if not a.fwd_only else 44.05

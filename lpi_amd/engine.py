@@ -76,7 +76,10 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
          float(alpha), _stream())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * (m_real or M) * N * K))
+        mr = m_real or M
+        nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (4 if residual is not None else 0)
+                                                                 + (aux.element_size() if aux is not None else 0))
+        prof.append((e0, e1, 2.0 * mr * N * K, nbytes))
 
 
 @dataclass
