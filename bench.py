@@ -28,7 +28,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-GFLOP_PER_PAIR = 89.68          # fwd 44.05 + bwd 45.63, ViT-B/16, P=16, dgrad only
+GFLOP_PER_PAIR = {"ViT-B/16": (89.68, 44.05), "ViT-L/14": (378.9, 185.8)}   # (fwd+bwd, fwd), P=16, dgrad only
 PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
 
 
@@ -64,10 +64,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--model", default="ViT-B/16")
+    ap.add_argument("--rank", type=int, default=4, help="CP rank r of the DecomposedPrompt")
+    ap.add_argument("--prompt-layers", type=int, default=9, help="layer_num of the DecomposedPrompt (reference: 9)")
     ap.add_argument("--fwd-only", action="store_true", help="BASELINE.json configs[1]: encoder forward + cosine matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the two towers on one stream")
+    ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
+    ap.add_argument("--text-lanes", type=int, default=1)
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -99,15 +103,15 @@ def main():
     images = torch.from_numpy(synth.images(B, cfg.image_resolution, seed=synth.IMAGE_SEED + rank)).to(dev)
     ids = torch.from_numpy(synth.token_ids(B, seed=synth.TOKEN_SEED + rank)).to(dev)
     fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not a.fwd_only)
-           for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+           for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
     opt = torch.optim.SGD(list(fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
 
     def step():
         if a.fwd_only:
             with torch.no_grad():
-                forward_loss(enc, images, ids, fac, a.depth, exchange.gather if exchange else None, overlap_towers=not a.no_overlap)
+                forward_loss(enc, images, ids, fac, a.depth, exchange.gather if exchange else None, overlap_towers=not a.no_overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes)
         else:
-            train_step(enc, images, ids, fac, a.depth, exchange, overlap_towers=not a.no_overlap)
+            train_step(enc, images, ids, fac, a.depth, exchange, overlap_towers=not a.no_overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes)
             opt.step()
 
     def sync():
@@ -159,18 +163,20 @@ def main():
                     "measured": "HIP events around every GEMM launch of 2 extra steps, towers on one stream (kernel alone on the GPU)"}
 
     if rank == 0:
-        gf = GFLOP_PER_PAIR if not a.fwd_only else 44.05
+        gfs = GFLOP_PER_PAIR.get(a.model)
+        gf = None if gfs is None else gfs[1 if a.fwd_only else 0]
         out = {
-            "metric": "image-text pairs/sec fwd+bwd (ViT-B/16, bs256/GPU)" if not a.fwd_only else "image-text pairs/sec fwd-only encoder + cosine matrix",
+            "metric": (f"image-text pairs/sec fwd+bwd ({a.model}, bs{B}/GPU)" if not a.fwd_only
+                       else f"image-text pairs/sec fwd-only encoder + cosine matrix ({a.model}, bs{B}/GPU)"),
             "value": round(pairs_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[2]: " if (a.model == "ViT-B/16" and B == 256 and a.depth == 3 and not a.fwd_only) else "")
-                       + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r=4 P=16, "
+            "config": {"workload": ("BASELINE.json configs[2]: " if (a.model == "ViT-B/16" and B == 256 and a.depth == 3 and a.rank == 4 and not a.fwd_only) else "")
+                       + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r={a.rank} P=16, "
                        + ("fwd-only + cosine matrix" if a.fwd_only else "fwd+bwd incl. DecomposedPrompt grads + SGD step"),
                        "global_batch": world * B, "image": f"{cfg.image_resolution}x{cfg.image_resolution}", "tokens": cfg.context_length,
                        "parallelism": f"dp{world}", "weights": "synthetic (numpy Philox, CLIP-init scales), frozen"},
-            "step_mfma_frac": round(pairs_s / world * gf * 1e9 / (PEAK_TF[a.dtype] * 1e12), 4),
+            "step_mfma_frac": None if gf is None else round(pairs_s / world * gf * 1e9 / (PEAK_TF[a.dtype] * 1e12), 4),
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:

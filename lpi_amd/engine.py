@@ -232,6 +232,24 @@ class DualEncoder:
         self.logit_scale_exp = float(math.exp(float(np.asarray(state_dict["logit_scale"] if not torch.is_tensor(state_dict["logit_scale"]) else state_dict["logit_scale"].cpu()))))
         self._head_ws = {}
 
+    # ------------------------------------------------------------------ lanes
+    def lane(self, i: int):
+        """Lane i > 0: an engine that SHARES the frozen weights but owns its workspace arena and HIP stream, so that
+        micro-batches can be in flight concurrently (step.py); lane 0 is this engine on the caller's stream."""
+        if i == 0:
+            return self
+        lanes = self.__dict__.setdefault("_lanes", {})
+        if i not in lanes:
+            import copy
+            c = copy.copy(self)
+            c.vis, c.txt = copy.copy(self.vis), copy.copy(self.txt)
+            c.vis._ws, c.txt._ws, c._head_ws = {}, {}, {}
+            c.__dict__.pop("_lanes", None)
+            c.__dict__.pop("_side_stream", None)
+            c.stream = torch.cuda.Stream(device=self.device)
+            lanes[i] = c
+        return lanes[i]
+
     # ------------------------------------------------------------------ helpers
     def _head(self, tag, B, d):
         key = (tag, B)

@@ -12,29 +12,38 @@ from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeImage
 from .synth import PROMPT_NAMES
 
 
-def _side_stream(enc):
-    st = getattr(enc, "_side_stream", None)
-    if st is None:
-        st = enc._side_stream = torch.cuda.Stream(device=enc.device)
-    return st
-
-
-def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = True):
+def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = True,
+                 vision_lanes: int = 1, text_lanes: int = 1):
     """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
     Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits)."""
     vis, txt = DecomposedPromptFn.apply(*[factors[k] for k in ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")])
     if overlap_towers:
-        # The towers are independent until the similarity matrix: run the text tower on a second HIP stream so its kernels fill
-        # the CUs the vision tower's last partial round of GEMM tiles leaves idle (autograd replays each node's backward on the
-        # stream its forward ran on, so the backward overlaps the same way).
+        # The towers are independent until the similarity matrix, and so are micro-batches of one tower: each (tower, micro-batch)
+        # "lane" runs on its own HIP stream with its own workspace.  One lane's HBM-bound kernels (LayerNorm, attention, GEMM
+        # epilogues) then overlap another lane's MFMA-bound GEMM main loops, and lanes fill each other's partial last round of
+        # GEMM tiles.  autograd replays each node's backward on the stream its forward ran on, so the backward overlaps the same
+        # way; the factor gradients are sums over the batch, so splitting it changes nothing but the summation order.
         main = torch.cuda.current_stream()
-        side = _side_stream(enc)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
-        img_f = EncodeImageFn.apply(enc, images, vis, depth)
-        main.wait_stream(side)
-        txt_f.record_stream(main)
+        B = images.shape[0]
+        nv = vision_lanes if B % vision_lanes == 0 else 1
+        ntx = text_lanes if B % text_lanes == 0 else 1
+        jobs = [("v", k, nv) for k in range(nv)] + [("t", k, ntx) for k in range(ntx)]
+        outs = {"v": [], "t": []}
+        for li, (kind, k, n) in enumerate(jobs):
+            eng = enc.lane(li)
+            sl = slice(k * (B // n), (k + 1) * (B // n))
+            st = main if li == 0 else eng.stream
+            if li:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                f = EncodeImageFn.apply(eng, images[sl], vis, depth) if kind == "v" else EncodeTextFn.apply(eng, ids[sl], txt, depth)
+            if li:
+                f.record_stream(main)
+            outs[kind].append(f)
+        for li in range(1, len(jobs)):
+            main.wait_stream(enc.lane(li).stream)
+        img_f = outs["v"][0] if nv == 1 else torch.cat(outs["v"])
+        txt_f = outs["t"][0] if ntx == 1 else torch.cat(outs["t"])
     else:
         img_f = EncodeImageFn.apply(enc, images, vis, depth)
         txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
@@ -44,7 +53,8 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
     return losses, img_f, txt_f, vis, txt
 
 
-def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = True):
+def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = True,
+               vision_lanes: int = 1, text_lanes: int = 1):
     """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
 
     exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
@@ -52,7 +62,7 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     for k in PROMPT_NAMES:
         factors[k].grad = None
     gather = exchange.gather if exchange is not None else None
-    losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers)
+    losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes)
     world = exchange.world if exchange is not None else 1
     total = losses["base_loss"] + losses["alignment_loss"] / world
     total.backward()

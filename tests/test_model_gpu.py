@@ -124,3 +124,23 @@ def test_eval_interfaces_f32(golden):
     assert maxerr(et.cpu().numpy(), g["extract_textual_vector"]) < 1e-4
     ti = enc.encode_text(ids, txt_all[torch.from_numpy(g["sel_t"]).to(DEV)])
     assert maxerr(ti.cpu().numpy(), g["textual_interface"]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+def test_patch14_rank8_depth2_vs_oracle(dtype, tol):
+    """ViT-L/14-style shapes at toy size: 14x14 patches (K = 588, zero padded), vision width 192 (3 heads) != text width 128,
+    CP rank 8, 12 reconstructed layers — extensions the reference never instantiates, checked against the oracle."""
+    cfg = synth.TINY14
+    sd = synth.clip_state_dict(cfg)
+    fac_np = synth.prompt_factors(12, 16, cfg.vision_width, cfg.transformer_width, r=8)
+    img, ids = synth.images(5, cfg.image_resolution), synth.token_ids(5)
+    ref = O.train_step(O.Oracle(cfg, sd, torch.float64), img, ids, fac_np, depth=2)
+    enc = DualEncoder(cfg, sd, dtype=dtype, device=DEV)
+    fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in fac_np.items()}
+    out = train_step(enc, torch.from_numpy(img).to(DEV), torch.from_numpy(ids).to(DEV), fac, 2)
+    for k in ("img_f", "txt_f"):
+        assert maxerr(out[k].cpu().numpy(), ref[k]) < tol, k
+    if dtype == "f32":
+        for k in synth.PROMPT_NAMES:
+            g, r = fac[k].grad.cpu().numpy(), ref["grad." + k]
+            assert maxerr(g, r) <= 5e-4 * np.abs(r).max() + 1e-6, k
