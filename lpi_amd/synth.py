@@ -64,7 +64,7 @@ VIT_L14 = ClipConfig("ViT-L/14", 768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12)
 TINY = ClipConfig("tiny", 128, 32, 2, 128, 16, 77, 49408, 128, 2, 2)
 
 # patch 14 (K = 588, zero padded to the GEMM K tile) like ViT-L/14, at toy size
-TINY14 = ClipConfig("tiny14", 128, 28, 2, 192, 14, 77, 49408, 128, 2, 2)
+TINY14 = ClipConfig("tiny14", 128, 28, 2, 256, 14, 77, 49408, 128, 2, 2)   # widths must be multiples of 128 (GEMM tile)
 
 CONFIGS = {c.name: c for c in (VIT_B16, VIT_L14, TINY, TINY14)}
 

@@ -128,7 +128,7 @@ def test_eval_interfaces_f32(golden):
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 3e-2)])
 def test_patch14_rank8_depth2_vs_oracle(dtype, tol):
-    """ViT-L/14-style shapes at toy size: 14x14 patches (K = 588, zero padded), vision width 192 (3 heads) != text width 128,
+    """ViT-L/14-style shapes at toy size: 14x14 patches (K = 588, zero padded), vision width 256 (4 heads) != text width 128,
     CP rank 8, 12 reconstructed layers — extensions the reference never instantiates, checked against the oracle."""
     cfg = synth.TINY14
     sd = synth.clip_state_dict(cfg)
