@@ -123,6 +123,12 @@ int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, const int32_
 int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float* dy, int lddy, const float* x,
                     const int32_t* idx, const float* gamma, const float* mean, const float* rstd,
                     float* dx, void* dx_cast, void* stream);
+/* pooled-row gather / scatter (f32): dst[b] = src[b*L + idx[b]]  /  dst[b*L + idx[b]] = src[b] (+ `cast_dtype` copy; the other
+ * rows of dst are the caller's, pre-zeroed).  Used to run the LAST block's MLP on the B pooled rows only: the heads read nothing
+ * else of its output (model.py:255, prompt_learner.py:61), so this is exact dead-row elimination. */
+int lpi_gather_rows(int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* stream);
+int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
+                     void* stream);
 int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, int ldy, float* inv_norm, void* stream);
 int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int lddy, const float* inv_norm,
                    float* dx, int lddx, void* stream);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "lpi_prompt_add": [_I, _I, _I, _I, _P, _P, _L, _P],
     "lpi_pool_ln_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "lpi_pool_ln_bwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "lpi_gather_rows": [_I, _I, _I, _P, _P, _P, _P],
+    "lpi_scatter_rows": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "lpi_l2norm_fwd": [_I, _I, _P, _I, _P, _I, _P, _P],
     "lpi_l2norm_bwd": [_I, _I, _P, _I, _P, _I, _P, _P, _I, _P],
     "lpi_eot_index": [_I, _I, _P, _P, _P],

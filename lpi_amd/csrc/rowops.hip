@@ -281,6 +281,33 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, c
     });
 }
 
+// dst[b,:] = src[b*L + idx[b], :]  (f32; idx NULL -> row 0)
+__global__ __launch_bounds__(256) void gather_rows_kernel(int B, int L, int d, const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* s = src + ((size_t)b * L + (idx ? idx[b] : 0)) * d;
+    float* o = dst + (size_t)b * d;
+    for_chunks(d, lane, [&](int, int col) { *reinterpret_cast<f32x4*>(o + col) = *reinterpret_cast<const f32x4*>(s + col); });
+}
+
+// dst[b*L + idx[b], :] = src[b,:] (f32) and its cast copy; the rest of dst is the caller's (pre-zeroed)
+template <typename TCAST>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(int B, int L, int d, const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, TCAST* __restrict__ dst_cast) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
+    const float* s = src + (size_t)b * d;
+    for_chunks(d, lane, [&](int, int col) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + col);
+        *reinterpret_cast<f32x4*>(dst + row * d + col) = v;
+        if (dst_cast) Elem<TCAST>::st4(dst_cast + row * d + col, v);
+    });
+}
+
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(int B, int E, const float* __restrict__ x, int ldx,
                                                         float* __restrict__ y, int ldy, float* __restrict__ inv_norm) {
     const int lane = threadIdx.x & 63;
@@ -468,6 +495,24 @@ extern "C" int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float*
     dim3 g(rows_grid(B)), b(256);
     if (cast_dtype == LPI_F32) LPI_LAUNCH(pool_ln_bwd_kernel<float>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (float*)dx_cast);
     else if (cast_dtype == LPI_BF16) LPI_LAUNCH(pool_ln_bwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, (bf16_t*)dx_cast);
+    else return LPI_EINVAL;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_gather_rows(int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* stream) {
+    if (!src || !dst || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
+    LPI_LAUNCH(gather_rows_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, src, idx, dst);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
+                                void* stream) {
+    if (!src || !dst || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
+    dim3 g(rows_grid(B)), b(256);
+    if (cast_dtype == LPI_F32) LPI_LAUNCH(scatter_rows_kernel<float>, g, b, 0, S(stream), B, L, d, src, idx, dst, (float*)dst_cast);
+    else if (cast_dtype == LPI_BF16) LPI_LAUNCH(scatter_rows_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, src, idx, dst, (bf16_t*)dst_cast);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;

@@ -28,6 +28,11 @@ from . import _lib
 from ._lib import BF16, EPI_DQUICKGELU, EPI_NONE, EPI_QUICKGELU, F32, call
 from .synth import ClipConfig
 
+import os as _os
+
+# exact dead-row elimination in the last block (see Tower.forward); LPI_POOLED_LAST=0 evaluates the full block instead (A/B switch)
+POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "1") != "0"
+
 _DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 
@@ -120,6 +125,7 @@ class Tower:
         self._ws.clear()   # one live shape per tower: the arena is large
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
+        Bp = _pad(B)
         T = _TORCH_DT[self.dt]
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
@@ -135,19 +141,25 @@ class Tower:
             "stat": [z(4, Mp) for _ in range(keep)],      # ln1 mean, ln1 rstd, ln2 mean, ln2 rstd
             "h": z(Mp, d, dtype=T),
             "g": z(Mp, 4 * d, dtype=T),
+            # the LAST block's MLP runs on the B pooled rows only (exact: the heads read nothing else of its output)
+            "Bp": Bp, "c_xmid": z(Bp, d), "c_h": z(Bp, d, dtype=T), "c_g": z(Bp, 4 * d, dtype=T),
+            "c_u": z(Bp, 4 * d, dtype=T) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
         }
         if train:
             ws.update({
                 "dx": z(Mp, d), "dh": z(Mp, d, dtype=T), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
                 "delta": z(B, H, L),
                 "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
+                "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
             })
         self._ws[key] = ws
         return ws
 
     # ------------------------------------------------------------------ forward
-    def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True):
-        """Runs the blocks over ws['x'][0]; returns the output residual stream tensor [Mp, d] (f32).
+    def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
+        """Runs the blocks over ws['x'][0]; returns the POOLED rows of the output residual stream, [Bp, d] f32: row b is token
+        pool_idx[b] of sample b (None: token 0 = CLS).  Only those rows are ever read by the heads (model.py:255,
+        prompt_learner.py:61), so the last block's MLP is evaluated on them alone.
 
         prompts: f32 tensor whose element (b, layer, p, :) sits at  b*prompt_bstride + (layer*P + p)*d."""
         sp, dt, s = self.spec, self.dt, _stream()
@@ -166,14 +178,22 @@ class Tower:
             gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
             gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
+            if i == len(self.blocks) - 1 and POOLED_LAST:
+                Bp, cst = ws["Bp"], ws["c_stat"]
+                call("lpi_gather_rows", B, L, d, xmid, pool_idx, ws["c_xmid"], s)
+                call("lpi_pool_ln_fwd", dt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                return ws["c_xout"]
             call("lpi_layernorm_fwd", dt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
             gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
-        return ws["x"][len(self.blocks) if train else len(self.blocks) % 2]
+        call("lpi_gather_rows", B, L, d, x_out, pool_idx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
+        return ws["c_xout"]
 
     # ------------------------------------------------------------------ backward (dgrad only)
-    def backward(self, ws, prompts=None, depth=1, dprompts=None):
-        """ws['dx'] (f32) [and ws['dxT']] hold dL/dx_out on entry and dL/dx_0 on exit.
+    def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
+        """ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
         dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
         sp, dt, s = self.spec, self.dt, _stream()
         d, H = sp.width, sp.heads
@@ -185,11 +205,30 @@ class Tower:
         for i in reversed(range(len(self.blocks))):
             blk = self.blocks[i]
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
-            du = ws["g"]
-            gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
-            gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
-            call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
-                 None if dt == F32 else dxT, d, s)
+            if i == len(self.blocks) - 1 and not POOLED_LAST:
+                dx.zero_()
+                if dt != F32:
+                    dxT.zero_()
+                call("lpi_scatter_rows", dt, B, L, d, ws["c_dx"], pool_idx, dx, None if dt == F32 else dxT, s)
+            if i == len(self.blocks) - 1 and POOLED_LAST:
+                # last block: MLP backward on the pooled rows, then scatter into the (zeroed) full-size gradient stream
+                Bp, cst = ws["Bp"], ws["c_stat"]
+                c_dx = ws["c_dx"]
+                c_dxT = ws["c_dxT"] if dt != F32 else c_dx
+                gemm(dt, c_dxT, blk["proj"].wt, ws["c_g"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
+                gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
+                call("lpi_layernorm_bwd", dt, dt, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
+                     None if dt == F32 else c_dxT, d, s)
+                dx.zero_()
+                if dt != F32:
+                    dxT.zero_()
+                call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
+            else:
+                du = ws["g"]
+                gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
+                gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
+                call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
+                     None if dt == F32 else dxT, d, s)
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
@@ -297,9 +336,9 @@ class DualEncoder:
         gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
         call("lpi_vis_assemble_fwd", B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
              ws["x"][0], fe["stat"][0], fe["stat"][1], s)
-        xo = self.vis.forward(ws, pr, pbs, depth, train)
+        xo = self.vis.forward(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
-        call("lpi_pool_ln_fwd", dt, B, L, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        call("lpi_pool_ln_fwd", dt, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         gemm(dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
@@ -322,17 +361,13 @@ class DualEncoder:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
         gemm(dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
-        ws["dx"].zero_()
-        if dt != F32:
-            ws["dxT"].zero_()
-        xo = ws["x"][len(self.vis.blocks)]
-        call("lpi_pool_ln_bwd", dt, B, L, d, hw["dpooled"], d, xo, None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
-             ws["dx"], None if dt == F32 else ws["dxT"], s)
+        call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
+             ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
-        self.vis.backward(ws, pr, depth, dpr)
+        self.vis.backward(ws, pr, depth, dpr, None)
         call("lpi_vis_assemble_bwd", B, cfg.n_patches, P, d, ws["dx"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
              ws["front"]["stat"][1], dpr[0], s)
         return dpr
@@ -353,8 +388,8 @@ class DualEncoder:
         call("lpi_eot_index", B, L, ids, hw["idx"], s)
         ctx = pr if (pr is not None and use_ctx) else None
         call("lpi_txt_embed_fwd", B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
-        xo = self.txt.forward(ws, pr, pbs, depth, train)
-        call("lpi_pool_ln_fwd", dt, B, L, d, xo, hw["idx"], self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        xo = self.txt.forward(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
+        call("lpi_pool_ln_fwd", dt, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         gemm(dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
@@ -376,17 +411,13 @@ class DualEncoder:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
         gemm(dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
-        ws["dx"].zero_()
-        if dt != F32:
-            ws["dxT"].zero_()
-        xo = ws["x"][len(self.txt.blocks)]
-        call("lpi_pool_ln_bwd", dt, B, L, d, hw["dpooled"], d, xo, hw["idx"], self.ln_final[0], hw["stat"][0], hw["stat"][1],
-             ws["dx"], None if dt == F32 else ws["dxT"], s)
+        call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_final[0], hw["stat"][0], hw["stat"][1],
+             ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
-        self.txt.backward(ws, pr, depth, dpr)
+        self.txt.backward(ws, pr, depth, dpr, hw["idx"])
         call("lpi_rows_sum_over_batch", B, L, 1, P, d, ws["dx"], dpr[0], 0, s)
         return dpr
 
