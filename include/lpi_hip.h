@@ -45,7 +45,8 @@ uint64_t lpi_launch_count(void);
 
 /* tuning knobs (speed only, never results): keys 0 / 1 = minimum number of 256x256 tiles for which lpi_gemm_nt uses
  * the 8-phase 256x256 kernel instead of the 128x128 one, for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it); key 2 = start stagger of every other first-round workgroup of that kernel in
- * units of ~3.4 us (default 0: measured null to negative on every shape, kept for experiments). */
+ * units of ~3.4 us (default 0: measured null to negative on every shape, kept for experiments); key 3 != 0 forces the two-pass
+ * attention backward where the fused single-pass kernel would be used (bf16, all four head matrices resident in LDS).. */
 int lpi_set_tuning(int key, int value);
 
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
@@ -81,12 +82,12 @@ int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, con
                  int causal, void* stream);
 
 /* ---- a1: DecomposedPrompt                          replaces: models/prompts/prompts.py:38-57 -----------
- * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout. */
+ * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout; scratch: Lyr*P*r floats. */
 int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,
                       float scale, float* out, void* stream);
 int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,
                       float scale, const float* dout, float* g1, float* g2, float* g3, int accumulate_g1,
-                      void* stream);
+                      float* scratch, void* stream);
 
 /* ---- a3: vision front end                          replaces: models/clip/model.py:227-251 --------------
  * patchify: image [B,3,R,R] f32 -> cols [B*G*G (padded rows untouched), Kp] `dtype`, Kp >= 3*ps*ps zero padded.

@@ -24,6 +24,8 @@
 #include <type_traits>
 #include "common.h"
 
+extern int g_lpi_tuning[8];
+
 namespace {
 
 constexpr int HD = 64;  // head_dim of every CLIP tower (width / 64 heads, model.py:292)
@@ -70,6 +72,13 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
             }
         }
     }
+}
+
+// this lane's KS row chunks of LDS row `row` (rows >= L were zero filled by the staging)
+template <typename T>
+__device__ __forceinline__ void lds_row_chunks(Chunk (&q)[AT<T>::KS], const char* lds, int row, int grp) {
+#pragma unroll
+    for (int ks = 0; ks < AT<T>::KS; ++ks) q[ks].u = *reinterpret_cast<const uint4*>(lds + row * AT<T>::RS + (grp + 4 * ks) * 16);
 }
 
 // this lane's KS row chunks (chunk g + 4*ks) of row `row` of a global matrix; zeros if !valid
@@ -468,6 +477,177 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, fused
+// One kernel for both passes when Q, K, V and dO of a head all fit in LDS (bf16: 4 x Lp x 144 B = 129 KB at L = 213): the head's
+// qkv and dctx rows are read from HBM once instead of twice — the two-pass backward is HBM bound (about 1 GB per vision layer),
+// this one moves a third less.  Phase A (queries) produces delta into LDS and dQ; after one barrier phase B (keys) produces
+// dK, dV.  Same tile bodies, same fixed summation order as the two-pass kernels.
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
+                                                            const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
+                                                            const float* __restrict__ lse, float* __restrict__ delta,
+                                                            T* __restrict__ dqkv, int lddqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int dm = H * HD;
+    const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
+    const int img = Lp * AT<T>::RS;
+    char* q_lds = smem;
+    char* k_lds = smem + img;
+    char* v_lds = smem + 2 * img;
+    char* do_lds = smem + 3 * img;
+    float* lse_lds = reinterpret_cast<float*>(smem + 4 * img);
+    float* dl_lds = lse_lds + Lp;
+    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    stage_rows2<T>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    for (int i = threadIdx.x; i < Lp; i += blockDim.x) lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4;
+    const float c = SCALE * LOG2E;
+    const char* const qp0 = q_lds + row_ptr_off<T>(lane);
+    const char* const kp0 = k_lds + row_ptr_off<T>(lane);
+    const char* const vp0 = v_lds + row_ptr_off<T>(lane);
+    const char* const dp0 = do_lds + row_ptr_off<T>(lane);
+    const char* const qt0 = q_lds + tr_ptr_off<T>(lane);
+    const char* const kt0 = k_lds + tr_ptr_off<T>(lane);
+    const char* const dt0 = do_lds + tr_ptr_off<T>(lane);
+
+    // ---- phase A: a wave owns NB x 16 queries -> delta, dQ
+    for (int q0 = wave * 16 * NB; q0 < L; q0 += nw * 16 * NB) {
+        int qrow[NB];
+        Chunk q[NB][AT<T>::KS], dO[NB][AT<T>::KS];
+        float dls[NB], lq[NB];
+        f32x4 dq[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            qrow[j] = q0 + 16 * j + (lane & 15);
+            const bool valid = qrow[j] < L;
+            lds_row_chunks<T>(q[j], q_lds, qrow[j], g);
+            lds_row_chunks<T>(dO[j], do_lds, qrow[j], g);
+            Chunk oc[AT<T>::KS];
+            load_row_chunks<T>(oc, ctx + h * HD, (size_t)b * L + qrow[j], ldctx, g, valid);
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < AT<T>::KS; ++ks) {
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dl += oc[ks].f[e] * dO[j][ks].f[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl += (float)oc[ks].h[e] * (float)dO[j][ks].h[e];
+                }
+            }
+            dl = group_sum(dl);
+            lq[j] = lse_lds[qrow[j]];                       // +inf for padded queries -> P = 0
+            dls[j] = dl * SCALE;
+            if (g == 0) {
+                dl_lds[qrow[j]] = valid ? dls[j] : 0.f;     // delta * scale, for phase B
+                if (valid) delta[((size_t)b * H + h) * L + qrow[j]] = dl;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        auto tile = [&](int kb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
+            mma_lds_rows<T>(s0, kp0 + kb * AT<T>::RS, q);
+            mma_lds_rows<T>(s1, kp0 + (kb + 16) * AT<T>::RS, q);
+            mma_lds_rows<T>(p0, vp0 + kb * AT<T>::RS, dO);
+            mma_lds_rows<T>(p1, vp0 + (kb + 16) * AT<T>::RS, dO);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e0 = fast_exp2(fmaf(s0[j][r], c, -lq[j]));
+                    float e1 = fast_exp2(fmaf(s1[j][r], c, -lq[j]));
+                    if constexpr (MASKED) {
+                        const int k0 = kb + 4 * g + r, k1 = k0 + 16;
+                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) e0 = 0.f;
+                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) e1 = 0.f;
+                    }
+                    s0[j][r] = e0 * fmaf(p0[j][r], SCALE, -dls[j]);
+                    s1[j][r] = e1 * fmaf(p1[j][r], SCALE, -dls[j]);
+                }
+            mma_transposed<T>(dq, kt0 + kb * AT<T>::RS, s0, s1);
+        };
+        const int qlast = q0 + 16 * NB - 1;
+        const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
+        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        int kb = 0;
+        for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
+        for (; kb < kend; kb += 32) tile(kb, std::true_type{});
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (qrow[j] < L) {
+                T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
+            }
+    }
+    __syncthreads();   // every row < Lp of dl_lds was written: the waves' 32-row spans tile [0, Lp)
+
+    // ---- phase B: a wave owns NB x 16 keys -> dK, dV
+    for (int k0 = wave * 16 * NB; k0 < L; k0 += nw * 16 * NB) {
+        int krow[NB];
+        Chunk kk[NB][AT<T>::KS], vv[NB][AT<T>::KS];
+        f32x4 dk[NB][4], dv[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            krow[j] = k0 + 16 * j + (lane & 15);
+            lds_row_chunks<T>(kk[j], k_lds, krow[j], g);
+            lds_row_chunks<T>(vv[j], v_lds, krow[j], g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dk[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        auto tile = [&](int qb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB], e0[NB], e1[NB];
+            mma_lds_rows<T>(s0, qp0 + qb * AT<T>::RS, kk);
+            mma_lds_rows<T>(s1, qp0 + (qb + 16) * AT<T>::RS, kk);
+            mma_lds_rows<T>(p0, dp0 + qb * AT<T>::RS, vv);
+            mma_lds_rows<T>(p1, dp0 + (qb + 16) * AT<T>::RS, vv);
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 4 * g);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 16 + 4 * g);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 4 * g);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 16 + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[j][r] = fast_exp2(fmaf(s0[j][r], c, -l0[r]));
+                    e1[j][r] = fast_exp2(fmaf(s1[j][r], c, -l1[r]));
+                    if constexpr (MASKED) {
+                        const int qa = qb + 4 * g + r, qc = qa + 16;
+                        if (krow[j] > qa) e0[j][r] = 0.f;
+                        if (krow[j] > qc) e1[j][r] = 0.f;
+                    }
+                    s0[j][r] = e0[j][r] * fmaf(p0[j][r], SCALE, -d0[r]);
+                    s1[j][r] = e1[j][r] * fmaf(p1[j][r], SCALE, -d1[r]);
+                }
+            mma_transposed<T>(dv, dt0 + qb * AT<T>::RS, e0, e1);
+            mma_transposed<T>(dk, qt0 + qb * AT<T>::RS, s0, s1);
+        };
+        int qb = CAUSAL ? (k0 / 32) * 32 : 0;
+        if constexpr (CAUSAL) {
+            const int qdiag = min(Lp, ((k0 + 16 * NB - 1) / 32 + 1) * 32);
+            for (; qb < qdiag; qb += 32) tile(qb, std::true_type{});
+        }
+        for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (krow[j] < L) {
+                T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
+                    Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
+                }
+            }
+    }
+}
+
 // waves per workgroup: each wave owns NB 16-row blocks per round; balance the rounds
 inline int pick_waves(int L) {
     const int nqb = (L + 16 * NB - 1) / (16 * NB);
@@ -507,6 +687,17 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
     const int thr = 64 * pick_waves(L);
+    const size_t ldsF = (size_t)4 * Lp * AT<T>::RS + (size_t)2 * Lp * sizeof(float);
+    // fused single pass for 2-byte operands (HBM bound: -7 % at L = 213, -23 % at L = 77); f32 is compute bound and faster with the
+    // two-pass kernels at two workgroups per CU.  Tuning key 3 != 0 forces the two-pass kernels.
+    if (sizeof(T) == 2 && ldsF <= 160 * 1024 && g_lpi_tuning[3] == 0) {
+        int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL>, ldsF);
+        if (ef) return ef;
+        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
+        LPI_CHECK_LAST();
+        return 0;
+    }
     int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL>, ldsA);
     if (e) return e;
     e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL>, ldsB);

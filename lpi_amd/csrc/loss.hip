@@ -72,62 +72,74 @@ __global__ __launch_bounds__(256) void cp_fwd_kernel(int Lyr, int P, int D, int 
     out[t] = s * sc;
 }
 
-// g3[d,k] = sc * sum_{l,p} dout[l,p,d] * d1[l,k] * d2[p,k]    (one thread per d, coalesced over d)
-__global__ __launch_bounds__(256) void cp_bwd_g3_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
-                                                       float sc, const float* __restrict__ dout, float* __restrict__ g3) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
+// g3[d,k] = sc * sum_{l,p} dout[l,p,d] * d1[l,k] * d2[p,k].  Block = 64 columns d; 16 waves each take the (l,p) rows
+// w, w+16, ... in order, lanes = columns (coalesced); the 16 partials are added in order (deterministic).
+__global__ __launch_bounds__(1024) void cp_bwd_g3_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                        float sc, const float* __restrict__ dout, float* __restrict__ g3) {
+    __shared__ float part[16][64][MAXR + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
     float acc[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
-    for (int l = 0; l < Lyr; ++l)
-        for (int p = 0; p < P; ++p) {
-            const float g = dout[((size_t)l * P + p) * D + d];
+    if (d < D)
+        for (int row = wave; row < Lyr * P; row += 16) {
+            const int l = row / P, p = row % P;
+            const float g = dout[(size_t)row * D + d];
 #pragma unroll
             for (int k = 0; k < MAXR; ++k)
                 if (k < r) acc[k] += g * (d1[l * r + k] * d2[p * r + k]);
         }
 #pragma unroll
-    for (int k = 0; k < MAXR; ++k)
-        if (k < r) g3[d * r + k] = acc[k] * sc;
+    for (int k = 0; k < MAXR; ++k) part[wave][lane][k] = acc[k];
+    __syncthreads();
+    if (wave == 0 && d < D)
+        for (int k = 0; k < r; ++k) {
+            float t = part[0][lane][k];
+            for (int w = 1; w < 16; ++w) t += part[w][lane][k];
+            g3[d * r + k] = t * sc;
+        }
 }
 
-// t[l,p,k] = sum_d dout[l,p,d] * d3[d,k]  (one wave per (l,p) row) -> scratch in LDS -> g1, g2   (single block)
-__global__ __launch_bounds__(1024) void cp_bwd_g12_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
-                                                         const float* __restrict__ d3, float sc, const float* __restrict__ dout,
-                                                         float* __restrict__ g1, float* __restrict__ g2, int accumulate_g1) {
-    extern __shared__ float tl[];  // [Lyr*P][r]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int row = wave; row < Lyr * P; row += nw) {
-        float acc[MAXR];
+// t[l,p,k] = sum_d dout[l,p,d] * d3[d,k]: one wave per (l,p) row, 4 rows per block -> scratch [Lyr*P*r]
+__global__ __launch_bounds__(256) void cp_bwd_t_kernel(int rows, int D, int r, const float* __restrict__ d3, const float* __restrict__ dout,
+                                                      float* __restrict__ t) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float acc[MAXR];
 #pragma unroll
-        for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
-        const float* g = dout + (size_t)row * D;
-        for (int d = lane; d < D; d += 64) {
-            const float v = g[d];
-#pragma unroll
-            for (int k = 0; k < MAXR; ++k)
-                if (k < r) acc[k] += v * d3[d * r + k];
-        }
+    for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
+    const float* g = dout + (size_t)row * D;
+    for (int d = lane; d < D; d += 64) {
+        const float v = g[d];
 #pragma unroll
         for (int k = 0; k < MAXR; ++k)
-            if (k < r) {
-                const float s = wave_sum(acc[k]);
-                if (lane == 0) tl[row * r + k] = s;
-            }
+            if (k < r) acc[k] += v * d3[d * r + k];
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k)
+        if (k < r) {
+            const float s = wave_sum(acc[k]);
+            if (lane == 0) t[row * r + k] = s;
+        }
+}
+
+// g1[l,k] = sc * sum_p t[l,p,k] d2[p,k];  g2[p,k] = sc * sum_l t[l,p,k] d1[l,k]     (tiny, single block)
+__global__ __launch_bounds__(256) void cp_bwd_g12_kernel(int Lyr, int P, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                        float sc, const float* __restrict__ t, float* __restrict__ g1, float* __restrict__ g2,
+                                                        int accumulate_g1) {
     for (int i = threadIdx.x; i < Lyr * r; i += blockDim.x) {
         const int l = i / r, k = i % r;
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += tl[(l * P + p) * r + k] * d2[p * r + k];
+        for (int p = 0; p < P; ++p) s += t[(l * P + p) * r + k] * d2[p * r + k];
         s *= sc;
         g1[i] = accumulate_g1 ? g1[i] + s : s;
     }
     for (int i = threadIdx.x; i < P * r; i += blockDim.x) {
         const int p = i / r, k = i % r;
         float s = 0.f;
-        for (int l = 0; l < Lyr; ++l) s += tl[(l * P + p) * r + k] * d1[l * r + k];
+        for (int l = 0; l < Lyr; ++l) s += t[(l * P + p) * r + k] * d1[l * r + k];
         g2[i] = s * sc;
     }
 }
@@ -288,13 +300,13 @@ extern "C" int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, 
 }
 
 extern "C" int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3, float scale,
-                                 const float* dout, float* g1, float* g2, float* g3, int accumulate_g1, void* stream) {
-    if (!d1 || !d2 || !d3 || !dout || !g1 || !g2 || !g3 || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
-    const size_t lds = (size_t)Lyr * P * r * sizeof(float);
-    if (lds > 64 * 1024) return LPI_EINVAL;
+                                 const float* dout, float* g1, float* g2, float* g3, int accumulate_g1, float* scratch, void* stream) {
+    if (!d1 || !d2 || !d3 || !dout || !g1 || !g2 || !g3 || !scratch || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
     const float sc = scale / (float)r;
-    LPI_LAUNCH(cp_bwd_g12_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, D, r, d1, d2, d3, sc, dout, g1, g2, accumulate_g1);
-    LPI_LAUNCH(cp_bwd_g3_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), Lyr, P, D, r, d1, d2, sc, dout, g3);
+    const int rows = Lyr * P;
+    LPI_LAUNCH(cp_bwd_t_kernel, dim3((rows + 3) / 4), dim3(256), 0, S(stream), rows, D, r, d3, dout, scratch);
+    LPI_LAUNCH(cp_bwd_g12_kernel, dim3(1), dim3(256), 0, S(stream), Lyr, P, r, d1, d2, sc, scratch, g1, g2, accumulate_g1);
+    LPI_LAUNCH(cp_bwd_g3_kernel, dim3((D + 63) / 64), dim3(1024), 0, S(stream), Lyr, P, D, r, d1, d2, sc, dout, g3);
     LPI_CHECK_LAST();
     return 0;
 }

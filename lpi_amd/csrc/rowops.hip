@@ -194,19 +194,28 @@ __global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, 
     for_chunks(d, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(dxr + col) = g.v[i]; });
 }
 
-// out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic (fixed order over b), one float4 column per thread
-__global__ __launch_bounds__(256) void rows_sum_kernel(int B, int L, int row0, int P, int d, const float* __restrict__ dx,
-                                                      float* __restrict__ out, int accumulate) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nch = d >> 2;
-    if (t >= P * nch) return;
-    const int p = t / nch, col = (t % nch) << 2;
+// out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic: 16 waves each sum a fixed subset of the batch in order, then
+// the 16 partials are added in order.  Block = (prompt row p, 256-column chunk); lane = one float4 column.
+__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, int P, int d, const float* __restrict__ dx,
+                                                       float* __restrict__ out, int accumulate) {
+    __shared__ f32x4 part[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x, col = (blockIdx.y * 64 + lane) << 2;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* src = dx + (size_t)(row0 + p) * d + col;
-    for (int b = 0; b < B; ++b) s += *reinterpret_cast<const f32x4*>(src + (size_t)b * L * d);
-    float* o = out + (size_t)p * d + col;
-    if (accumulate) s += *reinterpret_cast<const f32x4*>(o);
-    *reinterpret_cast<f32x4*>(o) = s;
+    if (col < d) {
+        const float* src = dx + (size_t)(row0 + p) * d + col;
+        for (int b = wave; b < B; b += 16) s += *reinterpret_cast<const f32x4*>(src + (size_t)b * L * d);
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col < d) {
+        f32x4 t = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) t += part[w][lane];
+        float* o = out + (size_t)p * d + col;
+        if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -447,8 +456,7 @@ extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* pa
 
 extern "C" int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate, void* stream) {
     if (!dx || !out || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || bad_row_dim(d)) return LPI_EINVAL;
-    const int n = P * (d >> 2);
-    LPI_LAUNCH(rows_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
+    LPI_LAUNCH(rows_sum_kernel, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -423,37 +423,40 @@ class DualEncoder:
 
 
 # ---------------------------------------------------------------------------------------------- loss / prompt ops
+_LOSS_WS = {}
+
+
 def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True):
     """Symmetric CE over the (global) n x n logits (loss/loss.py:75-87, slinet.py:139-141).
-    img_all/txt_all: f32 [n, E] on device.  Returns (loss[1], logits[n,n] view, dimg[n,E], dtxt[n,E])."""
+    img_all/txt_all: f32 [n, E] on device.  Returns (loss[1], logits[n,n] view, dimg[n,E], dtxt[n,E]).
+    The zero-padded operand buffers live in a per-shape workspace (padding rows stay zero; everything else is overwritten)."""
     n, E = img_all.shape
     dev = img_all.device
     npad = _pad(n)
     s = _stream()
-    A = torch.zeros(npad, E, device=dev)
-    Bm = torch.zeros(npad, E, device=dev)
+    key = (n, E, dev, torch.cuda.current_stream().cuda_stream)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        z = lambda *sh: torch.zeros(*sh, device=dev)  # noqa: E731
+        ws = _LOSS_WS[key] = {"A": z(npad, E), "B": z(npad, E), "logits": z(npad, npad), "lse": z(2, npad), "dlog": z(npad, npad),
+                              "At": z(E, npad), "Bt": z(E, npad), "dlt": z(npad, npad), "dI": z(npad, E), "dT": z(npad, E)}
+    A, Bm, logits, lse = ws["A"], ws["B"], ws["logits"], ws["lse"]
     A[:n].copy_(img_all)
     Bm[:n].copy_(txt_all)
-    logits = torch.zeros(npad, npad, device=dev)
     gemm(F32, A, Bm, logits, npad, npad, E, alpha=scale)
-    loss = torch.zeros(1, device=dev)
-    lse = torch.zeros(2, npad, device=dev)
-    dlog = torch.zeros(npad, npad, device=dev) if need_grad else None
+    loss = torch.empty(1, device=dev)
+    dlog = ws["dlog"] if need_grad else None
     call("lpi_clip_loss_fwd_bwd", n, logits, npad, 1.0, loss, dlog, npad, lse[0], lse[1], s)
     if not need_grad:
         return loss, logits[:n, :n], None, None
     # dI = scale * dlogits @ T ; dT = scale * dlogits^T @ I   (NT form: B operand = T^T / I^T)
-    At = torch.zeros(E, npad, device=dev)
-    Bt = torch.zeros(E, npad, device=dev)
+    At, Bt, dlt, dI, dT = ws["At"], ws["Bt"], ws["dlt"], ws["dI"], ws["dT"]
     call("lpi_transpose", F32, npad, E, A, E, At, npad, s)
     call("lpi_transpose", F32, npad, E, Bm, E, Bt, npad, s)
-    dlt = torch.zeros(npad, npad, device=dev)
     call("lpi_transpose", F32, npad, npad, dlog, npad, dlt, npad, s)
-    dI = torch.zeros(npad, E, device=dev)
-    dT = torch.zeros(npad, E, device=dev)
     gemm(F32, dlog, Bt, dI, npad, E, npad, alpha=scale)
     gemm(F32, dlt, At, dT, npad, E, npad, alpha=scale)
-    return loss, logits[:n, :n], dI[:n], dT[:n]
+    return loss, logits[:n, :n], dI[:n].clone(), dT[:n].clone()
 
 
 def prompt_cp_fwd(d1, d2, d3, scale=1.0):
@@ -469,7 +472,8 @@ def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0):
     P, D = d2.shape[0], d3.shape[0]
     g2 = torch.empty_like(d2)
     g3 = torch.empty_like(d3)
-    call("lpi_prompt_cp_bwd", Lyr, P, D, r, d1, d2, d3, float(scale), dout.contiguous(), g1, g2, g3, int(accumulate_g1), _stream())
+    scratch = torch.empty(Lyr * P * r, device=d1.device)
+    call("lpi_prompt_cp_bwd", Lyr, P, D, r, d1, d2, d3, float(scale), dout.contiguous(), g1, g2, g3, int(accumulate_g1), scratch, _stream())
     return g2, g3
 
 

@@ -23,7 +23,8 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
     fwd = lambda: call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, causal, s())  # noqa: E731
     bwd = lambda: call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, s())  # noqa: E731
     out = []
-    for fn, fl in ((fwd, 4.0 * L * L * 64 * H * B), (bwd, 8.0 * L * L * 64 * H * B)):
+    for fn, fl, key3 in ((fwd, 4.0 * L * L * 64 * H * B, 0), (bwd, 8.0 * L * L * 64 * H * B, 0), (bwd, 8.0 * L * L * 64 * H * B, 1)):
+        call("lpi_set_tuning", 3, key3)
         best = 1e9
         for _ in range(3):
             fn(); fn()
@@ -35,4 +36,5 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 100)
         out.append(f"{best:7.1f} us {fl / best / 1e6:6.1f} TF")
-    print(f"{name:7s} L={L:3d} fwd {out[0]} | bwd {out[1]}  (dense algorithmic FLOPs)")
+    call("lpi_set_tuning", 3, 0)
+    print(f"{name:7s} L={L:3d} fwd {out[0]} | bwd fused {out[1]} | bwd two-pass {out[2]}  (dense algorithmic FLOPs)")
