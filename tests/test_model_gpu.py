@@ -144,3 +144,60 @@ def test_patch14_rank8_depth2_vs_oracle(dtype, tol):
         for k in synth.PROMPT_NAMES:
             g, r = fac[k].grad.cpu().numpy(), ref["grad." + k]
             assert maxerr(g, r) <= 5e-4 * np.abs(r).max() + 1e-6, k
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_small_and_odd_batches_f32(batch):
+    """Ragged sizes: B=1 and B=3 (row padding to the GEMM tile, single-row contrastive matrix) vs the f64 oracle."""
+    cfg = synth.TINY
+    sd = synth.clip_state_dict(cfg)
+    fac_np = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    img, ids = synth.images(batch, cfg.image_resolution), synth.token_ids(batch)
+    ref = O.train_step(O.Oracle(cfg, sd, torch.float64), img, ids, fac_np, depth=2)
+    enc = DualEncoder(cfg, sd, dtype="f32", device=DEV)
+    fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in fac_np.items()}
+    out = train_step(enc, torch.from_numpy(img).to(DEV), torch.from_numpy(ids).to(DEV), fac, 2)
+    assert maxerr(out["img_f"].cpu().numpy(), ref["img_f"]) < 2e-5
+    assert abs(float(out["base_loss"]) - float(ref["base_loss"])) < 1e-5
+    for k in synth.PROMPT_NAMES:
+        g, r = fac[k].grad.cpu().numpy(), ref["grad." + k]
+        assert maxerr(g, r) <= 5e-4 * np.abs(r).max() + 1e-6, k
+
+
+def test_longest_caption_and_eot_position():
+    """EOT in the last slot (a caption that fills all 77 positions) and the shortest legal caption: EOT index + causal mask."""
+    cfg = synth.TINY
+    sd = synth.clip_state_dict(cfg)
+    ids = synth.token_ids(3)
+    ids[0, :] = 0
+    ids[0, :77] = [synth.SOT] + [synth.X_TOKEN] * 16 + list(range(400, 400 + 59)) + [synth.EOT]     # 1 + 16 + 59 + 1 = 77
+    ids[1, :] = 0
+    ids[1, :19] = [synth.SOT] + [synth.X_TOKEN] * 16 + [synth.DOT_TOKEN, synth.EOT]
+    assert ids[0].argmax() == 76 and ids[1].argmax() == 18
+    fac_np = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    orc = O.Oracle(cfg, sd, torch.float64)
+    fac_t = {k: torch.from_numpy(v).double() for k, v in fac_np.items()}
+    _, txt = O.decomposed_prompt(fac_t)
+    tp = txt.unsqueeze(0).expand(3, -1, -1, -1)
+    ref = O.l2_normalise(orc.encode_text(orc.text_embed(torch.from_numpy(ids), tp[:, 0]), torch.from_numpy(ids), tp, 2)).numpy()
+    enc = DualEncoder(cfg, sd, dtype="f32", device=DEV)
+    got = enc.encode_text(torch.from_numpy(ids).to(DEV), txt.float().to(DEV), depth=2).cpu().numpy()
+    assert maxerr(got, ref) < 2e-5
+
+
+def test_bitwise_reproducible_gradients():
+    """No atomics anywhere on the path: two runs of the same step give bit-identical features, losses and gradients."""
+    cfg = synth.TINY
+    sd = synth.clip_state_dict(cfg)
+    enc = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
+    img = torch.from_numpy(synth.images(6, cfg.image_resolution)).to(DEV)
+    ids = torch.from_numpy(synth.token_ids(6)).to(DEV)
+    runs = []
+    for _ in range(2):
+        fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True)
+               for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+        out = train_step(enc, img, ids, fac, 2)
+        torch.cuda.synchronize()
+        runs.append([out["img_f"].clone(), out["txt_f"].clone(), out["base_loss"].clone()] + [fac[k].grad.clone() for k in synth.PROMPT_NAMES])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
