@@ -47,14 +47,18 @@ def byte_alphabet():
     return table
 
 
+try:
+    import ftfy as _ftfy
+except ImportError:          # ftfy only repairs mojibake; plain text is unchanged by it
+    _ftfy = None
+
+
 def _clean(text: str) -> str:
-    try:
-        import ftfy
-        text = ftfy.fix_text(text)
-    except ImportError:     # ftfy only repairs mojibake; plain text is unchanged by it
-        pass
-    text = html.unescape(html.unescape(text)).strip()
-    return _WS.sub(" ", text).strip().lower()
+    if _ftfy is not None:
+        text = _ftfy.fix_text(text)
+    if "&" in text:
+        text = html.unescape(html.unescape(text))
+    return _WS.sub(" ", text.strip()).strip().lower()
 
 
 class SimpleTokenizer:
@@ -71,6 +75,7 @@ class SimpleTokenizer:
         self.rank = {m: i for i, m in enumerate(merges)}
         self.alpha = alpha
         self._memo = {}
+        self._text_memo = {}       # whole cleaned string -> ids: dataset captions repeat every epoch (the hot loop is host-bound otherwise)
 
     def _merge_word(self, word: str):
         """Greedy lowest-rank-first pair merging of one pre-token (already mapped to the byte alphabet)."""
@@ -100,12 +105,22 @@ class SimpleTokenizer:
         return ids
 
     def encode(self, text: str):
+        got = self._text_memo.get(text)
+        if got is not None:
+            return got
         out = []
+        alpha = self.alpha
         for tok in _SPLIT.findall(_clean(text)):
             if tok in (SOT_TEXT, EOT_TEXT):
                 out.append(self.encoder[tok])
                 continue
-            out.extend(self._merge_word("".join(self.alpha[b] for b in tok.encode("utf-8"))))
+            ids = self._memo.get(tok)
+            if ids is None:
+                ids = self._merge_word("".join(alpha[b] for b in tok.encode("utf-8")))
+                self._memo[tok] = ids
+            out.extend(ids)
+        if len(self._text_memo) < 2_000_000:
+            self._text_memo[text] = out
         return out
 
 
@@ -114,14 +129,18 @@ def tokenize(tokenizer: SimpleTokenizer, texts, context_length: int = 77, trunca
     import torch
     if isinstance(texts, str):
         texts = [texts]
+    import numpy as np
     sot, eot = tokenizer.encoder[SOT_TEXT], tokenizer.encoder[EOT_TEXT]
-    out = torch.zeros(len(texts), context_length, dtype=torch.long)
+    out = np.zeros((len(texts), context_length), dtype=np.int64)
     for i, t in enumerate(texts):
-        ids = [sot] + tokenizer.encode(t) + [eot]
-        if len(ids) > context_length:
+        ids = tokenizer.encode(t)
+        n = len(ids) + 2
+        if n > context_length:
             if not truncate:
                 raise RuntimeError(f"Input {t} is too long for context length {context_length}")
-            ids = ids[:context_length]
-            ids[-1] = eot
-        out[i, :len(ids)] = torch.tensor(ids)
-    return out
+            ids = ids[:context_length - 2]
+            n = context_length
+        out[i, 0] = sot
+        out[i, 1:n - 1] = ids
+        out[i, n - 1] = eot
+    return torch.from_numpy(out)
