@@ -62,8 +62,9 @@ int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K,
 
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
  * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x f32 [rows,d] (row stride ldx), y `dtype`.
- * bwd: dx[r,:] (f32, in/out: residual-stream gradient) += LN'(dy[r,:]); optionally also writes a `dtype`
- *      copy dx_cast (the next dgrad GEMM's operand).  dy is `dy_dtype`. */
+ * bwd: dx[r,:] (f32, in/out: residual-stream gradient) += LN'(dy[r,:]); optionally also writes a `cast_dtype`
+ *      copy dx_cast (the next dgrad GEMM's operand).  dx == NULL: dx_cast itself is the in/out gradient stream (bf16 mode keeps
+ *      no f32 copy).  dy is `dy_dtype`. */
 int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int ldx, const float* gamma, const float* beta,
                       void* y, int ldy, float* mean, float* rstd, void* stream);
 int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy,
@@ -93,14 +94,14 @@ int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float
  * patchify: image [B,3,R,R] f32 -> cols [B*G*G (padded rows untouched), Kp] `dtype`, Kp >= 3*ps*ps zero padded.
  * assemble + ln_pre: x0[b] = LN([cls+pos0 ; prompts[b,0] (no pos) ; patch_emb[b]+pos1..]) -> x0 f32 [B*L,d];
  * prompt0: f32, element (b,p,:) at prompt0 + b*prompt_bstride + p*d (bstride 0 = broadcast, slinet.py:119).
- * bwd: applies LN' to rows 1..P of dx0 IN PLACE (dx0 is dead afterwards; the other rows' input gradients are
+ * bwd (dx0 is `dtype`: f32, or the bf16 gradient stream): applies LN' to rows 1..P of dx0 IN PLACE (dx0 is dead afterwards; the other rows' input gradients are
  *      not needed because the backbone is frozen), then dprompt[p,:] = sum_b dx0[b,1+p,:] (f32 [P,d]; the batch
  *      sum is the gradient of the training-time stride-0 broadcast, slinet.py:119). */
 int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream);
 int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
                          const float* pos, const float* prompt0, long prompt_bstride,
                          const float* gamma, const float* beta, float* x0, float* mean, float* rstd, void* stream);
-int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, const float* prompt0, long prompt_bstride,
+int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, const float* prompt0, long prompt_bstride,
                          const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream);
 
 /* ---- a6/a7: text front end          replaces: models/clip/prompt_learner.py:52-53,128-163 --------------
@@ -108,8 +109,8 @@ int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, const float* p
  * bwd: dctx[p,:] (+)= sum_b dx0[b,1+p,:] */
 int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
                       const float* ctx, long ctx_bstride, float* x0, void* stream);
-int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate,
-                            void* stream);
+int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate,
+                            void* stream);   /* dx is `dtype` */
 
 /* ---- F1: deep prompts                               replaces: models/clip/model.py:189-193 -------------
  * x[b, 1..P, :] += prompt_l[b?, p, :]   (in place on the f32 residual stream) */

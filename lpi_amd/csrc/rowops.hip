@@ -103,12 +103,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY*
         xr.v[i] = *reinterpret_cast<const f32x4*>(xp + col);
     });
     ln_bwd_row(g, xr, d, lane, mean[row], rstd[row], gamma);
-    float* dxr = dx + (size_t)row * lddx;
-    for_chunks(d, lane, [&](int i, int col) {
-        f32x4 t = *reinterpret_cast<const f32x4*>(dxr + col) + g.v[i];
-        *reinterpret_cast<f32x4*>(dxr + col) = t;
-        if (dx_cast) Elem<TCAST>::st4(dx_cast + (size_t)row * ldcast + col, t);
-    });
+    if (dx) {
+        float* dxr = dx + (size_t)row * lddx;
+        for_chunks(d, lane, [&](int i, int col) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(dxr + col) + g.v[i];
+            *reinterpret_cast<f32x4*>(dxr + col) = t;
+            if (dx_cast) Elem<TCAST>::st4(dx_cast + (size_t)row * ldcast + col, t);
+        });
+    } else {   // the `cast` copy IS the gradient stream (in/out), no f32 stream is kept
+        TCAST* dxr = dx_cast + (size_t)row * ldcast;
+        for_chunks(d, lane, [&](int i, int col) { Elem<TCAST>::st4(dxr + col, Elem<TCAST>::ld4(dxr + col) + g.v[i]); });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
 }
 
 // LN' on the prompt rows only, in place on dx0 (the other rows' input gradients are not needed: frozen weights)
-__global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, int P, int d, float* __restrict__ dx0,
+template <typename TS>
+__global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, int P, int d, TS* __restrict__ dx0,
                                                                  const float* __restrict__ prompt0, long pbs,
                                                                  const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd) {
@@ -184,27 +190,28 @@ __global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, 
     const int b = w / P, p = w % P;
     const int row = b * L + 1 + p;
     Row g, x;
-    float* dxr = dx0 + (size_t)row * d;
+    TS* dxr = dx0 + (size_t)row * d;
     const float* pr = prompt0 + (size_t)b * pbs + (size_t)p * d;
     for_chunks(d, lane, [&](int i, int col) {
-        g.v[i] = *reinterpret_cast<const f32x4*>(dxr + col);
+        g.v[i] = Elem<TS>::ld4(dxr + col);
         x.v[i] = *reinterpret_cast<const f32x4*>(pr + col);
     });
     ln_bwd_row(g, x, d, lane, mean[row], rstd[row], gamma);
-    for_chunks(d, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(dxr + col) = g.v[i]; });
+    for_chunks(d, lane, [&](int i, int col) { Elem<TS>::st4(dxr + col, g.v[i]); });
 }
 
 // out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic: 16 waves each sum a fixed subset of the batch in order, then
 // the 16 partials are added in order.  Block = (prompt row p, 256-column chunk); lane = one float4 column.
-__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, int P, int d, const float* __restrict__ dx,
+template <typename TS>
+__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, int P, int d, const TS* __restrict__ dx,
                                                        float* __restrict__ out, int accumulate) {
     __shared__ f32x4 part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x, col = (blockIdx.y * 64 + lane) << 2;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (col < d) {
-        const float* src = dx + (size_t)(row0 + p) * d + col;
-        for (int b = wave; b < B; b += 16) s += *reinterpret_cast<const f32x4*>(src + (size_t)b * L * d);
+        const TS* src = dx + (size_t)(row0 + p) * d + col;
+        for (int b = wave; b < B; b += 16) s += Elem<TS>::ld4(src + (size_t)b * L * d);
     }
     part[wave][lane] = s;
     __syncthreads();
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int B, int L, int d, 
     const float* s = src + (size_t)b * d;
     for_chunks(d, lane, [&](int, int col) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(s + col);
-        *reinterpret_cast<f32x4*>(dst + row * d + col) = v;
+        if (dst) *reinterpret_cast<f32x4*>(dst + row * d + col) = v;
         if (dst_cast) Elem<TCAST>::st4(dst_cast + row * d + col, v);
     });
 }
@@ -411,7 +418,7 @@ extern "C" int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int
 extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy, const float* x, int ldx,
                                  const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
                                  int ldcast, void* stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
+    if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_cast) || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
 #define LNB(TDY, TC) LPI_LAUNCH((ln_bwd_kernel<TDY, TC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
@@ -454,21 +461,25 @@ extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* pa
     return 0;
 }
 
-extern "C" int lpi_rows_sum_over_batch(int B, int L, int row0, int P, int d, const float* dx, float* out, int accumulate, void* stream) {
+extern "C" int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate, void* stream) {
     if (!dx || !out || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || bad_row_dim(d)) return LPI_EINVAL;
-    LPI_LAUNCH(rows_sum_kernel, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, dx, out, accumulate);
+    if (dtype == LPI_F32) LPI_LAUNCH(rows_sum_kernel<float>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, (const float*)dx, out, accumulate);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(rows_sum_kernel<bf16_t>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, (const bf16_t*)dx, out, accumulate);
+    else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
 
-extern "C" int lpi_vis_assemble_bwd(int B, int G2, int P, int d, float* dx0, const float* prompt0, long prompt_bstride,
+extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, const float* prompt0, long prompt_bstride,
                                     const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream) {
     if (!dx0 || !prompt0 || !gamma || !mean || !rstd || !dprompt || B <= 0 || P <= 0 || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
     const int L = 1 + P + G2;
-    LPI_LAUNCH(vis_prompt_rows_bwd_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, dx0, prompt0,
-                       prompt_bstride, gamma, mean, rstd);
+    dim3 g(rows_grid((long)B * P)), bl(256);
+    if (dtype == LPI_F32) LPI_LAUNCH(vis_prompt_rows_bwd_kernel<float>, g, bl, 0, S(stream), B, L, P, d, (float*)dx0, prompt0, prompt_bstride, gamma, mean, rstd);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(vis_prompt_rows_bwd_kernel<bf16_t>, g, bl, 0, S(stream), B, L, P, d, (bf16_t*)dx0, prompt0, prompt_bstride, gamma, mean, rstd);
+    else return LPI_EINVAL;
     LPI_CHECK_LAST();
-    return lpi_rows_sum_over_batch(B, L, 1, P, d, dx0, dprompt, 0, stream);
+    return lpi_rows_sum_over_batch(dtype, B, L, 1, P, d, dx0, dprompt, 0, stream);
 }
 
 extern "C" int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
@@ -517,7 +528,7 @@ extern "C" int lpi_gather_rows(int B, int L, int d, const float* src, const int3
 
 extern "C" int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
                                 void* stream) {
-    if (!src || !dst || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
+    if (!src || (!dst && !dst_cast) || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
     dim3 g(rows_grid(B)), b(256);
     if (cast_dtype == LPI_F32) LPI_LAUNCH(scatter_rows_kernel<float>, g, b, 0, S(stream), B, L, d, src, idx, dst, (float*)dst_cast);
     else if (cast_dtype == LPI_BF16) LPI_LAUNCH(scatter_rows_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, src, idx, dst, (bf16_t*)dst_cast);

@@ -147,7 +147,8 @@ class Tower:
         }
         if train:
             ws.update({
-                "dx": z(Mp, d), "dh": z(Mp, d, dtype=T), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
+                "dx": z(Mp, d) if self.dt == F32 else None,      # bf16 mode: the bf16 stream dxT is the only gradient stream
+                "dh": z(Mp, d, dtype=T), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
                 "delta": z(B, H, L),
                 "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
                 "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
@@ -200,15 +201,13 @@ class Tower:
         B, L, Mp = ws["B"], ws["L"], ws["Mp"]
         M = B * L
         dx, dh, dctx, dqkv = ws["dx"], ws["dh"], ws["dctx"], ws["dqkv"]
-        dxT = ws["dxT"] if dt != F32 else dx
+        dxT = ws["dxT"] if dt != F32 else dx          # the stream the dgrad GEMMs read; in bf16 mode also the accumulator
         P = prompts.shape[-2] if prompts is not None else 0
         for i in reversed(range(len(self.blocks))):
             blk = self.blocks[i]
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
             if i == len(self.blocks) - 1 and not POOLED_LAST:
-                dx.zero_()
-                if dt != F32:
-                    dxT.zero_()
+                dxT.zero_()
                 call("lpi_scatter_rows", dt, B, L, d, ws["c_dx"], pool_idx, dx, None if dt == F32 else dxT, s)
             if i == len(self.blocks) - 1 and POOLED_LAST:
                 # last block: MLP backward on the pooled rows, then scatter into the (zeroed) full-size gradient stream
@@ -219,24 +218,22 @@ class Tower:
                 gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, s)
-                dx.zero_()
-                if dt != F32:
-                    dxT.zero_()
+                dxT.zero_()
                 call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
             else:
                 du = ws["g"]
                 gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
                 call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
-                     None if dt == F32 else dxT, d, s)
+                     None if dt == F32 else dxT, d, s)      # dx is None in bf16 mode: dxT accumulates in place
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
-                call("lpi_rows_sum_over_batch", B, L, 1, P, d, dx, dprompts[i], 0, s)
-        return dx
+                call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
+        return dxT
 
 
 class DualEncoder:
@@ -368,7 +365,7 @@ class DualEncoder:
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
         self.vis.backward(ws, pr, depth, dpr, None)
-        call("lpi_vis_assemble_bwd", B, cfg.n_patches, P, d, ws["dx"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
+        call("lpi_vis_assemble_bwd", dt, B, cfg.n_patches, P, d, ws["dx"] if dt == F32 else ws["dxT"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
              ws["front"]["stat"][1], dpr[0], s)
         return dpr
 
@@ -418,7 +415,7 @@ class DualEncoder:
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
         self.txt.backward(ws, pr, depth, dpr, hw["idx"])
-        call("lpi_rows_sum_over_batch", B, L, 1, P, d, ws["dx"], dpr[0], 0, s)
+        call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
 
 

@@ -158,6 +158,24 @@ def test_layernorm_fwd_bwd(dt, d):
     assert relerr(cast, ref) < TOL[dt]
 
 
+def test_layernorm_bwd_bf16_gradient_stream():
+    """dx == NULL: the bf16 copy is the in/out residual-gradient stream (no f32 stream kept in bf16 mode)."""
+    rows, d = 131, 768
+    x = rnd(rows, d, seed=5) * 2 + 0.3
+    gam = 1 + 0.1 * rnd(d, seed=6)
+    dy = rnd(rows, d, seed=8).to(torch.bfloat16)
+    dx0 = rnd(rows, d, seed=9).to(torch.bfloat16)
+    st = torch.zeros(2, rows, device=DEV)
+    y = torch.zeros(rows, d, device=DEV, dtype=torch.bfloat16)
+    xd = x.to(DEV)
+    call("lpi_layernorm_fwd", BF16, rows, d, xd, d, gam.to(DEV), torch.zeros(d, device=DEV), y, d, st[0], st[1], stream())
+    xr = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (d,), gam.double(), None, 1e-5).backward(dy.double())
+    stream_t = dx0.clone().to(DEV)
+    call("lpi_layernorm_bwd", BF16, BF16, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
+    assert relerr(stream_t, dx0.double() + xr.grad) < 1e-2
+
+
 def attn_ref(qkv, B, L, H, causal):
     d = H * 64
     q, k, v = qkv.double().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4)
