@@ -24,6 +24,9 @@ extern int g_lpi_tuning[8];
 
 namespace {
 
+#ifndef EPI_UNROLL
+#define EPI_UNROLL 4
+#endif
 constexpr int T256 = 256;
 constexpr int ROWB = 128;                 // bytes per staged row
 constexpr int HALF_BYTES = 128 * ROWB;    // 16 KiB
@@ -36,7 +39,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int stagger)
+    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int stagger, int group_m)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = group_m;
     const int group = bid / (GROUP_M * tiles_n);
     const int first_m = group * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
                     *reinterpret_cast<f32x4*>(smem + (wm * 64 + mi * 16 + lrow) * ERS + (nh * 128 + wn * 32 + ni * 16 + lcol) * 4) = acc[nh][ni][mh][mi];
         __syncthreads();
         const int r0 = wave * 16;
-#pragma unroll 4
+#pragma unroll EPI_UNROLL
         for (int rr = 0; rr < 16; ++rr) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(smem + (r0 + rr) * ERS + lane * 16);
             gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + mh * 128 + r0 + rr, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
@@ -240,7 +243,7 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
         attr_set = true;
     }
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-               ldr, (T*)aux, ldaux, alpha, tm, tn, g_lpi_tuning[2]);
+               ldr, (T*)aux, ldaux, alpha, tm, tn, g_lpi_tuning[2], g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
     LPI_CHECK_LAST();
     return 0;
 }
