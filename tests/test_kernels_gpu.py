@@ -238,7 +238,7 @@ def test_prompt_cp_fwd_bwd():
     assert relerr(g1, 2 * a.grad) < 1e-5
 
 
-@pytest.mark.parametrize("n", [4, 8, 256, 300])
+@pytest.mark.parametrize("n", [1, 4, 8, 256, 300, 2048])
 def test_clip_loss(n):
     Ed = 512
     i = torch.nn.functional.normalize(rnd(n, Ed, seed=1), dim=-1)
