@@ -149,6 +149,13 @@ int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, fl
 int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp,
                            float weight, float* loss, float* dvis, float* dtxt, void* stream);
 
+/* ---- a9: task loss (nt_bxent over the tasks' flattened prompts)   replaces: loss/loss.py:6-33, models/slinet.py:167-183 ----
+ * X f32 [T, D] (row t = prompts of task t, flattened), target int32 [T,T] (task_sim > 0.4), T <= 32.  loss[0] = weight * nt_bxent(X);
+ * dx_row [D] = d loss / d X[row,:] (only the current task's prompts train; NULL or row < 0: forward only).
+ * scratch: 2*T*T floats. */
+int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const int32_t* target, float temp, float weight,
+                         float* loss, float* dx_row, float* scratch, void* stream);
+
 /* ---- misc ---------------------------------------------------------------------------------------------- */
 int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, void* stream);
 int lpi_transpose(int dtype, int rows, int cols, const void* src, int lds, void* dst, int ldd, void* stream);

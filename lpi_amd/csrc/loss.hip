@@ -232,6 +232,77 @@ __global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv
     for (long i = threadIdx.x; i < (long)nr * Dt; i += blockDim.x) dtxt[i] = dt[i / Dt];
 }
 
+// ---------------------------------------------------------------------------------------------- task loss (nt_bxent)
+// loss/loss.py:6-33 as written: cos = cosine_similarity rows of X [T,D]; diag -> +inf; z = sigmoid(cos / temp);
+// l_ij = BCEWithLogits(z_ij, t_ij) = max(z,0) - z*t + log(1 + exp(-|z|)); per row mean over positives + mean over negatives; mean over rows.
+// Three tiny kernels: Gram matrix (one workgroup per pair), loss + dL/dcos (one workgroup), dX (one workgroup per row chunk).
+__global__ __launch_bounds__(256) void gram_kernel(int T, int D, const float* __restrict__ X, float* __restrict__ G) {
+    __shared__ float part[4];
+    const int i = blockIdx.x / T, j = blockIdx.x % T;
+    if (j < i) return;                       // symmetric: compute the upper triangle, mirror below
+    const float* a = X + (size_t)i * D;
+    const float* b = X + (size_t)j * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s += a[d] * b[d];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float g = (part[0] + part[1]) + (part[2] + part[3]);
+        G[i * T + j] = g;
+        G[j * T + i] = g;
+    }
+}
+
+constexpr int MAXT = 32;
+__global__ __launch_bounds__(64) void nt_bxent_kernel(int T, const float* __restrict__ G, const int32_t* __restrict__ target, float temp,
+                                                     float weight, float* __restrict__ loss, float* __restrict__ dcos) {
+    __shared__ float rowloss[MAXT];
+    const int i = threadIdx.x;
+    if (i < T) {
+        const float ni = fmaxf(sqrtf(G[i * T + i]), 1e-8f);            // F.cosine_similarity eps
+        float lp = 0.f, ln = 0.f, np_ = 0.f;
+        for (int j = 0; j < T; ++j) np_ += (float)target[i * T + j];
+        const float nn = (float)T - np_;
+        for (int j = 0; j < T; ++j) {
+            const float nj = fmaxf(sqrtf(G[j * T + j]), 1e-8f);
+            const float cs = (i == j) ? INFINITY : G[i * T + j] / (ni * nj);
+            const float z = (i == j) ? 1.f : 1.f / (1.f + expf(-cs / temp));
+            const float t = (float)target[i * T + j];
+            const float l = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
+            // d l / d z = sigmoid(z) - t ; d z / d cos = z (1 - z) / temp ; row weights 1/(num_pos T) or 1/(num_neg T)
+            const float wrow = (t != 0.f ? 1.f / np_ : 1.f / nn) / (float)T;
+            if (t != 0.f) lp += l; else ln += l;
+            dcos[i * T + j] = (i == j) ? 0.f : weight * wrow * (1.f / (1.f + expf(-z)) - t) * z * (1.f - z) / temp;
+        }
+        rowloss[i] = lp / np_ + ln / nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < T; ++k) s += rowloss[k];
+        loss[0] = weight * s / (float)T;
+    }
+}
+
+// dX[r,:] = sum_j (dcos[r,j] + dcos[j,r]) * ( x_j / (|x_r||x_j|) - cos_rj * x_r / |x_r|^2 )   for one row r
+__global__ __launch_bounds__(256) void nt_bxent_dx_kernel(int T, int D, int r, const float* __restrict__ X, const float* __restrict__ G,
+                                                         const float* __restrict__ dcos, float* __restrict__ dx) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    const float nr = fmaxf(sqrtf(G[r * T + r]), 1e-8f);
+    const float xr = X[(size_t)r * D + d];
+    float acc = 0.f;
+    for (int j = 0; j < T; ++j) {
+        if (j == r) continue;
+        const float nj = fmaxf(sqrtf(G[j * T + j]), 1e-8f);
+        const float c = G[r * T + j] / (nr * nj);
+        const float w = dcos[r * T + j] + dcos[j * T + r];
+        acc += w * (X[(size_t)j * D + d] / (nr * nj) - c * xr / (nr * nr));
+    }
+    dx[d] = acc;
+}
+
 // ---------------------------------------------------------------------------------------------- retrieval
 // rank of the best ground-truth column under np.argsort(score)[::-1] (later index first among equal scores)
 __global__ __launch_bounds__(256) void retrieval_rank_kernel(int n_rows, int n_cols, const float* __restrict__ s, int ld,
@@ -333,6 +404,18 @@ extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const floa
     const size_t lds = ((size_t)4 * Lyr * P + 2 * Lyr * Lyr + 2 * Lyr) * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
     LPI_LAUNCH(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const int32_t* target, float temp, float weight, float* loss,
+                                    float* dx_row, float* scratch, void* stream) {
+    if (!X || !target || !loss || !scratch || T <= 0 || T > MAXT || D <= 0 || temp <= 0.f || row >= T) return LPI_EINVAL;
+    float* G = scratch;            // [T*T]
+    float* dcos = scratch + T * T; // [T*T]
+    LPI_LAUNCH(gram_kernel, dim3(T * T), dim3(256), 0, S(stream), T, D, X, G);
+    LPI_LAUNCH(nt_bxent_kernel, dim3(1), dim3(64), 0, S(stream), T, G, target, temp, weight, loss, dcos);
+    if (dx_row && row >= 0) LPI_LAUNCH(nt_bxent_dx_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), T, D, row, X, G, dcos, dx_row);
     LPI_CHECK_LAST();
     return 0;
 }

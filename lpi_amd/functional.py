@@ -106,3 +106,30 @@ class AlignLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dv, dt = ctx.saved_tensors
         return dv * g, dt * g, None, None
+
+
+class NtBxentFn(torch.autograd.Function):
+    """nt_bxent_loss over the stacked, flattened prompts of tasks 0..t (loss/loss.py:6-33 via slinet.py:167-183).  Only row `row`
+    (the task being trained) receives a gradient: the other tasks' prompts are frozen (sprompt.py:230-237)."""
+
+    @staticmethod
+    def forward(ctx, X, target, temp, row):
+        Xc = X.detach().contiguous().float()
+        T, D = Xc.shape
+        loss = torch.empty(1, device=X.device)
+        need = X.requires_grad
+        dx = torch.empty(D, device=X.device) if need else None
+        scratch = torch.empty(2 * T * T, device=X.device)
+        E.call("lpi_nt_bxent_fwd_bwd", T, D, int(row) if need else -1, Xc, target.to(device=X.device, dtype=torch.int32).contiguous(),
+               float(temp), 1.0, loss, dx, scratch, E._stream())
+        ctx.row, ctx.shape = int(row), (T, D)
+        if need:
+            ctx.save_for_backward(dx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        full = torch.zeros(ctx.shape, device=dx.device)
+        full[ctx.row] = dx * g
+        return full, None, None, None

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from lpi_amd import synth
-from lpi_amd.functional import AlignLossFn, ClipLossFn, EncodeImageFn, EncodeTextFn
+from lpi_amd.functional import AlignLossFn, ClipLossFn, EncodeImageFn, EncodeTextFn, NtBxentFn
 from lpi_amd.retrieval.loss.loss import ClipLoss, nt_bxent_loss
 from lpi_amd.retrieval.models.clip.prompt_learner import PromptLearner, cfgc
 from lpi_amd.retrieval.models.prompts.prompts import DecomposedPrompt
@@ -142,8 +142,11 @@ class SliNet(nn.Module):
         sim = torch.tensor(np.loadtxt(path)[:task_id + 1, :task_id + 1])
         dev = self.prompts[0].dim_1_share.device
         target = (sim > 0.4).type(torch.int).to(dev)
-        vs = torch.stack([self.prompts[i]()[0].view(-1) for i in range(task_id + 1)])
-        ts = torch.stack([self.prompts[i]()[1].view(-1) for i in range(task_id + 1)])
+        dense = [self.prompts[i]() for i in range(task_id + 1)]
+        vs = torch.stack([v.reshape(-1) for v, _ in dense])
+        ts = torch.stack([t.reshape(-1) for _, t in dense])
+        if vs.is_cuda:      # HIP kernels (lpi_nt_bxent_fwd_bwd); the torch-op form below is only reachable without a GPU engine
+            return (NtBxentFn.apply(vs, target, 0.001, task_id) + NtBxentFn.apply(ts, target, 0.001, task_id)) / 2
         return (nt_bxent_loss(vs, target, 0.001) + nt_bxent_loss(ts, target, 0.001)) / 2
 
     # ------------------------------------------------------------------ slinet.py:185-220

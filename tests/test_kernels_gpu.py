@@ -284,3 +284,26 @@ def test_retrieval_rank_and_topk():
     call("lpi_topk", n_img, n_txt, 5, s.to(DEV), n_txt, idx, val, stream())
     refi = np.stack([np.argsort(s[i].numpy(), kind="stable")[::-1][:5] for i in range(n_img)])
     assert (idx.cpu().numpy() == refi).all()
+
+
+def test_nt_bxent_task_loss():
+    """Task loss (loss/loss.py:6-33 as written) forward + gradient of the current task's row vs torch autograd in f64."""
+    T, D = 5, 4096
+    X = rnd(T, D, seed=21)
+    X[1] = X[0] + 0.05 * rnd(D, seed=22)            # a similar pair so that the sigmoid is not saturated everywhere
+    tgt = torch.eye(T, dtype=torch.int32)
+    tgt[0, 1] = tgt[1, 0] = 1
+    temp, row = 0.5, 1
+    Xr = X.double().requires_grad_(True)
+    xn = Xr / Xr.norm(dim=-1, keepdim=True)
+    cs = (xn @ xn.t()).masked_fill(torch.eye(T, dtype=torch.bool), float("inf"))
+    l = torch.nn.functional.binary_cross_entropy_with_logits((cs / temp).sigmoid(), tgt.double(), reduction="none")
+    pos = tgt.bool()
+    ref = ((l * pos).sum(1) / pos.sum(1) + (l * ~pos).sum(1) / (~pos).sum(1)).mean()
+    ref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dx = torch.zeros(D, device=DEV)
+    scratch = torch.zeros(2 * T * T, device=DEV)
+    call("lpi_nt_bxent_fwd_bwd", T, D, row, X.to(DEV), tgt.to(DEV), temp, 1.0, loss, dx, scratch, stream())
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert relerr(dx, Xr.grad[row]) < 1e-4
