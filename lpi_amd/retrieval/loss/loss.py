@@ -23,29 +23,33 @@ def nt_bxent_loss(x, target, temperature=1.0):
     return (loss_pos / num_pos + loss_neg / (n - num_pos)).mean()
 
 
+class _ClipLossOnLogitsFn(torch.autograd.Function):
+    """Symmetric CE of a pre-scaled [n, n] logits matrix through lpi_clip_loss_fwd_bwd (row / column log-sum-exp kernels)."""
+
+    @staticmethod
+    def forward(ctx, lg):
+        from lpi_amd import engine as E
+        n = lg.shape[0]
+        lgc = lg.detach().float().contiguous()
+        loss = torch.zeros(1, device=lg.device)
+        dl = torch.zeros_like(lgc)
+        lse = torch.zeros(2, n, device=lg.device)
+        E.call("lpi_clip_loss_fwd_bwd", n, lgc, n, 1.0, loss, dl, n, lse[0], lse[1], E._stream())
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.saved_tensors[0] * g
+
+
 class ClipLoss(nn.Module):
+    """Same constructor keywords as the reference's ClipLoss (loss/loss.py:38-53); forward(logits) as loss.py:75-87."""
+
     def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=True, rank=0, world_size=1, use_horovod=False):
         super().__init__()
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size, self.use_horovod = rank, world_size, use_horovod
 
     def forward(self, logits):
-        from lpi_amd import engine as E
-
-        class _Fn(torch.autograd.Function):
-            @staticmethod
-            def forward(ctx, lg):
-                n = lg.shape[0]
-                lgc = lg.detach().float().contiguous()
-                loss = torch.zeros(1, device=lg.device)
-                dl = torch.zeros_like(lgc)
-                lse = torch.zeros(2, n, device=lg.device)
-                E.call("lpi_clip_loss_fwd_bwd", n, lgc, n, 1.0, loss, dl, n, lse[0], lse[1], E._stream())
-                ctx.save_for_backward(dl)
-                return loss[0]
-
-            @staticmethod
-            def backward(ctx, g):
-                return ctx.saved_tensors[0] * g
-
-        return _Fn.apply(logits)
+        return _ClipLossOnLogitsFn.apply(logits)
