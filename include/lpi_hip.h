@@ -81,6 +81,15 @@ int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, voi
 int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
                  const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
                  int causal, void* stream);
+/* The same attention for ONE query row per sample — token idx[b] (NULL: token 0) — used in the LAST block, whose output is read
+ * at the pooled token only (model.py:255 CLS, prompt_learner.py:61 EOT): exact dead-row elimination.  q, ctx, dctx, dq: [B, d]
+ * `dtype` (row b = sample b); K and V are read from columns d..3d of qkv [B*L, 3d]; lse: [B, H] f32.  causal != 0: keys <= idx[b].
+ * bwd writes dK, dV into columns d..3d of dqkv for all L rows of every sample (zeros behind the mask); columns 0..d are untouched. */
+int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ldqkv, const int32_t* idx,
+                        void* ctx, int ldctx, float* lse, int causal, void* stream);
+int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ldqkv, const int32_t* idx,
+                        const void* dctx, int lddctx, const float* lse, void* dq, int lddq, void* dqkv, int lddqkv, int causal,
+                        void* stream);
 
 /* ---- a1: DecomposedPrompt                          replaces: models/prompts/prompts.py:38-57 -----------
  * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout; scratch: Lyr*P*r floats. */
@@ -131,6 +140,9 @@ int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float* dy, int ld
 int lpi_gather_rows(int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* stream);
 int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
                      void* stream);
+/* dst[b*L + idx[b], :] += src[b, :]  (`dtype` both; idx NULL: token 0) — adds the pooled rows' dQ contribution to d(LN1 output). */
+int lpi_scatter_add_rows(int dtype, int B, int L, int d, const void* src, int ld_src, const int32_t* idx, void* dst, int ld_dst,
+                         void* stream);
 int lpi_l2norm_fwd(int B, int E, const float* x, int ldx, float* y, int ldy, float* inv_norm, void* stream);
 int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int lddy, const float* inv_norm,
                    float* dx, int lddx, void* stream);

@@ -31,6 +31,9 @@ SIGNATURES = {
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "lpi_attn_pooled_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
+    "lpi_attn_pooled_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
+    "lpi_scatter_add_rows": [_I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "lpi_prompt_cp_fwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P],
     "lpi_prompt_cp_bwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P],
     "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],

@@ -1,0 +1,224 @@
+// Attention with ONE query row per sample: the last block of a tower, where only the pooled token (CLS / EOT) is read by the
+// heads (model.py:255, prompt_learner.py:61), so Q, the softmax row, the context row and their gradients exist for that row alone;
+// K and V (and dK, dV) still cover every token of the sample.  Exact dead-row elimination of nn.MultiheadAttention
+// (model.py:179-184), not an approximation.  HBM-bound: one pass over the sample's K and V (forward) / K, V, dK, dV (backward).
+//
+// One 4-wave workgroup per (sample, head), keys interleaved over the waves.  Scores: 16 lanes x 4 dims per key, 4 keys per wave
+// instruction (each key row is one contiguous 128 B / 256 B read), 4-step xor reduction.  Softmax row in LDS; every wave reduces
+// it for itself.  Context / dQ / dK / dV: lane = head dim, loop over keys, so every row access is one whole head row; the four
+// partial context / dQ rows are summed through LDS in a fixed order.  No atomics: bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int WPB = 4;   // waves per workgroup
+
+__device__ __forceinline__ float reduce16(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+template <typename T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
+    int B, int L, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    T* __restrict__ ctx, int ldo, float* __restrict__ lse, int causal)
+{
+    extern __shared__ float sm[];
+    float* s = sm;                 // scores
+    float* p = sm + Lp;            // exp(score - max)
+    float* red = sm + 2 * Lp;      // [WPB][64] partial context rows
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H, d = H * DH;
+    const int row = idx ? idx[b] : 0;
+    const int nv = causal ? row + 1 : L;           // keys the query row may attend to
+    const int kk = lane >> 4, g = lane & 15;
+    const f32x4 q4 = Elem<T>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
+    const T* kbase = qkv + (size_t)b * L * ld + d + h * DH;
+    const T* vbase = kbase + d;
+    for (int j0 = wave * 4; j0 < nv; j0 += 4 * WPB) {
+        const int j = j0 + kk;
+        float v = 0.f;
+        if (j < nv) v = dot4(q4, Elem<T>::ld4(kbase + (size_t)j * ld + 4 * g));
+        v = reduce16(v);
+        if (g == 0 && j < nv) s[j] = v * 0.125f;   // 1/sqrt(64)
+    }
+    __syncthreads();
+    float m = -INFINITY;                           // every wave reduces the whole row itself: no cross-wave exchange
+    for (int j = lane; j < nv; j += WAVE) m = fmaxf(m, s[j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < nv; j += WAVE) sum += __expf(s[j] - m);
+    sum = wave_sum(sum);
+    for (int j = threadIdx.x; j < nv; j += WAVE * WPB) p[j] = __expf(s[j] - m);
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = wave; j < nv; j += WPB) acc += p[j] * Elem<T>::ld(vbase + (size_t)j * ld + lane);
+    red[wave * DH + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) t += red[w * DH + lane];
+        Elem<T>::st(ctx + (size_t)b * ldo + h * DH + lane, t / sum);
+        if (lane == 0) lse[bh] = m + __logf(sum);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
+    int B, int L, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    const T* __restrict__ dctx, int ldo, const float* __restrict__ lse, T* __restrict__ dq, int lddq, T* __restrict__ dqkv, int ldg, int causal)
+{
+    extern __shared__ float sm[];
+    float* p = sm;                 // softmax row
+    float* dp = sm + Lp;           // dctx . V_j
+    float* ds = sm + 2 * Lp;       // P_j (dP_j - delta) / 8
+    float* red = sm + 3 * Lp;      // [WPB][64] partial dQ rows
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H, d = H * DH;
+    const int row = idx ? idx[b] : 0;
+    const int nv = causal ? row + 1 : L;
+    const int kk = lane >> 4, g = lane & 15;
+    const f32x4 q4 = Elem<T>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
+    const f32x4 o4 = Elem<T>::ld4(dctx + (size_t)b * ldo + h * DH + 4 * g);
+    const T* kbase = qkv + (size_t)b * L * ld + d + h * DH;
+    const T* vbase = kbase + d;
+    const float ls = lse[bh];
+    for (int j0 = wave * 4; j0 < nv; j0 += 4 * WPB) {
+        const int j = j0 + kk;
+        float sc = 0.f, dv = 0.f;
+        if (j < nv) {
+            sc = dot4(q4, Elem<T>::ld4(kbase + (size_t)j * ld + 4 * g));
+            dv = dot4(o4, Elem<T>::ld4(vbase + (size_t)j * ld + 4 * g));
+        }
+        sc = reduce16(sc);
+        dv = reduce16(dv);
+        if (g == 0 && j < nv) {
+            p[j] = __expf(sc * 0.125f - ls);
+            dp[j] = dv;
+        }
+    }
+    __syncthreads();
+    float delta = 0.f;
+    for (int j = lane; j < nv; j += WAVE) delta += p[j] * dp[j];
+    delta = wave_sum(delta);
+    for (int j = threadIdx.x; j < nv; j += WAVE * WPB) ds[j] = p[j] * (dp[j] - delta) * 0.125f;
+    __syncthreads();
+    const float qd = Elem<T>::ld(q + (size_t)b * ldq + h * DH + lane);
+    const float od = Elem<T>::ld(dctx + (size_t)b * ldo + h * DH + lane);
+    T* dk = dqkv + (size_t)b * L * ldg + d + h * DH + lane;
+    T* dv = dk + d;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = wave; j < nv; j += WPB) {
+        const float dsj = ds[j];
+        acc += dsj * Elem<T>::ld(kbase + (size_t)j * ld + lane);
+        Elem<T>::st(dk + (size_t)j * ldg, dsj * qd);
+        Elem<T>::st(dv + (size_t)j * ldg, p[j] * od);
+    }
+    for (int j = nv + wave; j < L; j += WPB) {     // keys behind the causal mask get no gradient
+        Elem<T>::st(dk + (size_t)j * ldg, 0.f);
+        Elem<T>::st(dv + (size_t)j * ldg, 0.f);
+    }
+    red[wave * DH + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPB; ++w) t += red[w * DH + lane];
+        Elem<T>::st(dq + (size_t)b * lddq + h * DH + lane, t);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int B, int L, int d, const T* __restrict__ src, int lds_, const int* __restrict__ idx,
+                                                                T* __restrict__ dst, int ldd)
+{
+    const int b = blockIdx.x;
+    const int row = idx ? idx[b] : 0;
+    T* o = dst + ((size_t)b * L + row) * ldd;
+    const T* i = src + (size_t)b * lds_;
+    for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {
+        f32x4 a = Elem<T>::ld4(o + c), v = Elem<T>::ld4(i + c);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+        Elem<T>::st4(o + c, a);
+    }
+}
+
+}  // namespace
+
+extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
+                                   void* ctx, int ldo, float* lse, int causal, void* stream)
+{
+    if (!q || !qkv || !ctx || !lse || B <= 0 || L <= 0 || H <= 0) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if (ld < 3 * H * DH || ldq < H * DH || ldo < H * DH || (ld * esz) % 16 || (ldq * esz) % 16) return LPI_EINVAL;
+    if (((uintptr_t)q | (uintptr_t)qkv) & 15) return LPI_EINVAL;
+    const int Lp = (L + 63) / 64 * 64;
+    const size_t lds = (size_t)(2 * Lp + WPB * DH) * sizeof(float);
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(B * H), block(WAVE * WPB);
+    if (dtype == LPI_F32)
+        LPI_LAUNCH((attn_pooled_fwd_kernel<float>), grid, block, lds, s, B, L, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
+                   (float*)ctx, ldo, lse, causal);
+    else if (dtype == LPI_BF16)
+        LPI_LAUNCH((attn_pooled_fwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
+                   (bf16_t*)ctx, ldo, lse, causal);
+    else
+        return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
+                                   const void* dctx, int ldo, const float* lse, void* dq, int lddq, void* dqkv, int ldg, int causal,
+                                   void* stream)
+{
+    if (!q || !qkv || !dctx || !lse || !dq || !dqkv || B <= 0 || L <= 0 || H <= 0) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if (ld < 3 * H * DH || ldg < 3 * H * DH || ldq < H * DH || ldo < H * DH || lddq < H * DH) return LPI_EINVAL;
+    if ((ld * esz) % 16 || (ldq * esz) % 16 || (ldo * esz) % 16) return LPI_EINVAL;
+    if (((uintptr_t)q | (uintptr_t)qkv | (uintptr_t)dctx) & 15) return LPI_EINVAL;
+    const int Lp = (L + 63) / 64 * 64;
+    const size_t lds = (size_t)(3 * Lp + WPB * DH) * sizeof(float);
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(B * H), block(WAVE * WPB);
+    if (dtype == LPI_F32)
+        LPI_LAUNCH((attn_pooled_bwd_kernel<float>), grid, block, lds, s, B, L, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
+                   (const float*)dctx, ldo, lse, (float*)dq, lddq, (float*)dqkv, ldg, causal);
+    else if (dtype == LPI_BF16)
+        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
+                   (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
+    else
+        return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_scatter_add_rows(int dtype, int B, int L, int d, const void* src, int ld_src, const int* idx, void* dst, int ld_dst,
+                                    void* stream)
+{
+    if (!src || !dst || B <= 0 || L <= 0 || d <= 0 || (d & 3) || ld_src < d || ld_dst < d) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if ((ld_src * esz) % 8 || (ld_dst * esz) % 8 || (((uintptr_t)src | (uintptr_t)dst) & 7)) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F32)
+        LPI_LAUNCH((scatter_add_rows_kernel<float>), dim3(B), dim3(256), 0, s, B, L, d, (const float*)src, ld_src, idx, (float*)dst, ld_dst);
+    else if (dtype == LPI_BF16)
+        LPI_LAUNCH((scatter_add_rows_kernel<bf16_t>), dim3(B), dim3(256), 0, s, B, L, d, (const bf16_t*)src, ld_src, idx, (bf16_t*)dst, ld_dst);
+    else
+        return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}

@@ -31,7 +31,9 @@ from .synth import ClipConfig
 import os as _os
 
 # exact dead-row elimination in the last block (see Tower.forward); LPI_POOLED_LAST=0 evaluates the full block instead (A/B switch)
-POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "1") != "0"
+POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "2") != "0"
+# ... and its attention (query / softmax row / out_proj of the pooled token only); LPI_POOLED_LAST=1 keeps the full attention (A/B switch)
+POOLED_ATTN = POOLED_LAST and _os.environ.get("LPI_POOLED_LAST", "2") != "1"
 
 _DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
@@ -144,6 +146,8 @@ class Tower:
             # the LAST block's MLP runs on the B pooled rows only (exact: the heads read nothing else of its output)
             "Bp": Bp, "c_xmid": z(Bp, d), "c_h": z(Bp, d, dtype=T), "c_g": z(Bp, 4 * d, dtype=T),
             "c_u": z(Bp, 4 * d, dtype=T) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
+            # ... and so do its query, attention row and out_proj (K and V still cover every token)
+            "c_q": z(Bp, d, dtype=T), "c_ctx": z(Bp, d, dtype=T), "c_lse": z(B * H), "c_xin": z(Bp, d), "c_stat1": z(2, Bp),
         }
         if train:
             ws.update({
@@ -152,6 +156,7 @@ class Tower:
                 "delta": z(B, H, L),
                 "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
                 "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
+                "c_dctx": z(Bp, d, dtype=T), "c_dq": z(Bp, d, dtype=T),
             })
         self._ws[key] = ws
         return ws
@@ -176,10 +181,24 @@ class Tower:
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
                 call("lpi_prompt_add", B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
             call("lpi_layernorm_fwd", dt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
+            if i == len(self.blocks) - 1 and POOLED_ATTN:
+                # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
+                Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
+                wq, bq = blk["qkv"].w, blk["qkv"].b
+                gemm(dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
+                call("lpi_pool_ln_fwd", dt, B, L, d, x_in, pool_idx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
+                gemm(dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
+                call("lpi_attn_pooled_fwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
+                call("lpi_gather_rows", B, L, d, x_in, pool_idx, ws["c_xin"], s)
+                gemm(dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
+                call("lpi_pool_ln_fwd", dt, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                return ws["c_xout"]
             gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
             gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
-            if i == len(self.blocks) - 1 and POOLED_LAST:
+            if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 call("lpi_gather_rows", B, L, d, xmid, pool_idx, ws["c_xmid"], s)
                 call("lpi_pool_ln_fwd", dt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
@@ -218,9 +237,26 @@ class Tower:
                 gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, s)
+                if not POOLED_ATTN:
+                    dxT.zero_()
+                    call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
+            if i == len(self.blocks) - 1 and POOLED_ATTN:
+                # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
+                wqt = blk["qkv"].wt
+                gemm(dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
+                call("lpi_attn_pooled_bwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
+                     dqkv, 3 * d, int(sp.causal), s)
+                gemm(dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
+                gemm(dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
+                call("lpi_scatter_add_rows", dt, B, L, d, ws["c_dh"], d, pool_idx, dh, d, s)
                 dxT.zero_()
-                call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
-            else:
+                call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)      # residual path of the pooled rows
+                call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                     None if dt == F32 else dxT, d, s)
+                if prompts is not None and dprompts is not None and 0 < i < depth:
+                    call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
+                continue
+            if not (i == len(self.blocks) - 1 and POOLED_LAST):
                 du = ws["g"]
                 gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc

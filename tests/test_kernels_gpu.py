@@ -209,6 +209,62 @@ def test_attention_fwd_bwd(dt, B, L, H, causal):
         assert e < (5e-5 if dt == F32 else 4e-2), (name, e)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("B,L,H,causal", [(3, 213, 3, 0), (5, 77, 2, 1), (2, 21, 2, 0), (2, 273, 2, 0), (4, 32, 1, 1)])
+def test_attention_pooled_row_fwd_bwd(dt, B, L, H, causal):
+    """Single-query attention of the last block == the pooled row of the full attention (model.py:179-184), forward and backward:
+    ctx row, lse, dQ of that row, dK / dV of every row (zero behind the causal mask)."""
+    d = H * 64
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(1, L, (B,), generator=g).int() if causal else torch.zeros(B, dtype=torch.int32)
+    rows = (torch.arange(B) * L + idx.long())
+    qkv = rnd(B * L, 3 * d, seed=21).to(TD[dt])
+    dctx_rows = rnd(B, d, seed=22).to(TD[dt])
+    qd = qkv.to(DEV)
+    q_rows = qkv[rows, :d].contiguous().to(DEV)
+    ctx = torch.zeros(B, d, device=DEV, dtype=TD[dt])
+    lse = torch.zeros(B, H, device=DEV)
+    idx_d = idx.to(DEV) if causal else None
+    call("lpi_attn_pooled_fwd", dt, B, L, H, q_rows, d, qd, 3 * d, idx_d, ctx, d, lse, causal, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = attn_ref(qr, B, L, H, causal)
+    assert relerr(ctx, oref.detach()[rows]) < TOL[dt]
+    lref_rows = lref.detach()[torch.arange(B), :, idx.long()]
+    assert relerr(lse, lref_rows) < (1e-5 if dt == F32 else 2e-2)
+    dfull = torch.zeros(B * L, d, dtype=torch.float64)
+    dfull[rows] = dctx_rows.double()
+    oref.backward(dfull)
+    dq = torch.zeros(B, d, device=DEV, dtype=TD[dt])
+    dqkv = torch.full((B * L, 3 * d), 7.0, device=DEV, dtype=TD[dt])        # K/V columns must be fully overwritten
+    call("lpi_attn_pooled_bwd", dt, B, L, H, q_rows, d, qd, 3 * d, idx_d, dctx_rows.to(DEV), d, lse, dq, d, dqkv, 3 * d, causal, stream())
+    tol = 5e-5 if dt == F32 else 4e-2
+    assert relerr(dq, qr.grad[rows, :d]) < tol
+    assert relerr(dqkv[:, d:2 * d], qr.grad[:, d:2 * d]) < tol
+    assert relerr(dqkv[:, 2 * d:], qr.grad[:, 2 * d:]) < tol
+    assert bool((dqkv[:, :d] == 7.0).all())                                   # Q columns untouched
+    other = torch.ones(B * L, dtype=torch.bool)
+    other[rows] = False
+    assert float(qr.grad[other][:, :d].abs().max()) == 0.0                      # the reference too has no dQ elsewhere
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_scatter_add_rows(dt):
+    B, L, d = 5, 7, 128
+    dst = rnd(B * L, d, seed=31).to(TD[dt])
+    src = rnd(B, d, seed=32).to(TD[dt])
+    idx = torch.tensor([0, 6, 3, 3, 1], dtype=torch.int32)
+    out = dst.to(DEV)
+    call("lpi_scatter_add_rows", dt, B, L, d, src.to(DEV), d, idx.to(DEV), out, d, stream())
+    ref = dst.double().clone()
+    ref[torch.arange(B) * L + idx.long()] += src.double()
+    assert relerr(out, ref) < (1e-6 if dt == F32 else 8e-3)
+    out0 = dst.to(DEV)
+    call("lpi_scatter_add_rows", dt, B, L, d, src.to(DEV), d, None, out0, d, stream())
+    ref0 = dst.double().clone()
+    ref0[torch.arange(B) * L] += src.double()
+    assert relerr(out0, ref0) < (1e-6 if dt == F32 else 8e-3)
+
+
 def test_attention_large_scores_online_softmax():
     """Force the running-max rescale: one key dominates late in the sequence (cdna guide rule 26)."""
     B, L, H = 1, 213, 1

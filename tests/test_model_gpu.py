@@ -201,3 +201,25 @@ def test_bitwise_reproducible_gradients():
         runs.append([out["img_f"].clone(), out["txt_f"].clone(), out["base_loss"].clone()] + [fac[k].grad.clone() for k in synth.PROMPT_NAMES])
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 2e-2)])
+def test_last_block_dead_row_elimination_is_exact(monkeypatch, dtype, tol):
+    """The last block evaluated (a) in full, (b) with the MLP on the pooled rows only, (c) with the query / softmax row / out_proj
+    on the pooled rows too (the default) gives the same features and factor gradients: the heads read the pooled token only
+    (model.py:255, prompt_learner.py:61)."""
+    from lpi_amd import engine as E
+    cfg = synth.TINY
+    ids = synth.token_ids(5, n_ctx=16)
+    out = []
+    for last, attn in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(E, "POOLED_LAST", last)
+        monkeypatch.setattr(E, "POOLED_ATTN", attn)
+        res, _ = run_hip(cfg, dtype, 5, ids, 2)
+        out.append(res)
+    for res in out[1:]:
+        for k in ("img_f", "txt_f"):
+            assert maxerr(res[k], out[0][k]) <= tol, (k, maxerr(res[k], out[0][k]))
+        for k in GRADS:
+            scale = np.abs(out[0][k]).max()
+            assert maxerr(res[k], out[0][k]) <= max(50 * tol * scale, 1e-9), (k, maxerr(res[k], out[0][k]), scale)
