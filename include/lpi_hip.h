@@ -30,6 +30,9 @@ extern "C" {
 
 #define LPI_F32 0
 #define LPI_BF16 1
+#define LPI_F16 2          /* STORAGE type of the residual stream in bf16 mode (the reference's own activation type: it runs fp16 end to
+                            * end, model.py:371-392); never an MFMA operand type.  Accepted where a parameter is named x_dtype, and as
+                            * lpi_gemm_nt's c_dtype together with a residual of the same type. */
 
 #define LPI_EINVAL (-22)   /* bad shape / alignment / null pointer */
 #define LPI_ENOSYS (-38)   /* combination not built */
@@ -54,21 +57,23 @@ int lpi_set_tuning(int key, int value);
  * replaces: models/clip/model.py:175-177 (c_fc, c_proj), :172,185 (nn.MultiheadAttention in/out proj),
  *           :215,228 (conv1 as per-patch matmul), :257 (x @ proj); prompt_learner.py:61 (@ text_projection);
  *           slinet.py:139 (logit_scale * I @ T^T); and their autograd dgrads (B = pre-transposed weight).
- * A, B: `dtype` elements.  C: `c_dtype` elements.  bias, residual: f32 or NULL.  aux: `dtype` or NULL. */
+ * A, B: `dtype` elements.  C: `c_dtype` elements.  bias: f32 or NULL.  residual: f32 or NULL; with c_dtype == LPI_F16 (bf16
+ * operands, LPI_EPI_NONE only) the residual is required and is fp16 like C — the fp16 residual stream.  aux: `dtype` or NULL. */
 int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K,
                 const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                const float* bias, const float* residual, int ldr,
+                const float* bias, const void* residual, int ldr,
                 int epilogue, void* aux, int ldaux, float alpha, void* stream);
 
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
- * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x f32 [rows,d] (row stride ldx), y `dtype`.
+ * x_dtype: storage type of the residual stream x — LPI_F32, or LPI_F16 in bf16 mode (statistics and arithmetic are f32 either way).
+ * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x `x_dtype` [rows,d] (row stride ldx), y `dtype`.
  * bwd: dx[r,:] (f32, in/out: residual-stream gradient) += LN'(dy[r,:]); optionally also writes a `cast_dtype`
  *      copy dx_cast (the next dgrad GEMM's operand).  dx == NULL: dx_cast itself is the in/out gradient stream (bf16 mode keeps
  *      no f32 copy).  dy is `dy_dtype`. */
-int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int ldx, const float* gamma, const float* beta,
+int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, int ldx, const float* gamma, const float* beta,
                       void* y, int ldy, float* mean, float* rstd, void* stream);
-int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy,
-                      const float* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy,
+                      const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                       float* dx, int lddx, void* dx_cast, int ldcast, void* stream);
 
 /* ---- a4: prompted multi-head attention, head_dim 64   replaces: models/clip/model.py:183-185 -----------
@@ -101,43 +106,43 @@ int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float
 
 /* ---- a3: vision front end                          replaces: models/clip/model.py:227-251 --------------
  * patchify: image [B,3,R,R] f32 -> cols [B*G*G (padded rows untouched), Kp] `dtype`, Kp >= 3*ps*ps zero padded.
- * assemble + ln_pre: x0[b] = LN([cls+pos0 ; prompts[b,0] (no pos) ; patch_emb[b]+pos1..]) -> x0 f32 [B*L,d];
+ * assemble + ln_pre: x0[b] = LN([cls+pos0 ; prompts[b,0] (no pos) ; patch_emb[b]+pos1..]) -> x0 `x_dtype` [B*L,d];
  * prompt0: f32, element (b,p,:) at prompt0 + b*prompt_bstride + p*d (bstride 0 = broadcast, slinet.py:119).
  * bwd (dx0 is `dtype`: f32, or the bf16 gradient stream): applies LN' to rows 1..P of dx0 IN PLACE (dx0 is dead afterwards; the other rows' input gradients are
  *      not needed because the backbone is frozen), then dprompt[p,:] = sum_b dx0[b,1+p,:] (f32 [P,d]; the batch
  *      sum is the gradient of the training-time stride-0 broadcast, slinet.py:119). */
 int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream);
-int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
+int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
                          const float* pos, const float* prompt0, long prompt_bstride,
-                         const float* gamma, const float* beta, float* x0, float* mean, float* rstd, void* stream);
+                         const float* gamma, const float* beta, void* x0, float* mean, float* rstd, void* stream);
 int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, const float* prompt0, long prompt_bstride,
                          const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream);
 
 /* ---- a6/a7: text front end          replaces: models/clip/prompt_learner.py:52-53,128-163 --------------
  * x0[b,l] = (l in 1..P ? ctx[b,l-1] : tok_emb[ids[b,l]]) + pos[l]      (CLASS_TOKEN_POSITION == "end")
  * bwd: dctx[p,:] (+)= sum_b dx0[b,1+p,:] */
-int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
-                      const float* ctx, long ctx_bstride, float* x0, void* stream);
+int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
+                      const float* ctx, long ctx_bstride, void* x0, void* stream);   /* x0 is `x_dtype` */
 int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate,
                             void* stream);   /* dx is `dtype` */
 
 /* ---- F1: deep prompts                               replaces: models/clip/model.py:189-193 -------------
- * x[b, 1..P, :] += prompt_l[b?, p, :]   (in place on the f32 residual stream) */
-int lpi_prompt_add(int B, int L, int P, int d, float* x, const float* prompt_l, long prompt_bstride, void* stream);
+ * x[b, 1..P, :] += prompt_l[b?, p, :]   (in place on the `x_dtype` residual stream; prompt_l f32) */
+int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream);
 
 /* ---- a3/a7/a2: pooled head     replaces: model.py:255-257, prompt_learner.py:57-61, slinet.py:122,133 --
- * pool_ln: y[b,:] = LN(x[b*L + idx[b], :]) (idx NULL -> row 0 = CLS; else EOT position) -> y `dtype` [B,d]
+ * pool_ln: y[b,:] = LN(x[b*L + idx[b], :]) (x `x_dtype`; idx NULL -> row 0 = CLS; else EOT position) -> y `dtype` [B,d]
  * pool_ln_bwd: dx (f32 [B*L,d], pre-zeroed) row idx[b] = LN'(dy[b]);
  * l2norm fwd/bwd on f32 [B,E]:  y = x/||x||. */
-int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, const int32_t* idx, const float* gamma,
+int lpi_pool_ln_fwd(int dtype, int x_dtype, int B, int L, int d, const void* x, const int32_t* idx, const float* gamma,
                     const float* beta, void* y, int ldy, float* mean, float* rstd, void* stream);
 int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float* dy, int lddy, const float* x,
                     const int32_t* idx, const float* gamma, const float* mean, const float* rstd,
                     float* dx, void* dx_cast, void* stream);
-/* pooled-row gather / scatter (f32): dst[b] = src[b*L + idx[b]]  /  dst[b*L + idx[b]] = src[b] (+ `cast_dtype` copy; the other
+/* pooled-row gather (src `x_dtype` -> f32) / scatter (f32): dst[b] = src[b*L + idx[b]]  /  dst[b*L + idx[b]] = src[b] (+ `cast_dtype` copy; the other
  * rows of dst are the caller's, pre-zeroed).  Used to run the LAST block's MLP on the B pooled rows only: the heads read nothing
  * else of its output (model.py:255, prompt_learner.py:61), so this is exact dead-row elimination. */
-int lpi_gather_rows(int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* stream);
+int lpi_gather_rows(int x_dtype, int B, int L, int d, const void* src, const int32_t* idx, float* dst, void* stream);
 int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
                      void* stream);
 /* dst[b*L + idx[b], :] += src[b, :]  (`dtype` both; idx NULL: token 0) — adds the pooled rows' dQ contribution to d(LN1 output). */

@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_long, c_uint64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblpi_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU = 0, 1, 2
 
 
@@ -27,8 +27,8 @@ SIGNATURES = {
     "lpi_launch_count": [],
     "lpi_set_tuning": [_I, _I],
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
-    "lpi_layernorm_fwd": [_I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
-    "lpi_layernorm_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
+    "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
@@ -39,14 +39,14 @@ SIGNATURES = {
     "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "lpi_nt_bxent_fwd_bwd": [_I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "lpi_patchify": [_I, _I, _I, _I, _P, _P, _I, _P],
-    "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "lpi_vis_assemble_bwd": [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
-    "lpi_txt_embed_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P],
+    "lpi_txt_embed_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P],
     "lpi_rows_sum_over_batch": [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "lpi_prompt_add": [_I, _I, _I, _I, _P, _P, _L, _P],
-    "lpi_pool_ln_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    "lpi_prompt_add": [_I, _I, _I, _I, _I, _P, _P, _L, _P],
+    "lpi_pool_ln_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "lpi_pool_ln_bwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
-    "lpi_gather_rows": [_I, _I, _I, _P, _P, _P, _P],
+    "lpi_gather_rows": [_I, _I, _I, _I, _P, _P, _P, _P],
     "lpi_scatter_rows": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "lpi_l2norm_fwd": [_I, _I, _P, _I, _P, _I, _P, _P],
     "lpi_l2norm_bwd": [_I, _I, _P, _I, _P, _I, _P, _P, _I, _P],

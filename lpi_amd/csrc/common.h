@@ -5,6 +5,8 @@
 #include "../../include/lpi_hip.h"
 
 typedef unsigned short bf16_t;  // storage type of a bfloat16
+typedef _Float16 f16_t;         // IEEE half: storage type of the residual stream in bf16 mode
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -62,6 +64,24 @@ template <> struct Elem<bf16_t> {
         bf16x4 b;
         b[0] = (__bf16)v[0]; b[1] = (__bf16)v[1]; b[2] = (__bf16)v[2]; b[3] = (__bf16)v[3];
         *reinterpret_cast<bf16x4*>(p) = b;
+    }
+};
+
+template <> struct Elem<f16_t> {
+    static constexpr int DT = LPI_F16;
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+    __device__ static __forceinline__ f32x4 ld4(const f16_t* p) {
+        f16x4 h = *reinterpret_cast<const f16x4*>(p);
+        f32x4 r;
+        r[0] = (float)h[0]; r[1] = (float)h[1]; r[2] = (float)h[2]; r[3] = (float)h[3];
+        return r;
+    }
+    __device__ static __forceinline__ void st4(f16_t* p, f32x4 v) {
+        f16x4 h;
+        h[0] = (f16_t)v[0]; h[1] = (f16_t)v[1]; h[2] = (f16_t)v[2]; h[3] = (f16_t)v[3];
+        *reinterpret_cast<f16x4*>(p) = h;
     }
 };
 

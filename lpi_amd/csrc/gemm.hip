@@ -200,11 +200,13 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
 extern int g_lpi_tuning[8];
 
 extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                           void* C, int ldc, const float* bias, const float* residual, int ldr, int epilogue, void* aux,
+                           void* C, int ldc, const float* bias, const void* residual_, int ldr, int epilogue, void* aux,
                            int ldaux, float alpha, void* stream)
 {
+    const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
     const int esz = dtype == LPI_F32 ? 4 : 2;
     const int csz = c_dtype == LPI_F32 ? 4 : 2;
+    if (c_dtype == LPI_F16 && (dtype != LPI_BF16 || epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
     const int bk = ROW_BYTES / esz;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return LPI_EINVAL;
     if (M % BM || N % BN || K % bk) return LPI_EINVAL;
@@ -224,5 +226,7 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
         return dispatch_epi<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F32)
         return dispatch_epi<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F16)      // fp16 residual stream: x_out = x_in + (A.B^T + bias), both fp16
+        return launch_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
 }

@@ -299,5 +299,7 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
         return dispatch256<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F32)
         return dispatch256<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
+        return launch256_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
 }

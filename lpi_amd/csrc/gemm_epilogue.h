@@ -18,6 +18,10 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
     }
-    if constexpr (RES) v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
+    if constexpr (RES) {
+        // the residual stream has C's storage type when C is fp16 (bf16 mode), f32 otherwise; ldr counts elements of that type
+        if constexpr (sizeof(TC) == 2 && !__is_same(TC, bf16_t)) v += Elem<TC>::ld4(reinterpret_cast<const TC*>(residual) + (size_t)row * ldr + col);
+        else v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
+    }
     Elem<TC>::st4(C + (size_t)row * ldc + col, v);
 }

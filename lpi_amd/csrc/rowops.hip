@@ -16,37 +16,42 @@ namespace {
 constexpr float LN_EPS = 1e-5f;
 constexpr int MAXC = 8;  // float4 chunks per lane: d <= 2048
 
-struct Row {
-    f32x4 v[MAXC];
+// NC = compile-time bound on the chunks a lane holds (ceil(d / 256)): the LayerNorm kernels are instantiated per NC so that a row
+// costs NC float4 registers, not MAXC (with the run-time bound alone the d = 768 backward took 90-176 VGPRs: 2-5 waves per SIMD).
+template <int NC> struct RowT {
+    f32x4 v[NC];
 };
+typedef RowT<MAXC> Row;
 
-template <typename F> __device__ __forceinline__ void for_chunks(int d, int lane, F f) {
+template <int NC, typename F> __device__ __forceinline__ void for_chunks_n(int d, int lane, F f) {
     const int nch = d >> 2;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + (i << 6);
         if (c < nch) f(i, c << 2);
     }
 }
+template <typename F> __device__ __forceinline__ void for_chunks(int d, int lane, F f) { for_chunks_n<MAXC>(d, lane, f); }
 
 __device__ __forceinline__ float hsum(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // mean / rstd of the row held in r (two-pass, like ATen's CPU LayerNorm in effect)
-__device__ __forceinline__ void row_stats(const Row& r, int d, int lane, float& mu, float& rs) {
+template <int NC>
+__device__ __forceinline__ void row_stats(const RowT<NC>& r, int d, int lane, float& mu, float& rs) {
     float s = 0.f;
-    for_chunks(d, lane, [&](int i, int) { s += hsum(r.v[i]); });
+    for_chunks_n<NC>(d, lane, [&](int i, int) { s += hsum(r.v[i]); });
     mu = wave_sum(s) / (float)d;
     float ss = 0.f;
-    for_chunks(d, lane, [&](int i, int) { f32x4 c = r.v[i] - mu; ss += hsum(c * c); });
+    for_chunks_n<NC>(d, lane, [&](int i, int) { f32x4 c = r.v[i] - mu; ss += hsum(c * c); });
     const float var = wave_sum(ss) / (float)d;
     rs = 1.0f / sqrtf(var + LN_EPS);
 }
 
 // y = LN(r)
-template <typename TY>
-__device__ __forceinline__ void ln_apply_store(const Row& r, int d, int lane, float mu, float rs, const float* gamma,
+template <typename TY, int NC>
+__device__ __forceinline__ void ln_apply_store(const RowT<NC>& r, int d, int lane, float mu, float rs, const float* gamma,
                                                const float* beta, TY* y) {
-    for_chunks(d, lane, [&](int i, int col) {
+    for_chunks_n<NC>(d, lane, [&](int i, int col) {
         f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
         f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
         Elem<TY>::st4(y + col, (r.v[i] - mu) * rs * g + b);
@@ -54,9 +59,10 @@ __device__ __forceinline__ void ln_apply_store(const Row& r, int d, int lane, fl
 }
 
 // dxn = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); x row in `x`, dy row in `dy`; result left in dy
-__device__ __forceinline__ void ln_bwd_row(Row& dy, const Row& x, int d, int lane, float mu, float rs, const float* gamma) {
+template <int NC>
+__device__ __forceinline__ void ln_bwd_row(RowT<NC>& dy, const RowT<NC>& x, int d, int lane, float mu, float rs, const float* gamma) {
     float s1 = 0.f, s2 = 0.f;
-    for_chunks(d, lane, [&](int i, int col) {
+    for_chunks_n<NC>(d, lane, [&](int i, int col) {
         f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
         f32x4 gdy = g * dy.v[i];
         f32x4 xh = (x.v[i] - mu) * rs;
@@ -65,55 +71,178 @@ __device__ __forceinline__ void ln_bwd_row(Row& dy, const Row& x, int d, int lan
         s2 += hsum(gdy * xh);
     });
     const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
-    for_chunks(d, lane, [&](int i, int) {
+    for_chunks_n<NC>(d, lane, [&](int i, int) {
         f32x4 xh = (x.v[i] - mu) * rs;
         dy.v[i] = (dy.v[i] - c1 - xh * c2) * rs;
     });
 }
 
-template <typename TY>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const float* __restrict__ x, int ldx,
+template <typename TX, typename TY, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const TX* __restrict__ x, int ldx,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     TY* __restrict__ y, int ldy, float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    Row r;
-    const float* xr = x + (size_t)row * ldx;
-    for_chunks(d, lane, [&](int i, int col) { r.v[i] = *reinterpret_cast<const f32x4*>(xr + col); });
+    RowT<NC> r;
+    const TX* xr = x + (size_t)row * ldx;
+    for_chunks_n<NC>(d, lane, [&](int i, int col) { r.v[i] = Elem<TX>::ld4(xr + col); });
     float mu, rs;
     row_stats(r, d, lane, mu, rs);
     ln_apply_store<TY>(r, d, lane, mu, rs, gamma, beta, y + (size_t)row * ldy);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <typename TDY, typename TCAST>
+template <typename TX, typename TDY, typename TCAST, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
-                                                    const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                    const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    Row g, xr;
+    RowT<NC> g, xr;
     const TDY* dyr = dy + (size_t)row * lddy;
-    const float* xp = x + (size_t)row * ldx;
-    for_chunks(d, lane, [&](int i, int col) {
+    const TX* xp = x + (size_t)row * ldx;
+    for_chunks_n<NC>(d, lane, [&](int i, int col) {
         g.v[i] = Elem<TDY>::ld4(dyr + col);
-        xr.v[i] = *reinterpret_cast<const f32x4*>(xp + col);
+        xr.v[i] = Elem<TX>::ld4(xp + col);
     });
     ln_bwd_row(g, xr, d, lane, mean[row], rstd[row], gamma);
     if (dx) {
         float* dxr = dx + (size_t)row * lddx;
-        for_chunks(d, lane, [&](int i, int col) {
+        for_chunks_n<NC>(d, lane, [&](int i, int col) {
             f32x4 t = *reinterpret_cast<const f32x4*>(dxr + col) + g.v[i];
             *reinterpret_cast<f32x4*>(dxr + col) = t;
             if (dx_cast) Elem<TCAST>::st4(dx_cast + (size_t)row * ldcast + col, t);
         });
     } else {   // the `cast` copy IS the gradient stream (in/out), no f32 stream is kept
         TCAST* dxr = dx_cast + (size_t)row * ldcast;
-        for_chunks(d, lane, [&](int i, int col) { Elem<TCAST>::st4(dxr + col, Elem<TCAST>::ld4(dxr + col) + g.v[i]); });
+        for_chunks_n<NC>(d, lane, [&](int i, int col) { Elem<TCAST>::st4(dxr + col, Elem<TCAST>::ld4(dxr + col) + g.v[i]); });
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 mode with the fp16 residual stream: every operand is a 2-byte type, so a lane takes 8 elements (16 bytes) per access and
+// a 32-lane half wave owns a row — the same number of memory instructions as the 4-element kernels above moves two rows.
+// (Measured: with 8-byte accesses these kernels are instruction/latency-bound and halving the bytes bought nothing.)
+constexpr int MAXC8 = 8;   // 8-element chunks per lane of a half wave: d <= 2048
+
+template <int NC> struct Row8 {
+    float v[NC][8];
+};
+
+template <int NC, typename F> __device__ __forceinline__ void for_chunks8(int d, int hl, F f) {
+    const int nch = d >> 3;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = hl + (i << 5);
+        if (c < nch) f(i, c << 3);
+    }
+}
+
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void ld8(const f16_t* p, float (&o)[8]) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    const f16x8 h = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)h[j];
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[2 * j] = __uint_as_float(w[j] << 16);
+        o[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = b;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const f16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y, int ldy,
+                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+    const int hl = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    Row8<NC> r;
+    const f16_t* xr = x + (size_t)row * ldx;
+    for_chunks8<NC>(d, hl, [&](int i, int col) { ld8(xr + col, r.v[i]); });
+    float s = 0.f;
+    for_chunks8<NC>(d, hl, [&](int i, int) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += r.v[i][j];
+    });
+    const float mu = half_sum(s) / (float)d;
+    float ss = 0.f;
+    for_chunks8<NC>(d, hl, [&](int i, int) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float c = r.v[i][j] - mu; ss += c * c; }
+    });
+    const float rs = 1.0f / sqrtf(half_sum(ss) / (float)d + LN_EPS);
+    bf16_t* yr = y + (size_t)row * ldy;
+    for_chunks8<NC>(d, hl, [&](int i, int col) {
+        float g[8], b[8], o[8];
+        ld8(gamma + col, g);
+        ld8(beta + col, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (r.v[i][j] - mu) * rs * g[j] + b[j];
+        st8(yr + col, o);
+    });
+    if (hl == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx_stream (bf16, in/out) += LN'(dy): the bf16-mode backward with the fp16 saved input
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast) {
+    const int hl = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    Row8<NC> g, xh;
+    const bf16_t* dyr = dy + (size_t)row * lddy;
+    const f16_t* xr = x + (size_t)row * ldx;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for_chunks8<NC>(d, hl, [&](int i, int col) {
+        float gm[8];
+        ld8(dyr + col, g.v[i]);
+        ld8(xr + col, xh.v[i]);
+        ld8(gamma + col, gm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g.v[i][j] *= gm[j];
+            xh.v[i][j] = (xh.v[i][j] - mu) * rs;
+            s1 += g.v[i][j];
+            s2 += g.v[i][j] * xh.v[i][j];
+        }
+    });
+    const float c1 = half_sum(s1) / (float)d, c2 = half_sum(s2) / (float)d;
+    bf16_t* o = dxs + (size_t)row * ldcast;
+    for_chunks8<NC>(d, hl, [&](int i, int col) {
+        float acc[8];
+        ld8(o + col, acc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (g.v[i][j] - c1 - xh.v[i][j] * c2) * rs;
+        st8(o + col, acc);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -160,11 +289,12 @@ __device__ __forceinline__ void vis_pre_row(Row& r, int b, int l, int G2, int P,
     }
 }
 
+template <typename TX>
 __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, int P, int d, const float* __restrict__ patch_emb,
                                                               int ldpe, const float* __restrict__ cls, const float* __restrict__ pos,
                                                               const float* __restrict__ prompt0, long pbs,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                              TX* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd) {
     const int L = 1 + P + G2;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -174,7 +304,7 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
     vis_pre_row(r, b, l, G2, P, d, lane, patch_emb, ldpe, cls, pos, prompt0, pbs);
     float mu, rs;
     row_stats(r, d, lane, mu, rs);
-    ln_apply_store<float>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
+    ln_apply_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
@@ -227,9 +357,10 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, 
 
 // ---------------------------------------------------------------------------------------------------------
 // text front end
+template <typename TX>
 __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
-                                                       const float* __restrict__ ctx, long cbs, float* __restrict__ x0) {
+                                                       const float* __restrict__ ctx, long cbs, TX* __restrict__ x0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B * L) return;
@@ -237,29 +368,28 @@ __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, int P, int
     const float* src = (ctx && l >= 1 && l <= P) ? ctx + (size_t)b * cbs + (size_t)(l - 1) * d
                                                  : tok + (size_t)ids[row] * d;
     const float* pp = pos + (size_t)l * d;
-    float* o = x0 + (size_t)row * d;
+    TX* o = x0 + (size_t)row * d;
     for_chunks(d, lane, [&](int, int col) {
-        *reinterpret_cast<f32x4*>(o + col) = *reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col);
+        Elem<TX>::st4(o + col, *reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col));
     });
 }
 
-__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, int P, int d, float* __restrict__ x,
+template <typename TX>
+__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, int P, int d, TX* __restrict__ x,
                                                         const float* __restrict__ pr, long pbs) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
     const int b = w / P, p = w % P;
-    float* xr = x + ((size_t)b * L + 1 + p) * d;
+    TX* xr = x + ((size_t)b * L + 1 + p) * d;
     const float* s = pr + (size_t)b * pbs + (size_t)p * d;
-    for_chunks(d, lane, [&](int, int col) {
-        *reinterpret_cast<f32x4*>(xr + col) = *reinterpret_cast<const f32x4*>(xr + col) + *reinterpret_cast<const f32x4*>(s + col);
-    });
+    for_chunks(d, lane, [&](int, int col) { Elem<TX>::st4(xr + col, Elem<TX>::ld4(xr + col) + *reinterpret_cast<const f32x4*>(s + col)); });
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // pooled heads
-template <typename TY>
-__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, const float* __restrict__ x,
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, const TX* __restrict__ x,
                                                          const int32_t* __restrict__ idx, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, TY* __restrict__ y, int ldy,
                                                          float* __restrict__ mean, float* __restrict__ rstd) {
@@ -268,7 +398,7 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, c
     if (b >= B) return;
     const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
     Row r;
-    for_chunks(d, lane, [&](int i, int col) { r.v[i] = *reinterpret_cast<const f32x4*>(x + row * d + col); });
+    for_chunks(d, lane, [&](int i, int col) { r.v[i] = Elem<TX>::ld4(x + row * d + col); });
     float mu, rs;
     row_stats(r, d, lane, mu, rs);
     ln_apply_store<TY>(r, d, lane, mu, rs, gamma, beta, y + (size_t)b * ldy);
@@ -297,15 +427,16 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, c
     });
 }
 
-// dst[b,:] = src[b*L + idx[b], :]  (f32; idx NULL -> row 0)
-__global__ __launch_bounds__(256) void gather_rows_kernel(int B, int L, int d, const float* __restrict__ src, const int32_t* __restrict__ idx,
+// dst[b,:] (f32) = src[b*L + idx[b], :]  (idx NULL -> row 0)
+template <typename TX>
+__global__ __launch_bounds__(256) void gather_rows_kernel(int B, int L, int d, const TX* __restrict__ src, const int32_t* __restrict__ idx,
                                                          float* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float* s = src + ((size_t)b * L + (idx ? idx[b] : 0)) * d;
+    const TX* s = src + ((size_t)b * L + (idx ? idx[b] : 0)) * d;
     float* o = dst + (size_t)b * d;
-    for_chunks(d, lane, [&](int, int col) { *reinterpret_cast<f32x4*>(o + col) = *reinterpret_cast<const f32x4*>(s + col); });
+    for_chunks(d, lane, [&](int, int col) { *reinterpret_cast<f32x4*>(o + col) = Elem<TX>::ld4(s + col); });
 }
 
 // dst[b*L + idx[b], :] = src[b,:] (f32) and its cast copy; the rest of dst is the caller's (pre-zeroed)
@@ -402,32 +533,73 @@ inline int rows_grid(long rows) { return (int)((rows + 3) / 4); }
 
 #define S(stream) ((hipStream_t)(stream))
 
-extern "C" int lpi_layernorm_fwd(int dtype, int rows, int d, const float* x, int ldx, const float* gamma, const float* beta,
+// smallest instantiated chunk bound that covers d: ceil(d / 256) rounded up to one of 1, 2, 3, 4, 8
+#define LN_NC_SWITCH(d, CALL)                      \
+    do {                                           \
+        const int nc__ = ((d) + 255) / 256;        \
+        if (nc__ <= 1) { CALL(1); }                \
+        else if (nc__ == 2) { CALL(2); }           \
+        else if (nc__ == 3) { CALL(3); }           \
+        else if (nc__ == 4) { CALL(4); }           \
+        else { CALL(8); }                          \
+    } while (0)
+
+extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, int ldx, const float* gamma, const float* beta,
                                  void* y, int ldy, float* mean, float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || bad_row_dim(d) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
-    if (dtype == LPI_F32)
-        LPI_LAUNCH(ln_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (float*)y, ldy, mean, rstd);
-    else if (dtype == LPI_BF16)
-        LPI_LAUNCH(ln_fwd_kernel<bf16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), rows, d, x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
-    else
-        return LPI_EINVAL;
+    dim3 g(rows_grid(rows)), b(256);
+#define LNF(TX, TY, NC) LPI_LAUNCH((ln_fwd_kernel<TX, TY, NC>), g, b, 0, S(stream), rows, d, (const TX*)x, ldx, gamma, beta, (TY*)y, ldy, mean, rstd)
+#define LNF_FF(NC) LNF(float, float, NC)
+#define LNF_FB(NC) LNF(float, bf16_t, NC)
+#define LNF_HB(NC) LNF(f16_t, bf16_t, NC)
+#define LNF_H16(NC) LPI_LAUNCH(ln_fwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const f16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd)
+    if (dtype == LPI_F32 && x_dtype == LPI_F32) LN_NC_SWITCH(d, LNF_FF);
+    else if (dtype == LPI_BF16 && x_dtype == LPI_F32) LN_NC_SWITCH(d, LNF_FB);
+    else if (dtype == LPI_BF16 && x_dtype == LPI_F16 && !(d & 7) && !(ldx & 7) && !(ldy & 7) && !(((uintptr_t)x | (uintptr_t)y) & 15))
+        LN_NC_SWITCH(d, LNF_H16);
+    else if (dtype == LPI_BF16 && x_dtype == LPI_F16) LN_NC_SWITCH(d, LNF_HB);
+    else return LPI_EINVAL;
+#undef LNF
+#undef LNF_FF
+#undef LNF_FB
+#undef LNF_HB
+#undef LNF_H16
     LPI_CHECK_LAST();
     return 0;
 }
 
-extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int rows, int d, const void* dy, int lddy, const float* x, int ldx,
+extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
                                  const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
                                  int ldcast, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_cast) || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
-#define LNB(TDY, TC) LPI_LAUNCH((ln_bwd_kernel<TDY, TC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
-    if (dy_dtype == LPI_F32 && cast_dtype == LPI_F32) LNB(float, float);
-    else if (dy_dtype == LPI_F32 && cast_dtype == LPI_BF16) LNB(float, bf16_t);
-    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16) LNB(bf16_t, bf16_t);
-    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_F32) LNB(bf16_t, float);
+#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
+#define LNB_HBB(NC) LNB(f16_t, bf16_t, bf16_t, NC)
+#define LNB_FFF(NC) LNB(float, float, float, NC)
+#define LNB_FFB(NC) LNB(float, float, bf16_t, NC)
+#define LNB_FBB(NC) LNB(float, bf16_t, bf16_t, NC)
+#define LNB_FBF(NC) LNB(float, bf16_t, float, NC)
+#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast)
+    if (x_dtype == LPI_F16) {
+        if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16 && !dx && !(d & 7) && !(lddy & 7) && !(ldx & 7) && !(ldcast & 7) &&
+            !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx_cast) & 15))
+            LN_NC_SWITCH(d, LNB_H16);
+        else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16) LN_NC_SWITCH(d, LNB_HBB);
+        else return LPI_EINVAL;
+    } else if (x_dtype != LPI_F32) return LPI_EINVAL;
+    else if (dy_dtype == LPI_F32 && cast_dtype == LPI_F32) LN_NC_SWITCH(d, LNB_FFF);
+    else if (dy_dtype == LPI_F32 && cast_dtype == LPI_BF16) LN_NC_SWITCH(d, LNB_FFB);
+    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16) LN_NC_SWITCH(d, LNB_FBB);
+    else if (dy_dtype == LPI_BF16 && cast_dtype == LPI_F32) LN_NC_SWITCH(d, LNB_FBF);
     else return LPI_EINVAL;
 #undef LNB
+#undef LNB_HBB
+#undef LNB_FFF
+#undef LNB_FFB
+#undef LNB_FBB
+#undef LNB_FBF
+#undef LNB_H16
     LPI_CHECK_LAST();
     return 0;
 }
@@ -448,15 +620,21 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
     return 0;
 }
 
-extern "C" int lpi_vis_assemble_fwd(int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls, const float* pos,
-                                    const float* prompt0, long prompt_bstride, const float* gamma, const float* beta, float* x0,
+extern "C" int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls, const float* pos,
+                                    const float* prompt0, long prompt_bstride, const float* gamma, const float* beta, void* x0,
                                     float* mean, float* rstd, void* stream) {
     if (!patch_emb || !cls || !pos || !gamma || !beta || !x0 || !mean || !rstd || B <= 0 || G2 <= 0 || P < 0 || bad_row_dim(d) || (ldpe & 3))
         return LPI_EINVAL;
     if (P > 0 && (!prompt0 || (prompt_bstride & 3))) return LPI_EINVAL;
     const long rows = (long)B * (1 + P + G2);
-    LPI_LAUNCH(vis_assemble_fwd_kernel, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
-                       prompt0, prompt_bstride, gamma, beta, x0, mean, rstd);
+    if (x_dtype == LPI_F32)
+        LPI_LAUNCH(vis_assemble_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
+                   prompt0, prompt_bstride, gamma, beta, (float*)x0, mean, rstd);
+    else if (x_dtype == LPI_F16)
+        LPI_LAUNCH(vis_assemble_fwd_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
+                   prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd);
+    else
+        return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
@@ -482,27 +660,41 @@ extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void
     return lpi_rows_sum_over_batch(dtype, B, L, 1, P, d, dx0, dprompt, 0, stream);
 }
 
-extern "C" int lpi_txt_embed_fwd(int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
-                                 long ctx_bstride, float* x0, void* stream) {
+extern "C" int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
+                                 long ctx_bstride, void* x0, void* stream) {
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
-    LPI_LAUNCH(txt_embed_kernel, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0);
+    if (x_dtype == LPI_F32)
+        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0);
+    else if (x_dtype == LPI_F16)
+        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0);
+    else
+        return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
 
-extern "C" int lpi_prompt_add(int B, int L, int P, int d, float* x, const float* prompt_l, long prompt_bstride, void* stream) {
+extern "C" int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream) {
     if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
-    LPI_LAUNCH(prompt_add_kernel, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, x, prompt_l, prompt_bstride);
+    if (x_dtype == LPI_F32)
+        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, (float*)x, prompt_l, prompt_bstride);
+    else if (x_dtype == LPI_F16)
+        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, (f16_t*)x, prompt_l, prompt_bstride);
+    else
+        return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
 
-extern "C" int lpi_pool_ln_fwd(int dtype, int B, int L, int d, const float* x, const int32_t* idx, const float* gamma, const float* beta,
+extern "C" int lpi_pool_ln_fwd(int dtype, int x_dtype, int B, int L, int d, const void* x, const int32_t* idx, const float* gamma, const float* beta,
                                void* y, int ldy, float* mean, float* rstd, void* stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || L <= 0 || bad_row_dim(d) || (ldy & 3)) return LPI_EINVAL;
     dim3 g(rows_grid(B)), b(256);
-    if (dtype == LPI_F32) LPI_LAUNCH(pool_ln_fwd_kernel<float>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
-    else if (dtype == LPI_BF16) LPI_LAUNCH(pool_ln_fwd_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    if (dtype == LPI_F32 && x_dtype == LPI_F32)
+        LPI_LAUNCH((pool_ln_fwd_kernel<float, float>), g, b, 0, S(stream), B, L, d, (const float*)x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
+    else if (dtype == LPI_BF16 && x_dtype == LPI_F32)
+        LPI_LAUNCH((pool_ln_fwd_kernel<float, bf16_t>), g, b, 0, S(stream), B, L, d, (const float*)x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    else if (dtype == LPI_BF16 && x_dtype == LPI_F16)
+        LPI_LAUNCH((pool_ln_fwd_kernel<f16_t, bf16_t>), g, b, 0, S(stream), B, L, d, (const f16_t*)x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
@@ -519,9 +711,11 @@ extern "C" int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float*
     return 0;
 }
 
-extern "C" int lpi_gather_rows(int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* stream) {
+extern "C" int lpi_gather_rows(int x_dtype, int B, int L, int d, const void* src, const int32_t* idx, float* dst, void* stream) {
     if (!src || !dst || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
-    LPI_LAUNCH(gather_rows_kernel, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, src, idx, dst);
+    if (x_dtype == LPI_F32) LPI_LAUNCH(gather_rows_kernel<float>, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, (const float*)src, idx, dst);
+    else if (x_dtype == LPI_F16) LPI_LAUNCH(gather_rows_kernel<f16_t>, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, (const f16_t*)src, idx, dst);
+    else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }

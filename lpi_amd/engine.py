@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_DQUICKGELU, EPI_NONE, EPI_QUICKGELU, F32, call
+from ._lib import BF16, EPI_DQUICKGELU, EPI_NONE, EPI_QUICKGELU, F16, F32, call
 from .synth import ClipConfig
 
 import os as _os
@@ -36,7 +36,11 @@ POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "2") != "0"
 POOLED_ATTN = POOLED_LAST and _os.environ.get("LPI_POOLED_LAST", "2") != "1"
 
 _DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
-_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+# bf16 mode stores the forward residual stream in fp16 — the reference's own activation type (it runs fp16 end to end,
+# model.py:371-392) — which halves the bytes of the HBM-bound LayerNorms and residual epilogues; statistics, accumulation and the
+# pooled rows stay f32.  LPI_RESIDUAL=f32 keeps an f32 stream (A/B switch).  f32 (parity) mode always uses f32.
+RESIDUAL_F16 = _os.environ.get("LPI_RESIDUAL", "f16") != "f32"
 
 
 def _pad(n: int, m: int = 128) -> int:
@@ -73,7 +77,7 @@ GEMM_PROFILE = None
 def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None):
     """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows).
     m_real: un-padded row count, used only for algorithmic-FLOP accounting."""
-    cdt = F32 if c.dtype == torch.float32 else BF16
+    cdt = F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,7 +88,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if prof is not None:
         e1.record()
         mr = m_real or M
-        nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (4 if residual is not None else 0)
+        nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None else 0)
                                                                  + (aux.element_size() if aux is not None else 0))
         prof.append((e0, e1, 2.0 * mr * N * K, nbytes))
 
@@ -102,6 +106,7 @@ class Tower:
 
     def __init__(self, sd: dict, prefix: str, spec: TowerSpec, dt: int, device):
         self.spec, self.dt, self.device = spec, dt, device
+        self.xdt = F16 if (dt == BF16 and RESIDUAL_F16) else F32      # storage type of the forward residual stream
         self.blocks = []
         f = lambda k: torch.as_tensor(np.asarray(sd[k])) if not torch.is_tensor(sd[k]) else sd[k]  # noqa: E731
         for i in range(spec.layers):
@@ -128,14 +133,14 @@ class Tower:
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         Bp = _pad(B)
-        T = _TORCH_DT[self.dt]
+        T, TX = _TORCH_DT[self.dt], _TORCH_DT[self.xdt]
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
         keep = nl if train else 1
         ws = {
             "B": B, "L": L, "Mp": Mp,
-            "x": [z(Mp, d) for _ in range(nl + 1 if train else 2)],
-            "xmid": [z(Mp, d) for _ in range(keep)],
+            "x": [z(Mp, d, dtype=TX) for _ in range(nl + 1 if train else 2)],
+            "xmid": [z(Mp, d, dtype=TX) for _ in range(keep)],
             "qkv": [z(Mp, 3 * d, dtype=T) for _ in range(keep)],
             "ctx": [z(Mp, d, dtype=T) for _ in range(keep)],
             "lse": [z(B, H, L) for _ in range(keep)],
@@ -168,7 +173,7 @@ class Tower:
         prompt_learner.py:61), so the last block's MLP is evaluated on them alone.
 
         prompts: f32 tensor whose element (b, layer, p, :) sits at  b*prompt_bstride + (layer*P + p)*d."""
-        sp, dt, s = self.spec, self.dt, _stream()
+        sp, dt, xdt, s = self.spec, self.dt, self.xdt, _stream()
         d, H = sp.width, sp.heads
         B, L, Mp = ws["B"], ws["L"], ws["Mp"]
         M = B * L
@@ -179,19 +184,19 @@ class Tower:
             x_out = ws["x"][i + 1 if train else (i + 1) % 2]
             xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][k]
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
-                call("lpi_prompt_add", B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
-            call("lpi_layernorm_fwd", dt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
+                call("lpi_prompt_add", xdt, B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
+            call("lpi_layernorm_fwd", dt, xdt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
                 gemm(dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
-                call("lpi_pool_ln_fwd", dt, B, L, d, x_in, pool_idx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
+                call("lpi_pool_ln_fwd", dt, xdt, B, L, d, x_in, pool_idx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
                 gemm(dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
                 call("lpi_attn_pooled_fwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
-                call("lpi_gather_rows", B, L, d, x_in, pool_idx, ws["c_xin"], s)
+                call("lpi_gather_rows", xdt, B, L, d, x_in, pool_idx, ws["c_xin"], s)
                 gemm(dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
-                call("lpi_pool_ln_fwd", dt, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                call("lpi_pool_ln_fwd", dt, F32, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
                 gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
@@ -200,22 +205,22 @@ class Tower:
             gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
-                call("lpi_gather_rows", B, L, d, xmid, pool_idx, ws["c_xmid"], s)
-                call("lpi_pool_ln_fwd", dt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                call("lpi_gather_rows", xdt, B, L, d, xmid, pool_idx, ws["c_xmid"], s)
+                call("lpi_pool_ln_fwd", dt, xdt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
                 gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            call("lpi_layernorm_fwd", dt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
+            call("lpi_layernorm_fwd", dt, xdt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
             gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
-        call("lpi_gather_rows", B, L, d, x_out, pool_idx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
+        call("lpi_gather_rows", xdt, B, L, d, x_out, pool_idx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 
     # ------------------------------------------------------------------ backward (dgrad only)
     def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
         """ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
         dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
-        sp, dt, s = self.spec, self.dt, _stream()
+        sp, dt, xdt, s = self.spec, self.dt, self.xdt, _stream()
         d, H = sp.width, sp.heads
         B, L, Mp = ws["B"], ws["L"], ws["Mp"]
         M = B * L
@@ -235,7 +240,7 @@ class Tower:
                 c_dxT = ws["c_dxT"] if dt != F32 else c_dx
                 gemm(dt, c_dxT, blk["proj"].wt, ws["c_g"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
                 gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
-                call("lpi_layernorm_bwd", dt, dt, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
+                call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, s)
                 if not POOLED_ATTN:
                     dxT.zero_()
@@ -251,7 +256,7 @@ class Tower:
                 call("lpi_scatter_add_rows", dt, B, L, d, ws["c_dh"], d, pool_idx, dh, d, s)
                 dxT.zero_()
                 call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)      # residual path of the pooled rows
-                call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                      None if dt == F32 else dxT, d, s)
                 if prompts is not None and dprompts is not None and 0 < i < depth:
                     call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
@@ -260,12 +265,12 @@ class Tower:
                 du = ws["g"]
                 gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
-                call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
+                call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, s)      # dx is None in bf16 mode: dxT accumulates in place
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
-            call("lpi_layernorm_bwd", dt, dt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+            call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
                 call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
@@ -367,11 +372,11 @@ class DualEncoder:
             ws["front"] = fe
         call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
         gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
-        call("lpi_vis_assemble_fwd", B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
+        call("lpi_vis_assemble_fwd", self.vis.xdt, B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
              ws["x"][0], fe["stat"][0], fe["stat"][1], s)
         xo = self.vis.forward(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
-        call("lpi_pool_ln_fwd", dt, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         gemm(dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
@@ -420,9 +425,9 @@ class DualEncoder:
         hw = self._head("t", B, d)
         call("lpi_eot_index", B, L, ids, hw["idx"], s)
         ctx = pr if (pr is not None and use_ctx) else None
-        call("lpi_txt_embed_fwd", B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
+        call("lpi_txt_embed_fwd", self.txt.xdt, B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
         xo = self.txt.forward(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
-        call("lpi_pool_ln_fwd", dt, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
+        call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         gemm(dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:

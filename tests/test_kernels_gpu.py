@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from lpi_amd import _lib, engine as E  # noqa: E402
-from lpi_amd._lib import BF16, F32, call  # noqa: E402
+from lpi_amd._lib import BF16, F16, F32, call  # noqa: E402
 
 DEV = "cuda:0"
 TD = {F32: torch.float32, BF16: torch.bfloat16}
@@ -145,14 +145,14 @@ def test_layernorm_fwd_bwd(dt, d):
     y = torch.zeros(rows, d, device=DEV, dtype=TD[dt])
     st = torch.zeros(2, rows, device=DEV)
     xd = x.to(DEV)
-    call("lpi_layernorm_fwd", dt, rows, d, xd, d, gam.to(DEV), bet.to(DEV), y, d, st[0], st[1], stream())
+    call("lpi_layernorm_fwd", dt, F32, rows, d, xd, d, gam.to(DEV), bet.to(DEV), y, d, st[0], st[1], stream())
     xr = x.double().requires_grad_(True)
     yr = torch.nn.functional.layer_norm(xr, (d,), gam.double(), bet.double(), 1e-5)
     assert relerr(y, yr.detach()) < TOL[dt]
     yr.backward(dy.double())
     dx = dx0.clone().to(DEV)
     cast = torch.zeros(rows, d, device=DEV, dtype=TD[dt])
-    call("lpi_layernorm_bwd", dt, dt, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, cast, d, stream())
+    call("lpi_layernorm_bwd", dt, dt, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, cast, d, stream())
     ref = dx0.double() + xr.grad
     assert relerr(dx, ref) < 2e-5
     assert relerr(cast, ref) < TOL[dt]
@@ -168,12 +168,71 @@ def test_layernorm_bwd_bf16_gradient_stream():
     st = torch.zeros(2, rows, device=DEV)
     y = torch.zeros(rows, d, device=DEV, dtype=torch.bfloat16)
     xd = x.to(DEV)
-    call("lpi_layernorm_fwd", BF16, rows, d, xd, d, gam.to(DEV), torch.zeros(d, device=DEV), y, d, st[0], st[1], stream())
+    call("lpi_layernorm_fwd", BF16, F32, rows, d, xd, d, gam.to(DEV), torch.zeros(d, device=DEV), y, d, st[0], st[1], stream())
     xr = x.double().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (d,), gam.double(), None, 1e-5).backward(dy.double())
     stream_t = dx0.clone().to(DEV)
-    call("lpi_layernorm_bwd", BF16, BF16, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
+    call("lpi_layernorm_bwd", BF16, BF16, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
     assert relerr(stream_t, dx0.double() + xr.grad) < 1e-2
+
+
+def test_fp16_residual_stream_kernels():
+    """bf16 mode keeps the forward residual stream in fp16 (x_dtype = LPI_F16): LayerNorm fwd/bwd reading it, the GEMM residual
+    epilogue reading and writing it, the pooled-row LN / gather, and the prompt add in place on it — each against f64 on the SAME
+    fp16-rounded inputs."""
+    rows = 300
+    for d in (132, 512, 768):      # 132: not a multiple of 8 -> the 4-element kernels; else the half-wave-per-row 16-byte kernels
+        x16 = (rnd(rows, d, seed=5) * 3 + 0.5).half()
+        gam, bet = 1 + 0.1 * rnd(d, seed=6), 0.05 * rnd(d, seed=7)
+        y = torch.zeros(rows, d, device=DEV, dtype=torch.bfloat16)
+        st = torch.zeros(2, rows, device=DEV)
+        xd = x16.to(DEV)
+        call("lpi_layernorm_fwd", BF16, F16, rows, d, xd, d, gam.to(DEV), bet.to(DEV), y, d, st[0], st[1], stream())
+        xr = x16.double().requires_grad_(True)
+        yr = torch.nn.functional.layer_norm(xr, (d,), gam.double(), bet.double(), 1e-5)
+        assert relerr(y, yr.detach()) < 8e-3, d
+        assert relerr(st[0], x16.double().mean(1)) < 1e-5, d
+        assert relerr(st[1], 1 / torch.sqrt(x16.double().var(1, unbiased=False) + 1e-5)) < 1e-5, d
+        dy = rnd(rows, d, seed=8).to(torch.bfloat16)
+        dx0 = rnd(rows, d, seed=9).to(torch.bfloat16)
+        yr.backward(dy.double())
+        stream_t = dx0.clone().to(DEV)
+        call("lpi_layernorm_bwd", BF16, BF16, F16, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
+        assert relerr(stream_t, dx0.double() + xr.grad) < 1e-2, d
+    # residual GEMM: both kernels
+    for M, N, K, key in ((256, 256, 128, 1 << 30), (512, 768, 768, 1)):
+        call("lpi_set_tuning", 0, key)
+        try:
+            a = rnd(M, K, seed=1).to(torch.bfloat16)
+            b = rnd(N, K, seed=2, scale=0.05).to(torch.bfloat16)
+            bias, res = rnd(N, seed=3), (rnd(M, N, seed=4) * 4).half()
+            c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            E.gemm(BF16, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), residual=res.to(DEV))
+            ref = a.double() @ b.double().t() + bias.double() + res.double()
+            assert relerr(c, ref) < 1e-3, (M, N, K)
+        finally:
+            call("lpi_set_tuning", 0, 1)
+    with pytest.raises(_lib.LpiError):      # an fp16 C without the fp16 residual is not a built combination
+        E.gemm(BF16, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV))
+    # pooled rows
+    B, L = 5, 60
+    idx = torch.tensor([0, 59, 17, 3, 30], dtype=torch.int32)
+    sel = torch.arange(B) * L + idx.long()
+    out = torch.zeros(B, d, device=DEV)
+    call("lpi_gather_rows", F16, B, L, d, xd, idx.to(DEV), out, stream())
+    assert torch.equal(out.cpu(), x16[sel].float())
+    yp = torch.zeros(B, d, device=DEV, dtype=torch.bfloat16)
+    stp = torch.zeros(2, B, device=DEV)
+    call("lpi_pool_ln_fwd", BF16, F16, B, L, d, xd, idx.to(DEV), gam.to(DEV), bet.to(DEV), yp, d, stp[0], stp[1], stream())
+    assert torch.equal(yp.cpu(), y.cpu()[sel])
+    # prompt add in place
+    P = 4
+    pr = rnd(P, d, seed=11)
+    xa = x16.clone().to(DEV)
+    call("lpi_prompt_add", F16, B, L, P, d, xa, pr.to(DEV), 0, stream())
+    ref = x16.float().reshape(B, L, d).clone()
+    ref[:, 1:1 + P] += pr
+    assert torch.equal(xa.cpu(), ref.reshape(rows, d).half())
 
 
 def attn_ref(qkv, B, L, H, causal):

@@ -223,3 +223,25 @@ def test_last_block_dead_row_elimination_is_exact(monkeypatch, dtype, tol):
         for k in GRADS:
             scale = np.abs(out[0][k]).max()
             assert maxerr(res[k], out[0][k]) <= max(50 * tol * scale, 1e-9), (k, maxerr(res[k], out[0][k]), scale)
+
+
+def test_bf16_mode_fp16_residual_stream_vs_f32_stream(monkeypatch):
+    """bf16 mode stores the forward residual stream in fp16 (the reference's own activation type).  Against the same mode with an
+    f32 stream the features move by far less than the bf16 operand rounding already does, and both sit within the bf16-mode bar
+    of the f64 oracle."""
+    from lpi_amd import engine as E
+    cfg = synth.TINY
+    ids = synth.token_ids(6, n_ctx=16)
+    res = {}
+    for f16 in (True, False):
+        monkeypatch.setattr(E, "RESIDUAL_F16", f16)
+        res[f16], fac_np = run_hip(cfg, "bf16", 6, ids, 2)
+    ora = O.Oracle(cfg, synth.clip_state_dict(cfg), dtype=torch.float64)
+    ref = O.train_step(ora, synth.images(6, cfg.image_resolution), ids, fac_np, depth=2)
+    for k in ("img_f", "txt_f"):
+        assert maxerr(res[True][k], res[False][k]) <= 4e-3, (k, maxerr(res[True][k], res[False][k]))
+        assert maxerr(res[True][k], ref[k]) <= 2e-2 and maxerr(res[False][k], ref[k]) <= 2e-2
+    for k in GRADS:
+        a, b, r = (np.asarray(v, dtype=np.float64).ravel() for v in (res[True][k], res[False][k], ref[k]))
+        assert a @ r / (np.linalg.norm(a) * np.linalg.norm(r)) >= 0.99, k
+        assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.995, k
