@@ -17,7 +17,12 @@ import sys
 def load(path):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+        n = r["Kernel_Name"]
+        m = re.match(r"_ZN\d+_GLOBAL__N_1(\d+)", n)      # rocprofv3 leaves some instantiations (fp16 template arguments) mangled
+        if m:
+            k = int(m.group(1))
+            n = n[m.end():m.end() + k]
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
         n = re.sub(r"<.*", "", n).replace("void ", "")
         a = agg[n]
         a[0] += 1
