@@ -1,4 +1,4 @@
-// 256x256-tile NT GEMM, 8 waves, 8-phase schedule with LDS-DMA kept in flight across barriers (counted vmcnt).
+// 256x256-tile NT GEMM, 8 waves, phased schedule with LDS-DMA kept in flight across barriers (counted vmcnt).
 //
 // Same contract and epilogues as gemm.hip (C = epi(alpha * A . B^T + bias) + residual); selected by lpi_gemm_nt for
 // shapes with enough 256x256 tiles.  Why a second kernel: a 128x128 tile needs 64 KB of L2->LDS traffic per CU per 1024
@@ -8,15 +8,20 @@
 // Geometry: BK = 128 bytes of K per tile row (bf16 64, f32 32).  LDS = 2 K-tile buffers x {A half 0, A half 1, B half 0,
 // B half 1} x 16 KiB = 128 KiB.  Wave (wm in 0..1, wn in 0..3) owns rows {h*128 + wm*64 + 0..63 : h = 0,1} and columns
 // {h*128 + wn*32 + 0..31 : h = 0,1} of the tile, so each of its four 64x32 output quadrants reads ONE A half and ONE B half.
-// Per K-tile four phases, one quadrant each (16 MFMA 16x16x32 per wave in bf16):
-//     P1: read A(0),B(0)   compute (0,0)   stage A-half1 of K-tile kt+1
-//     P2: read B(1)        compute (0,1)   stage A-half0 of K-tile kt+2   (dead since P1)
-//     P3: read A(1)        compute (1,1)   stage B-half0 of K-tile kt+2   (B(0) stays in registers)
-//     P4:                  compute (1,0)   stage B-half1 of K-tile kt+2 ; s_waitcnt vmcnt(6)
-// A half tile is restaged only after the phase whose lgkmcnt(0)+barrier retired its last ds_read (WAR), and read only
-// after the vmcnt that retires it plus a barrier every wave has passed (RAW).  vmcnt(6) at P4 leaves the three newest
-// half tiles (2 LDS-DMA instructions each) in flight and guarantees K-tile kt+1 has landed.  Raw s_barrier only — a
-// __syncthreads() would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
+// Per K-tile two phases of two quadrants (32 MFMA 16x16x32 per wave in bf16), each between two raw barriers:
+//     X: read B(0), B(1), A(0)   compute (0,0), (1,0)   stage A-half1 of K-tile kt+1          ; s_waitcnt vmcnt(8)
+//     Y: read A(1)               compute (1,1), (0,1)   stage A-half0, B-half0, B-half1 of kt+2 ; s_waitcnt vmcnt(8)
+// (the B fragments stay in registers across X and Y).  A half tile is restaged only after the phase whose lgkmcnt(0)+barrier
+// retired its last ds_read (WAR), and read only after the counted vmcnt that retires it plus a barrier every wave has passed
+// (RAW).  vmcnt(8) leaves the four newest half tiles (2 LDS-DMA instructions each) in flight.  Raw s_barrier only — a
+// __syncthreads() would drain the LDS-DMA queue (cdna_hip_programming.md, "Pipelining across barriers").  The first version had
+// four phases of one quadrant (8 barriers per K-tile, three half tiles in flight): an empty loop of those barriers alone costs
+// 0.64 us per K-tile against 0.87 us of MFMA work (profiles/r01_gemm_ablation.md).
+// 1 (default): two phases of 32 MFMAs per K-tile; 0: the earlier four phases of 16 (kept for A/B: same results bit for bit,
+// 2.9 % slower over the eight vision-layer GEMMs, 11 % on the qkv shape)
+#ifndef LPI_TWO_PHASE
+#define LPI_TWO_PHASE 1
+#endif
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -147,6 +152,52 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     asm volatile("" ::: "memory")
 
     const int nk = K / BK;   // even, >= 2 (checked on the host)
+#if LPI_TWO_PHASE
+    // Two phases per K-tile (32 MFMAs each, 4 barriers per K-tile instead of 8; four half tiles in flight instead of three).
+    // X: quadrants (n0,m0),(n1,m0) from B0, B1, A0;   Y: quadrants (n1,m1),(n0,m1) from A1 (B fragments stay in registers).
+    // LDS-DMA: A1(kt+1) is issued in X(kt) (its slot was last read in Y(kt-1)); A0, B0, B1 of kt+2 in Y(kt) (read in X(kt)).
+    // Each wave waits for its own DMAs with a counted vmcnt BEFORE the phase's first barrier, so that with the one-barrier stagger
+    // both groups' data is visible when the reading phase starts: X waits for A1(kt) (8 younger instructions may stay in flight),
+    // Y for A0, B0, B1 of kt+1.
+    stage_A(0, 0, 0); stage_B(0, 0, 0); stage_B(0, 1, 0); stage_A(0, 1, 0);
+    stage_A(1, 0, 1); stage_B(1, 0, 1); stage_B(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    auto ktile = [&](int kt, const int BUF) {
+        const char* buf = smem + BUF * BUF_BYTES;
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        // X
+        read_B(fb0, buf + OFF_B0);
+        read_B(fb1, buf + OFF_B1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_A(buf + OFF_A0);
+        if (more1) {
+            stage_A(kt + 1, 1, BUF ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE_SYNC_IN();
+        mma_quadrant(acc, 0, 0, fb0);
+        mma_quadrant(acc, 1, 0, fb1);
+        PHASE_SYNC_OUT();
+        // Y
+        read_A(buf + OFF_A1);
+        if (more2) {
+            stage_A(kt + 2, 0, BUF); stage_B(kt + 2, 0, BUF); stage_B(kt + 2, 1, BUF);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (more1) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE_SYNC_IN();
+        mma_quadrant(acc, 1, 1, fb1);
+        mma_quadrant(acc, 0, 1, fb0);
+        PHASE_SYNC_OUT();
+    };
+#else
     // prologue: K-tile 0 (4 halves) -> buffer 0, first three halves of K-tile 1 -> buffer 1
     stage_A(0, 0, 0); stage_B(0, 0, 0); stage_B(0, 1, 0); stage_A(0, 1, 0);
     stage_A(1, 0, 1); stage_B(1, 0, 1); stage_B(1, 1, 1);
@@ -192,6 +243,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
         mma_quadrant(acc, 0, 1, fb0);
         PHASE_SYNC_OUT();
     };
+#endif
     for (int kt = 0; kt < nk; kt += 2) {
         ktile(kt, 0);
         ktile(kt + 1, 1);
