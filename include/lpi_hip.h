@@ -47,7 +47,7 @@ int lpi_version(void);
 uint64_t lpi_launch_count(void);
 
 /* tuning knobs (speed only, never results): keys 0 / 1 = minimum number of 256x256 tiles for which lpi_gemm_nt uses
- * the 8-phase 256x256 kernel instead of the 128x128 one, for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it); key 2 = start stagger of every other first-round workgroup of that kernel in
+ * the phased 256x256 kernel instead of the 128x128 one, for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it); key 2 = start stagger of every other first-round workgroup of that kernel in
  * units of ~3.4 us (default 0: measured null to negative on every shape, kept for experiments); key 3 != 0 forces the two-pass
  * attention backward where the fused single-pass kernel would be used (bf16, all four head matrices resident in LDS).. */
 int lpi_set_tuning(int key, int value);
