@@ -135,7 +135,7 @@ def test_gemm_rejects_bad_shapes():
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("d", [128, 512, 768, 1024])
+@pytest.mark.parametrize("d", [128, 512, 768, 1024, 1280, 2048])      # chunk-count instantiations 1, 2, 3, 4, 8, 8
 def test_layernorm_fwd_bwd(dt, d):
     rows = 203
     x = rnd(rows, d, seed=5) * 2 + 0.3
@@ -181,7 +181,7 @@ def test_fp16_residual_stream_kernels():
     epilogue reading and writing it, the pooled-row LN / gather, and the prompt add in place on it — each against f64 on the SAME
     fp16-rounded inputs."""
     rows = 300
-    for d in (132, 512, 768):      # 132: not a multiple of 8 -> the 4-element kernels; else the half-wave-per-row 16-byte kernels
+    for d in (132, 256, 512, 768, 1024, 2048):      # 132: not a multiple of 8 -> the 4-element kernels; else the half-wave-per-row 16-byte kernels
         x16 = (rnd(rows, d, seed=5) * 3 + 0.5).half()
         gam, bet = 1 + 0.1 * rnd(d, seed=6), 0.05 * rnd(d, seed=7)
         y = torch.zeros(rows, d, device=DEV, dtype=torch.bfloat16)

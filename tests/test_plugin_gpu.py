@@ -120,3 +120,15 @@ def test_incremental_train_two_tasks_end_to_end(tmp_path, monkeypatch):
     # task-1 prompts moved (trained), task-5 prompts did not
     p5 = net.prompts[5].dim_1_share.detach().clone()
     assert net.prompts[1].dim_1_share.grad is not None and net.prompts[5].dim_1_share.grad is None
+
+
+def test_empty_batch_fails_loudly():
+    """An empty batch is an error, not a silent no-op (there is no CPU fallback to absorb it)."""
+    from lpi_amd import _lib, synth
+    from lpi_amd.engine import DualEncoder
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device="cuda:0")
+    with pytest.raises((_lib.LpiError, ValueError, RuntimeError)):
+        enc.encode_image(torch.zeros(0, 3, cfg.image_resolution, cfg.image_resolution, device="cuda:0"))
+    with pytest.raises((_lib.LpiError, ValueError, RuntimeError)):
+        enc.encode_text(torch.zeros(0, 77, dtype=torch.int64, device="cuda:0"))
