@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the two towers on one stream")
+    ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
     a = ap.parse_args()
@@ -101,7 +102,12 @@ def main():
     enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=a.dtype, device=dev)
     B = a.batch
     images = torch.from_numpy(synth.images(B, cfg.image_resolution, seed=synth.IMAGE_SEED + rank)).to(dev)
-    ids = torch.from_numpy(synth.token_ids(B, seed=synth.TOKEN_SEED + rank)).to(dev)
+    ids_host = synth.token_ids(B, seed=synth.TOKEN_SEED + rank)          # [B, 77] as the tokenizer builds them, on the host
+    if not a.no_text_trim:
+        # token columns behind the longest caption's EOT are dead under the causal mask (engine.trim_token_ids): not computed
+        from lpi_amd.engine import trim_token_ids
+        ids_host = np.ascontiguousarray(trim_token_ids(ids_host))
+    ids = torch.from_numpy(ids_host).to(dev)
     fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not a.fwd_only)
            for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
     opt = torch.optim.SGD(list(fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
@@ -175,6 +181,7 @@ def main():
                        + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r={a.rank} P=16, "
                        + ("fwd-only + cosine matrix" if a.fwd_only else "fwd+bwd incl. DecomposedPrompt grads + SGD step"),
                        "global_batch": world * B, "image": f"{cfg.image_resolution}x{cfg.image_resolution}", "tokens": cfg.context_length,
+                       "text_rows_computed": int(ids.shape[1]),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
                        "parallelism": f"dp{world}", "weights": "synthetic (numpy Philox, CLIP-init scales), frozen"},
             "step_mfma_frac": None if gf is None else round(pairs_s / world * gf * 1e9 / (PEAK_TF[a.dtype] * 1e12), 4),
             "roofline": roofline,

@@ -124,13 +124,18 @@ class Tower:
         self._ws = {}
 
     # ------------------------------------------------------------------ workspace
-    def workspace(self, B: int, L: int, train: bool):
-        key = (B, L, train)
+    def workspace(self, B: int, L: int, train: bool, cap: Optional[int] = None):
+        """Arena for B samples of L tokens.  It is allocated for `cap` (>= L) tokens per sample and reused for any shorter L (the
+        text tower's L varies with the longest caption of the batch, see trim_token_ids): a call only re-binds L and the padded
+        row count; the [M, *] buffers are used by their first B*L rows, the [B, H, L] ones as flat storage."""
+        key = (B, train)
         ws = self._ws.get(key)
-        if ws is not None:
+        if ws is not None and ws["Lcap"] >= L:
+            ws["L"], ws["Mp"] = L, _pad(B * L, 256)
             return ws
         self._ws.clear()   # one live shape per tower: the arena is large
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
+        Lreal, L = L, max(L, cap or L)
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         Bp = _pad(B)
         T, TX = _TORCH_DT[self.dt], _TORCH_DT[self.xdt]
@@ -138,7 +143,7 @@ class Tower:
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
         keep = nl if train else 1
         ws = {
-            "B": B, "L": L, "Mp": Mp,
+            "B": B, "L": L, "Mp": Mp, "Lcap": L,
             "x": [z(Mp, d, dtype=TX) for _ in range(nl + 1 if train else 2)],
             "xmid": [z(Mp, d, dtype=TX) for _ in range(keep)],
             "qkv": [z(Mp, 3 * d, dtype=T) for _ in range(keep)],
@@ -163,6 +168,7 @@ class Tower:
                 "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
                 "c_dctx": z(Bp, d, dtype=T), "c_dq": z(Bp, d, dtype=T),
             })
+        ws["L"], ws["Mp"] = Lreal, _pad(B * Lreal, 256)
         self._ws[key] = ws
         return ws
 
@@ -421,7 +427,9 @@ class DualEncoder:
         if pr is not None and P != self.n_ctx:
             raise ValueError("prompt length must equal n_ctx")
         d = cfg.transformer_width
-        ws = self.txt.workspace(B, L, train)
+        if L > cfg.context_length:
+            raise ValueError("more tokens than the context length")
+        ws = self.txt.workspace(B, L, train, cap=cfg.context_length)
         hw = self._head("t", B, d)
         call("lpi_eot_index", B, L, ids, hw["idx"], s)
         ctx = pr if (pr is not None and use_ctx) else None
@@ -458,6 +466,22 @@ class DualEncoder:
         self.txt.backward(ws, pr, depth, dpr, hw["idx"])
         call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
+
+
+def trim_token_ids(ids):
+    """Drop the token columns after the longest caption's EOT: ids [B, n] (HOST tensor or numpy array) -> ids[:, :max_b(eot_b) + 1].
+
+    Exact dead-row elimination for the text tower: under the causal mask (model.py:347-353) a position attends only to earlier ones,
+    and the tower's output is read at the EOT position alone (prompt_learner.py:61), so rows behind every sample's EOT can reach
+    neither a feature nor a gradient; the engine takes any L <= context_length.  Done on the host, where the tokenizer's output
+    lives (prompt_learner.py:128-133), so it costs no device synchronisation."""
+    if torch.is_tensor(ids):
+        if ids.is_cuda:
+            raise ValueError("trim_token_ids works on host token ids (before the upload)")
+        n = int(ids.argmax(-1).max()) + 1
+    else:
+        n = int(np.asarray(ids).argmax(-1).max()) + 1
+    return ids[:, :n]
 
 
 # ---------------------------------------------------------------------------------------------- loss / prompt ops

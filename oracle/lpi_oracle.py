@@ -137,7 +137,9 @@ class Oracle:
     def encode_text(self, embeds, ids, prompts=None, depth=1):
         """TextEncoder.forward, prompt_learner.py:52-63."""
         W, c = self.W, self.cfg
-        x = embeds + W["positional_embedding"]
+        # The reference adds all context_length rows (prompt_learner.py:53); slicing to the sequence given is the identity at the
+        # reference's own length and lets tests/ state the dead-row property (columns behind every EOT change nothing).
+        x = embeds + W["positional_embedding"][: embeds.shape[1]]
         x = transformer(x, W, "transformer.", c.transformer_layers, c.transformer_heads, True, prompts, depth)
         x = layer_norm(x, W["ln_final.weight"], W["ln_final.bias"])
         x = x[torch.arange(x.shape[0]), ids.argmax(dim=-1)]

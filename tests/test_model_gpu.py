@@ -245,3 +245,21 @@ def test_bf16_mode_fp16_residual_stream_vs_f32_stream(monkeypatch):
         a, b, r = (np.asarray(v, dtype=np.float64).ravel() for v in (res[True][k], res[False][k], ref[k]))
         assert a @ r / (np.linalg.norm(a) * np.linalg.norm(r)) >= 0.99, k
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.995, k
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-6)])
+def test_trimming_text_rows_behind_the_longest_eot_is_exact(dtype, tol):
+    """Token columns behind the longest caption's EOT are dead under the causal mask: features and factor gradients computed on
+    ids[:, :max(eot)+1] equal those on the full 77 columns (f32: up to the padded-tile summation order; bf16: the same roundings
+    happen row by row, so bit-for-bit up to the batch-sum order of the prompt-row gradients)."""
+    from lpi_amd.engine import trim_token_ids
+    cfg = synth.TINY
+    ids = synth.token_ids(6, n_ctx=16, max_len=23)
+    short = np.ascontiguousarray(trim_token_ids(ids))
+    assert short.shape[1] < ids.shape[1] and short.shape[1] == int(ids.argmax(-1).max()) + 1
+    full, _ = run_hip(cfg, dtype, 6, ids, 2)
+    trim, _ = run_hip(cfg, dtype, 6, short, 2)
+    for k in ("img_f", "txt_f", "base_loss", "alignment_loss"):
+        assert maxerr(trim[k], full[k]) <= tol, (k, maxerr(trim[k], full[k]))
+    for k in GRADS:
+        assert maxerr(trim[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(trim[k], full[k]))

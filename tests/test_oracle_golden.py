@@ -103,3 +103,25 @@ def test_vitb16_train_step(golden, name, depth):
         idx = np.argsort(-S, axis=1, kind="stable")[:, : g[f"top5_{tag}"].shape[1]]
         safe = g[f"top5_margin_{tag}"] > 10 * err
         assert (idx[safe] == g[f"top5_{tag}"][safe]).all()
+
+
+def test_text_columns_behind_every_eot_are_dead_in_the_oracle():
+    """The property the engine's text trimming relies on (lpi_amd.engine.trim_token_ids), stated on the oracle that the fixtures pin
+    to the reference: with the causal mask (model.py:347-353) and the EOT gather (prompt_learner.py:61), dropping the token columns
+    behind the longest caption's EOT changes no feature, loss or factor gradient — here exactly (f64)."""
+    import numpy as np
+    import torch
+    from lpi_amd import synth
+    from lpi_amd.engine import trim_token_ids
+    cfg = synth.TINY
+    ora = O.Oracle(cfg, synth.clip_state_dict(cfg), dtype=torch.float64)
+    ids = synth.token_ids(5, n_ctx=16, max_len=20)
+    short = np.ascontiguousarray(trim_token_ids(ids))
+    assert short.shape[1] == int(ids.argmax(-1).max()) + 1 < ids.shape[1]
+    assert torch.equal(trim_token_ids(torch.from_numpy(ids)), torch.from_numpy(short))
+    fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    img = synth.images(5, cfg.image_resolution)
+    full = O.train_step(ora, img, ids, fac, depth=2)
+    trim = O.train_step(ora, img, short, fac, depth=2)
+    for k in full:
+        assert float(np.abs(np.asarray(full[k], dtype=np.float64) - np.asarray(trim[k], dtype=np.float64)).max()) == 0.0, k
