@@ -1,4 +1,6 @@
-# run bench.py with an alternate library: python tools/_ab.py <suffix|base> [bench args...]
+#!/usr/bin/env python3
+"""Run bench.py against an alternate build of the library (A/B of kernel variants inside one gpurun call):
+   python tools/bench_variant.py base|<suffix> [bench.py arguments...]      (suffix -> lpi_amd/csrc/liblpi_hip_<suffix>.so)"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import lpi_amd._lib as L
