@@ -46,10 +46,15 @@ int lpi_version(void);
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
 uint64_t lpi_launch_count(void);
 
-/* tuning knobs (speed only, never results): keys 0 / 1 = minimum number of 256x256 tiles for which lpi_gemm_nt uses
- * the phased 256x256 kernel instead of the 128x128 one, for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it); key 2 = start stagger of every other first-round workgroup of that kernel in
- * units of ~3.4 us (default 0: measured null to negative on every shape, kept for experiments); key 3 != 0 forces the two-pass
- * attention backward where the fused single-pass kernel would be used (bf16, all four head matrices resident in LDS).. */
+/* tuning knobs (speed only, never results):
+ *   key 0 / 1  minimum number of 256x256 tiles for which lpi_gemm_nt uses the phased 256x256 kernel instead of the 128x128 one,
+ *              for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it);
+ *   key 2      start stagger of every other first-round workgroup of that kernel in units of ~3.4 us (default 0: measured null
+ *              to negative on every shape, kept for experiments);
+ *   key 3      != 0 forces the two-pass attention backward where the fused single-pass kernel would be used (bf16, all four head
+ *              matrices resident in LDS);
+ *   key 4      row-tile group size of the 256x256 kernel's XCD-aware tile order (default 0 = 8; measured flat from 4 to 16);
+ *   keys 5-7   unused.  Returns LPI_EINVAL for a key outside 0..7. */
 int lpi_set_tuning(int key, int value);
 
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
