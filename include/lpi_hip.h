@@ -188,6 +188,17 @@ int lpi_retrieval_rank(int n_rows, int n_cols, const float* scores, int ld, cons
                        int32_t* rank, void* stream);
 int lpi_topk(int n_rows, int n_cols, int k, const float* scores, int ld, int32_t* idx, float* val, void* stream);
 
+/* ---- a6 (host side): CLIP byte-level BPE      replaces: models/clip/simple_tokenizer.py:62-132, clip.py:185-221 ------
+ * HOST functions (no GPU work, no stream).  create: `merges_utf8` is the decompressed text of bpe_simple_vocab_16e6.txt(.gz) —
+ * third-party data that is not shipped with this library; returns NULL on a malformed table.  encode: pattern split + byte mapping
+ * + pair merging of ONE cleaned, lower-cased UTF-8 string (cleaning — ftfy / html.unescape / whitespace — stays with the caller);
+ * writes at most max_ids ids and returns the full count.  tokenize = clip.tokenize: row t of out [n, context_length] int64 is
+ * SOT, ids, EOT, zero padding; returns 0, or t+1 for the first text that does not fit when truncate == 0 (clip.py:218 raises). */
+void* lpi_bpe_create(const char* merges_utf8, long nbytes);
+void lpi_bpe_destroy(void* handle);
+int lpi_bpe_encode(void* handle, const char* text_utf8, int32_t* ids, int max_ids);
+int lpi_bpe_tokenize(void* handle, const char* const* texts, int n, int context_length, int truncate, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

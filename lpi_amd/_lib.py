@@ -56,8 +56,13 @@ SIGNATURES = {
     "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],
     "lpi_retrieval_rank": [_I, _I, _P, _I, _P, _I, _P, _P],
     "lpi_topk": [_I, _I, _I, _P, _I, _P, _P, _P],
+    # host-side BPE tokenizer (a6)
+    "lpi_bpe_create": [_P, _L],
+    "lpi_bpe_destroy": [_P],
+    "lpi_bpe_encode": [_P, _P, _P, _I],
+    "lpi_bpe_tokenize": [_P, _P, _I, _I, _I, _P],
 }
-_RESTYPES = {"lpi_launch_count": c_uint64}
+_RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_destroy": None}
 
 _lib = None
 

@@ -4,15 +4,18 @@ embedding lookup, the ctx splice over positions 1..n_ctx (CLASS_TOKEN_POSITION =
 kernel (lpi_txt_embed_fwd).  Accepts a LongTensor of ready token ids in place of the caption list (bench / tests)."""
 import torch
 
-from .simple_tokenizer import SimpleTokenizer, tokenize
+from .simple_tokenizer import NativeTokenizer, SimpleTokenizer, tokenize
 
 _tokenizer = None
 
 
 def get_tokenizer():
+    """The C++ tokenizer of liblpi_hip.so (lpi_bpe_*); LPI_TOKENIZER=python selects the Python implementation of the same scheme
+    (both are validated against ids captured from the reference, tests/test_tokenizer.py)."""
     global _tokenizer
     if _tokenizer is None:
-        _tokenizer = SimpleTokenizer()
+        import os
+        _tokenizer = SimpleTokenizer() if os.environ.get("LPI_TOKENIZER", "native") == "python" else NativeTokenizer()
     return _tokenizer
 
 

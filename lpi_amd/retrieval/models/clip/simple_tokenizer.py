@@ -124,11 +124,60 @@ class SimpleTokenizer:
         return out
 
 
-def tokenize(tokenizer: SimpleTokenizer, texts, context_length: int = 77, truncate: bool = False):
+class NativeTokenizer:
+    """The same tokenizer with the split / merge / lookup done in C++ (``lpi_bpe_*`` in liblpi_hip.so, csrc/bpe.hip); text cleaning
+    stays here (Python's Unicode machinery).  Same ``encode`` / ``encoder`` surface as SimpleTokenizer for the ids this path needs."""
+
+    def __init__(self, bpe_path: str | None = None):
+        import ctypes
+        from lpi_amd import _lib
+        self._lib = _lib.load()
+        raw = gzip.open(find_vocab(bpe_path)).read()
+        self._h = self._lib.lpi_bpe_create(raw, len(raw))
+        if not self._h:
+            raise ValueError("malformed BPE merge table")
+        self._ctypes = ctypes
+        self._buf = (ctypes.c_int32 * 4096)()
+        self.encoder = {SOT_TEXT: 49406, EOT_TEXT: 49407}
+        ids = self.encode("x")
+        self.encoder["x</w>"] = ids[0]
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.lpi_bpe_destroy(h)
+
+    def encode(self, text: str):
+        n = self._lib.lpi_bpe_encode(self._h, _clean(text).encode("utf-8"), self._buf, len(self._buf))
+        if n < 0:
+            raise ValueError(f"lpi_bpe_encode failed with code {n}")
+        if n > len(self._buf):
+            self._buf = (self._ctypes.c_int32 * (2 * n))()
+            return self.encode(text)
+        return list(self._buf[:n])
+
+    def tokenize(self, texts, context_length: int = 77, truncate: bool = False):
+        """clip.tokenize in one native call: int64 [n, context_length] (numpy)."""
+        import numpy as np
+        ct = self._ctypes
+        enc = [_clean(t).encode("utf-8") for t in texts]
+        arr = (ct.c_char_p * len(enc))(*enc)
+        out = np.zeros((len(enc), context_length), dtype=np.int64)
+        rc = self._lib.lpi_bpe_tokenize(self._h, arr, len(enc), context_length, int(truncate), out.ctypes.data_as(ct.c_void_p))
+        if rc > 0:
+            raise RuntimeError(f"Input {texts[rc - 1]} is too long for context length {context_length}")
+        if rc < 0:
+            raise ValueError(f"lpi_bpe_tokenize failed with code {rc}")
+        return out
+
+
+def tokenize(tokenizer, texts, context_length: int = 77, truncate: bool = False):
     """[SOT] + ids + [EOT], zero padded to context_length; RuntimeError when too long (clip.py:205-219)."""
     import torch
     if isinstance(texts, str):
         texts = [texts]
+    if isinstance(tokenizer, NativeTokenizer):
+        return torch.from_numpy(tokenizer.tokenize(list(texts), context_length, truncate))
     import numpy as np
     sot, eot = tokenizer.encoder[SOT_TEXT], tokenizer.encoder[EOT_TEXT]
     out = np.zeros((len(texts), context_length), dtype=np.int64)

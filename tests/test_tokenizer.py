@@ -52,3 +52,37 @@ def test_synthetic_ids_shape():
     ids = synth.token_ids(5)
     assert ids.shape == (5, 77) and (ids[:, 0] == 49406).all() and (ids[:, 1:17] == 343).all()
     assert (ids.max(1) == 49407).all() and (np.argmax(ids, 1) >= 23).all()
+
+
+@needs_vocab
+def test_native_tokenizer_matches_reference_ids_and_python(golden):
+    """The C++ BPE (lpi_bpe_* in liblpi_hip.so) against the ids captured from the reference, and against the Python implementation
+    on a fuzz of ASCII / Latin / CJK / emoji / digit / punctuation / contraction mixes (both are this repo's own code; the fixture is
+    the reference's output)."""
+    import random
+    tk_py = T.SimpleTokenizer(VOCAB)
+    tk = T.NativeTokenizer(VOCAB)
+    g = golden("tokenizer")
+    texts = [str(t) for t in g["texts"]]
+    assert (T.tokenize(tk, texts).numpy() == g["ids"]).all()
+    assert tk.encoder["x</w>"] == 343
+    rng = random.Random(7)
+    alphabet = ("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789 .,;:!?'\"-_()[]{}<>|/\\@#$%^&*+=~`\t\n"
+                "éèüñçøßÆŒ¿¡€£¥©®°±²³½¾×÷ "
+                "αβγδЖдёשלוםمرحبا你好世界こんにちは한국어๑๒٣४５ⅣⅫ😀🎉👍🏽✈️‍")
+    words = ["don't", "it's", "we're", "I've", "I'm", "they'll", "he'd", "'sx", "'tis", "a's", "<|startoftext|>", "<|endoftext|>",
+             "&amp;", "&lt;b&gt;", "naïve", "co-op", "3.14", "x2y", "..."]
+    cases = list(words)
+    for _ in range(400):
+        n = rng.randint(0, 40)
+        s = "".join(rng.choice(alphabet) for _ in range(n))
+        if rng.random() < 0.5:
+            s = " ".join([s, rng.choice(words), rng.choice(words)])
+        cases.append(s)
+    for s in cases:
+        assert tk.encode(s) == tk_py.encode(s), repr(s)
+    short = [c for c in cases if len(tk_py.encode(c)) <= 75]
+    assert (T.tokenize(tk, short).numpy() == T.tokenize(tk_py, short).numpy()).all()
+    with pytest.raises(RuntimeError):
+        T.tokenize(tk, ["word " * 100])
+    assert T.tokenize(tk, ["word " * 100], truncate=True)[0, -1] == 49407
