@@ -117,8 +117,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float quick_gelu(float u) { return u / (1.0f + __expf(-1.702f * u)); }
+// sigmoid through v_rcp_f32 (1 ulp): a plain `/` compiles to the IEEE sequence (2 v_div_scale + v_rcp + 4 fma + v_div_fmas +
+// v_div_fixup per element), which doubled the VALU instructions of the QuickGELU / gelu' GEMM epilogues.  LPI_IEEE_DIV=1 keeps it
+// (A/B switch).
+#ifndef LPI_IEEE_DIV
+#define LPI_IEEE_DIV 0
+#endif
+__device__ __forceinline__ float fast_sigmoid1702(float u) {
+#if LPI_IEEE_DIV
+    return 1.0f / (1.0f + __expf(-1.702f * u));
+#else
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
+#endif
+}
+__device__ __forceinline__ float quick_gelu(float u) { return u * fast_sigmoid1702(u); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
-    float s = 1.0f / (1.0f + __expf(-1.702f * u));
+    const float s = fast_sigmoid1702(u);
     return s * (1.0f + 1.702f * u * (1.0f - s));
 }
