@@ -106,15 +106,66 @@ template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x4& acc, const 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
 }
 
+// Cross-lane reductions at VALU speed: DPP quad permutes and row mirrors inside each 16-lane row, then v_permlane16_swap /
+// v_permlane32_swap across rows (with vdst = src = v one instruction leaves {own, partner} in its two results).  `__shfl_xor`
+// compiles to ds_bpermute_b32 — an LDS-crossbar round trip per step, five or six dependent ones per reduction.  Every lane ends
+// with the full result.  LPI_SHFL_REDUCE=1 keeps the shuffle form (A/B switch; measured: no step-time difference — the LayerNorm
+// kernels are HBM-bound and their occupancy hid the crossbar latency — kept for the lower instruction count).
+#ifndef LPI_SHFL_REDUCE
+#define LPI_SHFL_REDUCE 0
+#endif
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_move<0x141>(v);    // row_half_mirror: the other quad of each 8 lanes
+    v += dpp_move<0x140>(v);    // row_mirror: the other 8 lanes of the row
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return v;
+}
+// sum over each 32-lane half of the wave
+__device__ __forceinline__ float half_sum(float v) {
+#if LPI_SHFL_REDUCE
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#else
+    v = row16_sum(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#if LPI_SHFL_REDUCE
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#else
+    v = half_sum(v);
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#if LPI_SHFL_REDUCE
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+#else
+    v = row16_max(v);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#endif
 }
 
 // sigmoid through v_rcp_f32 (1 ulp): a plain `/` compiles to the IEEE sequence (2 v_div_scale + v_rcp + 4 fma + v_div_fmas +

@@ -141,12 +141,6 @@ template <int NC, typename F> __device__ __forceinline__ void for_chunks8(int d,
     }
 }
 
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 __device__ __forceinline__ void ld8(const f16_t* p, float (&o)[8]) {
     typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
     const f16x8 h = *reinterpret_cast<const f16x8*>(p);
