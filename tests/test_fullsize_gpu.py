@@ -135,3 +135,29 @@ def test_bf16_full_size_close_to_f32(enc32, data):
     safe = (top2[:, 0] - top2[:, 1]) > 2e-3
     assert safe.float().mean() > 0.5
     assert (s32.argmax(1)[safe] == sb.argmax(1)[safe]).all()
+
+
+def test_vit_l14_depth12_rank8_vs_oracle():
+    """BASELINE configs[4]'s architecture in full (ViT-L/14: 24 vision layers of width 1024 / 16 heads, 12 text layers of width 768,
+    patch 14 -> 257 + 16 tokens, embed 768; prompt_depth 12, CP rank 8) at batch 2, f32 mode, against the f32 oracle: features and
+    losses to 1e-4, factor gradients to 5e-3 relative (ATen-vs-MFMA summation order over 24 layers)."""
+    import numpy as np
+    from lpi_amd import synth
+    from lpi_amd.engine import DualEncoder, trim_token_ids
+    from lpi_amd.step import train_step
+    from oracle import lpi_oracle as O
+    cfg = synth.VIT_L14
+    sd = synth.clip_state_dict(cfg)
+    fac_np = synth.prompt_factors(12, 16, cfg.vision_width, cfg.transformer_width, r=8)
+    img, ids = synth.images(2, cfg.image_resolution), synth.token_ids(2)
+    ref = O.train_step(O.Oracle(cfg, sd, torch.float32), img, ids, fac_np, depth=12)
+    enc = DualEncoder(cfg, sd, dtype="f32", device="cuda:0")
+    fac = {k: torch.from_numpy(v).to("cuda:0").requires_grad_(True) for k, v in fac_np.items()}
+    out = train_step(enc, torch.from_numpy(img).to("cuda:0"), torch.from_numpy(np.ascontiguousarray(trim_token_ids(ids))).to("cuda:0"), fac, 12)
+    for k in ("img_f", "txt_f", "base_loss", "alignment_loss"):
+        err = float(np.abs(out[k].cpu().numpy() - ref[k]).max())
+        assert err <= 1e-4, (k, err)
+    for k in synth.PROMPT_NAMES:
+        g, r = fac[k].grad.cpu().numpy(), ref["grad." + k]
+        err = float(np.abs(g - r).max())
+        assert err <= 5e-3 * np.abs(r).max() + 1e-7, (k, err, float(np.abs(r).max()))
