@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void cp_bwd_g12_kernel(int Lyr, int P, int r, 
 // slinet.py:143-158: v = mean_d(vis)/T, t = mean_d(txt)/T ([Lyr,P]); S = v t^T; loss = w * ClipLoss(S).  Single block.
 __global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv, int Dt, const float* __restrict__ vis,
                                                          const float* __restrict__ txt, float temp, float w, float* __restrict__ loss,
-                                                         float* __restrict__ dvis, float* __restrict__ dtxt) {
+                                                         float* __restrict__ dvis, float* __restrict__ dtxt, int means_ready) {
     extern __shared__ float sm[];
     float* v = sm;                 // [Lyr*P]
     float* t = v + Lyr * P;        // [Lyr*P]
@@ -177,15 +177,22 @@ __global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv
     float* dt = dv + Lyr * P;      // [Lyr*P]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nr = Lyr * P;
-    for (int row = wave; row < 2 * nr; row += nw) {
-        const bool isv = row < nr;
-        const int rr = isv ? row : row - nr;
-        const int D = isv ? Dv : Dt;
-        const float* src = (isv ? vis : txt) + (size_t)rr * D;
-        float s = 0.f;
-        for (int d = lane; d < D; d += 64) s += src[d];
-        s = wave_sum(s);
-        if (lane == 0) (isv ? v : t)[rr] = s / (float)D / temp;
+    if (means_ready) {      // align_means_kernel (one workgroup per row) left each row's mean/T in the first element of its gradient row
+        for (int i = threadIdx.x; i < nr; i += blockDim.x) {
+            v[i] = dvis[(size_t)i * Dv];
+            t[i] = dtxt[(size_t)i * Dt];
+        }
+    } else {
+        for (int row = wave; row < 2 * nr; row += nw) {
+            const bool isv = row < nr;
+            const int rr = isv ? row : row - nr;
+            const int D = isv ? Dv : Dt;
+            const float* src = (isv ? vis : txt) + (size_t)rr * D;
+            float s = 0.f;
+            for (int d = lane; d < D; d += 64) s += src[d];
+            s = wave_sum(s);
+            if (lane == 0) (isv ? v : t)[rr] = s / (float)D / temp;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Lyr * Lyr; i += blockDim.x) {
@@ -228,8 +235,37 @@ __global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv
         (isv ? dv : dt)[rr] = s / ((float)(isv ? Dv : Dt) * temp);
     }
     __syncthreads();
-    for (long i = threadIdx.x; i < (long)nr * Dv; i += blockDim.x) dvis[i] = dv[i / Dv];
-    for (long i = threadIdx.x; i < (long)nr * Dt; i += blockDim.x) dtxt[i] = dt[i / Dt];
+    // d mean_d / d x[.., d] is the same for every d: leave each row's value in its first element; align_expand_kernel (one
+    // workgroup per row) spreads it — one workgroup writing all Lyr*P*(Dv+Dt) floats took ~100 us
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) {
+        dvis[(size_t)i * Dv] = dv[i];
+        dtxt[(size_t)i * Dt] = dt[i];
+    }
+}
+
+// row means / T, one workgroup per prompt row, parked in the first element of that row of the (not yet written) gradient buffers
+__global__ __launch_bounds__(256) void align_means_kernel(int nr, int Dv, int Dt, const float* __restrict__ vis, const float* __restrict__ txt,
+                                                         float temp, float* __restrict__ dvis, float* __restrict__ dtxt) {
+    __shared__ float part[4];
+    const bool isv = (int)blockIdx.x < nr;
+    const int row = isv ? blockIdx.x : blockIdx.x - nr;
+    const int D = isv ? Dv : Dt;
+    const float* src = (isv ? vis : txt) + (size_t)row * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s += src[d];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) (isv ? dvis : dtxt)[(size_t)row * D] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)D / temp;
+}
+
+__global__ __launch_bounds__(256) void align_expand_kernel(int nr, int Dv, int Dt, float* __restrict__ dvis, float* __restrict__ dtxt) {
+    const int row = blockIdx.x < nr ? blockIdx.x : blockIdx.x - nr;
+    const int D = blockIdx.x < nr ? Dv : Dt;
+    float* o = (blockIdx.x < nr ? dvis : dtxt) + (size_t)row * D;
+    const float v = o[0];
+    __syncthreads();                       // every thread has read element 0 before thread 0 rewrites it
+    for (int d = threadIdx.x; d < D; d += 256) o[d] = v;
 }
 
 // ---------------------------------------------------------------------------------------------- task loss (nt_bxent)
@@ -403,7 +439,10 @@ extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const floa
     if (!vis || !txt || !loss || Lyr <= 0 || P <= 0 || Dv <= 0 || Dt <= 0 || temp <= 0.f) return LPI_EINVAL;
     const size_t lds = ((size_t)4 * Lyr * P + 2 * Lyr * Lyr + 2 * Lyr) * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
-    LPI_LAUNCH(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt);
+    const int grads = dvis && dtxt;      // with gradient buffers the row means and the final broadcast run grid-wide around the one-workgroup core
+    if (grads) LPI_LAUNCH(align_means_kernel, dim3(2 * Lyr * P), dim3(256), 0, S(stream), Lyr * P, Dv, Dt, vis, txt, temp, dvis, dtxt);
+    LPI_LAUNCH(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt, grads);
+    if (grads) LPI_LAUNCH(align_expand_kernel, dim3(2 * Lyr * P), dim3(256), 0, S(stream), Lyr * P, Dv, Dt, dvis, dtxt);
     LPI_CHECK_LAST();
     return 0;
 }
