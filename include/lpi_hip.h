@@ -69,6 +69,14 @@ int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K,
                 const float* bias, const void* residual, int ldr,
                 int epilogue, void* aux, int ldaux, float alpha, void* stream);
 
+/* The same GEMM for a FEW ROWS (the pooled rows of the last block, the heads: M = 128 or 256): K is cut into `ksplit` slices that
+ * run as independent workgroups writing f32 partial tiles to `scratch` (>= ksplit*M*N floats, caller-owned), then one kernel sums the
+ * slices in a fixed order and applies the same fused epilogue.  Deterministic.  K % (ksplit * 128 / sizeof(element)) == 0. */
+int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K,
+                       const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                       const float* bias, const void* residual, int ldr,
+                       int epilogue, void* aux, int ldaux, float alpha, int ksplit, float* scratch, void* stream);
+
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
  * x_dtype: storage type of the residual stream x — LPI_F32, or LPI_F16 in bf16 mode (statistics and arithmetic are f32 either way).
  * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x `x_dtype` [rows,d] (row stride ldx), y `dtype`.

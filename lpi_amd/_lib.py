@@ -27,6 +27,7 @@ SIGNATURES = {
     "lpi_launch_count": [],
     "lpi_set_tuning": [_I, _I],
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
+    "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],

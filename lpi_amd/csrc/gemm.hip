@@ -30,11 +30,15 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n)
+    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, long c_zstride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = ROW_BYTES / (int)sizeof(T);
+    // split-K launches (lpi_gemm_nt_splitk): blockIdx.y selects a K slice of length K; its partial sums go to slice y of C
+    A += (size_t)blockIdx.y * K;
+    B += (size_t)blockIdx.y * K;
+    C += (size_t)blockIdx.y * c_zstride;
 
     // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
     // run of the (n-panel major, m minor) tile list so the B panel and neighbouring A tiles stay in its L2.
@@ -153,7 +157,7 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
         attr_set = true;
     }
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
-                       (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn);
+                       (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn, 0L);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -192,7 +196,88 @@ int dispatch_epi(int epi, int M, int N, int K, const void* A, int lda, const voi
     return LPI_EINVAL;
 }
 
+// ---- split-K for small-M GEMMs (the pooled rows of the last block and the heads: M = 128 or 256) -------------------------------
+// A GEMM with a handful of tiles streams its whole K range through a handful of CUs (2-12 workgroups, 23-42 us each at B = 256,
+// 0.65 ms per step).  Here blockIdx.y cuts K into `ksplit` slices (the same 128x128 kernel, f32 partial tiles into `scratch`),
+// and a second kernel sums the slices in a fixed order and applies the usual fused epilogue: deterministic, no atomics.
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ksplit, const float* __restrict__ part, TC* __restrict__ C, int ldc,
+                                                           const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
+                                                           T* __restrict__ aux, int ldaux, float alpha)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 4 consecutive columns
+    const int n4 = N >> 2;
+    if (i >= (long)M * n4) return;
+    const int row = (int)(i / n4), col = (int)(i % n4) << 2;
+    const float* p = part + (size_t)row * N + col;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p + (size_t)k * M * N);
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, row, col, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+}
+
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
+int splitk_impl(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const float* residual,
+                int ldr, void* aux, int ldaux, float alpha, int ksplit, float* scratch, hipStream_t s)
+{
+    const int tm = M / BM, tn = N / BN;
+    auto kern = gemm_nt_kernel<T, float, LPI_EPI_NONE, false, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    LPI_LAUNCH(kern, dim3(tm * tn, ksplit), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K / ksplit, (const T*)A, lda, (const T*)B, ldb, scratch, N,
+               (const float*)nullptr, (const float*)nullptr, 0, (T*)nullptr, 0, 1.0f, tm, tn, (long)M * N);
+    const long n = (long)M * (N >> 2);
+    LPI_LAUNCH((splitk_reduce_kernel<T, TC, EPI, RES, SAVE_U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, N, ksplit, scratch, (TC*)C, ldc, bias,
+               residual, ldr, (T*)aux, ldaux, alpha);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+template <typename T, typename TC>
+int splitk_dispatch(int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                    const float* residual, int ldr, void* aux, int ldaux, float alpha, int ks, float* sc, hipStream_t s)
+{
+#define SK(EPI, RES, SU) return splitk_impl<T, TC, EPI, RES, SU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ks, sc, s)
+    if (epi == LPI_EPI_NONE) { if (residual) SK(LPI_EPI_NONE, true, false); SK(LPI_EPI_NONE, false, false); }
+    if (residual) return LPI_ENOSYS;
+    if (epi == LPI_EPI_QUICKGELU) { if (aux) SK(LPI_EPI_QUICKGELU, false, true); SK(LPI_EPI_QUICKGELU, false, false); }
+    if (epi == LPI_EPI_DQUICKGELU) { if (!aux) return LPI_EINVAL; SK(LPI_EPI_DQUICKGELU, false, false); }
+#undef SK
+    return LPI_EINVAL;
+}
+
 }  // namespace
+
+extern "C" int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                                  void* C, int ldc, const float* bias, const void* residual_, int ldr, int epilogue, void* aux,
+                                  int ldaux, float alpha, int ksplit, float* scratch, void* stream)
+{
+    const float* residual = (const float*)residual_;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    const int csz = c_dtype == LPI_F32 ? 4 : 2;
+    const int bk = ROW_BYTES / esz;
+    if (!A || !B || !C || !scratch || M <= 0 || N <= 0 || K <= 0 || ksplit < 1 || ksplit > 65535) return LPI_EINVAL;
+    if (M % BM || N % BN || K % (bk * ksplit)) return LPI_EINVAL;
+    if ((lda * esz) % 16 || (ldb * esz) % 16 || (ldc * csz) % 8 || lda < K || ldb < K || ldc < N) return LPI_EINVAL;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)scratch) & 15) return LPI_EINVAL;
+    if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
+    if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
+    if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
+    if (c_dtype == LPI_F16) return LPI_ENOSYS;     // the fp16 residual stream never has this few rows
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F32 && c_dtype == LPI_F32)
+        return splitk_dispatch<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_BF16)
+        return splitk_dispatch<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F32)
+        return splitk_dispatch<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
+    return LPI_ENOSYS;
+}
 
 bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
 int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

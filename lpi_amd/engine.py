@@ -74,6 +74,31 @@ class Linear:
 GEMM_PROFILE = None
 
 
+# Split-K for GEMMs with a few rows (pooled rows of the last block, heads): LPI_SPLITK=0 disables it (A/B switch).
+SPLITK = _os.environ.get("LPI_SPLITK", "1") != "0"
+_SPLITK_SCRATCH = {}
+
+
+def _splitk_plan(dt, M, N, K):
+    """Number of K slices for a small-M GEMM (0 = use the plain kernel): enough 128x128 workgroups to cover the chip, whole K tiles
+    per slice."""
+    if not SPLITK or M > 256 or M % 128 or N % 128:
+        return 0
+    nk = K // (32 if dt == F32 else 64)
+    tiles = (M // 128) * (N // 128)
+    cap = max(1, 384 // tiles)
+    ks = max((d for d in range(1, nk + 1) if nk % d == 0 and d <= cap), default=1)
+    return ks if ks > 1 else 0
+
+
+def _splitk_scratch(device, floats):
+    key = (device, torch.cuda.current_stream().cuda_stream)      # one scratch per stream: towers may run concurrently
+    buf = _SPLITK_SCRATCH.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = _SPLITK_SCRATCH[key] = torch.empty(max(floats, 8 << 20), dtype=torch.float32, device=device)
+    return buf
+
+
 def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None):
     """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows).
     m_real: un-padded row count, used only for algorithmic-FLOP accounting."""
@@ -82,9 +107,15 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
-         residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
-         float(alpha), _stream())
+    ks = _splitk_plan(dt, M, N, K) if cdt != F16 else 0
+    if ks:
+        call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
+             residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
+             float(alpha), ks, _splitk_scratch(c.device, ks * M * N), _stream())
+    else:
+        call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
+             residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
+             float(alpha), _stream())
     if prof is not None:
         e1.record()
         mr = m_real or M

@@ -422,3 +422,40 @@ def test_nt_bxent_task_loss():
     call("lpi_nt_bxent_fwd_bwd", T, D, row, X.to(DEV), tgt.to(DEV), temp, 1.0, loss, dx, scratch, stream())
     assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
     assert relerr(dx, Xr.grad[row]) < 1e-4
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("M,N,K,ks", [(128, 128, 256, 2), (256, 768, 3072, 24), (256, 3072, 768, 6), (256, 512, 768, 12), (128, 256, 512, 8)])
+def test_gemm_splitk_all_epilogues(dt, M, N, K, ks):
+    """Split-K path for small-M GEMMs: same results as f64 for every fused epilogue, and bitwise reproducible (fixed-order slice sum)."""
+    if dt == F32:
+        ks = min(ks, K // 32)
+    a = rnd(M, K, seed=1).to(TD[dt])
+    b = rnd(N, K, seed=2, scale=0.05).to(TD[dt])
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ab = a.double() @ b.double().t()
+    scratch = torch.empty(ks * M * N, device=DEV)
+
+    def run(c, bias=None, residual=None, epi=0, aux=None, alpha=1.0):
+        cdt = F32 if c.dtype == torch.float32 else BF16
+        call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None if bias is None else bias.to(DEV),
+             None if residual is None else residual.to(DEV), N if residual is not None else 0, epi, aux, N if aux is not None else 0,
+             float(alpha), ks, scratch, stream())
+        return c
+    c = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, alpha=0.5)
+    assert relerr(c, 0.5 * ab + bias.double()) < TOL[dt]
+    c2 = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, alpha=0.5)
+    assert torch.equal(c, c2)
+    cf = run(torch.zeros(M, N, device=DEV), bias=bias, residual=res)
+    assert relerr(cf, ab + bias.double() + res.double()) < TOL[dt]
+    u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
+    g = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, epi=E.EPI_QUICKGELU, aux=u)
+    uref = ab + bias.double()
+    assert relerr(u, uref) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
+    du = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), epi=E.EPI_DQUICKGELU, aux=u)
+    ud = u.double().cpu()
+    sg = torch.sigmoid(1.702 * ud)
+    assert relerr(du, ab * (sg * (1 + 1.702 * ud * (1 - sg)))) < TOL[dt]
+    with pytest.raises(_lib.LpiError):      # K must split into whole K tiles
+        call("lpi_gemm_nt_splitk", dt, F32 if dt == F32 else BF16, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None, None, 0, 0, None, 0, 1.0,
+             7, scratch, stream())

@@ -247,11 +247,11 @@ def test_bf16_mode_fp16_residual_stream_vs_f32_stream(monkeypatch):
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.995, k
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-6)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-3)])
 def test_trimming_text_rows_behind_the_longest_eot_is_exact(dtype, tol):
     """Token columns behind the longest caption's EOT are dead under the causal mask: features and factor gradients computed on
-    ids[:, :max(eot)+1] equal those on the full 77 columns (f32: up to the padded-tile summation order; bf16: the same roundings
-    happen row by row, so bit-for-bit up to the batch-sum order of the prompt-row gradients)."""
+    ids[:, :max(eot)+1] equal those on the full 77 columns up to summation order (the row count selects the GEMM kernel — 256x256,
+    128x128 or split-K — so in bf16 mode individual roundings may flip: bf16-level tolerance there, f32 parity tolerance in f32)."""
     from lpi_amd.engine import trim_token_ids
     cfg = synth.TINY
     ids = synth.token_ids(6, n_ctx=16, max_len=23)
