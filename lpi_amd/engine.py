@@ -121,7 +121,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
         mr = m_real or M
         nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None else 0)
                                                                  + (aux.element_size() if aux is not None else 0))
-        prof.append((e0, e1, 2.0 * mr * N * K, nbytes))
+        prof.append((e0, e1, 2.0 * mr * N * K, nbytes, M > 256))      # last field: dispatched to the 256x256 kernel (bf16: every M > 256 shape)
 
 
 @dataclass
