@@ -282,6 +282,10 @@ extern "C" int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K, c
 bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
 int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
+bool lpi_gemm256x128_eligible(int dtype, int M, int N, int K);
+int lpi_gemm256x128_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                           const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s,
+                           int group_m);
 extern int g_lpi_tuning[8];
 
 extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
@@ -302,6 +306,14 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == LPI_EPI_DQUICKGELU && !aux) return LPI_EINVAL;
+    // Half-empty launches: fewer than tuning key 5 (default 160) 256x256 tiles -> 256x128 tiles, twice the workgroups (bf16 only:
+    // the f32 path is MFMA-bound at any tile size).  Key 5 = 0 disables it.
+    if (dtype != LPI_F32 && g_lpi_tuning[5] > 0 && lpi_gemm256_eligible(dtype, M, N, K) && (M / 256) * (N / 256) < g_lpi_tuning[5] &&
+        (M / 256) * (N / 256) >= 16 && lpi_gemm256x128_eligible(dtype, M, N, K)) {
+        const int rc = lpi_gemm256x128_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s,
+                                              g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
+        if (rc != LPI_ENOSYS) return rc;
+    }
     // 256x256 8-phase kernel when the shape gives it enough tiles to fill the chip (tuning keys 0 / 1 = minimum tile count for bf16 / f32)
     if (lpi_gemm256_eligible(dtype, M, N, K) && (M / 256) * (N / 256) >= g_lpi_tuning[dtype == LPI_F32 ? 1 : 0])
         return lpi_gemm256_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);

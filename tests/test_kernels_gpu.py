@@ -459,3 +459,48 @@ def test_gemm_splitk_all_epilogues(dt, M, N, K, ks):
     with pytest.raises(_lib.LpiError):      # K must split into whole K tiles
         call("lpi_gemm_nt_splitk", dt, F32 if dt == F32 else BF16, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None, None, 0, 0, None, 0, 1.0,
              7, scratch, stream())
+
+
+def test_gemm_256x128_tiles_for_half_empty_launches():
+    """Launches with 16..159 256x256 tiles go to the 256x128-tile kernel (twice the workgroups): every epilogue, bit for bit the
+    results of the 256x256 kernel (tuning key 5 = 0 disables the rule)."""
+    M, N, K = 4096, 512, 768          # 32 tiles of 256x256 -> 64 of 256x128
+    a = rnd(M, K, seed=1).bfloat16().to(DEV)
+    b = rnd(N, K, seed=2, scale=0.05).bfloat16().to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    res16 = (rnd(M, N, seed=4) * 4).half().to(DEV)
+    u0 = rnd(M, N, seed=5).bfloat16().to(DEV)
+    ab = a.double().cpu() @ b.double().cpu().t()
+
+    def run_all():
+        out = {}
+        c = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, alpha=0.5)
+        out["plain"] = c
+        c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=res16)
+        out["f16res"] = c
+        c = torch.zeros(M, N, device=DEV)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias)
+        out["f32out"] = c
+        g, u = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, g, M, N, K, bias=bias, epi=E.EPI_QUICKGELU, aux=u)
+        out["gelu"], out["u"] = g, u
+        du = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u0)
+        out["dgelu"] = du
+        torch.cuda.synchronize()
+        return out
+    n0 = _lib.launch_count()
+    new = run_all()
+    assert _lib.launch_count() - n0 == 5
+    call("lpi_set_tuning", 5, 0)
+    try:
+        old = run_all()
+    finally:
+        call("lpi_set_tuning", 5, 160)
+    for k in new:
+        assert torch.equal(new[k], old[k]), k
+    assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < TOL[BF16]
+    assert relerr(new["f16res"], ab + bias.double().cpu() + res16.double().cpu()) < 2e-3
+    assert relerr(new["f32out"], ab + bias.double().cpu()) < TOL[BF16]
