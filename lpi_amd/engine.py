@@ -121,7 +121,11 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
         mr = m_real or M
         nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None else 0)
                                                                  + (aux.element_size() if aux is not None else 0))
-        prof.append((e0, e1, 2.0 * mr * N * K, nbytes, M > 256))      # last field: dispatched to the 256x256 kernel (bf16: every M > 256 shape)
+        # last field: which kernel lpi_gemm_nt's default rules pick (csrc/gemm.hip): split-K 128x128 for few rows, 256x128 tiles for
+        # bf16 launches with 16..159 256x256 tiles, else the 256x256 kernel
+        t256 = (M // 256) * (N // 256)
+        kind = "few_rows" if M <= 256 else ("k256x128" if (dt != F32 and 16 <= t256 < 160 and M % 256 == 0 and N % 256 == 0) else "k256")
+        prof.append((e0, e1, 2.0 * mr * N * K, nbytes, kind))
 
 
 @dataclass
