@@ -56,7 +56,9 @@ uint64_t lpi_launch_count(void);
  *   key 4      row-tile group size of the 256x256 kernel's XCD-aware tile order (default 0 = 8; measured flat from 4 to 16);
  *   key 5      bf16 launches with at least 16 but fewer than this many 256x256 tiles use 256x128 tiles instead (twice the
  *              workgroups for launches that would leave the chip half empty; default 160, 0 disables it; same results bit for bit);
- *   keys 6-7   unused.  Returns LPI_EINVAL for a key outside 0..7. */
+ *   key 6      != 0 (default): a 256x256 launch of 256k + rem tiles with rem <= 128 runs those rem tiles as 2*rem tiles of 256x128
+ *              inside the same launch — one round of half tiles instead of a half-empty round (bf16; same results bit for bit);
+ *   key 7      unused.  Returns LPI_EINVAL for a key outside 0..7. */
 int lpi_set_tuning(int key, int value);
 
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------

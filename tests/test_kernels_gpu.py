@@ -504,3 +504,43 @@ def test_gemm_256x128_tiles_for_half_empty_launches():
     assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < TOL[BF16]
     assert relerr(new["f16res"], ab + bias.double().cpu() + res16.double().cpu()) < 2e-3
     assert relerr(new["f32out"], ab + bias.double().cpu()) < TOL[BF16]
+
+
+@pytest.mark.parametrize("tm,N", [(43, 1536), (65, 1024), (48, 2048), (90, 768)])       # 258, 260, 384 (rem 128), 270 tiles
+def test_gemm_hybrid_tail_round(tm, N):
+    """A tile count of 256k + rem with rem <= 128 runs its last round as 256x128 half tiles inside the same launch (tuning key 6):
+    bit for bit the plain 256x256 launch, for every epilogue; and correct against f64."""
+    M, K = tm * 256, 512
+    assert 0 < (tm * N // 256) % 256 <= 128
+    a = rnd(M, K, seed=1).bfloat16().to(DEV)
+    b = rnd(N, K, seed=2, scale=0.05).bfloat16().to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    res16 = (rnd(M, N, seed=4) * 4).half().to(DEV)
+    u0 = rnd(M, N, seed=5).bfloat16().to(DEV)
+
+    def run_all():
+        out = {}
+        c = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, alpha=0.5)
+        out["plain"] = c
+        c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=res16)
+        out["f16res"] = c
+        g, u = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, g, M, N, K, bias=bias, epi=E.EPI_QUICKGELU, aux=u)
+        out["gelu"], out["u"] = g, u
+        du = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u0)
+        out["dgelu"] = du
+        torch.cuda.synchronize()
+        return out
+    new = run_all()
+    call("lpi_set_tuning", 6, 0)
+    try:
+        old = run_all()
+    finally:
+        call("lpi_set_tuning", 6, 1)
+    for k in new:
+        assert torch.equal(new[k], old[k]), k
+    ab = a.double().cpu() @ b.double().cpu().t()
+    assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < TOL[BF16]
