@@ -167,10 +167,12 @@ def main():
         traffic, tsrc = None, None
         pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
         if a.dtype == "bf16" and os.path.exists(pmc):      # measured by separate rocprofv3 --pmc passes (tools/pmc_summary.py)
-            k = json.load(open(pmc))["kernels"].get("gemm256_kernel")
-            if k:
-                traffic, tsrc = round(k["hbm_mb_per_launch"] * 1e6), "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
-        roofline = {"bound": "mfma", "kernel": "gemm256_kernel", "achieved": round(ach, 2),
+            ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel")]
+            if ks:      # the two entry kernels of the 256x256 GEMM, launch-weighted
+                traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks) * 1e6)
+                tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
+        roofline = {"bound": "mfma", "kernel": "gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM; the second runs a short last round as half tiles)",
+                    "achieved": round(ach, 2),
                     "peak": PEAK_TF[a.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[a.dtype], 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tsrc,
                     "algorithmic_bytes_per_launch": round(by / len(ev)),
