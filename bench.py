@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — image-text pairs/s, forward+backward, of the LPI retrieval hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 works as typed: when the process was not started by torch.distributed.run (no WORLD_SIZE in the environment) it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a CHILD process before anything touches the
+GPU, relays rank 0's JSON line and exits with the child's code.  Launched by torch.distributed.run (the driver's way), each rank
+reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.  One rank per GPU over RCCL (backend "nccl").
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM
 (SURVEY.md section 8(d)): DecomposedPrompt reconstruction -> prompted CLIP ViT-B/16 + text transformer forward ->
@@ -10,52 +15,35 @@ contrastive + alignment losses -> dgrad backward through all 24 blocks to the pr
 (methods/sprompt.py:297-311).  Workload at N=1 = BASELINE.json configs[2]: ViT-B/16, bs=256/GPU, prompt_depth=3, r=4.
 
 The JSON line carries, besides the driver's contract keys:
-  roofline     : the dominant kernel (gemm_nt_kernel, MFMA bound): algorithmic FLOPs (2*M*N*K over un-padded M) of every GEMM
-                 launch of a step / its duration, bracketed by HIP events on the launch stream in an instrumented pass that
-                 follows the timed region; peak = dense MFMA peak of the operand dtype (bf16 2500 TF, f32 157.3 TF).
-  step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair (all kernels, not just GEMMs).
-  cpu_baseline : the oracle (oracle/lpi_oracle.py, "port") timed on this host's cores on a bounded bs=8 sample.
+  value / ms_per_step : from the wall clock around EXACTLY K steps (barrier + synchronize on both sides, MAX over ranks);
+  median_ms_per_step  : median of the K per-step durations (HIP events recorded after every step inside that same region);
+  roofline     : the dominant kernel (the 256x256 GEMM, MFMA bound): executed FLOPs of its launches / their duration, bracketed by
+                 HIP events on the launch stream in an instrumented pass after the timed region; which kernel a launch went to is
+                 reported by the library (lpi_gemm_last_kernel), not re-derived here; `traffic` / `mfma_util` come from the
+                 committed rocprofv3 --pmc summary (profiles/r02_pmc.json) when its tuning stamp matches the running build;
+  step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair (all kernels, not just GEMMs);
+  parity_mode  : (N = 1) the f32-operand mode that meets the 1e-4 parity bar, same workload, a few steps;
+  fwd_only     : (N = 1) BASELINE.json configs[1]: encoder forward + cosine matrix;
+  collectives  : (N > 1) mean microseconds of the feature all-gather and the factor-gradient all-reduce per step;
+  cpu_baseline : the oracle (oracle/lpi_oracle.py, "port") timed on this host's cores on a bounded bs=8 sample, thread count swept.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 GFLOP_PER_PAIR = {"ViT-B/16": (89.68, 44.05), "ViT-L/14": (378.9, 185.8)}   # SURVEY.md section 8(d): (fwd+bwd, fwd), P=16, dgrad only
 PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+GEMM_KERNEL_NAMES = {0: "k128", 1: "k256", 2: "k256", 3: "k256x128", 4: "few_rows"}     # LPI_GEMM_K_* -> report bucket
 
 
-def cpu_baseline(cfg, depth, seconds_budget=25.0):
-    """Oracle fwd+loss+bwd at bs=8 (BASELINE.json configs[0] shape) on the host cores."""
-    from lpi_amd import synth
-    from oracle import lpi_oracle as O
-
-    B = 8
-    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
-    img = synth.images(B, cfg.image_resolution)
-    ids = synth.token_ids(B)
-    fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
-    O.train_step(orc, img, ids, fac, depth=depth)          # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.train_step(orc, img, ids, fac, depth=depth)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 5:
-            break
-    return {"value": round(B * n / el, 3), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} steps of bs={B} fwd+bwd, ViT-B/16 depth={depth} r=4, fp32, oracle/lpi_oracle.py on torch CPU "
-                      f"({torch.get_num_threads()} threads of {os.cpu_count()} cpus)"}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -69,121 +57,294 @@ def main():
     ap.add_argument("--fwd-only", action="store_true", help="BASELINE.json configs[1]: encoder forward + cosine matrix")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity_mode / fwd_only sub-records")
     ap.add_argument("--overlap", action="store_true",
                     help="run the two towers on two HIP streams (was +6.6 %% with the first kernels; -0.7 %% with the final ones: A/B switch)")
     ap.add_argument("--no-overlap", action="store_true", help="accepted for older command lines: one stream is the default")
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
-    a = ap.parse_args()
+    ap.add_argument("--cu-lanes", type=int, default=0,
+                    help="split the batch over this many CU-masked streams (lpi_amd/lanes.py); measured -4 %% with two lanes: A/B switch")
+    ap.add_argument("--cu-mode", default="half", choices=["xcd", "half", "block"], help="how the CUs are divided between the lanes")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="N > 1 ranks on ONE GPU with a gloo group (messages staged through the host): exercises the multi-rank path on a 1-GPU box")
+    return ap.parse_args()
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` typed by hand: start the ranks as a child torch.distributed.run BEFORE any GPU call in this process
+    (a process that has initialised the GPU must never exec or be replaced), relay rank 0's JSON line, return the child's exit code."""
+    import torch
+    ndev = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if a.gpus > ndev and not a.share_gpu:
+        print(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible (use --share-gpu to run the ranks on one GPU over gloo)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0 or line is None:
+        print(f"bench.py: the {a.gpus}-rank child run failed (exit code {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def cpu_baseline(cfg, depth, seconds_budget=30.0):
+    """Oracle fwd+loss+bwd at bs=8 (BASELINE.json configs[0] shape) on the host cores.  torch's default (all logical CPUs) oversubscribes
+    a bs=8 step, so the thread count is swept first (one step each) and the best one is timed."""
+    import torch
+    from lpi_amd import synth
+    from oracle import lpi_oracle as O
+
+    B = 8
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
+    img = synth.images(B, cfg.image_resolution)
+    ids = synth.token_ids(B)
+    fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    cand = sorted({t for t in (8, 16, 32, 64) if t <= ncpu} | {min(ncpu, default_threads)})
+    t_start = time.perf_counter()
+    sweep = {}
+    for t in cand:
+        torch.set_num_threads(t)
+        if not sweep:
+            O.train_step(orc, img, ids, fac, depth=depth)          # warm-up (allocator, first-touch)
+        t0 = time.perf_counter()
+        O.train_step(orc, img, ids, fac, depth=depth)
+        sweep[t] = time.perf_counter() - t0
+        if time.perf_counter() - t_start > 0.5 * seconds_budget:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(orc, img, ids, fac, depth=depth)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 0.5 * seconds_budget or n >= 6:
+            break
+    torch.set_num_threads(default_threads)
+    return {"value": round(B * n / el, 3), "unit": "pairs/s", "cores": best, "kind": "port",
+            "sample": f"{n} steps of bs={B} fwd+bwd, ViT-B/16 depth={depth} r=4, fp32, oracle/lpi_oracle.py on torch CPU with {best} threads "
+                      f"(best of a one-step sweep {{{', '.join(f'{t}: {B / s:.2f}' for t, s in sweep.items())}}} pairs/s; {ncpu} logical cpus)"}
+
+
+class Workload:
+    """Engine + synthetic inputs + optimiser for one (dtype, fwd_only) configuration on this rank."""
+
+    def __init__(self, a, dev, rank, dtype, fwd_only, exchange):
+        import numpy as np
+        import torch
+        from lpi_amd import synth
+        from lpi_amd.engine import DualEncoder, trim_token_ids
+        self.a, self.dev, self.dtype, self.fwd_only, self.exchange = a, dev, dtype, fwd_only, exchange
+        self.cfg = cfg = synth.CONFIGS[a.model]
+        self.enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=dev)
+        B = a.batch
+        self.images = torch.from_numpy(synth.images(B, cfg.image_resolution, seed=synth.IMAGE_SEED + rank)).to(dev)
+        ids_host = synth.token_ids(B, seed=synth.TOKEN_SEED + rank)          # [B, 77] as the tokenizer builds them, on the host
+        if not a.no_text_trim:
+            # token columns behind the longest caption's EOT are dead under the causal mask (engine.trim_token_ids): not computed
+            ids_host = np.ascontiguousarray(trim_token_ids(ids_host))
+        self.ids = torch.from_numpy(ids_host).to(dev)
+        self.fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not fwd_only)
+                    for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
+        self.opt = torch.optim.SGD(list(self.fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
+        self.cu_lanes = None
+        if a.cu_lanes >= 1:
+            from lpi_amd import lanes as _lanes
+            # --cu-lanes 1 (diagnostic): the whole batch on ONE lane that owns half of the chip
+            self._lane_objs = _lanes.make_lane_streams(max(2, a.cu_lanes), a.cu_mode, dev)[:a.cu_lanes]
+            self.cu_lanes = [m.stream for m in self._lane_objs]
+        self.overlap = a.overlap
+
+    def step(self):
+        import torch
+        from lpi_amd.step import forward_loss, train_step
+        a = self.a
+        if self.fwd_only:
+            with torch.no_grad():
+                forward_loss(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange.gather if self.exchange else None,
+                             overlap_towers=self.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes)
+        else:
+            train_step(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange, overlap_towers=self.overlap,
+                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes)
+            self.opt.step()
+
+    def run(self, steps, warmup, sync):
+        """-> (seconds for exactly `steps` steps, per-step milliseconds from HIP events)."""
+        import torch
+        for _ in range(warmup):
+            self.step()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        sync()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            self.step()
+            ev[i + 1].record()
+        sync()
+        el = time.perf_counter() - t0
+        per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+        return el, per
+
+    def gemm_roofline(self, nprof=2):
+        """Instrumented pass: HIP events around every GEMM launch; the library says which kernel each launch used."""
+        import torch
+        from lpi_amd import _lib, engine
+        a = self.a
+        engine.GEMM_PROFILE = []
+        overlap_saved, self.overlap = self.overlap, False     # time each kernel alone: no second stream sharing the GPU
+        lanes_saved, self.cu_lanes = self.cu_lanes, None
+        for _ in range(nprof):
+            self.step()
+        self.overlap, self.cu_lanes = overlap_saved, lanes_saved
+        torch.cuda.synchronize()
+        ev_all = engine.GEMM_PROFILE
+        engine.GEMM_PROFILE = None
+        bucket = lambda e: GEMM_KERNEL_NAMES.get(e[4], "other")  # noqa: E731
+        # the dominant kernel = the 256x256 GEMM (its two entry kernels); the few-row GEMMs (split-K 128x128 + reduce) and the
+        # half-empty launches that go to the 256x128-tile kernel are reported beside it, not averaged into its launch time
+        ev = [e for e in ev_all if bucket(e) == "k256"] or ev_all
+        small = [e for e in ev_all if bucket(e) in ("few_rows", "k128")]
+        half = [e for e in ev_all if bucket(e) == "k256x128"]
+        t_ms = lambda es: sum(e[0].elapsed_time(e[1]) for e in es)  # noqa: E731
+        ms, small_ms, half_ms = t_ms(ev), t_ms(small), t_ms(half)
+        fl, by, half_fl = sum(e[2] for e in ev), sum(e[3] for e in ev), sum(e[2] for e in half)
+        ach = fl / (ms * 1e-3) / 1e12
+        tuning = [int(_lib.load().lpi_get_tuning(k)) for k in range(8)]
+        traffic = mfma_util = tsrc = None
+        pmc = os.path.join(REPO, "profiles", "r02_pmc.json")
+        if os.path.exists(pmc):      # separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_summary.py
+            pj = json.load(open(pmc))
+            if pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(_lib.load().lpi_version()):
+                ks = [v for n, v in pj["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel")]
+                if ks:      # the two entry kernels of the 256x256 GEMM, launch-weighted
+                    w = sum(v["launches"] for v in ks)
+                    traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / w * 1e6)
+                    if all("mfma_busy_frac" in v for v in ks):
+                        mfma_util = round(sum(v["mfma_busy_frac"] * v["launches"] for v in ks) / w, 4)
+                    tsrc = "profiles/r02_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
+        return {"bound": "mfma", "kernel": "gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM; the second runs a short last round as half tiles)",
+                "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
+                "algorithmic_bytes_per_launch": round(by / len(ev)),
+                "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
+                "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
+                "few_row_gemms": {"launches_per_step": len(small) // nprof, "ms_per_step": round(small_ms / nprof, 3),
+                                  "kernel": "gemm_nt_kernel (split-K + splitk_reduce_kernel for M <= 256)"},
+                "half_empty_gemms": {"launches_per_step": len(half) // nprof, "ms_per_step": round(half_ms / nprof, 3),
+                                     "achieved_tflops": round(half_fl / (half_ms * 1e-3) / 1e12, 2) if half_ms else None,
+                                     "kernel": "gemm256x128_kernel (launches with 16..159 256x256 tiles)"},
+                "tuning": tuning,
+                "measured": f"HIP events around every GEMM launch of {nprof} extra steps, towers on one stream (kernel alone on the GPU); "
+                            "kernel attribution from lpi_gemm_last_kernel"}
+
+
+def main():
+    a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
-    from lpi_amd import engine, synth
-    from lpi_amd.engine import DualEncoder
-    from lpi_amd.step import forward_loss, train_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    dev_index = 0 if a.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     exchange = None
     if world > 1 or os.environ.get("LPI_FORCE_DIST") == "1":       # LPI_FORCE_DIST: exercise the RCCL path on a 1-GPU box
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-        from lpi_amd.dp import Exchange
-        exchange = Exchange()
-
-    cfg = synth.CONFIGS[a.model]
-    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=a.dtype, device=dev)
-    B = a.batch
-    images = torch.from_numpy(synth.images(B, cfg.image_resolution, seed=synth.IMAGE_SEED + rank)).to(dev)
-    ids_host = synth.token_ids(B, seed=synth.TOKEN_SEED + rank)          # [B, 77] as the tokenizer builds them, on the host
-    if not a.no_text_trim:
-        # token columns behind the longest caption's EOT are dead under the causal mask (engine.trim_token_ids): not computed
-        from lpi_amd.engine import trim_token_ids
-        ids_host = np.ascontiguousarray(trim_token_ids(ids_host))
-    ids = torch.from_numpy(ids_host).to(dev)
-    fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not a.fwd_only)
-           for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
-    opt = torch.optim.SGD(list(fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
-
-    def step():
-        if a.fwd_only:
-            with torch.no_grad():
-                forward_loss(enc, images, ids, fac, a.depth, exchange.gather if exchange else None, overlap_towers=a.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes)
+        if a.share_gpu:
+            dist.init_process_group("gloo")
         else:
-            train_step(enc, images, ids, fac, a.depth, exchange, overlap_towers=a.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes)
-            opt.step()
+            dist.init_process_group("nccl", device_id=dev)
+        from lpi_amd.dp import Exchange
+        exchange = Exchange(timing=True)
+    if os.environ.get("LPI_MAIN_STREAM") == "side" or a.cu_lanes:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # CU-masked lanes must not sit beside the (blocking) null stream
 
     def sync():
         if exchange is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    el = time.perf_counter() - t0
-    if exchange is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+    def rank_max(x):
+        if exchange is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if exchange.device_collectives else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    pairs_s = world * B * a.steps / el
+        return float(t.item())
 
-    roofline = None
-    if not a.no_roofline:
-        engine.GEMM_PROFILE = []
-        nprof = 2
-        overlap_saved, a.overlap = a.overlap, False     # time each kernel alone: no second stream sharing the GPU
-        for _ in range(nprof):
-            step()
-        a.overlap = overlap_saved
+    wl = Workload(a, dev, rank, a.dtype, a.fwd_only, exchange)
+    cfg, B = wl.cfg, a.batch
+    el, per = wl.run(a.steps, a.warmup, sync)
+    el = rank_max(el)
+    pairs_s = world * B * a.steps / el
+    median_ms = rank_max(float(np.median(per)))
+    collectives = None
+    if exchange is not None and exchange.timing:
         torch.cuda.synchronize()
-        ev_all = engine.GEMM_PROFILE
-        engine.GEMM_PROFILE = None
-        # the dominant kernel = the 256x256 GEMM; the few-row GEMMs (split-K 128x128 + reduce) and the half-empty launches that go to
-        # the 256x128-tile kernel are reported beside it, not averaged into its launch time
-        ev = [e for e in ev_all if e[4] == "k256"] or ev_all
-        small = [e for e in ev_all if e[4] == "few_rows"]
-        small_ms = sum(e[0].elapsed_time(e[1]) for e in small)
-        half = [e for e in ev_all if e[4] == "k256x128"]
-        half_ms = sum(e[0].elapsed_time(e[1]) for e in half)
-        half_fl = sum(e[2] for e in half)
-        ms = sum(e[0].elapsed_time(e[1]) for e in ev)
-        fl = sum(e[2] for e in ev)
-        by = sum(e[3] for e in ev)
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
-        pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if a.dtype == "bf16" and os.path.exists(pmc):      # measured by separate rocprofv3 --pmc passes (tools/pmc_summary.py)
-            ks = [v for n, v in json.load(open(pmc))["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel")]
-            if ks:      # the two entry kernels of the 256x256 GEMM, launch-weighted
-                traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks) * 1e6)
-                tsrc = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected)"
-        roofline = {"bound": "mfma", "kernel": "gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM; the second runs a short last round as half tiles)",
-                    "achieved": round(ach, 2),
-                    "peak": PEAK_TF[a.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[a.dtype], 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": tsrc,
-                    "algorithmic_bytes_per_launch": round(by / len(ev)),
-                    "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
-                    "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
-                    "few_row_gemms": {"launches_per_step": len(small) // nprof, "ms_per_step": round(small_ms / nprof, 3),
-                                      "kernel": "gemm_nt_kernel split-K + splitk_reduce_kernel"},
-                    "half_empty_gemms": {"launches_per_step": len(half) // nprof, "ms_per_step": round(half_ms / nprof, 3),
-                                         "achieved_tflops": round(half_fl / (half_ms * 1e-3) / 1e12, 2) if half_ms else None,
-                                         "kernel": "gemm256x128_kernel (launches with 16..159 256x256 tiles)"},
-                    "measured": "HIP events around every GEMM launch of 2 extra steps, towers on one stream (kernel alone on the GPU)"}
+        tl = exchange.timing[-2 * a.steps:] if not a.fwd_only else exchange.timing[-a.steps:]
+        collectives = {k: round(1e3 * float(np.mean([e0.elapsed_time(e1) for kk, e0, e1 in tl if kk == k])), 1)
+                       for k in sorted({kk for kk, _, _ in tl})}
+        collectives = {"mean_us_per_step": collectives, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
+                       "messages": "one all_gather_into_tensor of img_f||txt_f [B, 1024] f32 + one all_reduce(SUM) of the 5 284 factor gradients"}
+        exchange.timing = None
+
+    roofline = None if a.no_roofline else wl.gemm_roofline()
+
+    extras = {}
+    if world == 1 and not a.no_extras and not a.fwd_only and a.dtype == "bf16":
+        # the same workload in the parity mode (f32 operands: meets the 1e-4 bar, roofline vs the 157.3 TF f32 MFMA peak) ...
+        del wl.opt
+        gfs = GFLOP_PER_PAIR.get(a.model)
+        w32 = Workload(a, dev, rank, "f32", False, None)
+        e32, p32 = w32.run(6, 2, sync)
+        v32 = B * 6 / e32
+        extras["parity_mode"] = {"dtype": "f32", "value": round(v32, 2), "unit": "pairs/s", "steps": 6, "ms_per_step": round(1e3 * e32 / 6, 3),
+                                 "median_ms_per_step": round(float(np.median(p32)), 3),
+                                 "step_mfma_frac": None if gfs is None else round(v32 * gfs[0] * 1e9 / (PEAK_TF["f32"] * 1e12), 4),
+                                 "peak_tflops": PEAK_TF["f32"], "note": "f32-in / f32-accumulate MFMA; the mode whose logits / grads meet the 1e-4 parity bar"}
+        del w32
+        torch.cuda.empty_cache()
+        # ... and BASELINE.json configs[1]: forward-only encoders + cosine matrix, bf16
+        wf = Workload(a, dev, rank, "bf16", True, None)
+        ef, pf = wf.run(10, 3, sync)
+        vf = B * 10 / ef
+        extras["fwd_only"] = {"dtype": "bf16", "value": round(vf, 2), "unit": "pairs/s", "steps": 10, "ms_per_step": round(1e3 * ef / 10, 3),
+                              "median_ms_per_step": round(float(np.median(pf)), 3),
+                              "step_mfma_frac": None if gfs is None else round(vf * gfs[1] * 1e9 / (PEAK_TF["bf16"] * 1e12), 4),
+                              "workload": "BASELINE.json configs[1]: ViT-B/16 bs=256 prompt_depth=3 r=4, fwd-only encoder + cosine-sim matrix"}
+        del wf
+        torch.cuda.empty_cache()
 
     if rank == 0:
         gfs = GFLOP_PER_PAIR.get(a.model)
@@ -192,21 +353,26 @@ def main():
             "metric": (f"image-text pairs/sec fwd+bwd ({a.model}, bs{B}/GPU)" if not a.fwd_only
                        else f"image-text pairs/sec fwd-only encoder + cosine matrix ({a.model}, bs{B}/GPU)"),
             "value": round(pairs_s, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(1e3 * el / a.steps, 3), "median_ms_per_step": round(median_ms, 3),
+            "value_at_median": round(world * B / (median_ms * 1e-3), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: " if (a.model == "ViT-B/16" and B == 256 and a.depth == 3 and a.rank == 4 and not a.fwd_only) else "")
                        + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r={a.rank} P=16, "
                        + ("fwd-only + cosine matrix" if a.fwd_only else "fwd+bwd incl. DecomposedPrompt grads + SGD step"),
                        "global_batch": world * B, "image": f"{cfg.image_resolution}x{cfg.image_resolution}", "tokens": cfg.context_length,
-                       "text_rows_computed": int(ids.shape[1]),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
-                       "parallelism": f"dp{world}", "weights": "synthetic (numpy Philox, CLIP-init scales), frozen"},
+                       "text_rows_computed": int(wl.ids.shape[1]),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
+                       "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
+                       "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
+                       "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "
+                                    "the f32 mode (parity_mode), not of this line" if a.dtype == "bf16" else "f32 MFMA operands and accumulate (parity mode)"},
             "step_mfma_frac": None if gf is None else round(pairs_s / world * gf * 1e9 / (PEAK_TF[a.dtype] * 1e12), 4),
             "roofline": roofline,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.depth)
-        else:
-            out["cpu_baseline"] = None
+        out.update(extras)
+        if collectives is not None:
+            out["collectives"] = collectives
+        out["cpu_baseline"] = cpu_baseline(cfg, a.depth) if (world == 1 and not a.no_cpu_baseline) else None
         print(json.dumps(out), flush=True)
     if exchange is not None:
         dist.barrier()

@@ -60,6 +60,7 @@ uint64_t lpi_launch_count(void);
  *              inside the same launch — one round of half tiles instead of a half-empty round (bf16; same results bit for bit);
  *   key 7      unused.  Returns LPI_EINVAL for a key outside 0..7. */
 int lpi_set_tuning(int key, int value);
+int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..7 */
 
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
  * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
@@ -86,12 +87,13 @@ int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K,
  * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x `x_dtype` [rows,d] (row stride ldx), y `dtype`.
  * bwd: dx[r,:] (f32, in/out: residual-stream gradient) += LN'(dy[r,:]); optionally also writes a `cast_dtype`
  *      copy dx_cast (the next dgrad GEMM's operand).  dx == NULL: dx_cast itself is the in/out gradient stream (bf16 mode keeps
- *      no f32 copy).  dy is `dy_dtype`. */
+ *      no f32 copy).  dy is `dy_dtype`.  accumulate == 0: the gradient stream is WRITTEN (= LN'(dy)) instead of added to — the first
+ *      backward kernel of a tower then needs no zero-fill of the [rows, d] stream. */
 int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, int ldx, const float* gamma, const float* beta,
                       void* y, int ldy, float* mean, float* rstd, void* stream);
 int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy,
                       const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
-                      float* dx, int lddx, void* dx_cast, int ldcast, void* stream);
+                      float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
 
 /* ---- a4: prompted multi-head attention, head_dim 64   replaces: models/clip/model.py:183-185 -----------
  * qkv: [B*L, 3*d] `dtype` (q | k | v, heads contiguous by 64).  ctx: [B*L, d] `dtype`.  lse: [B, H, L] f32.
@@ -176,6 +178,23 @@ int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream);
  * dlogits (f32, same shape) = upstream * dloss/dlogits. */
 int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, float* loss, float* dlogits,
                           int lddl, float* row_lse, float* col_lse, void* stream);
+/* Data-parallel backward of the same loss (`local_loss=False` semantics of gather_features, sprompt.py:75-80): only the nloc rows
+ * r0..r0+nloc of the global matrix belong to this rank.  g[i,j] = dL/dlogits[r0+i, j], gt[i,j] = dL/dlogits[j, r0+i] (both
+ * [nloc, n] row-major, row stride ldg), from the row/column log-sum-exp vectors lpi_clip_loss_fwd_bwd left behind. */
+int lpi_clip_loss_local_grad(int n, const float* logits, int ld, const float* row_lse, const float* col_lse, float upstream,
+                             int r0, int nloc, float* g, float* gt, int ldg, void* stream);
+/* dst[r, 0:cols] = src[r, 0:cols], f32, row strides lds / ldd elements (packing / zero-padded operands; no framework copy kernels) */
+int lpi_zero(void* ptr, long bytes, void* stream);   /* hipMemsetAsync(ptr, 0, bytes) on `stream` */
+int lpi_copy_rows(int rows, int cols, const float* src, long lds, float* dst, long ldd, void* stream);
+/* a11 task-id selection, replaces get_visual_task_id / get_textual_task_id (methods/sprompt.py:336-368):
+ * sel[i] = argmin_t min_c sum_e |feat[i,e] - keys[t,c,e]|, keys [T, C, E] f32 (the KMeans centres of every task seen so far);
+ * dist (optional) [n, T] receives the per-task minima. */
+int lpi_l1_task_id(int n, int E, int T, int C, const float* feat, int ldf, const float* keys, int32_t* sel, float* dist,
+                   void* stream);
+/* a10 optimiser step, replaces optim.SGD(momentum, weight_decay).step() (methods/sprompt.py:253,311) on one flat f32 vector:
+ * d = grad + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf. */
+int lpi_sgd_step(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum, float weight_decay,
+                 int first, void* stream);
 
 /* ---- a8: alignment loss                                   replaces: models/slinet.py:143-158 ------------
  * v = mean_d(vis)/temp, t = mean_d(txt)/temp ([Lyr,P]); S = v t^T [Lyr,Lyr]; loss[0] = weight * ClipLoss(S);
@@ -210,6 +229,25 @@ void* lpi_bpe_create(const char* merges_utf8, long nbytes);
 void lpi_bpe_destroy(void* handle);
 int lpi_bpe_encode(void* handle, const char* text_utf8, int32_t* ids, int max_ids);
 int lpi_bpe_tokenize(void* handle, const char* const* texts, int n, int context_length, int truncate, int64_t* out);
+
+/* Which kernel the calling thread's last lpi_gemm_nt / lpi_gemm_nt_splitk launched (-1: none yet): measurement tools attribute a
+ * launch to a kernel with this instead of re-deriving the dispatch rules. */
+#define LPI_GEMM_K_128 0        /* gemm_nt_kernel, 128x128 tiles                                  */
+#define LPI_GEMM_K_256 1        /* gemm256_kernel, 256x256 tiles                                  */
+#define LPI_GEMM_K_256_TAIL 2   /* gemm256_tail_kernel: 256x256 tiles, short last round as halves */
+#define LPI_GEMM_K_256X128 3    /* gemm256x128_kernel                                             */
+#define LPI_GEMM_K_SPLITK 4     /* split-K gemm_nt_kernel + splitk_reduce_kernel                  */
+int lpi_gemm_last_kernel(void);
+
+/* ---- CU-partitioned lanes (speed only) --------------------------------------------------------------------
+ * A HIP stream whose kernels run on the CUs whose bits are set in mask[0..words) (hipExtStreamCreateWithCUMask): lpi_amd/step.py
+ * runs two half-batch lanes of the train step (sprompt.py:297-311 is a single stream in the reference) on two disjoint halves of
+ * the chip so that one lane's HBM-bound kernels overlap the other's matrix-core kernels.  lpi_probe_placement reports, per
+ * workgroup b of a `blocks` x `threads` launch holding `lds_bytes` of LDS: out[2b] = HW_REG_XCC_ID, out[2b+1] = HW_REG_HW_ID. */
+int lpi_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
+int lpi_stream_destroy(void* stream);
+int lpi_device_cu_count(void);
+int lpi_probe_placement(int blocks, int threads, int lds_bytes, int spin, uint32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,10 +26,12 @@ SIGNATURES = {
     "lpi_version": [],
     "lpi_launch_count": [],
     "lpi_set_tuning": [_I, _I],
+    "lpi_get_tuning": [_I],
+    "lpi_gemm_last_kernel": [],
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
-    "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
@@ -53,6 +55,11 @@ SIGNATURES = {
     "lpi_l2norm_bwd": [_I, _I, _P, _I, _P, _I, _P, _P, _I, _P],
     "lpi_eot_index": [_I, _I, _P, _P, _P],
     "lpi_clip_loss_fwd_bwd": [_I, _P, _I, _F, _P, _P, _I, _P, _P, _P],
+    "lpi_clip_loss_local_grad": [_I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _I, _P],
+    "lpi_zero": [_P, _L, _P],
+    "lpi_copy_rows": [_I, _I, _P, _L, _P, _L, _P],
+    "lpi_l1_task_id": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "lpi_sgd_step": [_L, _P, _P, _P, _F, _F, _F, _I, _P],
     "lpi_cast": [_I, _I, _L, _P, _P, _P],
     "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],
     "lpi_retrieval_rank": [_I, _I, _P, _I, _P, _I, _P, _P],
@@ -62,6 +69,11 @@ SIGNATURES = {
     "lpi_bpe_destroy": [_P],
     "lpi_bpe_encode": [_P, _P, _P, _I],
     "lpi_bpe_tokenize": [_P, _P, _I, _I, _I, _P],
+    # CU-partitioned lanes
+    "lpi_stream_create_cu_mask": [_P, _I, _P],
+    "lpi_stream_destroy": [_P],
+    "lpi_device_cu_count": [],
+    "lpi_probe_placement": [_I, _I, _I, _I, _P, _P],
 }
 _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_destroy": None}
 

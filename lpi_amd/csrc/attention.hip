@@ -655,17 +655,27 @@ inline int pick_waves(int L) {
     return (nqb + rounds - 1) / rounds;
 }
 
-// allow the full 160 KiB of a CU's LDS for a kernel (once per kernel function)
+// allow the full 160 KiB of a CU's LDS for a kernel: once per (kernel function, device), safe from any host thread
 int set_lds(const void* kern, size_t bytes) {
     if (bytes > 160 * 1024) return LPI_EINVAL;
-    static const void* done[16];
-    static int ndone = 0;
-    for (int i = 0; i < ndone; ++i)
-        if (done[i] == kern) return 0;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    if (ndone < 16) done[ndone++] = kern;
-    return 0;
+    static const void* fn[16];
+    static LdsOnce once[16];
+    static std::atomic<int> nfn{0};
+    static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    int slot = -1;
+    const int n = nfn.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (fn[i] == kern) { slot = i; break; }
+    if (slot < 0) {
+        while (lock.test_and_set(std::memory_order_acquire)) {}
+        const int m = nfn.load(std::memory_order_relaxed);
+        for (int i = 0; i < m; ++i)
+            if (fn[i] == kern) { slot = i; break; }
+        if (slot < 0 && m < 16) { fn[m] = kern; slot = m; nfn.store(m + 1, std::memory_order_release); }
+        lock.clear(std::memory_order_release);
+    }
+    if (slot < 0) return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return lpi_ensure_lds(once[slot], kern, 160 * 1024);
 }
 
 template <typename T, bool CAUSAL>

@@ -30,6 +30,25 @@ extern "C" void lpi_count_launch();
         if (e__ != hipSuccess) return (int)e__;               \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute and launches come from several host threads (forward on the
+// caller's thread, backward on autograd's): one atomic bit per device, one LdsOnce per kernel function.
+#include <atomic>
+struct LdsOnce {
+    std::atomic<uint64_t> devices{0};
+};
+inline int lpi_ensure_lds(LdsOnce& once, const void* kern, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return LPI_EINVAL;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (once.devices.load(std::memory_order_acquire) & bit) return 0;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    once.devices.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+// which GEMM kernel the last lpi_gemm_nt / lpi_gemm_nt_splitk call of this thread launched (LPI_GEMM_K_*; lpi_gemm_last_kernel)
+void lpi_note_gemm_kernel(int which);
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving

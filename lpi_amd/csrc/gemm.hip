@@ -150,12 +150,9 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
 {
     const int tm = M / BM, tn = N / BN;
     auto kern = gemm_nt_kernel<T, TC, EPI, RES, SAVE_U>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsOnce once;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
+    lpi_note_gemm_kernel(LPI_GEMM_K_128);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
                        (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn, 0L);
     LPI_CHECK_LAST();
@@ -223,12 +220,9 @@ int splitk_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
 {
     const int tm = M / BM, tn = N / BN;
     auto kern = gemm_nt_kernel<T, float, LPI_EPI_NONE, false, false>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsOnce once;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
+    lpi_note_gemm_kernel(LPI_GEMM_K_SPLITK);
     LPI_LAUNCH(kern, dim3(tm * tn, ksplit), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K / ksplit, (const T*)A, lda, (const T*)B, ldb, scratch, N,
                (const float*)nullptr, (const float*)nullptr, 0, (T*)nullptr, 0, 1.0f, tm, tn, (long)M * N);
     const long n = (long)M * (N >> 2);

@@ -115,12 +115,9 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
     if (sizeof(T) == 2 && g_lpi_tuning[6] != 0 && n_full >= 256 && rem > 0 && rem <= 128 && K / (ROWB / (int)sizeof(T)) >= 2) {
         auto tk = gemm256_tail_kernel<T, TC, EPI, RES, SAVE_U>;
         constexpr int LDS_TAIL = t128::LDS_BYTES > LDS_BYTES ? t128::LDS_BYTES : LDS_BYTES;
-        static bool tail_attr_set = false;
-        if (!tail_attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)tk, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TAIL);
-            if (e != hipSuccess) return (int)e;
-            tail_attr_set = true;
-        }
+        static LdsOnce tail_once;
+        if (int e = lpi_ensure_lds(tail_once, (const void*)tk, LDS_TAIL)) return e;
+        lpi_note_gemm_kernel(LPI_GEMM_K_256_TAIL);
         const int q = nwg >> 3, r = nwg & 7;
         const int max_left = q + (r ? 1 : 0) - (n_full >> 3);      // leftover tiles of the fullest XCD
         LPI_LAUNCH(tk, dim3(n_full + 16 * max_left), dim3(NTHR), LDS_TAIL, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
@@ -129,12 +126,9 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
         return 0;
     }
     auto kern = gemm256_kernel<T, TC, EPI, RES, SAVE_U>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsOnce once;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, LDS_BYTES)) return e;
+    lpi_note_gemm_kernel(LPI_GEMM_K_256);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
                ldr, (T*)aux, ldaux, alpha, tm, tn, g_lpi_tuning[2], g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
     LPI_CHECK_LAST();

@@ -49,12 +49,9 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
 {
     const int tm = M / TM, tn = N / TN;
     auto kern = gemm256x128_kernel<T, TC, EPI, RES, SAVE_U>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static LdsOnce once;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, LDS_BYTES)) return e;
+    lpi_note_gemm_kernel(LPI_GEMM_K_256X128);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
                ldr, (T*)aux, ldaux, alpha, tm, tn, group_m);
     LPI_CHECK_LAST();

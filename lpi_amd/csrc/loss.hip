@@ -75,6 +75,68 @@ __global__ __launch_bounds__(256) void clip_loss_grad_kernel(int n, const float*
     dl[(size_t)i * lddl + j] = g * (up / (2.f * (float)n));
 }
 
+// The LOCAL rows of dlogits and of dlogits^T (data-parallel step: a rank back-propagates only through its own B rows of the
+// global n x n matrix, sprompt.py:75-80).  g[i, j]  = dL/dlogits[r0 + i, j],  gt[i, j] = dL/dlogits[j, r0 + i],  i < nloc, j < n:
+// both row-major [nloc, n], so that dI_local = scale * g . T and dT_local = scale * gt . I are plain NT GEMMs.
+__global__ __launch_bounds__(256) void clip_loss_local_grad_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
+                                                                  const float* __restrict__ cl, float up, int r0, float* __restrict__ g,
+                                                                  float* __restrict__ gt, int ldg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    const int gi = r0 + i;
+    const float c = up / (2.f * (float)n);
+    const float v = x[(size_t)gi * ld + j];
+    g[(size_t)i * ldg + j] = (expf(v - rl[gi]) + expf(v - cl[j]) - (gi == j ? 2.f : 0.f)) * c;
+    const float w = x[(size_t)j * ld + gi];       // strided read: n * nloc floats in all, served by L2
+    gt[(size_t)i * ldg + j] = (expf(w - rl[j]) + expf(w - cl[gi]) - (gi == j ? 2.f : 0.f)) * c;
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] (f32, arbitrary row strides): pads / packs small operands without the host framework's copy kernels
+__global__ __launch_bounds__(256) void copy_rows_kernel(int rows, int cols, const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * cols) return;
+    const int r = (int)(t / cols), c = (int)(t % cols);
+    dst[r * ldd + c] = src[r * lds + c];
+}
+
+// ---------------------------------------------------------------------------------------------- task-id selection (a11)
+// sel[i] = argmin_t min_c sum_e |f[i,e] - key[t,c,e]|   (sprompt.py:336-368; first t among equal distances).  One wave per row.
+__global__ __launch_bounds__(256) void l1_task_id_kernel(int n, int E, int T, int C, const float* __restrict__ f, int ldf,
+                                                        const float* __restrict__ keys, int32_t* __restrict__ sel, float* __restrict__ dist) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* fr = f + (size_t)row * ldf;
+    float best = INFINITY;
+    int bt = 0;
+    for (int t = 0; t < T; ++t) {
+        float dmin = INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float* k = keys + ((size_t)t * C + c) * E;
+            float s = 0.f;
+            for (int e = lane; e < E; e += 64) s += fabsf(fr[e] - k[e]);
+            s = wave_sum(s);
+            dmin = fminf(dmin, s);
+        }
+        if (dist && lane == 0) dist[(size_t)row * T + t] = dmin;
+        if (dmin < best) { best = dmin; bt = t; }
+    }
+    if (lane == 0) sel[row] = bt;
+}
+
+// p = p - lr * (momentum-buffered gradient with weight decay): torch.optim.SGD(momentum, weight_decay), sprompt.py:253, over one flat
+// parameter vector.  first != 0: the momentum buffer is initialised with the gradient (torch's first step).
+__global__ __launch_bounds__(256) void sgd_step_kernel(long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                      float lr, float momentum, float wd, int first) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = g[i] + wd * p[i];
+    const float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] = p[i] - lr * b;
+}
+
 // ---------------------------------------------------------------------------------------------- CP prompt
 constexpr int MAXR = 16;
 
@@ -409,6 +471,38 @@ extern "C" int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float u
         LPI_LAUNCH(clip_loss_grad_kernel, dim3((n + 255) / 256, n), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream,
                            dlogits, lddl);
     }
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_clip_loss_local_grad(int n, const float* logits, int ld, const float* row_lse, const float* col_lse, float upstream,
+                                        int r0, int nloc, float* g, float* gt, int ldg, void* stream) {
+    if (!logits || !row_lse || !col_lse || !g || !gt || n <= 0 || ld < n || r0 < 0 || nloc <= 0 || r0 + nloc > n || ldg < n) return LPI_EINVAL;
+    LPI_LAUNCH(clip_loss_local_grad_kernel, dim3((n + 255) / 256, nloc), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream, r0, g, gt, ldg);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_copy_rows(int rows, int cols, const float* src, long lds, float* dst, long ldd, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return LPI_EINVAL;
+    const long n = (long)rows * cols;
+    LPI_LAUNCH(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), rows, cols, src, lds, dst, ldd);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_l1_task_id(int n, int E, int T, int C, const float* feat, int ldf, const float* keys, int32_t* sel, float* dist,
+                              void* stream) {
+    if (!feat || !keys || !sel || n <= 0 || E <= 0 || T <= 0 || C <= 0 || ldf < E) return LPI_EINVAL;
+    LPI_LAUNCH(l1_task_id_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, E, T, C, feat, ldf, keys, sel, dist);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_sgd_step(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum, float weight_decay,
+                            int first, void* stream) {
+    if (!param || !grad || !momentum_buf || n <= 0) return LPI_EINVAL;
+    LPI_LAUNCH(sgd_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), n, param, grad, momentum_buf, lr, momentum, weight_decay, first);
     LPI_CHECK_LAST();
     return 0;
 }

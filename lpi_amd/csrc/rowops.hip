@@ -97,7 +97,7 @@ template <typename TX, typename TDY, typename TCAST, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
                                                     const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast) {
+                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -112,13 +112,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY*
     if (dx) {
         float* dxr = dx + (size_t)row * lddx;
         for_chunks_n<NC>(d, lane, [&](int i, int col) {
-            f32x4 t = *reinterpret_cast<const f32x4*>(dxr + col) + g.v[i];
+            f32x4 t = g.v[i];
+            if (accumulate) t += *reinterpret_cast<const f32x4*>(dxr + col);
             *reinterpret_cast<f32x4*>(dxr + col) = t;
             if (dx_cast) Elem<TCAST>::st4(dx_cast + (size_t)row * ldcast + col, t);
         });
     } else {   // the `cast` copy IS the gradient stream (in/out), no f32 stream is kept
         TCAST* dxr = dx_cast + (size_t)row * ldcast;
-        for_chunks_n<NC>(d, lane, [&](int i, int col) { Elem<TCAST>::st4(dxr + col, Elem<TCAST>::ld4(dxr + col) + g.v[i]); });
+        for_chunks_n<NC>(d, lane, [&](int i, int col) {
+            f32x4 t = g.v[i];
+            if (accumulate) t += Elem<TCAST>::ld4(dxr + col);
+            Elem<TCAST>::st4(dxr + col, t);
+        });
     }
 }
 
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const 
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast) {
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate) {
     const int hl = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
@@ -232,7 +237,12 @@ __global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const 
     bf16_t* o = dxs + (size_t)row * ldcast;
     for_chunks8<NC>(d, hl, [&](int i, int col) {
         float acc[8];
-        ld8(o + col, acc);
+        if (accumulate) {
+            ld8(o + col, acc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += (g.v[i][j] - c1 - xh.v[i][j] * c2) * rs;
         st8(o + col, acc);
@@ -564,17 +574,17 @@ extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const 
 
 extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
                                  const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
-                                 int ldcast, void* stream) {
+                                 int ldcast, int accumulate, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_cast) || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
-#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast)
+#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast, accumulate)
 #define LNB_HBB(NC) LNB(f16_t, bf16_t, bf16_t, NC)
 #define LNB_FFF(NC) LNB(float, float, float, NC)
 #define LNB_FFB(NC) LNB(float, float, bf16_t, NC)
 #define LNB_FBB(NC) LNB(float, bf16_t, bf16_t, NC)
 #define LNB_FBF(NC) LNB(float, bf16_t, float, NC)
-#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast)
+#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast, accumulate)
     if (x_dtype == LPI_F16) {
         if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16 && !dx && !(d & 7) && !(lddy & 7) && !(ldx & 7) && !(ldcast & 7) &&
             !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx_cast) & 15))

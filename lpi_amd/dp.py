@@ -1,14 +1,17 @@
 """Data-parallel exchange for the contrastive step: one process per GPU, torch.distributed (backend "nccl" = RCCL
-over xGMI on ROCm; "gloo" in the CPU plumbing tests).
+over xGMI on ROCm; "gloo" in the CPU plumbing tests and in the two-processes-on-one-GPU test of the HIP path).
 
 The reference has no working multi-GPU path (README.md:13); its dead ``gather_features``
 (methods/sprompt.py:38-82) is the specification followed here with ``local_loss=False, gather_with_grad=False``:
 every rank all-gathers the L2-normalised features, evaluates the FULL global loss, and back-propagates only through
-its own rows; the prompt-factor gradients are then SUM all-reduced.  Both messages are tiny and latency bound
-(1 MB and 21 KB at B=256), so each is ONE fused collective: image||text features in one all-gather, the five factor
-gradients in one flat all-reduce (reduced after the CP contraction: 5 284 floats, not the 184 K dense ones).
-Data-independent loss terms (alignment / task loss) are identical on every rank and must count once: the step scales
-them by 1/W before the SUM.
+its own rows (engine.clip_loss_fwd_bwd computes the local rows of dlogits / dlogits^T only); the prompt-factor
+gradients are then SUM all-reduced.  Both messages are tiny and latency bound (1 MB and 21 KB at B=256), so each is
+ONE fused collective: image||text features in one all-gather, the five factor gradients in one flat all-reduce
+(reduced after the CP contraction: 5 284 floats, not the 184 K dense ones).  Data-independent loss terms (alignment /
+task loss) are identical on every rank and must count once: the step scales them by 1/W before the SUM.
+
+The gathered [W*B, 2E] buffer is handed to the loss as two row-strided views (no unpacking copies).  With a backend that
+cannot move device memory (gloo) the two messages are staged through the host.
 """
 from __future__ import annotations
 
@@ -17,26 +20,62 @@ import torch.distributed as dist
 
 
 class Exchange:
-    def __init__(self, group=None):
+    def __init__(self, group=None, timing: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.device_collectives = dist.get_backend(group) == "nccl"
+        self.timing = [] if timing else None      # (kind, start event, end event) per collective, for bench.py
+        self._local = {}
+
+    def _timed(self, kind, fn, on_device):
+        if self.timing is None or not on_device:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.timing.append((kind, e0, e1))
+        return out
 
     def gather(self, img_f: torch.Tensor, txt_f: torch.Tensor):
-        """-> (img_all [W*B,E], txt_all [W*B,E], first global row of this rank)."""
+        """-> (img_all [W*B,E], txt_all [W*B,E] (views of one [W*B, 2E] buffer), first global row of this rank)."""
         B, E = img_f.shape
-        local = torch.cat([img_f, txt_f], dim=1).contiguous()
-        out = torch.empty(self.world * B, 2 * E, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local, group=self.group)
-        return out[:, :E].contiguous(), out[:, E:].contiguous(), self.rank * B
+        key = (B, E, img_f.device, img_f.dtype)
+        local = self._local.get(key)
+        if local is None:
+            local = self._local[key] = torch.empty(B, 2 * E, dtype=img_f.dtype, device=img_f.device)
+        if img_f.is_cuda and img_f.dtype == torch.float32:
+            from . import _lib
+            s = torch.cuda.current_stream().cuda_stream
+            i, t = img_f.contiguous(), txt_f.contiguous()
+            _lib.call("lpi_copy_rows", B, E, i, E, local, 2 * E, s)
+            _lib.call("lpi_copy_rows", B, E, t, E, local[:, E:], 2 * E, s)
+        else:
+            local[:, :E].copy_(img_f)
+            local[:, E:].copy_(txt_f)
+        if self.device_collectives or not local.is_cuda:
+            out = torch.empty(self.world * B, 2 * E, dtype=local.dtype, device=local.device)
+            self._timed("all_gather", lambda: dist.all_gather_into_tensor(out, local, group=self.group), local.is_cuda)
+        else:       # host-staged (gloo with device tensors)
+            h = local.cpu()
+            oh = torch.empty(self.world * B, 2 * E, dtype=h.dtype)
+            dist.all_gather_into_tensor(oh, h, group=self.group)
+            out = oh.to(local.device)
+        return out[:, :E], out[:, E:], self.rank * B
 
     def allreduce_grads(self, params):
         """SUM all-reduce of the (small) prompt-factor gradients as one flat message."""
         params = [p for p in params if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.device_collectives or not flat.is_cuda:
+            self._timed("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group), flat.is_cuda)
+        else:
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            flat = h.to(flat.device)
         o = 0
         for p in params:
             n = p.grad.numel()

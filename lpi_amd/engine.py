@@ -121,10 +121,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
         mr = m_real or M
         nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None else 0)
                                                                  + (aux.element_size() if aux is not None else 0))
-        # last field: which kernel lpi_gemm_nt's default rules pick (csrc/gemm.hip): split-K 128x128 for few rows, 256x128 tiles for
-        # bf16 launches with 16..159 256x256 tiles, else the 256x256 kernel
-        t256 = (M // 256) * (N // 256)
-        kind = "few_rows" if M <= 256 else ("k256x128" if (dt != F32 and 16 <= t256 < 160 and M % 256 == 0 and N % 256 == 0) else "k256")
+        kind = int(_lib.load().lpi_gemm_last_kernel())      # LPI_GEMM_K_*: which kernel the dispatcher launched (same host thread)
         prof.append((e0, e1, 2.0 * mr * N * K, nbytes, kind))
 
 
@@ -157,6 +154,14 @@ class Tower:
                 blk[nm + ".b"] = f(p + nm + ".bias").to(device=device, dtype=torch.float32).contiguous()
             self.blocks.append(blk)
         self._ws = {}
+        self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
+
+    def _check_depth(self, prompts, depth):
+        """model.py:191 indexes prompts[:, layer_id]: the reference raises IndexError past the stack; so do we (before any kernel)."""
+        if prompts is not None and not (1 <= depth <= prompts.shape[-3]):
+            raise ValueError(f"prompt depth {depth} outside 1..{prompts.shape[-3]} (layers of the prompt stack)")
+        if depth > len(self.blocks):
+            raise ValueError(f"prompt depth {depth} exceeds the tower's {len(self.blocks)} blocks")
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B: int, L: int, train: bool, cap: Optional[int] = None):
@@ -219,6 +224,8 @@ class Tower:
         B, L, Mp = ws["B"], ws["L"], ws["Mp"]
         M = B * L
         P = prompts.shape[-2] if prompts is not None else 0
+        self._check_depth(prompts, depth)
+        self.serial += 1
         for i, blk in enumerate(self.blocks):
             k = i if train else 0
             x_in = ws["x"][i if train else i % 2]
@@ -268,11 +275,12 @@ class Tower:
         dx, dh, dctx, dqkv = ws["dx"], ws["dh"], ws["dctx"], ws["dqkv"]
         dxT = ws["dxT"] if dt != F32 else dx          # the stream the dgrad GEMMs read; in bf16 mode also the accumulator
         P = prompts.shape[-2] if prompts is not None else 0
+        self._check_depth(prompts, depth)
         for i in reversed(range(len(self.blocks))):
             blk = self.blocks[i]
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
             if i == len(self.blocks) - 1 and not POOLED_LAST:
-                dxT.zero_()
+                call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
                 call("lpi_scatter_rows", dt, B, L, d, ws["c_dx"], pool_idx, dx, None if dt == F32 else dxT, s)
             if i == len(self.blocks) - 1 and POOLED_LAST:
                 # last block: MLP backward on the pooled rows, then scatter into the (zeroed) full-size gradient stream
@@ -282,9 +290,9 @@ class Tower:
                 gemm(dt, c_dxT, blk["proj"].wt, ws["c_g"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
                 gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
-                     None if dt == F32 else c_dxT, d, s)
+                     None if dt == F32 else c_dxT, d, 1, s)
                 if not POOLED_ATTN:
-                    dxT.zero_()
+                    call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
                     call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
@@ -295,10 +303,11 @@ class Tower:
                 gemm(dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 gemm(dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
                 call("lpi_scatter_add_rows", dt, B, L, d, ws["c_dh"], d, pool_idx, dh, d, s)
-                dxT.zero_()
-                call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)      # residual path of the pooled rows
+                # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
+                # path of the pooled rows is added
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
-                     None if dt == F32 else dxT, d, s)
+                     None if dt == F32 else dxT, d, 0, s)
+                call("lpi_scatter_add_rows", dt, B, L, d, c_dxT, d, pool_idx, dxT, d, s)
                 if prompts is not None and dprompts is not None and 0 < i < depth:
                     call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
                 continue
@@ -307,12 +316,12 @@ class Tower:
                 gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
-                     None if dt == F32 else dxT, d, s)      # dx is None in bf16 mode: dxT accumulates in place
+                     None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
-                 None if dt == F32 else dxT, d, s)
+                 None if dt == F32 else dxT, d, 1, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
                 call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
         return dxT
@@ -351,12 +360,15 @@ class DualEncoder:
         self._head_ws = {}
 
     # ------------------------------------------------------------------ lanes
-    def lane(self, i: int):
+    def lane(self, i: int, stream=None):
         """Lane i > 0: an engine that SHARES the frozen weights but owns its workspace arena and HIP stream, so that
-        micro-batches can be in flight concurrently (step.py); lane 0 is this engine on the caller's stream."""
+        micro-batches can be in flight concurrently (step.py); lane 0 is this engine on the caller's stream.
+        stream: use this torch stream (e.g. a CU-masked one, lanes.py) instead of creating a plain one."""
         if i == 0:
             return self
         lanes = self.__dict__.setdefault("_lanes", {})
+        if i in lanes and stream is not None and lanes[i].stream is not stream:
+            lanes[i].stream = stream
         if i not in lanes:
             import copy
             c = copy.copy(self)
@@ -364,7 +376,7 @@ class DualEncoder:
             c.vis._ws, c.txt._ws, c._head_ws = {}, {}, {}
             c.__dict__.pop("_lanes", None)
             c.__dict__.pop("_side_stream", None)
-            c.stream = torch.cuda.Stream(device=self.device)
+            c.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
             lanes[i] = c
         return lanes[i]
 
@@ -396,8 +408,16 @@ class DualEncoder:
         return p, p.stride(0), p.shape[-2]
 
     # ------------------------------------------------------------------ vision
-    def encode_image(self, image, prompts=None, depth=1, train=False, normalise=True):
-        """image [B,3,R,R] f32 (device) -> features [B,E] f32 (L2-normalised like slinet.py:122 unless normalise=False)."""
+    def _stale(self, tower, serial, what):
+        if serial != tower.serial:
+            raise _lib.LpiError(
+                f"{what}: the {'vision' if tower is self.vis else 'text'} tower ran another forward since the forward this backward belongs to; "
+                "its workspace arena (saved activations) has been overwritten.  Run forward -> backward 1:1 per engine (use "
+                "DualEncoder.lane(i) for micro-batches that must be in flight together).")
+
+    def encode_image(self, image, prompts=None, depth=1, train=False, normalise=True, return_ctx=False):
+        """image [B,3,R,R] f32 (device) -> features [B,E] f32 (L2-normalised like slinet.py:122 unless normalise=False).
+        return_ctx: also return the backward context (held by the autograd node, functional.EncodeImageFn)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
         B = image.shape[0]
         image = image.to(device=self.device, dtype=torch.float32).contiguous()
@@ -424,13 +444,16 @@ class DualEncoder:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
         else:
             out.copy_(hw["feat"][:B])
-        self._vis_ctx = (ws, pr, pbs, P, depth, B, L, out)
-        return out
+        ctx = (ws, pr, pbs, P, depth, B, L, out, self.vis.serial)
+        self._vis_ctx = ctx
+        return (out, ctx) if return_ctx else out
 
-    def encode_image_backward(self, dout):
-        """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch."""
+    def encode_image_backward(self, dout, ctx=None):
+        """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch.
+        ctx: the context encode_image(return_ctx=True) returned (default: the engine's last forward)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
-        ws, pr, pbs, P, depth, B, L, out = self._vis_ctx
+        ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._vis_ctx
+        self._stale(self.vis, serial, "encode_image_backward")
         d, E = cfg.vision_width, cfg.embed_dim
         hw = self._head("v", B, d)
         dout = dout.contiguous().float()
@@ -452,7 +475,7 @@ class DualEncoder:
         return dpr
 
     # ------------------------------------------------------------------ text
-    def encode_text(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True):
+    def encode_text(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True, return_ctx=False):
         """ids [B,77] int64 (device).  prompts as in encode_image; row 0 of the prompt stack is the ctx spliced over
         positions 1..n_ctx (slinet.py:130, prompt_learner.py:155-163); use_ctx=False = extract_vector (:118-126)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
@@ -477,12 +500,14 @@ class DualEncoder:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
         else:
             out.copy_(hw["feat"][:B])
-        self._txt_ctx = (ws, pr, pbs, P, depth, B, L, out)
-        return out
+        ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial)
+        self._txt_ctx = ctx
+        return (out, ctx) if return_ctx else out
 
-    def encode_text_backward(self, dout):
+    def encode_text_backward(self, dout, ctx=None):
         cfg, dt, s = self.cfg, self.dt, _stream()
-        ws, pr, pbs, P, depth, B, L, out = self._txt_ctx
+        ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._txt_ctx
+        self._stale(self.txt, serial, "encode_text_backward")
         d, E = cfg.transformer_width, cfg.embed_dim
         hw = self._head("t", B, d)
         dout = dout.contiguous().float()
@@ -523,37 +548,80 @@ def trim_token_ids(ids):
 _LOSS_WS = {}
 
 
-def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True):
-    """Symmetric CE over the (global) n x n logits (loss/loss.py:75-87, slinet.py:139-141).
-    img_all/txt_all: f32 [n, E] on device.  Returns (loss[1], logits[n,n] view, dimg[n,E], dtxt[n,E]).
-    The zero-padded operand buffers live in a per-shape workspace (padding rows stay zero; everything else is overwritten)."""
+def _gemm_ready(t, n):
+    """True if the f32 matrix t [n, E] can be a GEMM operand as it is (whole 128-row tiles, unit inner stride, 16-byte aligned rows)."""
+    return (t.dtype == torch.float32 and n % 128 == 0 and t.stride(1) == 1 and (t.stride(0) * 4) % 16 == 0 and t.data_ptr() % 16 == 0)
+
+
+def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True, r0: int = 0, nloc: Optional[int] = None):
+    """Symmetric CE over the (global) n x n logits (loss/loss.py:75-87, slinet.py:139-141) and its gradient w.r.t. the LOCAL rows
+    r0 .. r0+nloc of both feature matrices (data parallel: `local_loss=False` semantics of sprompt.py:75-80 — every rank evaluates
+    the full loss but back-propagates only through its own rows; one rank: r0 = 0, nloc = n).
+    img_all/txt_all: f32 [n, E] on device (row-strided views are fine).  Returns (loss[1], logits[n,n] view, dimg[nloc,E], dtxt[nloc,E]).
+    Temporaries live in a per-shape workspace; the returned gradients are fresh tensors (they are saved on the autograd node)."""
     n, E = img_all.shape
+    nloc = n if nloc is None else nloc
+    if not (0 <= r0 and r0 + nloc <= n):
+        raise ValueError("local rows outside the global batch")
     dev = img_all.device
-    npad = _pad(n)
+    npad, lpad = _pad(n), _pad(nloc)
     s = _stream()
-    key = (n, E, dev, torch.cuda.current_stream().cuda_stream)
+    key = (n, nloc, E, dev, torch.cuda.current_stream().cuda_stream)
     ws = _LOSS_WS.get(key)
     if ws is None:
         z = lambda *sh: torch.zeros(*sh, device=dev)  # noqa: E731
-        ws = _LOSS_WS[key] = {"A": z(npad, E), "B": z(npad, E), "logits": z(npad, npad), "lse": z(2, npad), "dlog": z(npad, npad),
-                              "At": z(E, npad), "Bt": z(E, npad), "dlt": z(npad, npad), "dI": z(npad, E), "dT": z(npad, E)}
-    A, Bm, logits, lse = ws["A"], ws["B"], ws["logits"], ws["lse"]
-    A[:n].copy_(img_all)
-    Bm[:n].copy_(txt_all)
+        ws = _LOSS_WS[key] = {"A": z(npad, E), "B": z(npad, E), "logits": z(npad, npad), "lse": z(2, npad),
+                              "At": z(E, npad), "Bt": z(E, npad), "g": z(lpad, npad), "gt": z(lpad, npad)}
+    logits, lse = ws["logits"], ws["lse"]
+    ops = []
+    for src, name in ((img_all, "A"), (txt_all, "B")):
+        if _gemm_ready(src, n):
+            ops.append(src)
+        else:       # small / odd shapes: pack into the zero-padded operand buffer (rows >= n stay zero)
+            srcf = src if (src.dtype == torch.float32 and src.stride(1) == 1) else src.float().contiguous()
+            call("lpi_copy_rows", n, E, srcf, srcf.stride(0), ws[name], E, s)
+            ops.append(ws[name])
+    A, Bm = ops
     gemm(F32, A, Bm, logits, npad, npad, E, alpha=scale)
     loss = torch.empty(1, device=dev)
-    dlog = ws["dlog"] if need_grad else None
-    call("lpi_clip_loss_fwd_bwd", n, logits, npad, 1.0, loss, dlog, npad, lse[0], lse[1], s)
+    call("lpi_clip_loss_fwd_bwd", n, logits, npad, 1.0, loss, None, npad, lse[0], lse[1], s)
     if not need_grad:
         return loss, logits[:n, :n], None, None
-    # dI = scale * dlogits @ T ; dT = scale * dlogits^T @ I   (NT form: B operand = T^T / I^T)
-    At, Bt, dlt, dI, dT = ws["At"], ws["Bt"], ws["dlt"], ws["dI"], ws["dT"]
-    call("lpi_transpose", F32, npad, E, A, E, At, npad, s)
-    call("lpi_transpose", F32, npad, E, Bm, E, Bt, npad, s)
-    call("lpi_transpose", F32, npad, npad, dlog, npad, dlt, npad, s)
-    gemm(F32, dlog, Bt, dI, npad, E, npad, alpha=scale)
-    gemm(F32, dlt, At, dT, npad, E, npad, alpha=scale)
-    return loss, logits[:n, :n], dI[:n].clone(), dT[:n].clone()
+    # dI_loc = scale * g . T,  dT_loc = scale * gt . I  with g / gt the local rows of dlogits / dlogits^T (NT form: B operand = T^T / I^T)
+    At, Bt, g, gt = ws["At"], ws["Bt"], ws["g"], ws["gt"]
+    call("lpi_clip_loss_local_grad", n, logits, npad, lse[0], lse[1], 1.0, r0, nloc, g, gt, npad, s)
+    call("lpi_transpose", F32, npad if A is ws["A"] else n, E, A, A.stride(0), At, npad, s)
+    call("lpi_transpose", F32, npad if Bm is ws["B"] else n, E, Bm, Bm.stride(0), Bt, npad, s)
+    dI, dT = torch.empty(lpad, E, device=dev), torch.empty(lpad, E, device=dev)
+    gemm(F32, g, Bt, dI, lpad, E, npad, alpha=scale)
+    gemm(F32, gt, At, dT, lpad, E, npad, alpha=scale)
+    return loss, logits[:n, :n], dI[:nloc], dT[:nloc]
+
+
+def score_matrix(img_feats, txt_feats):
+    """The N_img x N_txt cosine score matrix of the evaluation (sprompt.py:509 `(image_feats @ text_feats.t()).t()`) and its transpose,
+    through the f32 NT GEMM (exact f32 products, f32 accumulation) and lpi_transpose: -> (score_i2t [Ni, Nt], score_t2i [Nt, Ni])."""
+    ni, E = img_feats.shape
+    nt = txt_feats.shape[0]
+    dev = img_feats.device
+    s = _stream()
+    nip, ntp = _pad(ni), _pad(nt)
+    ops = []
+    for src, n, npad in ((img_feats, ni, nip), (txt_feats, nt, ntp)):
+        if _gemm_ready(src, n):
+            ops.append(src)
+        else:
+            buf = torch.zeros(npad, E, device=dev)
+            srcf = src if (src.dtype == torch.float32 and src.stride(1) == 1) else src.float().contiguous()
+            call("lpi_copy_rows", n, E, srcf, srcf.stride(0), buf, E, s)
+            ops.append(buf)
+    full = torch.empty(nip, ntp, device=dev)
+    gemm(F32, ops[0], ops[1], full, nip, ntp, E)
+    i2t = torch.empty(ni, nt, device=dev)
+    call("lpi_copy_rows", ni, nt, full, ntp, i2t, nt, s)
+    t2i = torch.empty(nt, ni, device=dev)
+    call("lpi_transpose", F32, ni, nt, i2t, nt, t2i, ni, s)
+    return i2t, t2i
 
 
 def prompt_cp_fwd(d1, d2, d3, scale=1.0):

@@ -36,11 +36,14 @@ class EncodeImageFn(torch.autograd.Function):
         ctx.enc = enc
         ctx.pshape = prompts.shape
         train = prompts.requires_grad
-        return enc.encode_image(image, prompts.detach(), depth, train=train)
+        # the backward context (workspace arena + the tower's forward serial) lives on THIS node: a later forward on the same engine
+        # makes encode_image_backward raise instead of differentiating the wrong batch
+        out, ctx.lpi = enc.encode_image(image, prompts.detach(), depth, train=train, return_ctx=True)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        dpr = ctx.enc.encode_image_backward(g)
+        dpr = ctx.enc.encode_image_backward(g, ctx.lpi)
         if len(ctx.pshape) == 4:     # stride-0 expanded [B,Lyr,P,d] view: autograd sums the broadcast itself
             full = torch.zeros(ctx.pshape, device=dpr.device)
             full[0] = dpr
@@ -54,11 +57,12 @@ class EncodeTextFn(torch.autograd.Function):
         ctx.enc = enc
         ctx.pshape = prompts.shape
         train = prompts.requires_grad
-        return enc.encode_text(ids, prompts.detach(), depth, train=train)
+        out, ctx.lpi = enc.encode_text(ids, prompts.detach(), depth, train=train, return_ctx=True)
+        return out
 
     @staticmethod
     def backward(ctx, g):
-        dpr = ctx.enc.encode_text_backward(g)
+        dpr = ctx.enc.encode_text_backward(g, ctx.lpi)
         if len(ctx.pshape) == 4:
             full = torch.zeros(ctx.pshape, device=dpr.device)
             full[0] = dpr
@@ -78,10 +82,9 @@ class ClipLossFn(torch.autograd.Function):
         else:
             img_all, txt_all, r0 = img_f.detach().contiguous(), txt_f.detach().contiguous(), 0
         need = img_f.requires_grad or txt_f.requires_grad
-        loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need)
-        n = img_f.shape[0]
+        loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need, r0, img_f.shape[0])     # gradients of the local rows only
         if need:
-            ctx.save_for_backward(dI[r0:r0 + n], dT[r0:r0 + n])
+            ctx.save_for_backward(dI, dT)
         ctx.logits = logits
         return loss[0]
 

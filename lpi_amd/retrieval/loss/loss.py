@@ -1,26 +1,21 @@
-"""ClipLoss / nt_bxent_loss with the reference's call signatures (loss/loss.py:6-87).
+"""ClipLoss / nt_bxent_loss with the reference's call signatures (loss/loss.py:6-87), both on the HIP kernels.
 
 ClipLoss.forward(logits) takes a PRE-SCALED logits matrix, as in the reference; SliNet.cal_loss here does not go through it
 for the base loss (it fuses logits + loss in the HIP ClipLossFn) but it is kept for callers that hold a logits matrix.
-nt_bxent_loss (task loss, only when numtask != 1) runs in torch ops on <= 12 x 12 problems — SURVEY.md section 8(f) item 3,
-not part of the measured path."""
+nt_bxent_loss (task loss, only when numtask != 1) runs in lpi_nt_bxent_fwd_bwd.  There is no torch-op / CPU form of either."""
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 
-def nt_bxent_loss(x, target, temperature=1.0):
-    """loss.py:6-33, including its sigmoid-then-BCE-with-logits as written."""
-    n = x.size(0)
-    target = target.type(torch.float32).to(x.device)
-    xcs = F.cosine_similarity(x[None, :, :], x[:, None, :], dim=-1)
-    xcs = xcs.masked_fill(torch.eye(n, dtype=torch.bool, device=x.device), float("inf"))
-    loss = F.binary_cross_entropy_with_logits((xcs / temperature).sigmoid(), target, reduction="none")
-    pos = target.bool()
-    loss_pos = torch.where(pos, loss, torch.zeros_like(loss)).sum(1)
-    loss_neg = torch.where(~pos, loss, torch.zeros_like(loss)).sum(1)
-    num_pos = target.sum(1)
-    return (loss_pos / num_pos + loss_neg / (n - num_pos)).mean()
+def nt_bxent_loss(x, target, temperature=1.0, row=None):
+    """loss.py:6-33 (including its sigmoid-then-BCE-with-logits as written) through lpi_nt_bxent_fwd_bwd.  x: [T, D] on the GPU —
+    the stacked, flattened prompts of tasks 0..T-1 (slinet.py:179-181).  Only row `row` (default: the last = the task being trained;
+    the other tasks' prompts are frozen, sprompt.py:230-237) receives a gradient."""
+    from lpi_amd import _lib
+    from lpi_amd.functional import NtBxentFn
+    if not x.is_cuda:
+        raise _lib.LpiError("nt_bxent_loss runs on the MI355X HIP kernels only (x must be a cuda tensor); there is no CPU fallback")
+    return NtBxentFn.apply(x, target, float(temperature), x.size(0) - 1 if row is None else int(row))
 
 
 class _ClipLossOnLogitsFn(torch.autograd.Function):

@@ -49,6 +49,11 @@ def _dist_world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _dist_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 class SPrompts(BaseLearner):
     def __init__(self, args):
         super().__init__(args)
@@ -106,8 +111,9 @@ class SPrompts(BaseLearner):
             self.test_loader = DataLoader(test_dataset, batch_size=128, shuffle=False, num_workers=self.num_workers)
             final_res[i] = self._train(self.train_loader, self.test_loader)
         self.final_res = final_res
-        os.makedirs('./res', exist_ok=True)
-        self.save_dict(final_res, f'./res/{datetime.now()}.json')
+        if _dist_rank() == 0:       # every rank holds the same keys and evaluates the same test set: one writer
+            os.makedirs('./res', exist_ok=True)
+            self.save_dict(final_res, f'./res/{datetime.now()}.json')
 
     def save_dict(self, dictionary, file_path):
         with open(file_path, 'w') as file:
@@ -137,6 +143,8 @@ class SPrompts(BaseLearner):
         net = self._network
         for epoch in range(self.run_epoch):
             net.train()
+            if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+                train_loader.sampler.set_epoch(epoch)          # DistributedSampler: a new shuffle every epoch
             for i, (images, captions, _, _) in enumerate(train_loader):
                 images = images.to(self._device, non_blocking=True)
                 captions = captions if torch.is_tensor(captions) else list(captions)
@@ -166,11 +174,13 @@ class SPrompts(BaseLearner):
 
     # ------------------------------------------------------------------ sprompt.py:336-397
     def _task_id(self, feature, all_keys):
-        sel = []
-        for task_centers in all_keys:
-            d = (feature[:, None, :] - task_centers[None].to(feature.device)).abs().sum(-1)      # ((f-c)**2)**0.5 summed
-            sel.append(d.min(1)[0])
-        return torch.vstack(sel).min(0)[1]
+        """argmin over tasks of the minimum L1 distance to the task's KMeans centres (sprompt.py:343-350) — lpi_l1_task_id."""
+        keys = torch.stack([k.to(device=feature.device, dtype=torch.float32) for k in all_keys]).contiguous()      # [T, C, E]
+        T, C, E = keys.shape
+        f = feature.detach().float().contiguous()
+        sel = torch.empty(f.shape[0], dtype=torch.int32, device=f.device)
+        _lib.call("lpi_l1_task_id", f.shape[0], E, T, C, f, E, keys, sel, None, torch.cuda.current_stream().cuda_stream)
+        return sel.long()
 
     def get_visual_task_id(self, inputs):
         with torch.no_grad():
@@ -191,6 +201,12 @@ class SPrompts(BaseLearner):
             tf.append(t / t.norm(dim=-1, keepdim=True))
         vf = torch.cat(vf, 0).cpu().numpy()
         tf = torch.cat(tf, 0).cpu().numpy()
+        if _dist_world() > 1:       # every rank clusters the features of ALL shards, so the task keys are identical everywhere
+            import torch.distributed as dist
+            parts = [None] * _dist_world()
+            dist.all_gather_object(parts, (vf, tf))
+            vf = np.concatenate([p[0] for p in parts])
+            tf = np.concatenate([p[1] for p in parts])
         vc = KMeans(n_clusters=5, random_state=0).fit(vf)
         tc = KMeans(n_clusters=5, random_state=0).fit(tf)
         self.all_keys.append(torch.tensor(vc.cluster_centers_).to(self._device))
@@ -216,8 +232,8 @@ class SPrompts(BaseLearner):
             sel = self.get_textual_task_id(text)
             text_feats.append(self._network.textual_interface(text, sel))
         image_feats, text_feats = torch.cat(image_feats), torch.cat(text_feats)
-        score_t2i = (image_feats @ text_feats.t()).t().contiguous()      # sprompt.py:509
-        score_i2t = score_t2i.t().contiguous()
+        from lpi_amd.engine import score_matrix
+        score_i2t, score_t2i = score_matrix(image_feats, text_feats)      # sprompt.py:509: (I @ T^T) and its transpose, f32 MFMA GEMM
         final_res = self.itm_eval(score_i2t, score_t2i, ds.txt2img, ds.img2txt, category_i, texts_cat)
         return score_i2t.cpu().numpy(), score_t2i.cpu().numpy(), final_res
 

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from lpi_amd import synth
-from lpi_amd.functional import AlignLossFn, ClipLossFn, EncodeImageFn, EncodeTextFn, NtBxentFn
+from lpi_amd.functional import AlignLossFn, ClipLossFn, EncodeImageFn, EncodeTextFn
 from lpi_amd.retrieval.loss.loss import ClipLoss, nt_bxent_loss
 from lpi_amd.retrieval.models.clip.prompt_learner import PromptLearner, cfgc
 from lpi_amd.retrieval.models.prompts.prompts import DecomposedPrompt
@@ -150,9 +150,8 @@ class SliNet(nn.Module):
         dense = [self.prompts[i]() for i in range(task_id + 1)]
         vs = torch.stack([v.reshape(-1) for v, _ in dense])
         ts = torch.stack([t.reshape(-1) for _, t in dense])
-        if vs.is_cuda:      # HIP kernels (lpi_nt_bxent_fwd_bwd); the torch-op form below is only reachable without a GPU engine
-            return (NtBxentFn.apply(vs, target, 0.001, task_id) + NtBxentFn.apply(ts, target, 0.001, task_id)) / 2
-        return (nt_bxent_loss(vs, target, 0.001) + nt_bxent_loss(ts, target, 0.001)) / 2
+        # HIP kernels (lpi_nt_bxent_fwd_bwd); raises without a GPU like every other op of the path
+        return (nt_bxent_loss(vs, target, 0.001, task_id) + nt_bxent_loss(ts, target, 0.001, task_id)) / 2
 
     # ------------------------------------------------------------------ slinet.py:185-220
     def textual_interface(self, text, text_category):

@@ -240,6 +240,117 @@ def eval_case(net, cfg, batch):
     return res
 
 
+def sgd_steps(net, cfg, batch, steps):
+    """`steps` epochs of ONE batch each through the reference's optimiser set-up (sprompt.py:230-255: trainable filter, SGD(momentum .9,
+    lr, weight_decay) over network.parameters(), CosineAnnealingLR(T_max=epochs) stepped per epoch, :324) and hot loop (:297-311)."""
+    from torch import optim
+    net.numtask = 1
+    net.train()
+    for name, p in net.named_parameters():
+        p.requires_grad_(False)
+        if "prompts." + str(net.numtask - 1) + "." in name:
+            p.requires_grad_(True)
+    args = ref_args(cfg)
+    opt = optim.SGD(net.parameters(), momentum=0.9, lr=args["lrate"], weight_decay=args["weight_decay"])
+    sched = optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=steps)
+    img = torch.from_numpy(synth.images(batch, cfg.image_resolution))
+    caps = captions_for(batch)
+    res = {"lrate": np.float32(args["lrate"]), "weight_decay": np.float32(args["weight_decay"]), "steps": np.int32(steps)}
+    for st in range(steps):
+        img_f, txt_f, vp, tp = net(img, caps)
+        out = net.cal_loss(img_f, txt_f, vp, tp)
+        loss = sum(v for v in out["loss"].values())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        res[f"loss.{st}"] = np.float32(loss.item())
+        res[f"lr_after.{st}"] = np.float32(opt.param_groups[0]["lr"])
+        for name, p in net.named_parameters():
+            if p.requires_grad:
+                res[f"param.{st}.{name.split('.')[-1]}"] = p.detach().numpy().copy()
+    # restore the factors for whoever uses the net next
+    fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width, task=0)
+    for k, v in fac.items():
+        getattr(net.prompts[0], k).data = torch.from_numpy(v.copy())
+    return res
+
+
+def eval_shard(net, cfg, n_img, caps_per_img, n_tasks):
+    """The reference's whole retrieval evaluation (sprompt.py:433-548 `_evaluate_retrieval` -> :550-646 `itm_eval`) on a fixed synthetic
+    shard: task-id selection by L1 distance to per-task keys, per-sample prompted features, the N_img x N_txt score matrix, R@K — plus,
+    for index parity (F8), the per-row rank of the best ground truth under np.argsort(score)[::-1] and the margin that makes it safe."""
+    from methods.sprompt import SPrompts
+    from models.clip.clip import tokenize
+
+    net.numtask = n_tasks
+    net.eval()
+    n_txt = n_img * caps_per_img
+    img = torch.from_numpy(synth.images(n_img, cfg.image_resolution, seed=synth.IMAGE_SEED + 11))
+    words = ["red", "blue", "green", "small", "large", "old", "young", "wooden", "bright", "dark", "quiet", "busy"]
+    caps = [CAPTIONS[(t // caps_per_img) % len(CAPTIONS)] + f" {words[t % len(words)]} view {t}" for t in range(n_txt)]
+    cat_i = [i % n_tasks for i in range(n_img)]
+    cat_t = [(t // caps_per_img) % n_tasks for t in range(n_txt)]
+
+    class DS:
+        pass
+
+    ds = DS()
+    ds.text, ds.image, ds.text_cat = caps, list(range(n_img)), cat_t
+    ds.img2txt = {i: [caps_per_img * i + j for j in range(caps_per_img)] for i in range(n_img)}
+    ds.txt2img = {t: t // caps_per_img for t in range(n_txt)}
+
+    class Loader:
+        batch_size = 16
+        dataset = ds
+
+        def __iter__(self):
+            for i in range(0, n_img, self.batch_size):
+                j = min(n_img, i + self.batch_size)
+                yield img[i:j], torch.arange(i, j), torch.tensor(cat_i[i:j])
+
+    sp = object.__new__(SPrompts)
+    sp._network, sp.args, sp._device, sp._multiple_gpus, sp.cur_id = net, {"prompt_type": "lpi"}, torch.device("cpu"), [], n_tasks - 1
+    with torch.no_grad():
+        ev = net.extract_vector(img)            # un-prompted features (the task-id pass, sprompt.py:336-351)
+        et = net.extract_textual_vector(caps)
+    # keys: five un-prompted features of each task's own samples (so that those samples select their task with a wide margin)
+    vkeys = [ev[[i for i in range(n_img) if cat_i[i] == t][:5]].clone() for t in range(n_tasks)]
+    tkeys = [et[[i for i in range(n_txt) if cat_t[i] == t][:5]].clone() for t in range(n_tasks)]
+    sp.all_keys, sp.textual_all_keys = vkeys, tkeys
+    s_i2t, s_t2i, final_res = sp._evaluate_retrieval(Loader())
+    with torch.no_grad():
+        sel_v, sel_t = sp.get_visual_task_id(img), sp.get_textual_task_id(caps)
+        vfeat = net.visual_interface(img, sel_v)
+        tfeat = net.textual_interface(caps, sel_t)
+
+    def l1(f, keys):
+        return torch.stack([torch.stack([(f - c).abs().sum(1) for c in k]).min(0)[0] for k in keys], 1).numpy()
+
+    def ranks(S, gts):
+        r, m = np.zeros(len(S), np.int32), np.zeros(len(S), np.float32)
+        for i, row in enumerate(S):
+            inds = np.argsort(row)[::-1]
+            r[i] = min(int(np.where(inds == g)[0][0]) for g in gts[i])
+            others = np.delete(row, gts[i])
+            m[i] = min(float(np.abs(others - row[g]).min()) for g in gts[i])      # the rank is safe if no other score is this close
+        return r, m
+
+    r_i, m_i = ranks(s_i2t, [ds.img2txt[i] for i in range(n_img)])
+    r_t, m_t = ranks(s_t2i, [[ds.txt2img[t]] for t in range(n_txt)])
+    ids = torch.cat([tokenize(" ".join(["X"] * 16) + " " + c + ".") for c in caps])
+    return {"captions": np.array(caps), "token_ids": ids.numpy(), "cat_i": np.array(cat_i), "cat_t": np.array(cat_t),
+            "caps_per_img": np.int32(caps_per_img), "n_tasks": np.int32(n_tasks),
+            "vkeys": torch.stack(vkeys).numpy(), "tkeys": torch.stack(tkeys).numpy(),
+            "extract_vector": ev.numpy(), "extract_textual_vector": et.numpy(),
+            "visual_task_dist": l1(ev, vkeys), "textual_task_dist": l1(et, tkeys),
+            "visual_task_id": sel_v.numpy(), "textual_task_id": sel_t.numpy(),
+            "image_feats": vfeat.numpy(), "text_feats": tfeat.numpy(), "score_i2t": s_i2t.astype(np.float32),
+            "rank_i2t": r_i, "rank_margin_i2t": m_i, "rank_t2i": r_t, "rank_margin_t2i": m_t,
+            "itm_i2t": np.array([final_res["mscoco"]["i2t"][t] for t in range(n_tasks)]),
+            "itm_t2i": np.array([final_res["mscoco"]["t2i"][t] for t in range(n_tasks)])}
+
+
 def save(name, res, meta):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **res)
@@ -275,6 +386,12 @@ def main():
         undo()
         save("tiny_eval", eval_case(net, cfg, 6), meta)
 
+    if a.only in (None, "tiny", "tiny_sgd3"):
+        cfg = synth.TINY
+        net = build_slinet(cfg)
+        save("tiny_sgd3", sgd_steps(net, cfg, 4, 3), meta)       # post-step parameters of 3 SGD + cosine steps (a10)
+        save("tiny_eval_shard", eval_shard(net, cfg, 12, 2, 3), meta)
+
     if a.only in (None, "vitb16"):
         cfg = synth.VIT_B16
         net = build_slinet(cfg)
@@ -288,6 +405,11 @@ def main():
             r[k] = r[k][:3]
         save("vitb16_d3_patched", r, meta)
         undo()
+
+    if a.only in (None, "vitb16", "vitb16_eval"):
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        save("vitb16_eval", eval_shard(net, cfg, 32, 2, 3), meta)   # north_star: R@1 indices on a fixed synthetic shard at full size
 
     with open(meta_path, "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -161,3 +161,109 @@ def test_vit_l14_depth12_rank8_vs_oracle():
         g, r = fac[k].grad.cpu().numpy(), ref["grad." + k]
         err = float(np.abs(g - r).max())
         assert err <= 5e-3 * np.abs(r).max() + 1e-7, (k, err, float(np.abs(r).max()))
+
+
+def test_bf16_train_step_at_the_benchmarked_configuration(enc32, data):
+    """The exact configuration bench.py times — bf16 operands, B = 256, depth 3, text batch trimmed to the longest caption (so the
+    256x256 bf16 kernel with its hybrid tail, the 256x128 kernel, the fused attention backward at L = 213 / 59 and the fp16 residual
+    stream are all on the path) — against the f32 HIP step on the same inputs (which the fixtures pin to the reference)."""
+    from lpi_amd.engine import trim_token_ids
+    img, ids = data
+    ids_t = torch.from_numpy(np.ascontiguousarray(trim_token_ids(synth.token_ids(B)))).to(DEV)
+    assert ids_t.shape[1] < ids.shape[1]
+    f32, fb = factors(), factors()
+    o32 = train_step(enc32, img, ids, f32, 3)                      # untrimmed f32 = the parity path
+    o32 = {k: v.clone() for k, v in o32.items()}
+    encb = DualEncoder(CFG, synth.clip_state_dict(CFG), dtype="bf16", device=DEV)
+    ob = train_step(encb, img, ids_t, fb, 3)
+    torch.cuda.synchronize()
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))  # noqa: E731
+    report = {}
+    for k in synth.PROMPT_NAMES:
+        a, b = fb[k].grad.double().cpu(), f32[k].grad.double().cpu()
+        report[k] = (cos(a, b), float((a - b).abs().max() / b.abs().max()))
+        assert report[k][0] >= 0.99, (k, report[k])
+        assert report[k][1] <= 0.15, (k, report[k])
+    print("bf16 vs f32 factor gradients (cosine, max rel err):", {k: (round(c, 5), round(r, 4)) for k, (c, r) in report.items()})
+    for k, tol in (("base_loss", 2e-2), ("alignment_loss", 1e-5)):
+        assert abs(float(ob[k]) - float(o32[k])) <= tol * max(1.0, abs(float(o32[k]))), (k, float(ob[k]), float(o32[k]))
+    assert float((ob["img_f"] - o32["img_f"]).abs().max()) < 5e-3 and float((ob["txt_f"] - o32["txt_f"]).abs().max()) < 5e-3
+    # top-1 retrieval agreement wherever the f32 margin exceeds the measured bf16 logit error
+    l32 = (enc32.logit_scale_exp * o32["img_f"] @ o32["txt_f"].t()).cpu()
+    lb = (encb.logit_scale_exp * ob["img_f"] @ ob["txt_f"].t()).cpu()
+    err = float((lb - l32).abs().max())
+    top2 = l32.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * err
+    assert torch.equal(lb.argmax(1)[safe], l32.argmax(1)[safe])
+    print(f"bf16 logits: max |err| {err:.3e}; top-1 asserted on {int(safe.sum())} of {B} rows")
+    del encb
+    torch.cuda.empty_cache()
+
+
+def test_eval_shard_at_vitb16_size_matches_reference(golden):
+    """north_star: 'R@1 indices bit-identical to reference on a fixed synthetic shard'.  The reference's whole evaluation
+    (sprompt.py:433-646: task ids by L1 distance to keys, per-sample prompted features, N_img x N_txt score matrix, per-row rank of the
+    best ground truth, R@K) on 32 images x 64 captions x 3 tasks at ViT-B/16 size, through the plugin surface in f32 mode."""
+    import json
+    import os
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    g = golden("vitb16_eval")
+    ret = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lpi_amd", "retrieval")
+    args = json.load(open(os.path.join(ret, "configs", "lpi", "coco_lpi.json")))
+    args.update(device=[torch.device(DEV)], compute_dtype="f32", num_workers=0, trim_text=True)
+    m = SPrompts(args)
+    net = m._network.to(torch.device(DEV))
+    for t in range(len(net.prompts)):
+        for k, v in synth.prompt_factors(9, 16, CFG.vision_width, CFG.transformer_width, task=t).items():
+            getattr(net.prompts[t], k).data = torch.from_numpy(v.copy()).to(DEV)
+    n_tasks, cpi = int(g["n_tasks"]), int(g["caps_per_img"])
+    net.numtask = n_tasks
+    m.cur_id = n_tasks - 1
+    m.all_keys = [torch.from_numpy(k).to(DEV) for k in g["vkeys"]]
+    m.textual_all_keys = [torch.from_numpy(k).to(DEV) for k in g["tkeys"]]
+    n_img, n_txt = g["image_feats"].shape[0], g["text_feats"].shape[0]
+    img = torch.from_numpy(synth.images(n_img, 224, seed=synth.IMAGE_SEED + 11))
+
+    class DS:
+        text = torch.from_numpy(g["token_ids"])          # captions as the reference's tokenizer encoded them
+        text_cat = list(g["cat_t"])
+        img2txt = {i: [cpi * i + j for j in range(cpi)] for i in range(n_img)}
+        txt2img = {t: t // cpi for t in range(n_txt)}
+
+    class Loader:
+        dataset = DS()
+
+        def __iter__(self):
+            for i in range(0, n_img, 16):
+                yield img[i:i + 16], torch.arange(i, min(n_img, i + 16)), torch.from_numpy(g["cat_i"][i:i + 16])
+
+    net.eval()
+    with torch.no_grad():
+        ev = net.extract_vector(img.to(DEV))
+        assert float((ev.cpu() - torch.from_numpy(g["extract_vector"])).abs().max()) < 1e-4
+        sel_v = m.get_visual_task_id(img.to(DEV)).cpu().numpy()
+        sel_t = m.get_textual_task_id(DS.text).cpu().numpy()
+    for sel, ref, dist in ((sel_v, g["visual_task_id"], g["visual_task_dist"]), (sel_t, g["textual_task_id"], g["textual_task_dist"])):
+        srt = np.sort(dist, 1)
+        safe = (srt[:, 1] - srt[:, 0]) > 1e-2
+        assert safe.mean() > 0.9 and (sel[safe] == ref[safe]).all()          # integer task ids: exact wherever the choice is not a near-tie
+    s_i2t, s_t2i, final_res = m._evaluate_retrieval(Loader())
+    err = float(np.abs(s_i2t - g["score_i2t"]).max())
+    assert err < 1e-4, err                                                    # cosine scores within the north-star tolerance
+    assert np.array_equal(s_t2i, s_i2t.T)
+    # rank of the best ground truth per row, bit-exact wherever the reference's margin exceeds 10x the measured score error
+    s = torch.cuda.current_stream().cuda_stream
+    from lpi_amd import _lib
+    for S, gts, ref_r, ref_m, tag in ((s_i2t, [DS.img2txt[i] for i in range(n_img)], g["rank_i2t"], g["rank_margin_i2t"], "i2t"),
+                                      (s_t2i, [[DS.txt2img[t]] for t in range(n_txt)], g["rank_t2i"], g["rank_margin_t2i"], "t2i")):
+        gt = torch.tensor(gts, dtype=torch.int32, device=DEV)
+        r = torch.zeros(len(gts), dtype=torch.int32, device=DEV)
+        Sd = torch.from_numpy(np.ascontiguousarray(S)).to(DEV)
+        _lib.call("lpi_retrieval_rank", Sd.shape[0], Sd.shape[1], Sd, Sd.shape[1], gt, gt.shape[1], r, s)
+        safe = ref_m > 10 * err
+        print(f"eval shard {tag}: max |score err| {err:.2e}; ranks asserted on {int(safe.sum())} of {len(safe)} rows ({int((~safe).sum())} near-ties)")
+        assert safe.mean() > 0.8
+        assert np.array_equal(r.cpu().numpy()[safe], ref_r[safe])
+    if all((g["rank_margin_i2t"] > 10 * err).tolist()) and all((g["rank_margin_t2i"] > 10 * err).tolist()):
+        for t in range(n_tasks):          # R@1/5/10 per task as itm_eval reports them (sprompt.py:638-646)
+            assert np.allclose(final_res["mscoco"]["i2t"][t], g["itm_i2t"][t]) and np.allclose(final_res["mscoco"]["t2i"][t], g["itm_t2i"][t])

@@ -152,7 +152,7 @@ def test_layernorm_fwd_bwd(dt, d):
     yr.backward(dy.double())
     dx = dx0.clone().to(DEV)
     cast = torch.zeros(rows, d, device=DEV, dtype=TD[dt])
-    call("lpi_layernorm_bwd", dt, dt, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, cast, d, stream())
+    call("lpi_layernorm_bwd", dt, dt, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, cast, d, 1, stream())
     ref = dx0.double() + xr.grad
     assert relerr(dx, ref) < 2e-5
     assert relerr(cast, ref) < TOL[dt]
@@ -172,7 +172,7 @@ def test_layernorm_bwd_bf16_gradient_stream():
     xr = x.double().requires_grad_(True)
     torch.nn.functional.layer_norm(xr, (d,), gam.double(), None, 1e-5).backward(dy.double())
     stream_t = dx0.clone().to(DEV)
-    call("lpi_layernorm_bwd", BF16, BF16, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
+    call("lpi_layernorm_bwd", BF16, BF16, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, 1, stream())
     assert relerr(stream_t, dx0.double() + xr.grad) < 1e-2
 
 
@@ -197,7 +197,7 @@ def test_fp16_residual_stream_kernels():
         dx0 = rnd(rows, d, seed=9).to(torch.bfloat16)
         yr.backward(dy.double())
         stream_t = dx0.clone().to(DEV)
-        call("lpi_layernorm_bwd", BF16, BF16, F16, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, stream())
+        call("lpi_layernorm_bwd", BF16, BF16, F16, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], None, d, stream_t, d, 1, stream())
         assert relerr(stream_t, dx0.double() + xr.grad) < 1e-2, d
     # residual GEMM: both kernels
     for M, N, K, key in ((256, 256, 128, 1 << 30), (512, 768, 768, 1)):
@@ -544,3 +544,108 @@ def test_gemm_hybrid_tail_round(tm, N):
         assert torch.equal(new[k], old[k]), k
     ab = a.double().cpu() @ b.double().cpu().t()
     assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < TOL[BF16]
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 2 kernels
+@pytest.mark.parametrize("n,r0,nloc", [(6, 2, 3), (256, 128, 128), (300, 44, 256)])
+def test_clip_loss_local_rows(n, r0, nloc):
+    """engine.clip_loss_fwd_bwd with a local row window (the data-parallel backward, sprompt.py:75-80) vs f64 autograd: the loss is the
+    global one; the gradients are those of the window's rows of BOTH feature matrices; strided (gathered-buffer) views are accepted."""
+    torch.manual_seed(n)
+    E_, scale = 128, 14.3
+    buf = torch.nn.functional.normalize(torch.randn(n, 2 * E_, dtype=torch.float64), dim=1)
+    i64, t64 = buf[:, :E_].clone().requires_grad_(True), buf[:, E_:].clone().requires_grad_(True)
+    lg = scale * i64 @ t64.t()
+    lab = torch.arange(n)
+    ref = (torch.nn.functional.cross_entropy(lg, lab) + torch.nn.functional.cross_entropy(lg.t(), lab)) / 2
+    ref.backward()
+    d = buf.float().to(DEV)
+    loss, logits, dI, dT = E.clip_loss_fwd_bwd(d[:, :E_], d[:, E_:], scale, True, r0, nloc)       # row-strided views of one buffer
+    assert dI.shape == (nloc, E_) and dT.shape == (nloc, E_)
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, abs(float(ref)))
+    assert float((logits.cpu().double() - lg.detach()).abs().max()) < 2e-5
+    assert float((dI.cpu().double() - i64.grad[r0:r0 + nloc]).abs().max()) < 1e-6 + 1e-4 * float(i64.grad.abs().max())
+    assert float((dT.cpu().double() - t64.grad[r0:r0 + nloc]).abs().max()) < 1e-6 + 1e-4 * float(t64.grad.abs().max())
+
+
+def test_l1_task_id_kernel():
+    """lpi_l1_task_id vs the reference's formula (sprompt.py:343-350): (((f - c)**2)**0.5).sum(1), min over centres, argmin over tasks."""
+    torch.manual_seed(5)
+    n, E_, T, C = 37, 512, 4, 5
+    f = torch.randn(n, E_)
+    keys = torch.randn(T, C, E_)
+    keys[2, 1] = f[3]                      # an exact hit
+    ref_d = torch.stack([torch.stack([(((f - c) ** 2) ** 0.5).sum(1) for c in keys[t]]).min(0)[0] for t in range(T)])   # [T, n]
+    ref = ref_d.min(0)[1]
+    sel = torch.empty(n, dtype=torch.int32, device=DEV)
+    dist = torch.empty(n, T, device=DEV)
+    call("lpi_l1_task_id", n, E_, T, C, f.to(DEV), E_, keys.to(DEV), sel, dist, stream())
+    assert float((dist.cpu() - ref_d.t()).abs().max()) < 1e-3
+    srt = ref_d.t().sort(1)[0]
+    safe = (srt[:, 1] - srt[:, 0]) > 1e-2
+    assert safe.sum() >= n - 2
+    assert torch.equal(sel.cpu().long()[safe], ref[safe]) and int(sel[3]) == 2
+
+
+def test_sgd_step_kernel_matches_torch_sgd():
+    """lpi_sgd_step == torch.optim.SGD(momentum=.9, weight_decay=2e-4) (sprompt.py:253) over three steps with a changing lr."""
+    torch.manual_seed(1)
+    p0 = torch.randn(5284)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p_ref], lr=0.05, momentum=0.9, weight_decay=2e-4)
+    p = p0.clone().to(DEV)
+    buf = torch.zeros_like(p)
+    for st, lr in enumerate((0.05, 0.0375, 0.0125)):
+        g = torch.randn(5284) * 1e-3
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        p_ref.grad = g.clone()
+        opt.step()
+        call("lpi_sgd_step", p.numel(), p, g.to(DEV), buf, lr, 0.9, 2e-4, int(st == 0), stream())
+        assert float((p.cpu() - p_ref.detach()).abs().max()) < 1e-6
+
+
+def test_layernorm_bwd_overwrite_mode():
+    """accumulate = 0 writes LN'(dy) into the gradient stream (whatever it held); accumulate = 1 adds — both stream types."""
+    torch.manual_seed(2)
+    rows, d = 300, 768
+    x, dy, gam = torch.randn(rows, d), torch.randn(rows, d), torch.rand(d) + 0.5
+    xd = x.to(DEV)
+    st = torch.zeros(2, rows, device=DEV)
+    y = torch.zeros(rows, d, device=DEV)
+    call("lpi_layernorm_fwd", F32, F32, rows, d, xd, d, gam.to(DEV), torch.zeros(d, device=DEV), y, d, st[0], st[1], stream())
+    junk = torch.randn(rows, d)
+    outs = {}
+    for acc in (0, 1):
+        dx = junk.clone().to(DEV)
+        call("lpi_layernorm_bwd", F32, F32, F32, rows, d, dy.to(DEV), d, xd, d, gam.to(DEV), st[0], st[1], dx, d, None, d, acc, stream())
+        outs[acc] = dx.cpu()
+    assert float((outs[1] - outs[0] - junk).abs().max()) < 1e-5
+    x64 = x.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(x64, (d,), gam.double(), None, 1e-5).backward(dy.double())
+    assert float((outs[0].double() - x64.grad).abs().max()) < 1e-4
+    # bf16 gradient stream over the fp16 residual stream (the half-wave kernel)
+    xh = x.half().to(DEV)
+    call("lpi_layernorm_fwd", BF16, F16, rows, d, xh, d, gam.to(DEV), torch.zeros(d, device=DEV), torch.zeros(rows, d, device=DEV, dtype=torch.bfloat16), d, st[0], st[1], stream())
+    o = {}
+    for acc in (0, 1):
+        s_ = junk.clone().to(torch.bfloat16).to(DEV)
+        call("lpi_layernorm_bwd", BF16, BF16, F16, rows, d, dy.to(torch.bfloat16).to(DEV), d, xh, d, gam.to(DEV), st[0], st[1], None, d, s_, d, acc, stream())
+        o[acc] = s_.float().cpu()
+    assert float((o[0].double() - x64.grad).abs().max()) < 0.05
+    assert float((o[1] - o[0] - junk.to(torch.bfloat16).float()).abs().max()) < 0.06
+
+
+def test_copy_rows_and_score_matrix():
+    torch.manual_seed(3)
+    a = torch.randn(50, 200, device=DEV)
+    out = torch.zeros(50, 96, device=DEV)
+    call("lpi_copy_rows", 50, 96, a[:, 8:], 200, out, 96, stream())
+    assert torch.equal(out, a[:, 8:104])
+    i = torch.nn.functional.normalize(torch.randn(33, 512), dim=1)
+    t = torch.nn.functional.normalize(torch.randn(70, 512), dim=1)
+    s_i2t, s_t2i = E.score_matrix(i.to(DEV), t.to(DEV))
+    ref = i.double() @ t.double().t()
+    assert s_i2t.shape == (33, 70) and s_t2i.shape == (70, 33)
+    assert float((s_i2t.cpu().double() - ref).abs().max()) < 2e-6
+    assert torch.equal(s_t2i, s_i2t.t().contiguous())

@@ -263,3 +263,53 @@ def test_trimming_text_rows_behind_the_longest_eot_is_exact(dtype, tol):
         assert maxerr(trim[k], full[k]) <= tol, (k, maxerr(trim[k], full[k]))
     for k in GRADS:
         assert maxerr(trim[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(trim[k], full[k]))
+
+
+def test_vitb16_fixture_through_the_f32_256x256_kernel(golden):
+    """The reference fixtures end to end with EVERY eligible f32 GEMM forced onto the 256x256 kernel (tuning key 1 = 1; the default
+    rule sends f32 launches below 1500 tiles, i.e. all of a bs=8 step, to the 128x128 kernel): same 1e-4 bars as the default path."""
+    cfg = synth.VIT_B16
+    g = golden("vitb16_d3_patched")
+    _lib.call("lpi_set_tuning", 1, 1)
+    try:
+        assert _lib.load().lpi_get_tuning(1) == 1
+        res, _ = run_hip(cfg, "f32", 8, g["token_ids"], 3)
+        assert _lib.load().lpi_gemm_last_kernel() >= 0
+    finally:
+        _lib.call("lpi_set_tuning", 1, 1500)
+    check(res, g, tol=1e-4, gtol=5e-3, gabs=1e-4)
+    res_default, _ = run_hip(cfg, "f32", 8, g["token_ids"], 3)
+    assert maxerr(res["logits"], res_default["logits"]) < 2e-5          # the two kernels differ by f32 summation order only
+
+
+def test_stale_backward_context_raises():
+    """a second forward on the same engine between a forward and its backward must not silently differentiate the wrong
+    batch — the context lives on the autograd node and the engine raises."""
+    from lpi_amd.functional import EncodeImageFn
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device=DEV)
+    fac = dev_factors(cfg)
+    from lpi_amd.engine import prompt_cp_fwd
+    vis = prompt_cp_fwd(fac["dim_1_share"], fac["dim_2_visual"], fac["dim_3_visual"]).requires_grad_(True)
+    img = torch.from_numpy(synth.images(4, 32)).to(DEV)
+    f1 = EncodeImageFn.apply(enc, img, vis, 1)
+    with torch.no_grad():
+        enc.encode_image(img[:2], None)                # e.g. an eval hook / a second micro-batch on the same engine
+    with pytest.raises(_lib.LpiError, match="another forward"):
+        f1.sum().backward()
+    f2 = EncodeImageFn.apply(enc, img, vis, 1)          # 1:1 again: fine
+    f2.sum().backward()
+    assert vis.grad is not None and torch.isfinite(vis.grad).all()
+
+
+def test_prompt_depth_is_validated():
+    """depth beyond the prompt stack (DecomposedPrompt has 9 layers) would read past the buffer; the reference raises
+    IndexError on prompts[:, layer_id] (model.py:191) — here a ValueError before any kernel runs."""
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device=DEV)
+    pr = torch.zeros(1, 16, cfg.vision_width, device=DEV)
+    img = torch.from_numpy(synth.images(2, 32)).to(DEV)
+    with pytest.raises(ValueError, match="depth"):
+        enc.encode_image(img, pr, depth=2)
+    with pytest.raises(ValueError, match="depth"):
+        enc.encode_image(img, torch.zeros(9, 16, cfg.vision_width, device=DEV), depth=0)

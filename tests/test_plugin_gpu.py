@@ -132,3 +132,34 @@ def test_empty_batch_fails_loudly():
         enc.encode_image(torch.zeros(0, 3, cfg.image_resolution, cfg.image_resolution, device="cuda:0"))
     with pytest.raises((_lib.LpiError, ValueError, RuntimeError)):
         enc.encode_text(torch.zeros(0, 77, dtype=torch.int64, device="cuda:0"))
+
+
+def test_parameters_after_three_sgd_cosine_steps_match_reference(golden, monkeypatch):
+    """a10: not only the gradients but the PARAMETERS after k optimiser steps — SGD(momentum .9, lr .05, wd 2e-4) over
+    network.parameters() with CosineAnnealingLR(T_max = epochs) stepped per epoch (sprompt.py:253-255, 311, 324) — through the plugin's
+    own _train / train_function, three epochs of one batch, against the reference's parameters after each... the last step."""
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    g = golden("tiny_sgd3")
+    steps = int(g["steps"])
+    m = SPrompts(tiny_args(epochs=steps, lrate=float(g["lrate"]), weight_decay=float(g["weight_decay"])))
+    net = m._network.to(DEV)
+    set_factors(net)
+    net.numtask = 1
+    ids = torch.from_numpy(golden("tiny_d1")["token_ids"])          # same four captions as the fixture's batch
+    img = torch.from_numpy(synth.images(4, 32))
+    monkeypatch.setattr(m, "clustering", lambda dataloader: None)
+    monkeypatch.setattr(m, "_evaluate_retrieval", lambda loader: (None, None, {}))
+    m._train([(img, ids, 0, 0)], None)
+    for k in synth.PROMPT_NAMES:
+        got = getattr(net.prompts[0], k).detach().cpu().numpy()
+        ref = g[f"param.{steps - 1}.{k}"]
+        start = synth.prompt_factors(9, 16, 128, 128, task=0)[k]
+        moved = np.abs(ref - start).max()
+        assert moved > 0                                             # the fixture's parameters did move
+        assert np.abs(got - ref).max() <= 2e-3 * moved + 1e-6, (k, np.abs(got - ref).max(), moved)
+
+
+def test_nt_bxent_loss_has_no_cpu_fallback():
+    from lpi_amd.retrieval.loss.loss import nt_bxent_loss
+    with pytest.raises(_lib.LpiError):
+        nt_bxent_loss(torch.randn(3, 8), torch.eye(3), 0.001)
