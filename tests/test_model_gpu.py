@@ -288,7 +288,7 @@ def test_stale_backward_context_raises():
     from lpi_amd.functional import EncodeImageFn
     cfg = synth.TINY
     enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device=DEV)
-    fac = dev_factors(cfg)
+    fac, _ = dev_factors(cfg, requires_grad=False)
     from lpi_amd.engine import prompt_cp_fwd
     vis = prompt_cp_fwd(fac["dim_1_share"], fac["dim_2_visual"], fac["dim_3_visual"]).requires_grad_(True)
     img = torch.from_numpy(synth.images(4, 32)).to(DEV)
