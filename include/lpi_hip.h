@@ -58,7 +58,10 @@ uint64_t lpi_launch_count(void);
  *              workgroups for launches that would leave the chip half empty; default 160, 0 disables it; same results bit for bit);
  *   key 6      != 0 (default): a 256x256 launch of 256k + rem tiles with rem <= 128 runs those rem tiles as 2*rem tiles of 256x128
  *              inside the same launch — one round of half tiles instead of a half-empty round (bf16; same results bit for bit);
- *   key 7      unused.  Returns LPI_EINVAL for a key outside 0..7. */
+ *   key 7      attention kernel generation for bf16 operands: 0 (default) the persistent LDS-DMA backward of attention2.hip where it is
+ *              faster (L > 160), 1 the one-head-per-workgroup kernels of attention.hip everywhere, 2 / 3 force the persistent forward /
+ *              backward at every L they take (same results bit for bit).
+ *   Returns LPI_EINVAL for a key outside 0..7. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..7 */
 

@@ -41,7 +41,7 @@ template <> struct AT<float> {
 };
 template <> struct AT<bf16_t> {
     static constexpr int KS = 2;
-    static constexpr int RS = 144;      // 64 bf16 + 16 B pad
+    static constexpr int RS = 160;      // 64 bf16 + 32 B pad: conflict-free on the 64-bank LDS for both the ds_read_b128 row reads and the ds_read_b64_tr_b16 reads (144 B was 2-way on both: 43 % of LDS cycles were bank conflicts, profiles/r02_pmc.json)
 };
 
 // stage rows [0, L) x 64 elements of two matrices (global row strides ld0/ld1 elements) into two LDS images, zero rows
@@ -256,8 +256,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
                 }
                 lsum[j] = fmaf(lsum[j], alpha, ps);
                 m[j] = mn;
+                // rescale the running output only when some lane's maximum moved (wave-uniform test; x * 1.0f is exact, so skipping it
+                // changes no bit): after the first tiles of a row the maximum rarely changes, and these 16 multiplies are a quarter
+                // of the tile's vector instructions
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[j][i] *= alpha;
+                    for (int i = 0; i < 4; ++i) o[j][i] *= alpha;
+                }
             }
             mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
         };
@@ -272,7 +277,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
         for (int j = 0; j < NB; ++j) {
             const float ltot = group_sum(lsum[j]);
             const float inv = 1.0f / ltot;
-            if (qrow[j] < L) {
+            if constexpr (sizeof(T) == 2) {
+                f32x4 os[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) os[dt] = o[j][dt] * inv;
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(ctx) + ((size_t)b * L + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
+                if (qrow[j] < L && g == 0) lse[((size_t)b * H + h) * L + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
+            } else if (qrow[j] < L) {
                 T* dst = ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, o[j][dt] * inv);
@@ -367,12 +378,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (qrow[j] < L) {
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (sizeof(T) == 2) {
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+            } else if (qrow[j] < L) {
                 T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
+        }
     }
 }
 
@@ -465,8 +479,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
         }
         for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (krow[j] < L) {
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (sizeof(T) == 2) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + krow[j]) * lddqkv + h * HD;
+                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
+                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
+            } else if (krow[j] < L) {
                 T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -474,6 +492,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
                     Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
                 }
             }
+        }
     }
 }
 
@@ -579,12 +598,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (qrow[j] < L) {
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (sizeof(T) == 2) {
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+            } else if (qrow[j] < L) {
                 T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
+        }
     }
     __syncthreads();   // every row < Lp of dl_lds was written: the waves' 32-row spans tile [0, Lp)
 
@@ -636,8 +658,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
         }
         for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
-            if (krow[j] < L) {
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (sizeof(T) == 2) {
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + krow[j]) * lddqkv + h * HD;
+                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
+                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
+            } else if (krow[j] < L) {
                 T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -645,6 +671,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
                     Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
                 }
             }
+        }
     }
 }
 
@@ -728,6 +755,15 @@ inline bool bad_attn(int dtype, int B, int L, int H, int ld) {
 
 }  // namespace
 
+// second generation (attention2.hip): persistent workgroups, LDS-DMA double buffering; bf16 only.  Tuning key 7: 0 = use it where it
+// is faster (default: the backward at L > 160), 1 = first-generation kernels everywhere (A/B and bit-for-bit cross-check),
+// 2 = force the second-generation forward, 3 = force the second-generation backward at every L it takes.
+bool lpi_attn2_fwd_ok(int L);
+bool lpi_attn2_bwd_ok(int L);
+int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal, hipStream_t s);
+int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s);
+
 extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal,
                             void* stream) {
     if (!qkv || !ctx || !lse || bad_attn(dtype, B, L, H, ldqkv) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
@@ -735,8 +771,13 @@ extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32)
         return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
-    if (dtype == LPI_BF16)
+    if (dtype == LPI_BF16) {
+        // measured (MI355X, B = 256): the persistent forward is SLOWER than two one-head workgroups per CU (112.7 vs 102.5 us at L = 213:
+        // the forward is bound by dependent-chain latency at low occupancy, and 14 waves per CU hide more of it than 7 with DMA
+        // double buffering), so it is opt-in (key 7 = 2)
+        if (g_lpi_tuning[7] == 2 && lpi_attn2_fwd_ok(L)) return lpi_attn2_fwd(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, s);
         return causal ? fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+    }
     return LPI_EINVAL;
 }
 
@@ -750,8 +791,13 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
     if (dtype == LPI_F32)
         return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
-    if (dtype == LPI_BF16)
+    if (dtype == LPI_BF16) {
+        // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
+        // at L = 213); at short L several one-head workgroups per CU are faster (34.5 vs 37.2 us at L = 59): key 7 = 3 forces it
+        if (g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
+            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s);
         return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
                       : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
+    }
     return LPI_EINVAL;
 }

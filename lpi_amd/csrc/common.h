@@ -125,6 +125,26 @@ template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x4& acc, const 
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
 }
 
+// Store one 64-element bf16 row of a TRANSPOSED 16x16-tile accumulator set: o[dt] (dt = 0..3) holds, for output row (lane & 15),
+// the elements 16 dt + 4 g + 0..3 (g = lane >> 4) — the layout of O^T / dQ^T / dK^T / dV^T in the attention kernels.  Stored straight
+// from that layout a lane writes 4 x 8 bytes and an instruction touches 16 rows x 32 B.  Two v_permlane16_swap per dt pair trade the
+// g-odd lanes' piece of tile 2p for the g-even lanes' piece of tile 2p+1, after which every lane owns 8 CONSECUTIVE elements: 2 x 16-byte
+// stores per row, 16 rows x 64 B per instruction (half the store instructions, the same bytes and bits).  Must be called with all
+// lanes active; `valid` masks the store only.  row_ptr = &row[0] of this lane's output row.
+__device__ __forceinline__ void store_row_bf16_t(bf16_t* row_ptr, const f32x4 (&o)[4], int g, bool valid) {
+    typedef __attribute__((ext_vector_type(2))) float f2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_;
+    auto pk = [](float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, b2_)); };
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint32_t x0 = pk(o[2 * p][0], o[2 * p][1]), x1 = pk(o[2 * p][2], o[2 * p][3]);
+        const uint32_t y0 = pk(o[2 * p + 1][0], o[2 * p + 1][1]), y1 = pk(o[2 * p + 1][2], o[2 * p + 1][3]);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);      // {x rows 0,2 | y rows 0,2 -> x rows 1,3}, {x rows 1,3 -> y rows 0,2 | y rows 1,3}
+        const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+        if (valid) *reinterpret_cast<uint4*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+
 // Cross-lane reductions at VALU speed: DPP quad permutes and row mirrors inside each 16-lane row, then v_permlane16_swap /
 // v_permlane32_swap across rows (with vdst = src = v one instruction leaves {own, partner} in its two results).  `__shfl_xor`
 // compiles to ds_bpermute_b32 — an LDS-crossbar round trip per step, five or six dependent ones per reduction.  Every lane ends

@@ -649,3 +649,30 @@ def test_copy_rows_and_score_matrix():
     assert s_i2t.shape == (33, 70) and s_t2i.shape == (70, 33)
     assert float((s_i2t.cpu().double() - ref).abs().max()) < 2e-6
     assert torch.equal(s_t2i, s_i2t.t().contiguous())
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(24, 213, 12, 0), (40, 59, 8, 1), (3, 77, 8, 1), (2, 21, 2, 0), (5, 33, 3, 1), (2, 224, 2, 0), (300, 64, 4, 0)])
+def test_attention_second_generation_equals_first_bit_for_bit(B, L, H, causal):
+    """attention2.hip (persistent workgroups, LDS-DMA double buffering, swizzled 128-byte LDS rows) keeps attention.hip's tile
+    arithmetic and summation order: same bits, forward and backward, incl. workgroups that walk several heads (B*H > workgroups)
+    and heads whose padded rows [L, Lp) sit in images that earlier heads used."""
+    d = H * 64
+    qkv = rnd(B * L, 3 * d, seed=41).to(torch.bfloat16).to(DEV)
+    dctx = rnd(B * L, d, seed=42).to(torch.bfloat16).to(DEV)
+    out = {}
+    try:
+        for gen in (1, 0):
+            ctx = torch.full((B * L, d), 3.0, device=DEV, dtype=torch.bfloat16)
+            lse = torch.zeros(B, H, L, device=DEV)
+            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, L, device=DEV)
+            call("lpi_set_tuning", 7, 1 if gen else 2)          # 2: the persistent forward
+            call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, causal, stream())
+            call("lpi_set_tuning", 7, 1 if gen else 3)          # 3: the persistent backward at every L
+            call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, stream())
+            torch.cuda.synchronize()
+            out[gen] = (ctx, lse, dqkv, delta)
+    finally:
+        call("lpi_set_tuning", 7, 0)
+    for a, b, name in zip(out[1], out[0], ("ctx", "lse", "dqkv", "delta")):
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))

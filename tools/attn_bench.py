@@ -12,7 +12,7 @@ dt = F32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else BF16
 TD = torch.float32 if dt == F32 else torch.bfloat16
 dev = "cuda:0"
 s = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
-for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 1)):
+for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 1), ("text59", 256, 59, 8, 1)):
     d = H * 64
     qkv = torch.randn(B * L, 3 * d, device=dev).to(TD)
     dctx = torch.randn(B * L, d, device=dev).to(TD)
@@ -23,8 +23,10 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
     fwd = lambda: call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, causal, s())  # noqa: E731
     bwd = lambda: call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, s())  # noqa: E731
     out = []
-    for fn, fl, key3 in ((fwd, 4.0 * L * L * 64 * H * B, 0), (bwd, 8.0 * L * L * 64 * H * B, 0), (bwd, 8.0 * L * L * 64 * H * B, 1)):
+    for fn, fl, key3, key7 in ((fwd, 4.0 * L * L * 64 * H * B, 0, 1), (bwd, 8.0 * L * L * 64 * H * B, 0, 1), (bwd, 8.0 * L * L * 64 * H * B, 1, 1),
+                               (fwd, 4.0 * L * L * 64 * H * B, 0, 2), (bwd, 8.0 * L * L * 64 * H * B, 0, 3)):
         call("lpi_set_tuning", 3, key3)
+        call("lpi_set_tuning", 7, key7)
         best = 1e9
         for _ in range(3):
             fn(); fn()
@@ -37,4 +39,6 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
             best = min(best, e0.elapsed_time(e1) * 100)
         out.append(f"{best:7.1f} us {fl / best / 1e6:6.1f} TF")
     call("lpi_set_tuning", 3, 0)
-    print(f"{name:7s} L={L:3d} fwd {out[0]} | bwd fused {out[1]} | bwd two-pass {out[2]}  (dense algorithmic FLOPs)")
+    call("lpi_set_tuning", 7, 0)
+    print(f"{name:7s} L={L:3d} gen1: fwd {out[0]} | bwd fused {out[1]} | bwd two-pass {out[2]}  (dense algorithmic FLOPs)")
+    print(f"{name:7s} L={L:3d} gen2: fwd {out[3]} | bwd {out[4]}")
