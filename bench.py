@@ -373,10 +373,15 @@ def main():
         if collectives is not None:
             out["collectives"] = collectives
         out["cpu_baseline"] = cpu_baseline(cfg, a.depth) if (world == 1 and not a.no_cpu_baseline) else None
-        print(json.dumps(out), flush=True)
-    if exchange is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    line = json.dumps(out) if rank == 0 else None
+    try:
+        if exchange is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        if line is not None:      # after the process group is gone: RCCL's banner / teardown chatter cannot follow the one JSON line
+            sys.stdout.flush()
+            print(line, flush=True)
 
 
 if __name__ == "__main__":

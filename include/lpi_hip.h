@@ -97,6 +97,14 @@ int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, in
 int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy,
                       const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                       float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
+/* The same backward for P rows per sample only (the first block: nothing upstream of the prompt slots is trainable, sprompt.py:230-237):
+ * dy is compact [B*P, d]; x, mean/rstd and the gradient stream are the full [B*L, .] arrays, touched at rows b*L + row0 + p. */
+int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, int row0, int P, int d, const void* dy, int lddy,
+                           const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                           float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
+/* dst[(b*P + p), 0:cols] = src[(b*L + row0 + p), 0:cols] (`dtype` elements, 16-byte aligned rows): packs the prompt rows of a stream */
+int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, const void* src, int ld_src, void* dst, int ld_dst,
+                          void* stream);
 
 /* ---- a4: prompted multi-head attention, head_dim 64   replaces: models/clip/model.py:183-185 -----------
  * qkv: [B*L, 3*d] `dtype` (q | k | v, heads contiguous by 64).  ctx: [B*L, d] `dtype`.  lse: [B, H, L] f32.

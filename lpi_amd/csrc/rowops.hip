@@ -97,12 +97,15 @@ template <typename TX, typename TDY, typename TCAST, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
                                                     const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate) {
+                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate,
+                                                    int mapP, int mapL, int map0) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int crow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (crow >= rows) return;
+    // row map (mapP != 0): dy is COMPACT [B*P, d]; x / statistics / dx live at row (crow / P) * L + row0 + crow % P of the full stream
+    const int row = mapP ? (crow / mapP) * mapL + map0 + crow % mapP : crow;
     RowT<NC> g, xr;
-    const TDY* dyr = dy + (size_t)row * lddy;
+    const TDY* dyr = dy + (size_t)crow * lddy;
     const TX* xp = x + (size_t)row * ldx;
     for_chunks_n<NC>(d, lane, [&](int i, int col) {
         g.v[i] = Elem<TDY>::ld4(dyr + col);
@@ -211,12 +214,14 @@ __global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const 
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate) {
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate,
+                                                        int mapP, int mapL, int map0) {
     const int hl = threadIdx.x & 31;
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
-    if (row >= rows) return;
+    const int crow = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (crow >= rows) return;
+    const int row = mapP ? (crow / mapP) * mapL + map0 + crow % mapP : crow;      // see ln_bwd_kernel
     Row8<NC> g, xh;
-    const bf16_t* dyr = dy + (size_t)row * lddy;
+    const bf16_t* dyr = dy + (size_t)crow * lddy;
     const f16_t* xr = x + (size_t)row * ldx;
     const float mu = mean[row], rs = rstd[row];
     float s1 = 0.f, s2 = 0.f;
@@ -357,6 +362,17 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, 
         if (accumulate) t += *reinterpret_cast<const f32x4*>(o);
         *reinterpret_cast<f32x4*>(o) = t;
     }
+}
+
+// dst[(b*P + p), 0:cols] = src[(b*L + row0 + p), 0:cols]  in 16-byte chunks (cols * sizeof(T) a multiple of 16)
+__global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
+                                                               uint4* __restrict__ dst, long ldd16) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * P * chunks) return;
+    const int c = (int)(t % chunks);
+    const long r = t / chunks;
+    const long srow = (r / P) * L + row0 + r % P;
+    dst[r * ldd16 + c] = src[srow * lds16 + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -572,19 +588,19 @@ extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const 
     return 0;
 }
 
-extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
-                                 const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
-                                 int ldcast, int accumulate, void* stream) {
+static int ln_bwd_impl(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
+                       const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
+                       int ldcast, int accumulate, int mapP, int mapL, int map0, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_cast) || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
-#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast, accumulate)
+#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast, accumulate, mapP, mapL, map0)
 #define LNB_HBB(NC) LNB(f16_t, bf16_t, bf16_t, NC)
 #define LNB_FFF(NC) LNB(float, float, float, NC)
 #define LNB_FFB(NC) LNB(float, float, bf16_t, NC)
 #define LNB_FBB(NC) LNB(float, bf16_t, bf16_t, NC)
 #define LNB_FBF(NC) LNB(float, bf16_t, float, NC)
-#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast, accumulate)
+#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast, accumulate, mapP, mapL, map0)
     if (x_dtype == LPI_F16) {
         if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16 && !dx && !(d & 7) && !(lddy & 7) && !(ldx & 7) && !(ldcast & 7) &&
             !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx_cast) & 15))
@@ -606,6 +622,22 @@ extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int 
 #undef LNB_H16
     LPI_CHECK_LAST();
     return 0;
+}
+
+extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
+                                 const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
+                                 int ldcast, int accumulate, void* stream) {
+    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, 0, 0, 0, stream);
+}
+
+// LayerNorm backward of P rows per sample only: dy is compact [B*P, d]; x, mean / rstd and the gradient stream are the full [B*L, .]
+// arrays, touched at rows b*L + row0 + p.  The first block's backward needs the input gradient at the prompt rows alone (nothing
+// upstream of the prompt slots is trainable: sprompt.py:230-237).
+extern "C" int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, int row0, int P, int d, const void* dy, int lddy,
+                                      const void* x, int ldx, const float* gamma, const float* mean, const float* rstd, float* dx, int lddx,
+                                      void* dx_cast, int ldcast, int accumulate, void* stream) {
+    if (B <= 0 || L <= 0 || P <= 0 || row0 < 0 || row0 + P > L) return LPI_EINVAL;
+    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, B * P, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, P, L, row0, stream);
 }
 
 extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream) {
@@ -639,6 +671,19 @@ extern "C" int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, co
                    prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd);
     else
         return LPI_EINVAL;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, const void* src, int ld_src, void* dst, int ld_dst,
+                                     void* stream) {
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if (!src || !dst || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || cols <= 0 || ld_src < cols || ld_dst < cols) return LPI_EINVAL;
+    if ((cols * esz) % 16 || (ld_src * esz) % 16 || (ld_dst * esz) % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return LPI_EINVAL;
+    const int chunks = cols * esz / 16;
+    const long n = (long)B * P * chunks;
+    LPI_LAUNCH(gather_batch_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), B, L, row0, P, chunks, (const uint4*)src,
+               (long)ld_src * esz / 16, (uint4*)dst, (long)ld_dst * esz / 16);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -41,6 +41,9 @@ _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 # model.py:371-392) — which halves the bytes of the HBM-bound LayerNorms and residual epilogues; statistics, accumulation and the
 # pooled rows stay f32.  LPI_RESIDUAL=f32 keeps an f32 stream (A/B switch).  f32 (parity) mode always uses f32.
 RESIDUAL_F16 = _os.environ.get("LPI_RESIDUAL", "f16") != "f32"
+# first block's backward: only the prompt rows of dL/dx_0 are ever read (nothing upstream of the prompt slots is trainable), so its
+# in_proj dgrad GEMM and LN1 backward run on B*P rows instead of B*L.  LPI_L0_PROMPT_ROWS=0 computes every row (A/B switch).
+L0_PROMPT_ROWS = _os.environ.get("LPI_L0_PROMPT_ROWS", "1") != "0"
 
 
 def _pad(n: int, m: int = 128) -> int:
@@ -207,6 +210,8 @@ class Tower:
                 "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
                 "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
                 "c_dctx": z(Bp, d, dtype=T), "c_dq": z(Bp, d, dtype=T),
+                # the first block's prompt-row backward: up to 32 prompt rows per sample, packed
+                "p_dqkv": z(_pad(B * 32, 256), 3 * d, dtype=T), "p_dh": z(_pad(B * 32, 256), d, dtype=T),
             })
         ws["L"], ws["Mp"] = Lreal, _pad(B * Lreal, 256)
         self._ws[key] = ws
@@ -319,6 +324,16 @@ class Tower:
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
+            if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
+                # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
+                # CLS and token embeddings are frozen) -> in_proj dgrad and LN1 backward on the packed B*P prompt rows.  The residual
+                # path of those rows is already in the stream; every other row of it is left without this block's attention term.
+                pq, ph = ws["p_dqkv"], ws["p_dh"]
+                call("lpi_gather_batch_rows", dt, B, L, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
+                gemm(dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
+                call("lpi_layernorm_bwd_rows", dt, dt, xdt, B, L, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                     None if dt == F32 else dxT, d, 1, s)
+                continue
             gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, 1, s)

@@ -163,6 +163,62 @@ def test_vit_l14_depth12_rank8_vs_oracle():
         assert err <= 5e-3 * np.abs(r).max() + 1e-7, (k, err, float(np.abs(r).max()))
 
 
+def test_vit_l14_bf16_mode_close_to_oracle():
+    """BASELINE configs[4] names ViT-L/14, depth 12, r = 8 in BF16: the throughput mode on that architecture (L = 273: the two-pass
+    attention backward, 1024 / 768-wide GEMMs, 16 / 12 heads) at batch 3 against the f32 oracle, with the bf16-mode bars."""
+    import numpy as np
+    from oracle import lpi_oracle as O
+    cfg = synth.VIT_L14
+    sd = synth.clip_state_dict(cfg)
+    fac_np = synth.prompt_factors(12, 16, cfg.vision_width, cfg.transformer_width, r=8)
+    img, ids = synth.images(3, cfg.image_resolution), synth.token_ids(3)
+    ref = O.train_step(O.Oracle(cfg, sd, torch.float32), img, ids, fac_np, depth=12)
+    enc = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
+    fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in fac_np.items()}
+    out = train_step(enc, torch.from_numpy(img).to(DEV), torch.from_numpy(ids).to(DEV), fac, 12)
+    for k in ("img_f", "txt_f"):
+        err = float(np.abs(out[k].cpu().numpy() - ref[k]).max())
+        assert err <= 2e-2, (k, err)
+    assert abs(float(out["base_loss"]) - float(ref["base_loss"])) <= 3e-2 * max(1.0, abs(float(ref["base_loss"])))
+    assert abs(float(out["alignment_loss"]) - float(ref["alignment_loss"])) <= 1e-4
+    cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+    for k in synth.PROMPT_NAMES:
+        c = cos(fac[k].grad.double().cpu().numpy(), ref["grad." + k].astype(np.float64))
+        assert c >= 0.98, (k, c)
+    del enc
+    torch.cuda.empty_cache()
+
+
+def test_eight_rank_global_loss_at_configs3_size(enc32, data):
+    """BASELINE configs[3]: 8 ranks x 256 pairs -> the 2048 x 2048 contrastive matrix.  Eight virtual ranks' f32 HIP features (8
+    forward passes of 256 pairs with per-rank seeds, as bench.py draws them) are gathered into the [2048, 1024] buffer the RCCL
+    all-gather produces; every rank's loss kernels (full global loss, gradient of its 256 local rows only) are checked against f64
+    autograd on the global batch, and the ranks' row blocks tile the global gradient exactly once."""
+    W = 8
+    fac = factors(False)
+    buf = torch.empty(W * B, 2 * CFG.embed_dim, device=DEV)
+    with torch.no_grad():
+        for r in range(W):
+            im = torch.from_numpy(synth.images(B, 224, seed=synth.IMAGE_SEED + r)).to(DEV)
+            tk = torch.from_numpy(synth.token_ids(B, seed=synth.TOKEN_SEED + r)).to(DEV)
+            _, fi, ft, _, _ = forward_loss(enc32, im, tk, fac, 3)
+            buf[r * B:(r + 1) * B, :CFG.embed_dim] = fi
+            buf[r * B:(r + 1) * B, CFG.embed_dim:] = ft
+    from lpi_amd.engine import clip_loss_fwd_bwd
+    i64 = buf[:, :CFG.embed_dim].double().cpu().requires_grad_(True)
+    t64 = buf[:, CFG.embed_dim:].double().cpu().requires_grad_(True)
+    lg = enc32.logit_scale_exp * i64 @ t64.t()
+    lab = torch.arange(W * B)
+    ref = (torch.nn.functional.cross_entropy(lg, lab) + torch.nn.functional.cross_entropy(lg.t(), lab)) / 2
+    ref.backward()
+    for r in range(W):
+        loss, logits, dI, dT = clip_loss_fwd_bwd(buf[:, :CFG.embed_dim], buf[:, CFG.embed_dim:], enc32.logit_scale_exp, True, r * B, B)
+        assert logits.shape == (W * B, W * B)
+        assert abs(float(loss) - float(ref)) < 2e-5 * max(1.0, float(ref))
+        assert float((dI.double().cpu() - i64.grad[r * B:(r + 1) * B]).abs().max()) < 1e-7 + 1e-4 * float(i64.grad.abs().max())
+        assert float((dT.double().cpu() - t64.grad[r * B:(r + 1) * B]).abs().max()) < 1e-7 + 1e-4 * float(t64.grad.abs().max())
+
+
 def test_bf16_train_step_at_the_benchmarked_configuration(enc32, data):
     """The exact configuration bench.py times — bf16 operands, B = 256, depth 3, text batch trimmed to the longest caption (so the
     256x256 bf16 kernel with its hybrid tail, the 256x128 kernel, the fused attention backward at L = 213 / 59 and the fp16 residual

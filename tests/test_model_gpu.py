@@ -313,3 +313,20 @@ def test_prompt_depth_is_validated():
         enc.encode_image(img, pr, depth=2)
     with pytest.raises(ValueError, match="depth"):
         enc.encode_image(img, torch.zeros(9, 16, cfg.vision_width, device=DEV), depth=0)
+
+
+@pytest.mark.parametrize("cfg_name,dtype,depth,tol", [("tiny", "f32", 2, 2e-6), ("ViT-B/16", "f32", 3, 2e-5), ("ViT-B/16", "bf16", 3, 2e-2)])
+def test_first_block_backward_on_prompt_rows_only_is_exact(monkeypatch, cfg_name, dtype, depth, tol):
+    """Nothing upstream of the prompt slots is trainable (sprompt.py:230-237), so the first block's in_proj dgrad and LN1 backward may
+    run on the B*P prompt rows alone: same factor gradients as computing every row (f32: summation order of a smaller GEMM only)."""
+    from lpi_amd import engine as Eng
+    cfg = synth.CONFIGS[cfg_name]
+    ids = synth.token_ids(5)
+    grads = {}
+    for flag in (False, True):
+        monkeypatch.setattr(Eng, "L0_PROMPT_ROWS", flag)
+        res, _ = run_hip(cfg, dtype, 5, ids, depth)
+        grads[flag] = {k: res[k] for k in GRADS}
+    for k in GRADS:
+        scale = np.abs(grads[False][k]).max()
+        assert maxerr(grads[True][k], grads[False][k]) <= tol * scale + 1e-9, (k, maxerr(grads[True][k], grads[False][k]), scale)
