@@ -104,6 +104,11 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
     _lib = lib
+    # LPI_TUNING="key=value,key=value": speed-only knobs of lpi_set_tuning applied at load (A/B runs of bench.py; never results)
+    for kv in filter(None, os.environ.get("LPI_TUNING", "").split(",")):
+        k, v = kv.split("=")
+        if lib.lpi_set_tuning(int(k), int(v)) != 0:
+            raise LpiError(f"LPI_TUNING: bad knob {kv!r}")
     return lib
 
 

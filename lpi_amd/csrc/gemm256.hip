@@ -130,7 +130,7 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
     if (int e = lpi_ensure_lds(once, (const void*)kern, LDS_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_256);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-               ldr, (T*)aux, ldaux, alpha, tm, tn, g_lpi_tuning[2], g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
+               ldr, (T*)aux, ldaux, alpha, tm, tn, 0, g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -177,9 +177,22 @@ bool lpi_gemm256_eligible(int dtype, int M, int N, int K) {
     return nk >= 2 && (nk % 2) == 0;
 }
 
+int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
+
 int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s)
 {
+    // bf16 operands: the persistent kernel (gemm256p.hip: the K-tile ring runs across a workgroup's tiles, the next tile's first K-tile
+    // lands under the epilogue); tuning key 2 = -1 keeps one tile per workgroup (A/B switch; same results bit for bit)
+    // Measured (MI355X, B = 256 shapes): store-only epilogues gain 2-12 % (qkv 184 -> 162 us, fc+gelu 297 -> 281, dout 61 -> 56); epilogues
+    // that LOAD (residual, gelu'(u)) lose 9-31 %: their loads queue behind the in-flight LDS-DMA in the in-order vmcnt queue, so the
+    // first use waits for the next tile's K-tile 0 anyway and the four-pass epilogue only adds barriers.  Key 2 = 1 forces it for all.
+    const bool loads_in_epilogue = residual != nullptr || epilogue == LPI_EPI_DQUICKGELU;
+    if (dtype == LPI_BF16 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || g_lpi_tuning[2] == 1)) {
+        const int rc = lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
+        if (rc != LPI_ENOSYS) return rc;
+    }
     if (dtype == LPI_F32 && c_dtype == LPI_F32)
         return dispatch256<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_BF16)

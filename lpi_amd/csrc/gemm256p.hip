@@ -1,0 +1,377 @@
+// PERSISTENT 256x256-tile NT GEMM: the phased kernel of gemm256.hip with the K-tile ring kept running ACROSS tiles.
+//
+// Same contract, epilogues and arithmetic as gemm256.hip (same bits: the per-tile MFMA sequence and the f32 epilogue are unchanged);
+// selected by lpi_gemm256_launch for bf16 operands (tuning key 0 >= 0; a negative key 0 keeps the one-tile-per-workgroup kernels).
+//
+// Why: with one tile per workgroup every tile pays a ~3 us prologue (workgroup launch, address set-up, the first 14 LDS-DMA
+// instructions' round trip) with the matrix pipe idle, on top of 16-25 us of main loop + epilogue (profiles/r01_gemm_ablation.md) —
+// and the epilogue needs 133 KB of LDS, so nothing of the next tile could be in flight under it.  Here a workgroup owns its CU for
+// the whole launch (grid = min(#CUs, tiles)) and walks the tiles w, w + G, w + 2G, ... of the same XCD-aware order:
+//   * the LAST two K-tiles of tile t already issue the LDS-DMA of tile t+1's K-tile 0 into the ring slot they vacate (the slot of
+//     the even K-tiles), exactly where the schedule would have staged K-tile kt+2 of the same tile: the ring does not drain;
+//   * the epilogue runs in FOUR passes of 64 rows through the OTHER slot alone (64 rows x 1024 B = the 64 KiB slot of the odd
+//     K-tiles; 16-byte chunks XOR-swizzled by row & 7 instead of padded rows), so tile t+1's K-tile 0 lands under the epilogue of
+//     tile t; after two passes every wave waits for its own pieces of it (vmcnt(16): the 16+ stores of those passes may stay in
+//     flight), and the remaining two passes' barriers make it visible to all;
+//   * after the last pass the three early halves of K-tile 1 are issued and the main loop resumes at K-tile 0 without any wait
+//     (its first wait, in phase Y, is the schedule's usual vmcnt(8)).
+// LDS: 128 KiB (two ring slots), the epilogue staging is the odd slot; the hybrid short last round (256x128 half tiles, tile body
+// of gemm256x128_tile.h) runs after a workgroup's full tiles with its own ring.
+#include "gemm256x128_tile.h"
+
+extern int g_lpi_tuning[8];
+
+namespace {
+
+constexpr int T256 = 256;
+constexpr int ROWB = 128;                 // bytes per staged row
+constexpr int HALF_BYTES = 128 * ROWB;    // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES; // 64 KiB per K-tile
+constexpr int NTHR = 512;
+constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
+constexpr int STG = BUF_BYTES;            // epilogue staging = ring slot 1 (the odd K-tiles'), 64 rows x 1024 B
+constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
+
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
+__global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
+    int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+    TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
+    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m, int tail_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = ROWB / (int)sizeof(T);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+
+    // tile (tm, tn) of virtual workgroup id vb: the same XCD-aware order as gemm256_kernel (ids that share vb & 7 share an XCD)
+    auto coords = [&](int vb, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int group = t / (group_m * tiles_n);
+        const int first_m = group * group_m;
+        const int gsz = min(tiles_m - first_m, group_m);
+        const int in_group = t - group * group_m * tiles_n;
+        m0 = (first_m + in_group % gsz) * T256;
+        n0 = (in_group / gsz) * T256;
+    };
+
+    // ---- staging: a half tile = 128 rows x 128 B = 2 LDS-DMA instructions of 512 lanes x 16 B (as gemm256_tile.h), but addressed as
+    // SGPR base + 32-bit VGPR offset: the base of (tile, K-tile, half, instruction) is scalar arithmetic and a thread keeps two offsets
+    // for the whole launch — with 64-bit per-lane pointers re-formed for every tile the kernel spilled, and a scratch reload is a
+    // vector-memory operation that sits in the same in-order vmcnt queue as the LDS-DMA.
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    const unsigned a_off = (unsigned)(((size_t)srow * lda + schunk * EPC) * sizeof(T));
+    const unsigned b_off = (unsigned)(((size_t)srow * ldb + schunk * EPC) * sizeof(T));
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
+    auto glds16 = [&](const T* sbase, unsigned voff, unsigned lds_addr) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
+    auto stage_A = [&](int m0, int kt, int h, int buf) {
+        const T* sb = A + (size_t)(m0 + h * 128) * lda + (size_t)kt * BK;
+        const int lo = buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0);
+        glds16(sb, a_off, lds_w + lo);
+        glds16(sb + (size_t)64 * lda, a_off, lds_w + lo + 8192);
+    };
+    auto stage_B = [&](int n0, int kt, int h, int buf) {
+        const T* sb = B + (size_t)(n0 + h * 128) * ldb + (size_t)kt * BK;
+        const int lo = buf * BUF_BYTES + (h ? OFF_B1 : OFF_B0);
+        glds16(sb, b_off, lds_w + lo);
+        glds16(sb + (size_t)64 * ldb, b_off, lds_w + lo + 8192);
+    };
+
+    // ---- fragment offsets within a half tile
+    const int frow = lane & 15, fg = lane >> 4, fsw = frow >> 1;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * ROWB + (((ks << 2) | fg) ^ fsw) * 16;
+    const int a_base = (wm * 64) * ROWB;
+    const int b_base = (wn * 32) * ROWB;
+
+    Chunk fa[4][2], fb0[2][2], fb1[2][2];
+    f32x4 acc[2][2][2][4];   // [nh][ni][mh][mi]
+    auto read_A = [&](const char* half) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[mi][ks].u = *reinterpret_cast<const uint4*>(half + a_base + mi * 16 * ROWB + foff[ks]);
+    };
+    auto read_B = [&](Chunk (&fb)[2][2], const char* half) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[ni][ks].u = *reinterpret_cast<const uint4*>(half + b_base + ni * 16 * ROWB + foff[ks]);
+    };
+    auto mma_quadrant = [&](f32x4 (&c)[2][2][2][4], int nh, int mh, const Chunk (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma_chunk<T>(c[nh][ni][mh][mi], fb[ni][ks], fa[mi][ks]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define PHASE_SYNC_IN()                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                         \
+    __builtin_amdgcn_sched_barrier(0)
+#define PHASE_SYNC_OUT()                                  \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("" ::: "memory")
+
+    const int nk = K / BK;   // even, >= 2 (checked on the host)
+
+    int vb = blockIdx.x;
+    if (vb < n_full) {
+        int m0, n0;
+        coords(vb, m0, n0);
+        m0 = __builtin_amdgcn_readfirstlane(m0);
+        n0 = __builtin_amdgcn_readfirstlane(n0);
+        // prologue of the FIRST tile only: K-tile 0 (4 halves) -> slot 0, first three halves of K-tile 1 -> slot 1
+        stage_A(m0, 0, 0, 0); stage_B(n0, 0, 0, 0); stage_B(n0, 0, 1, 0); stage_A(m0, 0, 1, 0);
+        stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bool first = true;
+        for (;;) {
+            const int nvb = vb + G;
+            const bool has_next = nvb < n_full;
+            int nm0 = 0, nn0 = 0;
+            if (has_next) coords(nvb, nm0, nn0);
+            nm0 = __builtin_amdgcn_readfirstlane(nm0);      // wave-uniform: the next tile's staging pointers are formed where they are used
+            nn0 = __builtin_amdgcn_readfirstlane(nn0);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Stagger: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind (gemm256_tile.h); balanced after the loop
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+
+            // one K-tile = phases X and Y of gemm256_tile.h; `skip_wait`: K-tile 0 of a later tile (landed under the previous epilogue)
+            auto ktile = [&](int kt, const int BUF, bool skip_wait) {
+                const char* buf = smem + BUF * BUF_BYTES;
+                const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+                // X
+                read_B(fb0, buf + OFF_B0);
+                read_B(fb1, buf + OFF_B1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_A(buf + OFF_A0);
+                if (more1) {
+                    stage_A(m0, kt + 1, 1, BUF ^ 1);
+                    if (!skip_wait) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else if (has_next) {
+                    stage_A(nm0, 0, 1, BUF ^ 1);         // next tile's K-tile 0, half A1 -> slot 0 (this is K-tile nk-1 in slot 1)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                PHASE_SYNC_IN();
+                mma_quadrant(acc, 0, 0, fb0);
+                mma_quadrant(acc, 1, 0, fb1);
+                PHASE_SYNC_OUT();
+                // Y
+                read_A(buf + OFF_A1);
+                if (more2) {
+                    stage_A(m0, kt + 2, 0, BUF); stage_B(n0, kt + 2, 0, BUF); stage_B(n0, kt + 2, 1, BUF);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else if (more1) {
+                    if (has_next) {                      // K-tile nk-2 (slot 0): next tile's K-tile 0 takes the slot's three early halves
+                        stage_A(nm0, 0, 0, BUF); stage_B(nn0, 0, 0, BUF); stage_B(nn0, 0, 1, BUF);
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    }
+                } else if (!has_next) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                PHASE_SYNC_IN();
+                mma_quadrant(acc, 1, 1, fb1);
+                mma_quadrant(acc, 0, 1, fb0);
+                PHASE_SYNC_OUT();
+            };
+            ktile(0, 0, !first);
+            ktile(1, 1, false);
+            for (int kt = 2; kt < nk; kt += 2) {
+                ktile(kt, 0, false);
+                ktile(kt + 1, 1, false);
+            }
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+
+            // ---- epilogue: four passes of 64 rows through slot 1 (pass p: mh = p >> 1, mi in {2 (p & 1), 2 (p & 1) + 1}, both wm).
+            // Staging row s = wm * 32 + (mi & 1) * 16 + lrow holds tile row mh * 128 + wm * 64 + mi * 16 + lrow as 64 16-byte chunks
+            // (chunk c = output columns 4c .. 4c+3) at physical chunk c ^ (s & 7): the 8 lanes of a ds_write_b128 group (8 rows, one
+            // column group) spread over 8 chunks = all 32 banks of a 128-byte span; a whole-row read is any permutation.
+            // every epilogue address is derived from a lane / wave id laundered through an empty asm: they are invariant across the tile
+            // loop, and hoisted out of it they stayed live through the main loop — 38 spilled VGPRs whose scratch reloads (vector-memory
+            // operations, counted in vmcnt) drained the LDS-DMA queue in every phase
+            int lane_e = lane, wave_e = wave;
+            asm volatile("" : "+v"(lane_e));
+            asm volatile("" : "+s"(wave_e));
+            const int lrow = lane_e & 15, lslot = lane_e >> 4;
+            const int wm_e = wave_e >> 2, wn_e = wave_e & 3;
+            const int ecol = n0 + lane_e * 4;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
+            char* const stg = smem + STG;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int mh = p >> 1;
+                if (p) {          // the previous pass's staging reads are done before this pass overwrites them
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+#pragma unroll
+                for (int mi2 = 0; mi2 < 2; ++mi2) {
+                    const int s_row = wm_e * 32 + mi2 * 16 + lrow;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int chunk = nh * 32 + wn_e * 8 + ni * 4 + lslot;
+                            *reinterpret_cast<f32x4*>(stg + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][(p & 1) * 2 + mi2];
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll 4
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int s_row = wave_e * 8 + rr;
+                    const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + s_row * 1024 + ((lane_e ^ (s_row & 7)) << 4));
+                    gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+                }
+                // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
+                // all but the 16 youngest operations done.  Passes 2 and 3's barriers then publish it to every wave.
+                if (p == 1 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
+            if (!has_next) break;
+            // the staging slot is free again once every wave has read its rows: K-tile 1's three early halves of the next tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            vb = nvb; m0 = nm0; n0 = nn0;
+            stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
+            first = false;
+        }
+    }
+#undef PHASE_SYNC_IN
+#undef PHASE_SYNC_OUT
+
+    // ---- hybrid short last round: the rem = nwg - n_full leftover tiles as 2 * rem half tiles of 256x128 (mapping of gemm256_tail_kernel)
+    if (tail_blocks > 0) {
+        for (int j = blockIdx.x; j < tail_blocks; j += G) {
+            __syncthreads();      // LDS hand-over between tile bodies
+            const int k = (j >> 4) * 8 + (j & 7), half = (j >> 3) & 1;
+            const int q = nwg >> 3, r = nwg & 7, per = n_full >> 3;
+            const int xcd = k & 7, idx = per + (k >> 3);
+            const int count = q + (xcd < r ? 1 : 0);
+            if (idx >= count) continue;
+            const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+            const int group = t / (group_m * tiles_n);
+            const int first_m = group * group_m;
+            const int gsz = min(tiles_m - first_m, group_m);
+            const int in_group = t - group * group_m * tiles_n;
+            const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+            t128::tile<T, TC, EPI, RES, SAVE_U>(tm * 256, tn * 256 + half * 128, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, smem);
+        }
+    }
+}
+
+int cu_count_p() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
+int launchp_impl(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                 const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    const int tm = M / T256, tn = N / T256;
+    const int nwg = tm * tn;
+    const int ncu = cu_count_p();
+    const int gm = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8;
+    // hybrid short last round as in gemm256.hip: rem <= ncu/2 leftover tiles run as half tiles (tuning key 6)
+    int rem = nwg % ncu, n_full = nwg - rem, tail_blocks = 0;
+    if (g_lpi_tuning[6] != 0 && n_full >= ncu && rem > 0 && rem <= ncu / 2 && (ncu % 8) == 0) {
+        const int q = nwg >> 3, r = nwg & 7;
+        const int max_left = q + (r ? 1 : 0) - (n_full >> 3);
+        tail_blocks = 16 * max_left;
+    } else {
+        n_full = nwg;
+    }
+    auto kern = gemm256p_kernel<T, TC, EPI, RES, SAVE_U>;
+    constexpr int LDS = t128::LDS_BYTES > LDS_P ? t128::LDS_BYTES : LDS_P;
+    static LdsOnce once;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, LDS)) return e;
+    lpi_note_gemm_kernel(tail_blocks ? LPI_GEMM_K_256_TAIL : LPI_GEMM_K_256);
+    const int grid = std::min(ncu, std::max(n_full, tail_blocks));
+    LPI_LAUNCH(kern, dim3(grid), dim3(NTHR), LDS, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual, ldr,
+               (T*)aux, ldaux, alpha, tm, tn, n_full, gm, tail_blocks);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+template <typename T, typename TC, int EPI>
+int launchp(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+            const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    if constexpr (EPI == LPI_EPI_NONE) {
+        if (residual) return launchp_impl<T, TC, EPI, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    } else {
+        if (residual) return LPI_ENOSYS;
+        if constexpr (EPI == LPI_EPI_QUICKGELU) {
+            if (aux) return launchp_impl<T, TC, EPI, false, true>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+            return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        } else {
+            if (!aux) return LPI_EINVAL;
+            return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+        }
+    }
+}
+
+template <typename T, typename TC>
+int dispatchp(int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+              const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    switch (epi) {
+    case LPI_EPI_NONE: return launchp<T, TC, LPI_EPI_NONE>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    case LPI_EPI_QUICKGELU: return launchp<T, TC, LPI_EPI_QUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    case LPI_EPI_DQUICKGELU: return launchp<T, TC, LPI_EPI_DQUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    }
+    return LPI_EINVAL;
+}
+
+}  // namespace
+
+// bf16 operands only (the f32 path is MFMA-bound: its prologue share is small and its K-tile geometry differs)
+int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s)
+{
+    if (dtype == LPI_BF16 && c_dtype == LPI_BF16)
+        return dispatchp<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F32)
+        return dispatchp<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
+        return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    return LPI_ENOSYS;
+}

@@ -676,3 +676,50 @@ def test_attention_second_generation_equals_first_bit_for_bit(B, L, H, causal):
         call("lpi_set_tuning", 7, 0)
     for a, b, name in zip(out[1], out[0], ("ctx", "lse", "dqkv", "delta")):
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("tm,N,K", [(3, 512, 128), (40, 2048, 512), (43, 1536, 512), (213, 768, 768), (100, 768, 256), (30, 3072, 768)])
+def test_gemm_persistent_equals_one_tile_per_workgroup(tm, N, K):
+    """gemm256p.hip (a workgroup per CU walks its tiles; the next tile's K-tile 0 lands under a 4-pass epilogue) vs gemm256.hip
+    (tuning key 2 = -1): same bits for every epilogue — fewer tiles than CUs, several tiles per workgroup, two-K-tile problems,
+    hybrid short last rounds — and repeated runs are identical (a race would show as differing bits)."""
+    M = tm * 256
+    a = rnd(M, K, seed=1).bfloat16().to(DEV)
+    b = rnd(N, K, seed=2, scale=0.05).bfloat16().to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    res16 = (rnd(M, N, seed=4) * 4).half().to(DEV)
+    res32 = rnd(M, N, seed=6).to(DEV)
+    u0 = rnd(M, N, seed=5).bfloat16().to(DEV)
+
+    def run_all():
+        out = {}
+        c = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, alpha=0.5)
+        out["plain"] = c
+        c = torch.full((M, N), 7.0, device=DEV, dtype=torch.float16)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=res16)
+        out["f16res"] = c
+        c = torch.full((M, N), 7.0, device=DEV)
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=res32)
+        out["f32res"] = c
+        g, u = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, g, M, N, K, bias=bias, epi=E.EPI_QUICKGELU, aux=u)
+        out["gelu"], out["u"] = g, u
+        du = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        E.gemm(BF16, a, b, du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u0)
+        out["dgelu"] = du
+        torch.cuda.synchronize()
+        return out
+    call("lpi_set_tuning", 0, 1)
+    call("lpi_set_tuning", 5, 0)              # keep the 256x128 stand-alone kernel out of it: this test is about the 256x256 pair
+    try:
+        call("lpi_set_tuning", 2, 1)          # 1: the persistent kernel for EVERY epilogue (default 0: store-only epilogues)
+        new, new2 = run_all(), run_all()
+        call("lpi_set_tuning", 2, -1)
+        old = run_all()
+    finally:
+        call("lpi_set_tuning", 2, 0)
+        call("lpi_set_tuning", 5, 160)
+    for k in new:
+        assert torch.equal(new[k], old[k]), (k, float((new[k].float() - old[k].float()).abs().max()))
+        assert torch.equal(new[k], new2[k]), k
