@@ -187,7 +187,8 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
     // lands under the epilogue); tuning key 2 = -1 keeps one tile per workgroup (A/B switch; same results bit for bit)
     // Measured (MI355X, B = 256 shapes): store-only epilogues gain 2-12 % (qkv 184 -> 162 us, fc+gelu 297 -> 281, dout 61 -> 56); epilogues
     // that LOAD (residual, gelu'(u)) lose 9-31 %: their loads queue behind the in-flight LDS-DMA in the in-order vmcnt queue, so the
-    // first use waits for the next tile's K-tile 0 anyway and the four-pass epilogue only adds barriers.  Key 2 = 1 forces it for all.
+    // first use waits for the next tile's K-tile 0 anyway and the four-pass epilogue only adds barriers (issuing that K-tile 0 after the
+    // epilogue's second pass instead — what the kernel does for them — changes nothing: 1.08 / 1.08 / 1.30).  Key 2 = 1 forces it for all.
     const bool loads_in_epilogue = residual != nullptr || epilogue == LPI_EPI_DQUICKGELU;
     if (dtype == LPI_BF16 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || g_lpi_tuning[2] == 1)) {
         const int rc = lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);

@@ -129,6 +129,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     asm volatile("" ::: "memory")
 
     const int nk = K / BK;   // even, >= 2 (checked on the host)
+    // Epilogues that LOAD (residual, gelu'(u)): their loads share the in-order vmcnt queue with the LDS-DMA, so a next-tile K-tile 0
+    // issued from the main loop makes the first epilogue load wait for it.  For them the eight DMA instructions of the next tile's
+    // K-tile 0 are issued after pass 1 of the epilogue instead (only passes 2 and 3 queue behind them).
+    constexpr bool LATE = RES || EPI == LPI_EPI_DQUICKGELU;
 
     int vb = blockIdx.x;
     if (vb < n_full) {
@@ -144,9 +148,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
         bool first = true;
         for (;;) {
             const int nvb = vb + G;
-            const bool has_next = nvb < n_full;
+            const bool more_tiles = nvb < n_full;
+            const bool has_next = more_tiles && !LATE;       // next tile's K-tile 0 staged from the main loop
             int nm0 = 0, nn0 = 0;
-            if (has_next) coords(nvb, nm0, nn0);
+            if (more_tiles) coords(nvb, nm0, nn0);
             nm0 = __builtin_amdgcn_readfirstlane(nm0);      // wave-uniform: the next tile's staging pointers are formed where they are used
             nn0 = __builtin_amdgcn_readfirstlane(nn0);
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-#pragma unroll 4
+#pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
                     const int s_row = wave_e * 8 + rr;
                     const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
@@ -257,8 +262,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                 // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
                 // all but the 16 youngest operations done.  Passes 2 and 3's barriers then publish it to every wave.
                 if (p == 1 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                if constexpr (LATE) {
+                    if (p == 1 && more_tiles) {      // slot 0 is free since the main loop ended; passes 2 and 3 run behind these
+                        stage_A(nm0, 0, 0, 0); stage_B(nn0, 0, 0, 0); stage_B(nn0, 0, 1, 0); stage_A(nm0, 0, 1, 0);
+                    }
+                    // passes 2 and 3 issued >= 32 vector-memory operations after them: all but the 16 youngest done => K-tile 0 landed
+                    if (p == 3 && more_tiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                }
             }
-            if (!has_next) break;
+            if (!more_tiles) break;
             // the staging slot is free again once every wave has read its rows: K-tile 1's three early halves of the next tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();

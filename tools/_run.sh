@@ -1,4 +1,2 @@
 timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" -p no:cacheprovider 2>&1 | tail -3
-for v in -1 0 -1 0; do
-LPI_TUNING="2=$v" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo " <= key2=$v"
-done
+timeout 300 python tools/gemm_ab.py 2 -1 0 2>&1 | tail -14
