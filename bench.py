@@ -236,14 +236,15 @@ class Workload:
         if os.path.exists(pmc):      # separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_summary.py
             pj = json.load(open(pmc))
             if pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(_lib.load().lpi_version()):
-                ks = [v for n, v in pj["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel")]
-                if ks:      # the two entry kernels of the 256x256 GEMM, launch-weighted
+                ks = [v for n, v in pj["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel", "gemm256p_kernel")]
+                if ks:      # the entry kernels of the 256x256 GEMM (persistent / one tile per workgroup / with a half-tile last round), launch-weighted
                     w = sum(v["launches"] for v in ks)
                     traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / w * 1e6)
                     if all("mfma_busy_frac" in v for v in ks):
                         mfma_util = round(sum(v["mfma_busy_frac"] * v["launches"] for v in ks) / w, 4)
                     tsrc = "profiles/r02_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
-        return {"bound": "mfma", "kernel": "gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM; the second runs a short last round as half tiles)",
+        return {"bound": "mfma", "kernel": "gemm256p_kernel / gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM: persistent for store-only epilogues, "
+                                            "one tile per workgroup for loading epilogues, the last with a short last round as half tiles)",
                 "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(by / len(ev)),

@@ -105,10 +105,12 @@ template <> struct Elem<f16_t> {
 };
 
 // 16-byte fragment chunk as it sits in a lane's registers
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 union Chunk {
     uint4 u;
     f32x4 f;
     bf16x8 h;
+    f16x8 hh;      // the same 16 bytes as 8 IEEE halves (f16 operand mode)
 };
 
 // acc += A_chunk (x) B_chunk over the chunk's k values, 16x16 output tile.
@@ -123,6 +125,37 @@ template <> __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const C
 }
 template <> __device__ __forceinline__ void mma_chunk<bf16_t>(f32x4& acc, const Chunk& a, const Chunk& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+// fp16 operands (the reference's own arithmetic type, model.py:394-415): same rate, 3 more mantissa bits than bf16
+template <> __device__ __forceinline__ void mma_chunk<f16_t>(f32x4& acc, const Chunk& a, const Chunk& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hh, b.hh, acc, 0, 0, 0);
+}
+
+// two floats -> one dword of T (round to nearest even): v_cvt_pk_bf16_f32 / v_cvt_pkrtz... (f16: v_cvt_pk via two v_cvt_f16_f32)
+template <typename T> __device__ __forceinline__ uint32_t pack2_t(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2_t<bf16_t>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, b2_));
+}
+template <> __device__ __forceinline__ uint32_t pack2_t<f16_t>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f2_;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, h2_));
+}
+// element e (0..7) of a chunk of T as float
+template <typename T> __device__ __forceinline__ float chunk_elem(const Chunk& c, int e);
+template <> __device__ __forceinline__ float chunk_elem<bf16_t>(const Chunk& c, int e) { return (float)c.h[e]; }
+template <> __device__ __forceinline__ float chunk_elem<f16_t>(const Chunk& c, int e) { return (float)c.hh[e]; }
+// a chunk of 8 halves -> the same 8 values as bf16 (the backward's operand type; gradients do not fit fp16's range)
+__device__ __forceinline__ void chunk_f16_to_bf16(Chunk& c) {
+    Chunk o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = pack2_t<bf16_t>((float)c.hh[2 * i], (float)c.hh[2 * i + 1]);
+        if (i == 0) o.u.x = w; else if (i == 1) o.u.y = w; else if (i == 2) o.u.z = w; else o.u.w = w;
+    }
+    c = o;
 }
 
 // Store one 64-element bf16 row of a TRANSPOSED 16x16-tile accumulator set: o[dt] (dt = 0..3) holds, for output row (lane & 15),

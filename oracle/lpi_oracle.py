@@ -28,6 +28,21 @@ import torch
 
 LN_EPS = 1e-5  # nn.LayerNorm default, model.py:154-160
 
+# Precision-mode EMULATION (tests/test_precision_modes.py only; None = exact arithmetic in the oracle's dtype, the parity oracle).
+# OPERAND_DTYPE: every matrix-product operand of the two towers is rounded to this type first (products and sums stay in the oracle's
+# dtype: what an MFMA with f32 accumulation does).  STREAM_DTYPE: the residual stream is rounded to this type after every block
+# (the HIP path's fp16 stream in bf16 mode).  Answers "what does the operand type cost" without any kernel.
+OPERAND_DTYPE = None
+STREAM_DTYPE = None
+
+
+def _op(t):
+    return t if OPERAND_DTYPE is None else t.to(OPERAND_DTYPE).to(t.dtype)
+
+
+def _stream(t):
+    return t if STREAM_DTYPE is None else t.to(STREAM_DTYPE).to(t.dtype)
+
 
 # ----------------------------------------------------------------------------- element ops
 def layer_norm(x, w, b):
@@ -65,17 +80,17 @@ def attention(x, w_in, b_in, w_out, b_out, heads, causal):
     the diagonal for the text tower (model.py:347-353)."""
     B, L, d = x.shape
     hd = d // heads
-    qkv = x @ w_in.t() + b_in
+    qkv = _op(_op(x) @ _op(w_in).t() + b_in)      # (stored in the operand type)
     q, k, v = qkv.split(d, dim=-1)
     q = q.reshape(B, L, heads, hd).transpose(1, 2) * (hd ** -0.5)
     k = k.reshape(B, L, heads, hd).transpose(1, 2)
     v = v.reshape(B, L, heads, hd).transpose(1, 2)
-    s = q @ k.transpose(-1, -2)
+    s = _op(q) @ _op(k).transpose(-1, -2)
     if causal:
         s = s + torch.full((L, L), float("-inf"), dtype=x.dtype).triu_(1)
     p = torch.softmax(s, dim=-1)
-    o = (p @ v).transpose(1, 2).reshape(B, L, d)
-    return o @ w_out.t() + b_out
+    o = (_op(p) @ _op(v)).transpose(1, 2).reshape(B, L, d)
+    return _op(o) @ _op(w_out).t() + b_out
 
 
 def res_block(x, W, pre, heads, causal):
@@ -83,9 +98,10 @@ def res_block(x, W, pre, heads, causal):
     x = x + attention(layer_norm(x, W[pre + "ln_1.weight"], W[pre + "ln_1.bias"]),
                       W[pre + "attn.in_proj_weight"], W[pre + "attn.in_proj_bias"],
                       W[pre + "attn.out_proj.weight"], W[pre + "attn.out_proj.bias"], heads, causal)
+    x = _stream(x)
     h = layer_norm(x, W[pre + "ln_2.weight"], W[pre + "ln_2.bias"])
-    h = quick_gelu(h @ W[pre + "mlp.c_fc.weight"].t() + W[pre + "mlp.c_fc.bias"])
-    return x + h @ W[pre + "mlp.c_proj.weight"].t() + W[pre + "mlp.c_proj.bias"]
+    h = quick_gelu(_op(h) @ _op(W[pre + "mlp.c_fc.weight"]).t() + W[pre + "mlp.c_fc.bias"])
+    return _stream(x + _op(h) @ _op(W[pre + "mlp.c_proj.weight"]).t() + W[pre + "mlp.c_proj.bias"])
 
 
 def transformer(x, W, prefix, layers, heads, causal, prompts, depth):
