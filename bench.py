@@ -39,7 +39,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 GFLOP_PER_PAIR = {"ViT-B/16": (89.68, 44.05), "ViT-L/14": (378.9, 185.8)}   # (fwd+bwd, fwd), P=16, dgrad only
-PEAK_TF = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
+PEAK_TF = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md:41-43
 GEMM_KERNEL_NAMES = {0: "k128", 1: "k256", 2: "k256", 3: "k256x128", 4: "few_rows"}     # LPI_GEMM_K_* -> report bucket
 
 
@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--model", default="ViT-B/16")

@@ -39,6 +39,10 @@ template <> struct AT<float> {
     static constexpr int KS = 4;        // k-steps of 4 chunks per 64-element row
     static constexpr int RS = 272;      // LDS row stride in bytes (64 f32 + 16 B pad)
 };
+template <> struct AT<f16_t> {
+    static constexpr int KS = 2;
+    static constexpr int RS = 160;      // as bf16
+};
 template <> struct AT<bf16_t> {
     static constexpr int KS = 2;
     static constexpr int RS = 160;      // 64 bf16 + 32 B pad: conflict-free on the 64-bank LDS for both the ds_read_b128 row reads and the ds_read_b64_tr_b16 reads (144 B was 2-way on both: 43 % of LDS cycles were bank conflicts, profiles/r02_pmc.json)
@@ -47,7 +51,9 @@ template <> struct AT<bf16_t> {
 // stage rows [0, L) x 64 elements of two matrices (global row strides ld0/ld1 elements) into two LDS images, zero rows
 // [L, Lp).  8 independent 16-byte loads are kept in flight per thread before any LDS write: the loop is latency bound
 // (the qkv buffer is far larger than the caches), and a one-load-at-a-time loop costs a full HBM round trip per iteration.
-template <typename T>
+// CV0 / CV1: the matrix is stored as fp16 (saved by an f16-mode forward) and is converted to bf16 on its way into LDS (the backward's
+// operands are bf16: gradients do not fit fp16's range)
+template <typename T, bool CV0 = false, bool CV1 = false>
 __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1, const T* g1, int ld0, int ld1, int L, int Lp) {
     constexpr int NCH = HD * (int)sizeof(T) / 16;
     const int n = Lp * NCH, nt = blockDim.x;
@@ -67,6 +73,8 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
         for (int j = 0; j < 4; ++j) {
             const int i = base + j * nt, row = i / NCH, c = i % NCH;
             if (i < n) {
+                if constexpr (CV0) { Chunk t; t.u = v0[j]; chunk_f16_to_bf16(t); v0[j] = t.u; }
+                if constexpr (CV1) { Chunk t; t.u = v1[j]; chunk_f16_to_bf16(t); v1[j] = t.u; }
                 *reinterpret_cast<uint4*>(lds0 + row * AT<T>::RS + c * 16) = v0[j];
                 *reinterpret_cast<uint4*>(lds1 + row * AT<T>::RS + c * 16) = v1[j];
             }
@@ -82,12 +90,13 @@ __device__ __forceinline__ void lds_row_chunks(Chunk (&q)[AT<T>::KS], const char
 }
 
 // this lane's KS row chunks (chunk g + 4*ks) of row `row` of a global matrix; zeros if !valid
-template <typename T>
+template <typename T, bool CV = false>
 __device__ __forceinline__ void load_row_chunks(Chunk (&q)[AT<T>::KS], const T* g, size_t row, int ld, int grp, bool valid) {
 #pragma unroll
     for (int ks = 0; ks < AT<T>::KS; ++ks) {
         q[ks].u = make_uint4(0, 0, 0, 0);
         if (valid) q[ks].u = *reinterpret_cast<const uint4*>(g + row * ld + (grp + 4 * ks) * Elem<T>::EPC);
+        if constexpr (CV) chunk_f16_to_bf16(q[ks]);
     }
 }
 
@@ -126,7 +135,7 @@ __device__ __forceinline__ void mma_transposed(f32x4 (&acc)[NB][4], const char* 
         Chunk b[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            b[j].u = make_uint4(pack_bf16(p0[j][0], p0[j][1]), pack_bf16(p0[j][2], p0[j][3]), pack_bf16(p1[j][0], p1[j][1]), pack_bf16(p1[j][2], p1[j][3]));
+            b[j].u = make_uint4(pack2_t<T>(p0[j][0], p0[j][1]), pack2_t<T>(p0[j][2], p0[j][3]), pack2_t<T>(p1[j][0], p1[j][1]), pack2_t<T>(p1[j][2], p1[j][3]));
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(tp + dt * 32));
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
                 f32x4 os[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) os[dt] = o[j][dt] * inv;
-                store_row_bf16_t(reinterpret_cast<bf16_t*>(ctx) + ((size_t)b * L + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
+                store_row16_t<T>(ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
                 if (qrow[j] < L && g == 0) lse[((size_t)b * H + h) * L + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
             } else if (qrow[j] < L) {
                 T* dst = ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD + 4 * g;
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
 }
 
 // ------------------------------------------------------------------------------------------------ backward A
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
                                                          const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                          const float* __restrict__ lse, float* __restrict__ delta,
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
     const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
-    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
             qrow[j] = q0 + 16 * j + (lane & 15);
             const bool valid = qrow[j] < L;
             const size_t grow = (size_t)b * L + qrow[j];
-            load_row_chunks<T>(q[j], qg, qrow[j], ldqkv, g, valid);
+            load_row_chunks<T, SV16>(q[j], qg, qrow[j], ldqkv, g, valid);
             load_row_chunks<T>(dO[j], dctx + h * HD, grow, lddctx, g, valid);
             Chunk oc[AT<T>::KS];
             load_row_chunks<T>(oc, ctx + h * HD, grow, ldctx, g, valid);
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
                     for (int e = 0; e < 4; ++e) dl += oc[ks].f[e] * dO[j][ks].f[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dl += (float)oc[ks].h[e] * (float)dO[j][ks].h[e];
+                    for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)oc[ks].hh[e] : (float)oc[ks].h[e]) * (float)dO[j][ks].h[e];
                 }
             }
             dl = group_sum(dl);
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
 }
 
 // ------------------------------------------------------------------------------------------------ backward B
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ dctx, int lddctx, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv) {
@@ -409,10 +418,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
 #pragma unroll
     for (int j = 0; j < NB; ++j) {          // first key blocks: fetched ahead of the staging
         const int kr = (wave * NB + j) * 16 + (lane & 15);
-        load_row_chunks<T>(kk[j], qg + dm, kr, ldqkv, g, kr < L);
-        load_row_chunks<T>(vv[j], qg + 2 * dm, kr, ldqkv, g, kr < L);
+        load_row_chunks<T, SV16>(kk[j], qg + dm, kr, ldqkv, g, kr < L);
+        load_row_chunks<T, SV16>(vv[j], qg + 2 * dm, kr, ldqkv, g, kr < L);
     }
-    stage_rows2<T>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
         lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;  // padded queries -> P = 0
         dl_lds[i] = i < L ? delta[((size_t)b * H + h) * L + i] * SCALE : 0.f;
@@ -431,8 +440,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
         if (k0 != wave * 16 * NB) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                load_row_chunks<T>(kk[j], qg + dm, krow[j], ldqkv, g, krow[j] < L);
-                load_row_chunks<T>(vv[j], qg + 2 * dm, krow[j], ldqkv, g, krow[j] < L);
+                load_row_chunks<T, SV16>(kk[j], qg + dm, krow[j], ldqkv, g, krow[j] < L);
+                load_row_chunks<T, SV16>(vv[j], qg + 2 * dm, krow[j], ldqkv, g, krow[j] < L);
             }
         }
         f32x4 dk[NB][4], dv[NB][4];
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
 // qkv and dctx rows are read from HBM once instead of twice — the two-pass backward is HBM bound (about 1 GB per vision layer),
 // this one moves a third less.  Phase A (queries) produces delta into LDS and dQ; after one barrier phase B (keys) produces
 // dK, dV.  Same tile bodies, same fixed summation order as the two-pass kernels.
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
@@ -517,8 +526,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
     char* do_lds = smem + 3 * img;
     float* lse_lds = reinterpret_cast<float*>(smem + 4 * img);
     float* dl_lds = lse_lds + Lp;
-    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
-    stage_rows2<T>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;
     __syncthreads();
 
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
                     for (int e = 0; e < 4; ++e) dl += oc[ks].f[e] * dO[j][ks].f[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dl += (float)oc[ks].h[e] * (float)dO[j][ks].h[e];
+                    for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)oc[ks].hh[e] : (float)oc[ks].h[e]) * (float)dO[j][ks].h[e];
                 }
             }
             dl = group_sum(dl);
@@ -685,8 +694,8 @@ inline int pick_waves(int L) {
 // allow the full 160 KiB of a CU's LDS for a kernel: once per (kernel function, device), safe from any host thread
 int set_lds(const void* kern, size_t bytes) {
     if (bytes > 160 * 1024) return LPI_EINVAL;
-    static const void* fn[16];
-    static LdsOnce once[16];
+    static const void* fn[32];
+    static LdsOnce once[32];
     static std::atomic<int> nfn{0};
     static std::atomic_flag lock = ATOMIC_FLAG_INIT;
     int slot = -1;
@@ -698,7 +707,7 @@ int set_lds(const void* kern, size_t bytes) {
         const int m = nfn.load(std::memory_order_relaxed);
         for (int i = 0; i < m; ++i)
             if (fn[i] == kern) { slot = i; break; }
-        if (slot < 0 && m < 16) { fn[m] = kern; slot = m; nfn.store(m + 1, std::memory_order_release); }
+        if (slot < 0 && m < 32) { fn[m] = kern; slot = m; nfn.store(m + 1, std::memory_order_release); }
         lock.clear(std::memory_order_release);
     }
     if (slot < 0) return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -717,7 +726,7 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
     return 0;
 }
 
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SV16 = false>
 int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s) {
     const int Lp = (L + 31) / 32 * 32;
@@ -728,21 +737,21 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     // fused single pass for 2-byte operands (HBM bound: -7 % at L = 213, -23 % at L = 77); f32 is compute bound and faster with the
     // two-pass kernels at two workgroups per CU.  Tuning key 3 != 0 forces the two-pass kernels.
     if (sizeof(T) == 2 && ldsF <= 160 * 1024 && g_lpi_tuning[3] == 0) {
-        int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL>, ldsF);
+        int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL, SV16>, ldsF);
         if (ef) return ef;
-        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
                    (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
         LPI_CHECK_LAST();
         return 0;
     }
-    int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL>, ldsA);
+    int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL, SV16>, ldsA);
     if (e) return e;
-    e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL>, ldsB);
+    e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL, SV16>, ldsB);
     if (e) return e;
-    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
                (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
-    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
+    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
                lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
     return 0;
@@ -771,6 +780,8 @@ extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32)
         return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+    if (dtype == LPI_F16)       // f16 operand mode: q, k, v and ctx are fp16 (the reference's own arithmetic type)
+        return causal ? fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<f16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
     if (dtype == LPI_BF16) {
         // measured (MI355X, B = 256): the persistent forward is SLOWER than two one-head workgroups per CU (112.7 vs 102.5 us at L = 213:
         // the forward is bound by dependent-chain latency at low occupancy, and 14 waves per CU hide more of it than 7 with DMA
@@ -791,6 +802,10 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
     if (dtype == LPI_F32)
         return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
+    if (dtype == LPI_F16)       // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
+                                // q, k, v are converted on their way into LDS / registers (first-generation kernels: the LDS-DMA cannot convert)
+        return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
+                      : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
     if (dtype == LPI_BF16) {
         // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
         // at L = 213); at short L several one-head workgroups per CU are faster (34.5 vs 37.2 us at L = 59): key 7 = 3 forces it

@@ -72,9 +72,10 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
     }
 }
 
-template <typename T>
+// TS: storage type of the SAVED q / qkv (fp16 after an f16-mode forward, else T); dctx, dq, dqkv are T.  All arithmetic is f32.
+template <typename T, typename TS = T>
 __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
-    int B, int L, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    int B, int L, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
     const T* __restrict__ dctx, int ldo, const float* __restrict__ lse, T* __restrict__ dq, int lddq, T* __restrict__ dqkv, int ldg, int causal)
 {
     extern __shared__ float sm[];
@@ -88,17 +89,17 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
     const int row = idx ? idx[b] : 0;
     const int nv = causal ? row + 1 : L;
     const int kk = lane >> 4, g = lane & 15;
-    const f32x4 q4 = Elem<T>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
+    const f32x4 q4 = Elem<TS>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
     const f32x4 o4 = Elem<T>::ld4(dctx + (size_t)b * ldo + h * DH + 4 * g);
-    const T* kbase = qkv + (size_t)b * L * ld + d + h * DH;
-    const T* vbase = kbase + d;
+    const TS* kbase = qkv + (size_t)b * L * ld + d + h * DH;
+    const TS* vbase = kbase + d;
     const float ls = lse[bh];
     for (int j0 = wave * 4; j0 < nv; j0 += 4 * WPB) {
         const int j = j0 + kk;
         float sc = 0.f, dv = 0.f;
         if (j < nv) {
-            sc = dot4(q4, Elem<T>::ld4(kbase + (size_t)j * ld + 4 * g));
-            dv = dot4(o4, Elem<T>::ld4(vbase + (size_t)j * ld + 4 * g));
+            sc = dot4(q4, Elem<TS>::ld4(kbase + (size_t)j * ld + 4 * g));
+            dv = dot4(o4, Elem<TS>::ld4(vbase + (size_t)j * ld + 4 * g));
         }
         sc = reduce16(sc);
         dv = reduce16(dv);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
     delta = wave_sum(delta);
     for (int j = threadIdx.x; j < nv; j += WAVE * WPB) ds[j] = p[j] * (dp[j] - delta) * 0.125f;
     __syncthreads();
-    const float qd = Elem<T>::ld(q + (size_t)b * ldq + h * DH + lane);
+    const float qd = Elem<TS>::ld(q + (size_t)b * ldq + h * DH + lane);
     const float od = Elem<T>::ld(dctx + (size_t)b * ldo + h * DH + lane);
     T* dk = dqkv + (size_t)b * L * ldg + d + h * DH + lane;
     T* dv = dk + d;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
 #pragma unroll 4
     for (int j = wave; j < nv; j += WPB) {
         const float dsj = ds[j];
-        acc += dsj * Elem<T>::ld(kbase + (size_t)j * ld + lane);
+        acc += dsj * Elem<TS>::ld(kbase + (size_t)j * ld + lane);
         Elem<T>::st(dk + (size_t)j * ldg, dsj * qd);
         Elem<T>::st(dv + (size_t)j * ldg, p[j] * od);
     }
@@ -174,6 +175,9 @@ extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q
     else if (dtype == LPI_BF16)
         LPI_LAUNCH((attn_pooled_fwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
                    (bf16_t*)ctx, ldo, lse, causal);
+    else if (dtype == LPI_F16)
+        LPI_LAUNCH((attn_pooled_fwd_kernel<f16_t>), grid, block, lds, s, B, L, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
+                   (f16_t*)ctx, ldo, lse, causal);
     else
         return LPI_ENOSYS;
     LPI_CHECK_LAST();
@@ -199,6 +203,9 @@ extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q
                    (const float*)dctx, ldo, lse, (float*)dq, lddq, (float*)dqkv, ldg, causal);
     else if (dtype == LPI_BF16)
         LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
+                   (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
+    else if (dtype == LPI_F16)      // saved q / qkv are fp16 (f16-mode forward); the gradients in and out are bf16
+        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t, f16_t>), grid, block, lds, s, B, L, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
                    (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
     else
         return LPI_ENOSYS;

@@ -164,10 +164,9 @@ __device__ __forceinline__ void chunk_f16_to_bf16(Chunk& c) {
 // g-odd lanes' piece of tile 2p for the g-even lanes' piece of tile 2p+1, after which every lane owns 8 CONSECUTIVE elements: 2 x 16-byte
 // stores per row, 16 rows x 64 B per instruction (half the store instructions, the same bytes and bits).  Must be called with all
 // lanes active; `valid` masks the store only.  row_ptr = &row[0] of this lane's output row.
-__device__ __forceinline__ void store_row_bf16_t(bf16_t* row_ptr, const f32x4 (&o)[4], int g, bool valid) {
-    typedef __attribute__((ext_vector_type(2))) float f2_;
-    typedef __attribute__((ext_vector_type(2))) __bf16 b2_;
-    auto pk = [](float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, b2_)); };
+template <typename T16>
+__device__ __forceinline__ void store_row16_t(T16* row_ptr, const f32x4 (&o)[4], int g, bool valid) {
+    auto pk = [](float a, float b) { return pack2_t<T16>(a, b); };
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const uint32_t x0 = pk(o[2 * p][0], o[2 * p][1]), x1 = pk(o[2 * p][2], o[2 * p][3]);
@@ -177,6 +176,9 @@ __device__ __forceinline__ void store_row_bf16_t(bf16_t* row_ptr, const f32x4 (&
         if (valid) *reinterpret_cast<uint4*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
     }
 }
+
+__device__ __forceinline__ void store_row_bf16_t(bf16_t* row_ptr, const f32x4 (&o)[4], int g, bool valid) { store_row16_t<bf16_t>(row_ptr, o, g, valid); }
+
 
 // Cross-lane reductions at VALU speed: DPP quad permutes and row mirrors inside each 16-lane row, then v_permlane16_swap /
 // v_permlane32_swap across rows (with vdst = src = v one instruction leaves {own, partner} in its two results).  `__shfl_xor`

@@ -30,7 +30,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, long c_zstride)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, long c_zstride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -154,7 +154,7 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
     if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_128);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
-                       (TC*)C, ldc, bias, residual, ldr, (T*)aux, ldaux, alpha, tm, tn, 0L);
+                       (TC*)C, ldc, bias, residual, ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, 0L);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -200,7 +200,7 @@ int dispatch_epi(int epi, int M, int N, int K, const void* A, int lda, const voi
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ksplit, const float* __restrict__ part, TC* __restrict__ C, int ldc,
                                                            const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-                                                           T* __restrict__ aux, int ldaux, float alpha)
+                                                           typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 4 consecutive columns
     const int n4 = N >> 2;
@@ -224,10 +224,10 @@ int splitk_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
     if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_SPLITK);
     LPI_LAUNCH(kern, dim3(tm * tn, ksplit), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K / ksplit, (const T*)A, lda, (const T*)B, ldb, scratch, N,
-               (const float*)nullptr, (const float*)nullptr, 0, (T*)nullptr, 0, 1.0f, tm, tn, (long)M * N);
+               (const float*)nullptr, (const float*)nullptr, 0, (typename AuxT<T>::type*)nullptr, 0, 1.0f, tm, tn, (long)M * N);
     const long n = (long)M * (N >> 2);
     LPI_LAUNCH((splitk_reduce_kernel<T, TC, EPI, RES, SAVE_U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, N, ksplit, scratch, (TC*)C, ldc, bias,
-               residual, ldr, (T*)aux, ldaux, alpha);
+               residual, ldr, (typename AuxT<T>::type*)aux, ldaux, alpha);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -262,7 +262,7 @@ extern "C" int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K, c
     if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
     if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
     if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
-    if (c_dtype == LPI_F16) return LPI_ENOSYS;     // the fp16 residual stream never has this few rows
+    if (c_dtype == LPI_F16 && dtype != LPI_F16) return LPI_ENOSYS;     // bf16 mode: the fp16 residual stream never has this few rows
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32 && c_dtype == LPI_F32)
         return splitk_dispatch<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
@@ -270,6 +270,10 @@ extern "C" int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K, c
         return splitk_dispatch<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F32)
         return splitk_dispatch<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F16)
+        return splitk_dispatch<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32)
+        return splitk_dispatch<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
     return LPI_ENOSYS;
 }
 
@@ -289,7 +293,9 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
     const int esz = dtype == LPI_F32 ? 4 : 2;
     const int csz = c_dtype == LPI_F32 ? 4 : 2;
-    if (c_dtype == LPI_F16 && (dtype != LPI_BF16 || epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
+    if (c_dtype == LPI_F16 && dtype == LPI_BF16 && (epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
+    if (c_dtype == LPI_F16 && dtype == LPI_F32) return LPI_ENOSYS;
+    if (c_dtype == LPI_BF16 && dtype == LPI_F16) return LPI_ENOSYS;      // f16 operands write f16 or f32
     const int bk = ROW_BYTES / esz;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return LPI_EINVAL;
     if (M % BM || N % BN || K % bk) return LPI_EINVAL;
@@ -319,5 +325,9 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
         return dispatch_epi<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F16)      // fp16 residual stream: x_out = x_in + (A.B^T + bias), both fp16
         return launch_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F16)
+        return dispatch_epi<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32)
+        return dispatch_epi<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
 }

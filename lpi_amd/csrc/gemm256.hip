@@ -32,7 +32,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int stagger, int group_m)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int stagger, int group_m)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -70,7 +70,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256_tail_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = tiles_m * tiles_n;
@@ -121,7 +121,7 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
         const int q = nwg >> 3, r = nwg & 7;
         const int max_left = q + (r ? 1 : 0) - (n_full >> 3);      // leftover tiles of the fullest XCD
         LPI_LAUNCH(tk, dim3(n_full + 16 * max_left), dim3(NTHR), LDS_TAIL, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-                   ldr, (T*)aux, ldaux, alpha, tm, tn, n_full, gm);
+                   ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, n_full, gm);
         LPI_CHECK_LAST();
         return 0;
     }
@@ -130,7 +130,7 @@ int launch256_impl(int M, int N, int K, const void* A, int lda, const void* B, i
     if (int e = lpi_ensure_lds(once, (const void*)kern, LDS_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_256);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-               ldr, (T*)aux, ldaux, alpha, tm, tn, 0, g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
+               ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, 0, g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -190,7 +190,7 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
     // first use waits for the next tile's K-tile 0 anyway and the four-pass epilogue only adds barriers (issuing that K-tile 0 after the
     // epilogue's second pass instead — what the kernel does for them — changes nothing: 1.08 / 1.08 / 1.30).  Key 2 = 1 forces it for all.
     const bool loads_in_epilogue = residual != nullptr || epilogue == LPI_EPI_DQUICKGELU;
-    if (dtype == LPI_BF16 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || g_lpi_tuning[2] == 1)) {
+    if (dtype != LPI_F32 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || g_lpi_tuning[2] == 1)) {
         const int rc = lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
         if (rc != LPI_ENOSYS) return rc;
     }
@@ -202,5 +202,9 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
         return dispatch256<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
         return launch256_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F16)
+        return dispatch256<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32)
+        return dispatch256<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
 }

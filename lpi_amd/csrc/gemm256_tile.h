@@ -24,7 +24,7 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 =
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __device__ __forceinline__ void tile(int m0, int n0, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                      TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-                                     T* __restrict__ aux, int ldaux, float alpha, char* smem)
+                                     typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, char* smem)
 {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);

@@ -36,7 +36,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m, int tail_blocks)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m, int tail_blocks)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -337,7 +337,7 @@ int launchp_impl(int M, int N, int K, const void* A, int lda, const void* B, int
     lpi_note_gemm_kernel(tail_blocks ? LPI_GEMM_K_256_TAIL : LPI_GEMM_K_256);
     const int grid = std::min(ncu, std::max(n_full, tail_blocks));
     LPI_LAUNCH(kern, dim3(grid), dim3(NTHR), LDS, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual, ldr,
-               (T*)aux, ldaux, alpha, tm, tn, n_full, gm, tail_blocks);
+               (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, n_full, gm, tail_blocks);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -385,5 +385,9 @@ int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void*
         return dispatchp<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
         return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F16)
+        return dispatchp<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32)
+        return dispatchp<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
 }

@@ -20,7 +20,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256x128_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    T* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int group_m)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int group_m)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -53,7 +53,7 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
     if (int e = lpi_ensure_lds(once, (const void*)kern, LDS_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_256X128);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHR), LDS_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual,
-               ldr, (T*)aux, ldaux, alpha, tm, tn, group_m);
+               ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, group_m);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -108,5 +108,9 @@ int lpi_gemm256x128_launch(int dtype, int c_dtype, int M, int N, int K, const vo
         return dispatch<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s, group_m);
     if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
         return launch_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s, group_m);
+    if (dtype == LPI_F16 && c_dtype == LPI_F16)
+        return dispatch<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s, group_m);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32)
+        return dispatch<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s, group_m);
     return LPI_ENOSYS;
 }

@@ -18,7 +18,7 @@ constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES; // 144 KiB >= 128 rows x 528 B o
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __device__ __forceinline__ void tile(int m0, int n0, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
                                      TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-                                     T* __restrict__ aux, int ldaux, float alpha, char* smem)
+                                     typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, char* smem)
 {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = ROWB / (int)sizeof(T);

@@ -2,19 +2,26 @@
 #pragma once
 #include "common.h"
 
+// Storage type of the saved QuickGELU pre-activation u (`aux`): the operand type, except in f16 operand mode, where u is kept in bf16 —
+// it is read only by the BACKWARD's gelu'(u) epilogue, whose operands (gradients) are bf16 (they do not fit fp16's range).
+template <typename T> struct AuxT { typedef T type; };
+template <> struct AuxT<f16_t> { typedef bf16_t type; };
+
 // RES (residual present) and SAVE_U (QuickGELU pre-activation wanted) are COMPILE-TIME: a run-time "pointer or not" test per
 // element makes hipcc branch around every load and wait vmcnt(0) each time — 32 serial HBM round trips per lane
 // (cdna_hip_programming.md, "Three .s-level traps" (c)).  Without branches the unrolled loads are batched.
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true>
 __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
-                                                    const float* __restrict__ residual, int ldr, T* __restrict__ aux, int ldaux) {
+                                                    const float* __restrict__ residual, int ldr, typename AuxT<T>::type* __restrict__ aux,
+                                                    int ldaux) {
+    typedef typename AuxT<T>::type TA;
     f32x4 v = acc * alpha + bv;
     if constexpr (EPI == LPI_EPI_QUICKGELU) {
-        if constexpr (SAVE_U) Elem<T>::st4(aux + (size_t)row * ldaux + col, v);
+        if constexpr (SAVE_U) Elem<TA>::st4(aux + (size_t)row * ldaux + col, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
     } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
-        f32x4 u = Elem<T>::ld4(aux + (size_t)row * ldaux + col);
+        f32x4 u = Elem<TA>::ld4(aux + (size_t)row * ldaux + col);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
     }

@@ -175,10 +175,16 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
     for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
     *reinterpret_cast<bf16x8*>(p) = b;
 }
+__device__ __forceinline__ void st8(f16_t* p, const float (&v)[8]) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
+    *reinterpret_cast<f16x8*>(p) = h;
+}
 
-template <int NC>
+template <int NC, typename TY = bf16_t>
 __global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const f16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16_t* __restrict__ y, int ldy,
+                                                        const float* __restrict__ beta, TY* __restrict__ y, int ldy,
                                                         float* __restrict__ mean, float* __restrict__ rstd) {
     const int hl = threadIdx.x & 31;
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const 
         for (int j = 0; j < 8; ++j) { const float c = r.v[i][j] - mu; ss += c * c; }
     });
     const float rs = 1.0f / sqrtf(half_sum(ss) / (float)d + LN_EPS);
-    bf16_t* yr = y + (size_t)row * ldy;
+    TY* yr = y + (size_t)row * ldy;
     for_chunks8<NC>(d, hl, [&](int i, int col) {
         float g[8], b[8], o[8];
         ld8(gamma + col, g);
@@ -573,7 +579,14 @@ extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const 
 #define LNF_FB(NC) LNF(float, bf16_t, NC)
 #define LNF_HB(NC) LNF(f16_t, bf16_t, NC)
 #define LNF_H16(NC) LPI_LAUNCH(ln_fwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const f16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd)
+#define LNF_H16H(NC) LPI_LAUNCH((ln_fwd_h16_kernel<NC, f16_t>), dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const f16_t*)x, ldx, gamma, beta, (f16_t*)y, ldy, mean, rstd)
+#define LNF_HH(NC) LNF(f16_t, f16_t, NC)
+#define LNF_FH(NC) LNF(float, f16_t, NC)
     if (dtype == LPI_F32 && x_dtype == LPI_F32) LN_NC_SWITCH(d, LNF_FF);
+    else if (dtype == LPI_F16 && x_dtype == LPI_F16 && !(d & 7) && !(ldx & 7) && !(ldy & 7) && !(((uintptr_t)x | (uintptr_t)y) & 15))
+        LN_NC_SWITCH(d, LNF_H16H);          // f16 operand mode: fp16 stream in, fp16 operand out
+    else if (dtype == LPI_F16 && x_dtype == LPI_F16) LN_NC_SWITCH(d, LNF_HH);
+    else if (dtype == LPI_F16 && x_dtype == LPI_F32) LN_NC_SWITCH(d, LNF_FH);
     else if (dtype == LPI_BF16 && x_dtype == LPI_F32) LN_NC_SWITCH(d, LNF_FB);
     else if (dtype == LPI_BF16 && x_dtype == LPI_F16 && !(d & 7) && !(ldx & 7) && !(ldy & 7) && !(((uintptr_t)x | (uintptr_t)y) & 15))
         LN_NC_SWITCH(d, LNF_H16);
@@ -584,6 +597,9 @@ extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const 
 #undef LNF_FB
 #undef LNF_HB
 #undef LNF_H16
+#undef LNF_H16H
+#undef LNF_HH
+#undef LNF_FH
     LPI_CHECK_LAST();
     return 0;
 }
@@ -651,6 +667,7 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
     dim3 g((unsigned)((total + 255) / 256)), b(256);
     if (dtype == LPI_F32) LPI_LAUNCH(patchify_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (float*)cols, ldcols);
     else if (dtype == LPI_BF16) LPI_LAUNCH(patchify_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (bf16_t*)cols, ldcols);
+    else if (dtype == LPI_F16) LPI_LAUNCH(patchify_kernel<f16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (f16_t*)cols, ldcols);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
@@ -744,6 +761,10 @@ extern "C" int lpi_pool_ln_fwd(int dtype, int x_dtype, int B, int L, int d, cons
         LPI_LAUNCH((pool_ln_fwd_kernel<float, bf16_t>), g, b, 0, S(stream), B, L, d, (const float*)x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
     else if (dtype == LPI_BF16 && x_dtype == LPI_F16)
         LPI_LAUNCH((pool_ln_fwd_kernel<f16_t, bf16_t>), g, b, 0, S(stream), B, L, d, (const f16_t*)x, idx, gamma, beta, (bf16_t*)y, ldy, mean, rstd);
+    else if (dtype == LPI_F16 && x_dtype == LPI_F32)
+        LPI_LAUNCH((pool_ln_fwd_kernel<float, f16_t>), g, b, 0, S(stream), B, L, d, (const float*)x, idx, gamma, beta, (f16_t*)y, ldy, mean, rstd);
+    else if (dtype == LPI_F16 && x_dtype == LPI_F16)
+        LPI_LAUNCH((pool_ln_fwd_kernel<f16_t, f16_t>), g, b, 0, S(stream), B, L, d, (const f16_t*)x, idx, gamma, beta, (f16_t*)y, ldy, mean, rstd);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;

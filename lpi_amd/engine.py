@@ -35,7 +35,13 @@ POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "2") != "0"
 # ... and its attention (query / softmax row / out_proj of the pooled token only); LPI_POOLED_LAST=1 keeps the full attention (A/B switch)
 POOLED_ATTN = POOLED_LAST and _os.environ.get("LPI_POOLED_LAST", "2") != "1"
 
-_DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+_DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "f16": F16, "fp16": F16, "float16": F16, "half": F16}
+
+
+def _grad_dtype(dt: int) -> int:
+    """Operand / storage type of the BACKWARD for a forward operand type: f32 stays f32; bf16 and f16 forwards both back-propagate in
+    bf16 (gradients do not fit fp16's range without loss scaling; the reference, which runs fp16 end to end, simply lives with that)."""
+    return F32 if dt == F32 else BF16
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
 # bf16 mode stores the forward residual stream in fp16 — the reference's own activation type (it runs fp16 end to end,
 # model.py:371-392) — which halves the bytes of the HBM-bound LayerNorms and residual epilogues; statistics, accumulation and the
@@ -67,8 +73,8 @@ class Linear:
         if k_pad is not None and k_pad != w.shape[1]:
             w = torch.nn.functional.pad(w, (0, k_pad - w.shape[1]))
         self.out_features, self.in_features = w.shape
-        self.w = w.to(_TORCH_DT[dt]).contiguous()
-        self.wt = w.t().contiguous().to(_TORCH_DT[dt]).contiguous()
+        self.w = w.to(_TORCH_DT[dt]).contiguous()                                         # forward operand
+        self.wt = w.t().contiguous().to(_TORCH_DT[_grad_dtype(dt)]).contiguous()          # dgrad operand (W^T, K-contiguous)
         self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
 
 
@@ -110,7 +116,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    ks = _splitk_plan(dt, M, N, K) if cdt != F16 else 0
+    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) else 0
     if ks:
         call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
              residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
@@ -141,7 +147,8 @@ class Tower:
 
     def __init__(self, sd: dict, prefix: str, spec: TowerSpec, dt: int, device):
         self.spec, self.dt, self.device = spec, dt, device
-        self.xdt = F16 if (dt == BF16 and RESIDUAL_F16) else F32      # storage type of the forward residual stream
+        self.gdt = _grad_dtype(dt)                                      # operand / storage type of the backward
+        self.xdt = F16 if (dt != F32 and RESIDUAL_F16) else F32       # storage type of the forward residual stream
         self.blocks = []
         f = lambda k: torch.as_tensor(np.asarray(sd[k])) if not torch.is_tensor(sd[k]) else sd[k]  # noqa: E731
         for i in range(spec.layers):
@@ -181,7 +188,8 @@ class Tower:
         Lreal, L = L, max(L, cap or L)
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         Bp = _pad(B)
-        T, TX = _TORCH_DT[self.dt], _TORCH_DT[self.xdt]
+        T, TX, TG = _TORCH_DT[self.dt], _TORCH_DT[self.xdt], _TORCH_DT[self.gdt]
+        TU = TG if self.dt == F16 else T      # the saved QuickGELU pre-activation: read by the backward only (gemm_epilogue.h, AuxT)
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
         keep = nl if train else 1
@@ -192,27 +200,31 @@ class Tower:
             "qkv": [z(Mp, 3 * d, dtype=T) for _ in range(keep)],
             "ctx": [z(Mp, d, dtype=T) for _ in range(keep)],
             "lse": [z(B, H, L) for _ in range(keep)],
-            "u": [z(Mp, 4 * d, dtype=T) for _ in range(keep)] if train else [None],
+            "u": [z(Mp, 4 * d, dtype=TU) for _ in range(keep)] if train else [None],
             "stat": [z(4, Mp) for _ in range(keep)],      # ln1 mean, ln1 rstd, ln2 mean, ln2 rstd
             "h": z(Mp, d, dtype=T),
             "g": z(Mp, 4 * d, dtype=T),
             # the LAST block's MLP runs on the B pooled rows only (exact: the heads read nothing else of its output)
             "Bp": Bp, "c_xmid": z(Bp, d), "c_h": z(Bp, d, dtype=T), "c_g": z(Bp, 4 * d, dtype=T),
-            "c_u": z(Bp, 4 * d, dtype=T) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
+            "c_u": z(Bp, 4 * d, dtype=TU) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
             # ... and so do its query, attention row and out_proj (K and V still cover every token)
             "c_q": z(Bp, d, dtype=T), "c_ctx": z(Bp, d, dtype=T), "c_lse": z(B * H), "c_xin": z(Bp, d), "c_stat1": z(2, Bp),
         }
         if train:
             ws.update({
                 "dx": z(Mp, d) if self.dt == F32 else None,      # bf16 mode: the bf16 stream dxT is the only gradient stream
-                "dh": z(Mp, d, dtype=T), "dctx": z(Mp, d, dtype=T), "dqkv": z(Mp, 3 * d, dtype=T),
+                "dh": z(Mp, d, dtype=TG), "dctx": z(Mp, d, dtype=TG), "dqkv": z(Mp, 3 * d, dtype=TG),
                 "delta": z(B, H, L),
-                "dxT": z(Mp, d, dtype=T) if self.dt != F32 else None,
-                "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=T) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=T),
-                "c_dctx": z(Bp, d, dtype=T), "c_dq": z(Bp, d, dtype=T),
+                "dxT": z(Mp, d, dtype=TG) if self.dt != F32 else None,
+                "c_dx": z(Bp, d), "c_dxT": z(Bp, d, dtype=TG) if self.dt != F32 else None, "c_dh": z(Bp, d, dtype=TG),
+                "c_dctx": z(Bp, d, dtype=TG), "c_dq": z(Bp, d, dtype=TG),
                 # the first block's prompt-row backward: up to 32 prompt rows per sample, packed
-                "p_dqkv": z(_pad(B * 32, 256), 3 * d, dtype=T), "p_dh": z(_pad(B * 32, 256), d, dtype=T),
+                "p_dqkv": z(_pad(B * 32, 256), 3 * d, dtype=TG), "p_dh": z(_pad(B * 32, 256), d, dtype=TG),
+                # the [*, 4d] MLP buffers double as dL/dg in the backward: a view in the gradient type (same element size)
+                "du": None, "c_du": None,
             })
+        if train:
+            ws["du"], ws["c_du"] = ws["g"].view(TG), ws["c_g"].view(TG)
         ws["L"], ws["Mp"] = Lreal, _pad(B * Lreal, 256)
         self._ws[key] = ws
         return ws
@@ -273,7 +285,8 @@ class Tower:
     def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
         """ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
         dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
-        sp, dt, xdt, s = self.spec, self.dt, self.xdt, _stream()
+        sp, dt, xdt, s = self.spec, self.gdt, self.xdt, _stream()        # dt: the BACKWARD's operand / storage type from here on
+        adt = F16 if self.dt == F16 else dt       # attention backward: F16 = "saved q, k, v, ctx are fp16; gradients and operands bf16"
         d, H = sp.width, sp.heads
         B, L, Mp = ws["B"], ws["L"], ws["Mp"]
         M = B * L
@@ -292,8 +305,8 @@ class Tower:
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 c_dx = ws["c_dx"]
                 c_dxT = ws["c_dxT"] if dt != F32 else c_dx
-                gemm(dt, c_dxT, blk["proj"].wt, ws["c_g"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
-                gemm(dt, ws["c_g"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
+                gemm(dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
+                gemm(dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, 1, s)
                 if not POOLED_ATTN:
@@ -303,7 +316,7 @@ class Tower:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
                 gemm(dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
-                call("lpi_attn_pooled_bwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
+                call("lpi_attn_pooled_bwd", adt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
                      dqkv, 3 * d, int(sp.causal), s)
                 gemm(dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 gemm(dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
@@ -317,13 +330,13 @@ class Tower:
                     call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
                 continue
             if not (i == len(self.blocks) - 1 and POOLED_LAST):
-                du = ws["g"]
+                du = ws["du"]
                 gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
             gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
-            call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
+            call("lpi_attn_bwd", adt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
                 # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
                 # CLS and token embeddings are frozen) -> in_proj dgrad and LN1 backward on the packed B*P prompt rows.  The residual
@@ -351,7 +364,8 @@ class DualEncoder:
         _require_gpu(self.device)
         _lib.load()
         self.dt = _DT[dtype]
-        self.dtype_name = "f32" if self.dt == F32 else "bf16"
+        self.gdt = _grad_dtype(self.dt)
+        self.dtype_name = {F32: "f32", BF16: "bf16", F16: "f16"}[self.dt]
         self.n_ctx = n_ctx
         dev, dt = self.device, self.dt
         t = lambda k: (state_dict[k] if torch.is_tensor(state_dict[k]) else torch.as_tensor(np.asarray(state_dict[k]))).to(  # noqa: E731
@@ -400,10 +414,10 @@ class DualEncoder:
         key = (tag, B)
         hw = self._head_ws.get(key)
         if hw is None:
-            Bp, E, dev, T = _pad(B), self.cfg.embed_dim, self.device, _TORCH_DT[self.dt]
+            Bp, E, dev, T, TG = _pad(B), self.cfg.embed_dim, self.device, _TORCH_DT[self.dt], _TORCH_DT[self.gdt]
             z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
             hw = {"pooled": z(Bp, d, dtype=T), "stat": z(2, Bp), "feat": z(Bp, E), "inv": z(Bp),
-                  "dfeat": z(Bp, E), "dfeatT": z(Bp, E, dtype=T) if self.dt != F32 else None, "dpooled": z(Bp, d),
+                  "dfeat": z(Bp, E), "dfeatT": z(Bp, E, dtype=TG) if self.dt != F32 else None, "dpooled": z(Bp, d),
                   "idx": torch.zeros(Bp, dtype=torch.int32, device=dev)}
             self._head_ws[key] = hw
         return hw
@@ -466,7 +480,7 @@ class DualEncoder:
     def encode_image_backward(self, dout, ctx=None):
         """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch.
         ctx: the context encode_image(return_ctx=True) returned (default: the engine's last forward)."""
-        cfg, dt, s = self.cfg, self.dt, _stream()
+        cfg, dt, s = self.cfg, self.gdt, _stream()         # the backward's operand / storage type
         ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._vis_ctx
         self._stale(self.vis, serial, "encode_image_backward")
         d, E = cfg.vision_width, cfg.embed_dim
@@ -520,7 +534,7 @@ class DualEncoder:
         return (out, ctx) if return_ctx else out
 
     def encode_text_backward(self, dout, ctx=None):
-        cfg, dt, s = self.cfg, self.dt, _stream()
+        cfg, dt, s = self.cfg, self.gdt, _stream()         # the backward's operand / storage type
         ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._txt_ctx
         self._stale(self.txt, serial, "encode_text_backward")
         d, E = cfg.transformer_width, cfg.embed_dim

@@ -723,3 +723,98 @@ def test_gemm_persistent_equals_one_tile_per_workgroup(tm, N, K):
     for k in new:
         assert torch.equal(new[k], old[k]), (k, float((new[k].float() - old[k].float()).abs().max()))
         assert torch.equal(new[k], new2[k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------- f16 operand mode
+def test_gemm_f16_operands_all_epilogues():
+    """fp16 MFMA operands (v_mfma_f32_16x16x32_f16, the reference's own arithmetic type): every forward epilogue, on the 128x128, the
+    256x128, the one-tile 256x256 and the persistent 256x256 kernels, vs f64.  The saved pre-activation u is bf16 (AuxT)."""
+    for (M, N, K), keys in (((256, 256, 128), {}), ((4608, 1024, 512), {}), ((3 * 256, 3072, 768), {0: 1}), ((66 * 256, 1024, 512), {0: 1, 5: 0}),
+                            ((66 * 256, 1024, 512), {0: 1, 5: 0, 2: -1})):
+        a = rnd(M, K, seed=1).half()
+        b = rnd(N, K, seed=2, scale=0.05).half()
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        ab = a.double() @ b.double().t()
+        try:
+            for k, v in keys.items():
+                call("lpi_set_tuning", k, v)
+            c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            E.gemm(F16, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), alpha=0.5)
+            assert relerr(c, 0.5 * ab + bias.double()) < 2e-3
+            r16 = res.half()
+            c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            E.gemm(F16, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), residual=r16.to(DEV))
+            assert relerr(c, ab + bias.double() + r16.double()) < 2e-3
+            cf = torch.zeros(M, N, device=DEV)
+            E.gemm(F16, a.to(DEV), b.to(DEV), cf, M, N, K, bias=bias.to(DEV), residual=res.to(DEV))
+            assert relerr(cf, ab + bias.double() + res.double()) < 1e-3
+            g = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+            u = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+            E.gemm(F16, a.to(DEV), b.to(DEV), g, M, N, K, bias=bias.to(DEV), epi=E.EPI_QUICKGELU, aux=u)
+            uref = ab + bias.double()
+            assert relerr(u, uref) < TOL[BF16] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < 2e-3
+        finally:
+            for k, v in ((0, 1), (5, 160), (2, 0)):
+                call("lpi_set_tuning", k, v)
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(2, 213, 3, 0), (3, 77, 2, 1), (2, 21, 2, 0), (1, 273, 2, 0), (2, 59, 8, 1)])
+def test_attention_f16_forward_bf16_backward(B, L, H, causal):
+    """f16 operand mode: the forward runs on fp16 q, k, v; the backward reads those SAVED fp16 tensors and a bf16 dctx, converts q, k, v
+    to bf16 on their way into LDS, and writes bf16 dqkv (fused and two-pass kernels) — against f64 autograd."""
+    d = H * 64
+    qkv = rnd(B * L, 3 * d, seed=11).half()
+    dctx = rnd(B * L, d, seed=12).bfloat16()
+    qd = qkv.to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=torch.float16)
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd", F16, B, L, H, qd, 3 * d, ctx, d, lse, causal, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = attn_ref(qr, B, L, H, causal)
+    assert relerr(ctx, oref.detach()) < 3e-3
+    assert relerr(lse, lref.detach()) < 3e-3
+    oref.backward(dctx.double())
+    for key3 in (0, 1):
+        call("lpi_set_tuning", 3, key3)
+        try:
+            dqkv = torch.zeros(B * L, 3 * d, device=DEV, dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, L, device=DEV)
+            call("lpi_attn_bwd", F16, B, L, H, qd, 3 * d, ctx, d, dctx.to(DEV), d, lse, delta, dqkv, 3 * d, causal, stream())
+            for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+                e = relerr(dqkv[:, sl], qr.grad[:, sl])
+                assert e < 4e-2, (name, key3, e)
+        finally:
+            call("lpi_set_tuning", 3, 0)
+
+
+def test_layernorm_f16_output_and_pooled_attention_f16():
+    torch.manual_seed(4)
+    rows, d = 300, 768
+    x, gam, bet = torch.randn(rows, d), torch.rand(d) + 0.5, torch.randn(d) * 0.1
+    ref = torch.nn.functional.layer_norm(x.half().double(), (d,), gam.double(), bet.double(), 1e-5)
+    st = torch.zeros(2, rows, device=DEV)
+    y = torch.zeros(rows, d, device=DEV, dtype=torch.float16)
+    call("lpi_layernorm_fwd", F16, F16, rows, d, x.half().to(DEV), d, gam.to(DEV), bet.to(DEV), y, d, st[0], st[1], stream())
+    assert relerr(y, ref) < 2e-3
+    # pooled attention: f16 forward, backward with f16 saved tensors and bf16 gradients
+    B, L, H = 3, 77, 2
+    dd = H * 64
+    idx = torch.tensor([5, 40, 76], dtype=torch.int32)
+    rws = torch.arange(B) * L + idx.long()
+    qkv = rnd(B * L, 3 * dd, seed=21).half()
+    q_rows = qkv[rws, :dd].contiguous().to(DEV)
+    ctx = torch.zeros(B, dd, device=DEV, dtype=torch.float16)
+    lse = torch.zeros(B, H, device=DEV)
+    call("lpi_attn_pooled_fwd", F16, B, L, H, q_rows, dd, qkv.to(DEV), 3 * dd, idx.to(DEV), ctx, dd, lse, 1, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, _ = attn_ref(qr, B, L, H, 1)
+    assert relerr(ctx, oref.detach()[rws]) < 3e-3
+    dctx_rows = rnd(B, dd, seed=22).bfloat16()
+    dfull = torch.zeros(B * L, dd, dtype=torch.float64)
+    dfull[rws] = dctx_rows.double()
+    oref.backward(dfull)
+    dq = torch.zeros(B, dd, device=DEV, dtype=torch.bfloat16)
+    dqkv = torch.zeros(B * L, 3 * dd, device=DEV, dtype=torch.bfloat16)
+    call("lpi_attn_pooled_bwd", F16, B, L, H, q_rows, dd, qkv.to(DEV), 3 * dd, idx.to(DEV), dctx_rows.to(DEV), dd, lse, dq, dd, dqkv, 3 * dd, 1, stream())
+    assert relerr(dq, qr.grad[rws, :dd]) < 4e-2
+    assert relerr(dqkv[:, dd:2 * dd], qr.grad[:, dd:2 * dd]) < 4e-2 and relerr(dqkv[:, 2 * dd:], qr.grad[:, 2 * dd:]) < 4e-2

@@ -1,5 +1,5 @@
-# full GPU suite + default bench + profiles for the docs
-mkdir -p gpurun_out/r2e
-timeout 1500 python -m pytest tests -x -q -m gpu -p no:cacheprovider 2>&1 | tail -5 > gpurun_out/r2e/pytest.txt; cat gpurun_out/r2e/pytest.txt
-timeout 600 python bench.py > gpurun_out/r2e/bench.json 2> gpurun_out/r2e/bench.err; tail -c 300 gpurun_out/r2e/bench.json
-bash tools/collect_r02.sh r2e_prof > gpurun_out/r2e/collect.txt 2>&1; tail -3 gpurun_out/r2e/collect.txt
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "f16" -p no:cacheprovider 2>&1 | tail -15
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "f16" -p no:cacheprovider -s 2>&1 | tail -15
+for dt in bf16 f16 bf16 f16; do
+python bench.py --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo " <= $dt"
+done
