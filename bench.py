@@ -24,6 +24,7 @@ The JSON line carries, besides the driver's contract keys:
   step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair (all kernels, not just GEMMs);
   parity_mode  : (N = 1) the f32-operand mode that meets the 1e-4 parity bar, same workload, a few steps;
   fwd_only     : (N = 1) BASELINE.json configs[1]: encoder forward + cosine matrix;
+  f16_mode     : (N = 1) the same step with fp16 MFMA operands in the forward (the reference's arithmetic type): 4x lower logit error;
   collectives  : (N > 1) mean microseconds of the feature all-gather and the factor-gradient all-reduce per step;
   cpu_baseline : the oracle (oracle/lpi_oracle.py, "port") timed on this host's cores on a bounded bs=8 sample, thread count swept.
 """
@@ -345,6 +346,18 @@ def main():
                               "step_mfma_frac": None if gfs is None else round(vf * gfs[1] * 1e9 / (PEAK_TF["bf16"] * 1e12), 4),
                               "workload": "BASELINE.json configs[1]: ViT-B/16 bs=256 prompt_depth=3 r=4, fwd-only encoder + cosine-sim matrix"}
         del wf
+        torch.cuda.empty_cache()
+        # ... and the f16 operand mode: fp16 MFMA operands / activations in the forward (the reference's own arithmetic type), bf16 backward
+        wh = Workload(a, dev, rank, "f16", False, None)
+        eh, ph = wh.run(10, 3, sync)
+        vh = B * 10 / eh
+        extras["f16_mode"] = {"dtype": "f16", "value": round(vh, 2), "unit": "pairs/s", "steps": 10, "ms_per_step": round(1e3 * eh / 10, 3),
+                              "median_ms_per_step": round(float(np.median(ph)), 3),
+                              "step_mfma_frac": None if gfs is None else round(vh * gfs[0] * 1e9 / (PEAK_TF["f16"] * 1e12), 4),
+                              "note": "compute_dtype='f16': v_mfma_f32_16x16x32_f16 forward, bf16 gradient stream; on the ViT-B/16 fixture 4.6x lower "
+                                      "feature error and 4x lower logit error than the bf16 line (tests/test_model_gpu.py); the fp16 MFMA runs "
+                                      "5-9 % slower than the bf16 one on the same GEMM shapes (power-limited clock), hence not the default"}
+        del wh
         torch.cuda.empty_cache()
 
     if rank == 0:

@@ -140,6 +140,16 @@ __device__ __forceinline__ void zero_pad_rows(char* smem, int n_img, int L, int 
     }
 }
 
+// rows [0, L) of an image: fp16 -> bf16 in place (the XOR swizzle permutes whole 16-byte chunks, so the layout is irrelevant here)
+__device__ __forceinline__ void convert_image_f16_to_bf16(char* img, int L) {
+    for (int i = threadIdx.x; i < L * (RB / 16); i += blockDim.x) {
+        Chunk c;
+        c.u = *reinterpret_cast<const uint4*>(img + i * 16);
+        chunk_f16_to_bf16(c);
+        *reinterpret_cast<uint4*>(img + i * 16) = c.u;
+    }
+}
+
 #define LPI_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define LPI_BARRIER()                                              \
     do {                                                           \
@@ -274,7 +284,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(int L, int Lp, int H, in
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <bool CAUSAL>
+// SV16: the saved qkv / ctx are fp16 (f16-mode forward); dctx, dqkv and the MFMA operands are bf16.  LDS-DMA cannot convert, so the K, V
+// and Q images are converted IN PLACE once they have landed (each thread its own 16-byte chunks: no hazard), the wave's own Q rows in
+// registers; O is only dotted with dO.
+template <bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, int total, const T* __restrict__ qkv, int ldqkv,
                                                        const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                        const float* __restrict__ lse, float* __restrict__ delta,
@@ -337,6 +350,15 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
         const int b = bh / H, h = bh % H;
         const int nbh = bh + gridDim.x;
         const T* qg = head_ptr(bh);
+        if constexpr (SV16) {       // this head's K, V images have landed (and are visible: barrier B3 / the prologue's): fp16 -> bf16
+            convert_image_f16_to_bf16(k_lds, L);
+            convert_image_f16_to_bf16(v_lds, L);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) chunk_f16_to_bf16(own.q[j][ks]);
+            LPI_BARRIER();
+        }
         // Q, dO of THIS head -> their images (free since the previous head's phase B), landing under phase A
         stage_dma(lds0, qg, ldqkv, L, wave, nw, lane);
         stage_dma(lds0 + 3 * img, dctx + (size_t)b * L * lddctx + h * HD, lddctx, L, wave, nw, lane);
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl += (float)own.o[j][ks].h[e] * (float)own.d[j][ks].h[e];
+                for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)own.o[j][ks].hh[e] : (float)own.o[j][ks].h[e]) * (float)own.d[j][ks].h[e];
             dl = grp_sum(dl);
             dlt[j] = dl;
             lq[j] = own.lq[j] * LOG2E;
@@ -404,6 +426,10 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
             store_row_bf16_t(dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, valid);
         }
         LPI_BARRIER();            // B1: Q, dO, lse, delta images complete and visible
+        if constexpr (SV16) {
+            convert_image_f16_to_bf16(q_lds, L);
+            LPI_BARRIER();
+        }
 
         // ---- phase B: this wave's 2 x 16 keys -> dK, dV.  Its own K, V rows move to registers first: the K, V images are then free.
         Chunk kk[NB][KS], vv[NB][KS];
@@ -525,23 +551,25 @@ int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, in
 }
 
 int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s) {
+                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)4 * Lp * RB + (size_t)2 * Lp * sizeof(float);
     const int thr = 64 * ((Lp + 31) / 32);       // one 32-row block per wave
     const int total = B * H;
     const int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
     const int grid = std::min(total, cu_count() * per_cu);
-    static LdsOnce o0, o1;
-    if (causal) {
-        if (int e = set_lds2(o1, (const void*)attn_bwd2_kernel<true>)) return e;
-        LPI_LAUNCH((attn_bwd2_kernel<true>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
-    } else {
-        if (int e = set_lds2(o0, (const void*)attn_bwd2_kernel<false>)) return e;
-        LPI_LAUNCH((attn_bwd2_kernel<false>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
-    }
+    static LdsOnce o0, o1, o2, o3;
+#define BWD2(C, S, O)                                                                                                                    \
+    do {                                                                                                                                 \
+        if (int e = set_lds2(O, (const void*)attn_bwd2_kernel<C, S>)) return e;                                                          \
+        LPI_LAUNCH((attn_bwd2_kernel<C, S>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, \
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);                                                                \
+    } while (0)
+    if (causal && saved_f16) BWD2(true, true, o3);
+    else if (causal) BWD2(true, false, o1);
+    else if (saved_f16) BWD2(false, true, o2);
+    else BWD2(false, false, o0);
+#undef BWD2
     LPI_CHECK_LAST();
     return 0;
 }

@@ -818,3 +818,28 @@ def test_layernorm_f16_output_and_pooled_attention_f16():
     call("lpi_attn_pooled_bwd", F16, B, L, H, q_rows, dd, qkv.to(DEV), 3 * dd, idx.to(DEV), dctx_rows.to(DEV), dd, lse, dq, dd, dqkv, 3 * dd, 1, stream())
     assert relerr(dq, qr.grad[rws, :dd]) < 4e-2
     assert relerr(dqkv[:, dd:2 * dd], qr.grad[:, dd:2 * dd]) < 4e-2 and relerr(dqkv[:, 2 * dd:], qr.grad[:, 2 * dd:]) < 4e-2
+
+
+@pytest.mark.parametrize("B,L,H,causal", [(24, 213, 12, 0), (5, 59, 8, 1)])
+def test_attention_backward_generations_agree_for_f16_saved_tensors(B, L, H, causal):
+    """f16 mode's backward: the persistent kernel (LDS-DMA, images converted fp16 -> bf16 in place) == the first-generation kernel
+    (converted on the way into LDS), bit for bit."""
+    d = H * 64
+    qkv = rnd(B * L, 3 * d, seed=41).half().to(DEV)
+    dctx = rnd(B * L, d, seed=42).bfloat16().to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=torch.float16)
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd", F16, B, L, H, qkv, 3 * d, ctx, d, lse, causal, stream())
+    out = {}
+    try:
+        for gen in (1, 3):
+            call("lpi_set_tuning", 7, gen)
+            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, L, device=DEV)
+            call("lpi_attn_bwd", F16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, stream())
+            torch.cuda.synchronize()
+            out[gen] = (dqkv, delta)
+    finally:
+        call("lpi_set_tuning", 7, 0)
+    for a, b, name in zip(out[1], out[3], ("dqkv", "delta")):
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
