@@ -61,7 +61,8 @@ uint64_t lpi_launch_count(void);
  *              inside the same launch — one round of half tiles instead of a half-empty round (bf16; same results bit for bit);
  *   key 7      attention kernel generation for bf16 operands: 0 (default) the persistent LDS-DMA backward of attention2.hip where it is
  *              faster (L > 160), 1 the one-head-per-workgroup kernels of attention.hip everywhere, 2 / 3 force the persistent forward /
- *              backward at every L they take (same results bit for bit).
+ *              backward at every L they take (same results bit for bit), 4 the single-pass backward (non-causal; dQ summed in a
+ *              different, still fixed, order).
  *   Returns LPI_EINVAL for a key outside 0..7. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..7 */

@@ -772,6 +772,10 @@ bool lpi_attn2_bwd_ok(int L);
 int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal, hipStream_t s);
 int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                   const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16);
+// third generation: ONE pass per head (dK, dV and dQ from one evaluation of S, P, dP, dS; key 7 = 0 default where it applies, 4 forces it)
+bool lpi_attn3_bwd_ok(int L, int causal);
+int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+                  const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16);
 
 extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal,
                             void* stream) {
@@ -804,6 +808,8 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
     if (dtype == LPI_F16) {     // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
                                 // q, k, v are converted on their way into LDS / registers, or in place after the LDS-DMA (persistent kernel)
+        if (g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+            return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
         if (g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 1);
         return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
@@ -812,6 +818,11 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
     if (dtype == LPI_BF16) {
         // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
         // at L = 213); at short L several one-head workgroups per CU are faster (34.5 vs 37.2 us at L = 59): key 7 = 3 forces it
+        // the single-pass kernel is opt-in (key 7 = 4): 29 % fewer MFMAs and half the exponentials buy nothing (244.7 vs 243.1 us at L = 213,
+        // B = 256) — at 7 waves per CU the backward is bound by the latency of its dependent chain (LDS read -> MFMA -> exp -> LDS -> MFMA),
+        // not by matrix or vector issue
+        if (g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+            return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
         if (g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 0);
         return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)

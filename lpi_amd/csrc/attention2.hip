@@ -503,6 +503,204 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, third generation
+// ONE pass per head instead of two: the two-phase backward recomputes S, P, dP and dS once per orientation (phase A: scores with the
+// query as column, to contract dS over KEYS for dQ; phase B: with the key as column, to contract over QUERIES for dK, dV) — 56 MFMAs and
+// two exponentials per score.  Here a wave owns 32 keys (K, V rows in registers, K^T fragments too) and walks the query tiles once:
+// the phase-B arithmetic gives dK, dV, and the same dS tile, transposed through a 2 KiB per-wave LDS scratch (written as [key][query]
+// bf16 rows, read back with ds_read_b64_tr_b16 — the transposing read — as the B operand), gives this wave's dQ contribution
+// K_own^T . dS^T for that query tile.  The contributions of the seven waves to a query tile are added in a FIXED order in an LDS
+// buffer: at step t wave w works on tile (w + t) mod n, so no two waves touch a tile in the same step and the order of additions is
+// the same in every run (no atomics: bitwise reproducible).  40 MFMAs and one exponential per score (-29 % / -50 %).
+// LDS: Q, dO, K images (3 x Lp x 128 B) + dQ accumulators (Lp x 64 f32) + 2 KiB scratch per wave + lse / delta vectors = 155.8 KiB at
+// L = 213: one workgroup per CU; the next head's images are issued as soon as the last step is done (under the dK / dV stores and the
+// dQ write-out).  Non-causal only (the vision tower: the text tower's short, causal heads stay on the first generation).
+template <bool SV16>
+__global__ __launch_bounds__(512) void attn_bwd3_kernel(int L, int Lp, int H, int total, const T* __restrict__ qkv, int ldqkv,
+                                                       const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
+                                                       const float* __restrict__ lse, float* __restrict__ delta,
+                                                       T* __restrict__ dqkv, int lddqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;      // nw == Lp / 32: one 32-row block per wave, as keys AND as dQ tile owner
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int dm = H * HD;
+    const int img = Lp * RB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    char* const q_lds = smem;
+    char* const do_lds = smem + img;
+    char* const k_lds = smem + 2 * img;
+    float* const dq_lds = reinterpret_cast<float*>(smem + 3 * img);                   // [tile][qsub][dt][lane] f32x4
+    char* const scr = smem + 3 * img + Lp * HD * 4 + wave * 2048;                     // this wave's [32 keys][32 queries] bf16, swizzled
+    float* const lse_lds = reinterpret_cast<float*>(smem + 3 * img + Lp * HD * 4 + nw * 2048);
+    float* const dl_lds = lse_lds + Lp;
+    const RdOff off = make_offsets(lane);
+    const float c = SCALE * LOG2E;
+    const int k0 = wave * 32;                 // this wave's keys / its rows in the delta pre-pass
+    // scratch addressing: 64-byte rows (32 queries x bf16), 8-byte slot index XOR ((row >> 2 & 1) << 2 | (row >> 3 & 1) << 1):
+    // conflict-free for the transposing reads (tools/lds_swizzle_check.py)
+    auto sw = [](int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1); };
+    int scr_w[NB][2];                         // write: row = 16 j + (lane & 15), slot = 4 tile + g
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = 16 * j + (lane & 15);
+            scr_w[j][t] = row * 64 + (((4 * t + g) ^ sw(row)) << 3);
+        }
+    int scr_r[2][2];                          // transposing read: row = 16 hi + 4 g + ((lane & 15) >> 2), slot = 4 qsub + (lane & 3)
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int row = 16 * hi + 4 * g + ((lane & 15) >> 2);
+            scr_r[qs][hi] = row * 64 + (((4 * qs + (lane & 3)) ^ sw(row)) << 3);
+        }
+
+    zero_pad_rows(smem, 3, L, Lp);
+    auto head_ptr = [&](int bh) { return qkv + (size_t)(bh / H) * L * ldqkv + (bh % H) * HD; };
+    auto stage_head = [&](int bh) {
+        const int b = bh / H, h = bh % H;
+        const T* qg = head_ptr(bh);
+        stage_dma(lds0 + 2 * img, qg + dm, ldqkv, L, wave, nw, lane);
+        stage_dma(lds0, qg, ldqkv, L, wave, nw, lane);
+        stage_dma(lds0 + img, dctx + (size_t)b * L * lddctx + h * HD, lddctx, L, wave, nw, lane);
+    };
+
+    int bh = blockIdx.x;
+    stage_head(bh);
+    for (; bh < total; bh += gridDim.x) {
+        const int b = bh / H, h = bh % H;
+        const T* qg = head_ptr(bh);
+        // this wave's V rows and O rows (delta) straight from global memory, its lse row values; then everything has landed
+        Chunk vv[NB][KS], oc[NB][KS];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int r = k0 + 16 * j + (lane & 15);
+            glb_rows(vv[j], qg + 2 * dm, r, ldqkv, g, r < L);
+            glb_rows(oc[j], ctx + h * HD, (size_t)b * L + r, ldctx, g, r < L);
+        }
+        const int ti = threadIdx.x;
+        const float lse_t = (ti < L) ? lse[((size_t)b * H + h) * L + ti] : INFINITY;      // padded queries -> P = 0
+        LPI_WAIT_VM0();
+        if (ti < Lp) lse_lds[ti] = lse_t * LOG2E;
+        LPI_BARRIER();
+        if constexpr (SV16) {
+            convert_image_f16_to_bf16(k_lds, L);
+            convert_image_f16_to_bf16(q_lds, L);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) chunk_f16_to_bf16(vv[j][ks]);
+            LPI_BARRIER();
+        }
+        // delta = rowsum(dO * O) of this wave's 32 rows -> dl_lds (x scale) and global; K rows and K^T fragments of its 32 keys
+        Chunk kk[NB][KS], kT[4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            Chunk dr[KS];
+            lds_rows(dr, do_lds, k0 + 16 * j, off);
+            float dl = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)oc[j][ks].hh[e] : (float)oc[j][ks].h[e]) * (float)dr[ks].h[e];
+            dl = grp_sum(dl);
+            const int r = k0 + 16 * j + (lane & 15);
+            if (g == 0) {
+                dl_lds[r] = r < L ? dl * SCALE : 0.f;
+                if (r < L) delta[((size_t)b * H + h) * L + r] = dl;
+            }
+            lds_rows(kk[j], k_lds, k0 + 16 * j, off);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const char* win = k_lds + k0 * RB;
+            short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(win + off.tr[dt]));
+            short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(win + 16 * RB + off.tr[dt]));
+            const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+            kT[dt].u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+        }
+        f32x4 dk[NB][4], dv[NB][4];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dk[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        LPI_BARRIER();            // lse / delta vectors complete
+
+        for (int t = 0; t < nw; ++t) {
+            int tile = wave + t;
+            if (tile >= nw) tile -= nw;
+            const int qb = tile * 32;
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB], e0[NB], e1[NB];
+            mma_rows(s0, q_lds + qb * RB, off, kk);
+            mma_rows(s1, q_lds + (qb + 16) * RB, off, kk);
+            mma_rows(p0, do_lds + qb * RB, off, vv);
+            mma_rows(p1, do_lds + (qb + 16) * RB, off, vv);
+            const f32x4 l0 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 4 * g);
+            const f32x4 l1 = *reinterpret_cast<const f32x4*>(lse_lds + qb + 16 + 4 * g);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 4 * g);
+            const f32x4 d1 = *reinterpret_cast<const f32x4*>(dl_lds + qb + 16 + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e0[j][r] = exp2_fast(fmaf(s0[j][r], c, -l0[r]));
+                    e1[j][r] = exp2_fast(fmaf(s1[j][r], c, -l1[r]));
+                    s0[j][r] = e0[j][r] * fmaf(p0[j][r], SCALE, -d0[r]);
+                    s1[j][r] = e1[j][r] * fmaf(p1[j][r], SCALE, -d1[r]);
+                }
+            // dS tile -> this wave's scratch as [key][query] bf16 (one 8-byte store per accumulator tile)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                *reinterpret_cast<uint2*>(scr + scr_w[j][0]) = make_uint2(pack2(s0[j][0], s0[j][1]), pack2(s0[j][2], s0[j][3]));
+                *reinterpret_cast<uint2*>(scr + scr_w[j][1]) = make_uint2(pack2(s1[j][0], s1[j][1]), pack2(s1[j][2], s1[j][3]));
+            }
+            mma_tr(dv, do_lds + qb * RB, off, e0, e1);
+            mma_tr(dk, q_lds + qb * RB, off, s0, s1);
+            // dQ^T[d, q] contribution of this wave's keys for the tile's two 16-query blocks, added into the LDS accumulators
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(scr + scr_r[qs][0]));
+                short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(scr + scr_r[qs][1]));
+                Chunk bq;
+                const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+                bq.u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                float* acc_p = dq_lds + ((size_t)(tile * 2 + qs) * 4 * 64 + lane) * 4;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma_chunk<T>(a, kT[dt], bq);
+                    if (t != 0) a += *reinterpret_cast<const f32x4*>(acc_p + dt * 256);
+                    *reinterpret_cast<f32x4*>(acc_p + dt * 256) = a;
+                }
+            }
+            LPI_BARRIER();        // step t done by every wave: tile (w + t + 1) mod n is free for wave w
+        }
+        // the images are free: the next head's are issued now and land under the stores below
+        const int nbh = bh + gridDim.x;
+        if (nbh < total) stage_head(nbh);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int kr = k0 + 16 * j + (lane & 15);
+            T* dst = dqkv + ((size_t)b * L + kr) * lddqkv + h * HD;
+            store_row16_t<T>(dst + dm, dk[j], g, kr < L);
+            store_row16_t<T>(dst + 2 * dm, dv[j], g, kr < L);
+        }
+        // dQ write-out: wave w converts and stores tile w (the accumulator layout is the transposed-tile layout of store_row16_t)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const float* acc_p = dq_lds + ((size_t)(wave * 2 + qs) * 4 * 64 + lane) * 4;
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = *reinterpret_cast<const f32x4*>(acc_p + dt * 256);
+            const int qr = k0 + 16 * qs + (lane & 15);
+            store_row16_t<T>(dqkv + ((size_t)b * L + qr) * lddqkv + h * HD, o, g, qr < L);
+        }
+    }
+}
+
 int set_lds2(LdsOnce& once, const void* kern) { return lpi_ensure_lds(once, kern, 160 * 1024); }
 
 int cu_count() {
@@ -545,6 +743,33 @@ int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, in
     } else {
         if (int e = set_lds2(o0, (const void*)attn_fwd2_kernel<false>)) return e;
         LPI_LAUNCH((attn_fwd2_kernel<false>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+    }
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+// third generation (single pass): non-causal, one workgroup per CU
+bool lpi_attn3_bwd_ok(int L, int causal) {
+    const int Lp = (L + 31) / 32 * 32;
+    return !causal && L >= 1 && Lp <= 256 && (size_t)3 * Lp * RB + (size_t)Lp * HD * 4 + (size_t)(Lp / 32) * 2048 + 2 * Lp * sizeof(float) <= 160 * 1024;
+}
+int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+                  const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16) {
+    const int Lp = (L + 31) / 32 * 32;
+    const size_t lds = (size_t)3 * Lp * RB + (size_t)Lp * HD * 4 + (size_t)(Lp / 32) * 2048 + 2 * Lp * sizeof(float);
+    const int thr = 64 * (Lp / 32);
+    const int total = B * H;
+    const int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
+    const int grid = std::min(total, cu_count() * per_cu);
+    static LdsOnce o0, o1;
+    if (saved_f16) {
+        if (int e = set_lds2(o1, (const void*)attn_bwd3_kernel<true>)) return e;
+        LPI_LAUNCH((attn_bwd3_kernel<true>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
+    } else {
+        if (int e = set_lds2(o0, (const void*)attn_bwd3_kernel<false>)) return e;
+        LPI_LAUNCH((attn_bwd3_kernel<false>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
     }
     LPI_CHECK_LAST();
     return 0;

@@ -843,3 +843,42 @@ def test_attention_backward_generations_agree_for_f16_saved_tensors(B, L, H, cau
         call("lpi_set_tuning", 7, 0)
     for a, b, name in zip(out[1], out[3], ("dqkv", "delta")):
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("saved", ["bf16", "f16"])
+@pytest.mark.parametrize("B,L,H", [(2, 213, 3), (24, 213, 12), (3, 197, 2), (2, 224, 2), (5, 64, 4), (40, 33, 3)])
+def test_attention_single_pass_backward(saved, B, L, H):
+    """attention2.hip's third-generation backward (one pass: dK, dV and — through a per-wave LDS transpose of dS — dQ, contributions
+    added in a fixed order) against f64 autograd, against the two-phase kernels (same operands; dQ's summation order differs, so close
+    rather than equal), and bitwise equal to itself across runs."""
+    d = H * 64
+    tq = torch.float16 if saved == "f16" else torch.bfloat16
+    dt = F16 if saved == "f16" else BF16
+    qkv = rnd(B * L, 3 * d, seed=51).to(tq)
+    dctx = rnd(B * L, d, seed=52).bfloat16().to(DEV)
+    qd = qkv.to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=tq)
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, 0, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, _ = attn_ref(qr, B, L, H, 0)
+    oref.backward(dctx.double().cpu())
+    out = {}
+    try:
+        for gen in (1, 4, 4):
+            call("lpi_set_tuning", 7, gen)
+            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, L, device=DEV)
+            call("lpi_attn_bwd", dt, B, L, H, qd, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, stream())
+            torch.cuda.synchronize()
+            out.setdefault(gen, []).append((dqkv, delta))
+    finally:
+        call("lpi_set_tuning", 7, 0)
+    new, new2, old = out[4][0], out[4][1], out[1][0]
+    assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
+    assert torch.equal(new[1], old[1])                                             # delta: same arithmetic
+    assert relerr(new[0][:, d:], old[0][:, d:].double().cpu()) < 2e-2              # dK, dV: same products, query tiles summed in a rotated order
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        e = relerr(new[0][:, sl], qr.grad[:, sl])
+        assert e < 4e-2, (name, e)
+    assert relerr(new[0][:, :d], old[0][:, :d].double().cpu()) < 2e-2
