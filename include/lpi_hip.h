@@ -49,9 +49,10 @@ uint64_t lpi_launch_count(void);
 /* tuning knobs (speed only, never results):
  *   key 0 / 1  minimum number of 256x256 tiles for which lpi_gemm_nt uses the phased 256x256 kernel instead of the 128x128 one,
  *              for bf16 / f32 operands (defaults 1 / 1500; INT_MAX disables it);
- *   key 2      >= 0 (default 0): bf16 launches of the 256x256 kernel whose epilogue only stores use its PERSISTENT form (a workgroup per
- *              CU walks its tiles, the next tile's first K-tile lands under the epilogue; same results bit for bit); 1: every
- *              epilogue; -1: one tile per workgroup everywhere;
+ *   key 2      >= 0 (default 0): 2-byte-operand launches of the 256x256 kernel use its PERSISTENT form (a workgroup per CU walks its
+ *              tiles; store-only epilogues: the next tile's first K-tile lands under the epilogue; epilogues that load a 2-byte
+ *              residual / u tile: that tile comes to LDS by LDS-DMA; same results bit for bit); 2: store-only epilogues only;
+ *              -1: one tile per workgroup everywhere;
  *   key 3      != 0 forces the two-pass attention backward where the fused single-pass kernel would be used (bf16, all four head
  *              matrices resident in LDS);
  *   key 4      row-tile group size of the 256x256 kernel's XCD-aware tile order (default 0 = 8; measured flat from 4 to 16);

@@ -185,12 +185,14 @@ int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* 
 {
     // bf16 operands: the persistent kernel (gemm256p.hip: the K-tile ring runs across a workgroup's tiles, the next tile's first K-tile
     // lands under the epilogue); tuning key 2 = -1 keeps one tile per workgroup (A/B switch; same results bit for bit)
-    // Measured (MI355X, B = 256 shapes): store-only epilogues gain 2-12 % (qkv 184 -> 162 us, fc+gelu 297 -> 281, dout 61 -> 56); epilogues
-    // that LOAD (residual, gelu'(u)) lose 9-31 %: their loads queue behind the in-flight LDS-DMA in the in-order vmcnt queue, so the
-    // first use waits for the next tile's K-tile 0 anyway and the four-pass epilogue only adds barriers (issuing that K-tile 0 after the
-    // epilogue's second pass instead — what the kernel does for them — changes nothing: 1.08 / 1.08 / 1.30).  Key 2 = 1 forces it for all.
+    // Store-only epilogues: the next tile's first K-tile lands under the epilogue (qkv 184 -> 162 us, fc+gelu 297 -> 275, dout 61 -> 56).
+    // Epilogues that LOAD a 2-byte tile (the fp16 residual stream, the bf16 u of gelu'(u)): that tile comes to LDS by LDS-DMA two
+    // passes ahead, so the epilogue issues no vector-memory load (with plain loads they queued behind the in-flight DMA in the in-order
+    // vmcnt queue and the persistent kernel LOST 8-30 % on them).  f32 residuals (few-row GEMMs only) stay on the one-tile kernels.
+    // Tuning key 2: -1 one tile per workgroup everywhere; 2 persistent for store-only epilogues only (A/B).
     const bool loads_in_epilogue = residual != nullptr || epilogue == LPI_EPI_DQUICKGELU;
-    if (dtype != LPI_F32 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || g_lpi_tuning[2] == 1)) {
+    const bool side16 = (residual != nullptr && c_dtype == LPI_F16) || epilogue == LPI_EPI_DQUICKGELU;
+    if (dtype != LPI_F32 && g_lpi_tuning[2] >= 0 && (!loads_in_epilogue || (side16 && g_lpi_tuning[2] != 2))) {
         const int rc = lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
         if (rc != LPI_ENOSYS) return rc;
     }

@@ -133,6 +133,38 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     // issued from the main loop makes the first epilogue load wait for it.  For them the eight DMA instructions of the next tile's
     // K-tile 0 are issued after pass 1 of the epilogue instead (only passes 2 and 3 queue behind them).
     constexpr bool LATE = RES || EPI == LPI_EPI_DQUICKGELU;
+    // SIDE16: ... and when that loaded operand is a 2-byte tile (the fp16 residual stream, or the bf16 pre-activation u of gelu'(u)) it is
+    // brought to LDS by LDS-DMA instead: the 64 rows x 512 B of each epilogue pass into one half of ring slot 0 (free once the main loop
+    // is in its last K-tile), two passes ahead.  The epilogue then issues no vector-memory LOAD at all: nothing waits in the in-order
+    // vmcnt queue behind a DMA, and the load latency of each pass (exposed four times per tile in the one-tile kernel) is hidden.
+    // The bias vector goes to LDS once per launch for the same reason.  No next-tile K prefetch for these (slot 0 is taken).
+    constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
+    typedef typename AuxT<T>::type TA;
+    const char* const side_base = SIDE16 ? (RES ? reinterpret_cast<const char*>(residual) : reinterpret_cast<const char*>(aux)) : nullptr;
+    const int side_ld = RES ? ldr : ldaux;
+    float* const bias_lds = reinterpret_cast<float*>(smem + LDS_P);
+    if constexpr (SIDE16) {
+        for (int i = tid * 4; i < N; i += NTHR * 4)
+            *reinterpret_cast<f32x4*>(bias_lds + i) = bias ? *reinterpret_cast<const f32x4*>(bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
+    // pass p of the tile at (m0, n0): staging row s (0..63) = tile row mh*128 + (s>>5)*64 + ((p&1)*2 + ((s>>4)&1))*16 + (s&15); its 256
+    // 2-byte elements -> LDS slot-0 half (p & 1), row s at byte s*512 (linear: what a wave reads back is one whole row).
+    // Wave w issues instructions i = 0..3: LDS bytes [(4w+i)*1024, +1024) of the half = rows 2(4w+i), 2(4w+i)+1.
+    auto stage_side = [&](int m0, int n0, int p) {
+        const char* sb = side_base + ((size_t)m0 * side_ld + n0) * 2;
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));          // keep these address computations where they are used (see the epilogue's note on LICM)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sr = 2 * (4 * wave + i) + (l2 >> 5);
+            const int trow = (p >> 1) * 128 + (sr >> 5) * 64 + ((p & 1) * 2 + ((sr >> 4) & 1)) * 16 + (sr & 15);
+            const unsigned voff = (unsigned)trow * (unsigned)side_ld * 2u + (unsigned)(l2 & 31) * 16u;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_w + (p & 1) * 32768 + i * 1024 + wave * 3072) : "memory");
+        }
+    };
 
     int vb = blockIdx.x;
     if (vb < n_full) {
@@ -182,6 +214,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (SIDE16) {      // last K-tile (slot 1): slot 0 is free -> the side tiles of epilogue passes 0 and 1
+                        stage_side(m0, n0, 0);
+                        stage_side(m0, n0, 1);
+                    }
                 }
                 PHASE_SYNC_IN();
                 mma_quadrant(acc, 0, 0, fb0);
@@ -199,7 +235,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                     } else {
                         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     }
-                } else if (!has_next) {
+                } else if (!has_next && !SIDE16) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 PHASE_SYNC_IN();
@@ -229,7 +265,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
             const int wm_e = wave_e >> 2, wn_e = wave_e & 3;
             const int ecol = n0 + lane_e * 4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
+            if constexpr (SIDE16) bv = *reinterpret_cast<const f32x4*>(bias_lds + ecol);
+            else if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
             char* const stg = smem + STG;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -237,6 +274,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                 if (p) {          // the previous pass's staging reads are done before this pass overwrites them
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
+                }
+                if constexpr (SIDE16) {      // pass p+1's side tile -> the half pass p-1 has just finished reading (passes 0, 1: main loop)
+                    if (p >= 1 && p <= 2) stage_side(m0, n0, p + 1);
                 }
 #pragma unroll
                 for (int mi2 = 0; mi2 < 2; ++mi2) {
@@ -249,6 +289,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                             *reinterpret_cast<f32x4*>(stg + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][(p & 1) * 2 + mi2];
                         }
                 }
+                if constexpr (SIDE16) {
+                    // this wave's pieces of pass p's side tile have landed once at most the YOUNGER operations are outstanding: the 4 DMA
+                    // instructions of the next side tile and the 8 stores of the previous pass, in issue order
+                    //   side(0) side(1) | stores(0) side(2) | stores(1) side(3) | stores(2) | stores(3)
+                    if (p == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (p == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -257,12 +305,26 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                     const int s_row = wave_e * 8 + rr;
                     const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
                     const f32x4 v = *reinterpret_cast<const f32x4*>(stg + s_row * 1024 + ((lane_e ^ (s_row & 7)) << 4));
-                    gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+                    if constexpr (SIDE16) {
+                        // the arithmetic of gemm_epilogue_store, with the residual / u row read from LDS
+                        f32x4 o = v * alpha + bv;
+                        const char* sp = smem + (p & 1) * 32768 + s_row * 512 + lane_e * 8;
+                        if constexpr (EPI == LPI_EPI_DQUICKGELU) {
+                            const f32x4 u = Elem<TA>::ld4(reinterpret_cast<const TA*>(sp));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] *= quick_gelu_grad(u[j]);
+                        } else {
+                            o += Elem<TC>::ld4(reinterpret_cast<const TC*>(sp));
+                        }
+                        Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                    } else {
+                        gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+                    }
                 }
                 // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
                 // all but the 16 youngest operations done.  Passes 2 and 3's barriers then publish it to every wave.
                 if (p == 1 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                if constexpr (LATE) {
+                if constexpr (LATE && !SIDE16) {
                     if (p == 1 && more_tiles) {      // slot 0 is free since the main loop ended; passes 2 and 3 run behind these
                         stage_A(nm0, 0, 0, 0); stage_B(nn0, 0, 0, 0); stage_B(nn0, 0, 1, 0); stage_A(nm0, 0, 1, 0);
                     }
@@ -276,8 +338,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             vb = nvb; m0 = nm0; n0 = nn0;
-            stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
-            first = false;
+            if constexpr (SIDE16) {      // both slots were the epilogue's: a full prologue, as for the first tile
+                stage_A(m0, 0, 0, 0); stage_B(n0, 0, 0, 0); stage_B(n0, 0, 1, 0); stage_A(m0, 0, 1, 0);
+                stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
+                first = false;
+            }
         }
     }
 #undef PHASE_SYNC_IN
@@ -331,9 +400,11 @@ int launchp_impl(int M, int N, int K, const void* A, int lda, const void* B, int
         n_full = nwg;
     }
     auto kern = gemm256p_kernel<T, TC, EPI, RES, SAVE_U>;
-    constexpr int LDS = t128::LDS_BYTES > LDS_P ? t128::LDS_BYTES : LDS_P;
+    constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
+    if (SIDE16 && N > 8192) return LPI_ENOSYS;          // the bias vector must fit behind the ring (the caller falls back to the one-tile kernel)
+    const int LDS = std::max<int>(t128::LDS_BYTES, LDS_P + (SIDE16 ? N * 4 : 0));
     static LdsOnce once;
-    if (int e = lpi_ensure_lds(once, (const void*)kern, LDS)) return e;
+    if (int e = lpi_ensure_lds(once, (const void*)kern, 160 * 1024)) return e;
     lpi_note_gemm_kernel(tail_blocks ? LPI_GEMM_K_256_TAIL : LPI_GEMM_K_256);
     const int grid = std::min(ncu, std::max(n_full, tail_blocks));
     LPI_LAUNCH(kern, dim3(grid), dim3(NTHR), LDS, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual, ldr,

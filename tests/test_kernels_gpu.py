@@ -713,7 +713,7 @@ def test_gemm_persistent_equals_one_tile_per_workgroup(tm, N, K):
     call("lpi_set_tuning", 0, 1)
     call("lpi_set_tuning", 5, 0)              # keep the 256x128 stand-alone kernel out of it: this test is about the 256x256 pair
     try:
-        call("lpi_set_tuning", 2, 1)          # 1: the persistent kernel for EVERY epilogue (default 0: store-only epilogues)
+        call("lpi_set_tuning", 2, 0)          # default: the persistent kernel for store-only epilogues and 2-byte side tiles
         new, new2 = run_all(), run_all()
         call("lpi_set_tuning", 2, -1)
         old = run_all()
