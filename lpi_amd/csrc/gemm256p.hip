@@ -277,6 +277,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                 }
                 if constexpr (SIDE16) {      // pass p+1's side tile -> the half pass p-1 has just finished reading (passes 0, 1: main loop)
                     if (p >= 1 && p <= 2) stage_side(m0, n0, p + 1);
+                    // pass 2 was the last reader of half 0 = the A0 | A1 halves of ring slot 0: the next tile's K-tile 0 A rows (the ones
+                    // that come from HBM; the B rows are weights and sit in L2) get a pass of head start
+                    if (p == 3 && more_tiles) { stage_A(nm0, 0, 0, 0); stage_A(nm0, 0, 1, 0); }
                 }
 #pragma unroll
                 for (int mi2 = 0; mi2 < 2; ++mi2) {
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                     // instructions of the next side tile and the 8 stores of the previous pass, in issue order
                     //   side(0) side(1) | stores(0) side(2) | stores(1) side(3) | stores(2) | stores(3)
                     if (p == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if (p == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (p == 3 && !more_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // p == 3 with a next tile: stores(2) + its 4 A-row DMA instructions
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -338,10 +341,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             vb = nvb; m0 = nm0; n0 = nn0;
-            if constexpr (SIDE16) {      // both slots were the epilogue's: a full prologue, as for the first tile
-                stage_A(m0, 0, 0, 0); stage_B(n0, 0, 0, 0); stage_B(n0, 0, 1, 0); stage_A(m0, 0, 1, 0);
+            if constexpr (SIDE16) {      // both slots were the epilogue's: the rest of a full prologue (K-tile 0's A halves are in flight)
+                stage_B(n0, 0, 0, 0); stage_B(n0, 0, 1, 0);
                 stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // all of K-tile 0 (and the epilogue's stores, older) landed
                 __builtin_amdgcn_s_barrier();
             } else {
                 stage_A(m0, 1, 0, 1); stage_B(n0, 1, 0, 1); stage_B(n0, 1, 1, 1);
