@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" -p no:cacheprovider 2>&1 | tail -3
-timeout 300 python tools/gemm_ab.py 2 2 0 2>&1 | tail -14
+for cfg in "" "--overlap" "--overlap --text-cus 32" "--overlap --text-cus 40" "--overlap --text-cus 48" ""; do
+python bench.py $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-roofline 2>&1 | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|Error.*' | head -3 | tr '\n' ' '; echo " <= $cfg"
+done
