@@ -64,9 +64,10 @@ uint64_t lpi_launch_count(void);
  *              faster (L > 160), 1 the one-head-per-workgroup kernels of attention.hip everywhere, 2 / 3 force the persistent forward /
  *              backward at every L they take (same results bit for bit), 4 the single-pass backward (non-causal; dQ summed in a
  *              different, still fixed, order).
- *   Returns LPI_EINVAL for a key outside 0..7. */
+ *   key 8      != 0: lpi_gemm_nt_grouped never groups (issues its problems one after the other; A/B switch, same bits).
+ *   keys 9..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
-int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..7 */
+int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */
 
 /* ---- a4: nn.Linear / in_proj / out_proj / c_fc / c_proj / conv1-as-matmul and every dgrad --------------
  * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T + bias[N]) + residual[M,N]
@@ -87,6 +88,27 @@ int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K,
                        const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        const float* bias, const void* residual, int ldr,
                        int epilogue, void* aux, int ldaux, float alpha, int ksplit, float* scratch, void* stream);
+
+/* SEVERAL such GEMMs in one launch (a GROUPED launch): `count` problems of the same operand type, output type and epilogue kind
+ * (residual / aux present in all of them or in none) — e.g. the vision tower's and the text tower's c_fc of the same layer
+ * (models/clip/model.py:175-177 runs them as two nn.Linear calls of two independent towers).  With count == 2 and shapes the
+ * persistent 256x256 kernel takes, the second problem's tiles follow the first's in one persistent launch: they fill the first
+ * problem's partial last round of CUs and run at the large kernel's rate instead of as a small launch of their own.  Any other
+ * combination is issued as `count` lpi_gemm_nt calls in order — the results are the same bits either way.  `descs` is HOST memory
+ * (read during the call); the pointers inside are device memory.  The launches are attributed to kernel LPI_GEMM_K_256* when grouped
+ * (lpi_gemm_last_kernel). */
+typedef struct lpi_gemm_desc {
+    int M, N, K;
+    const void* A; int lda;
+    const void* B; int ldb;
+    void* C; int ldc;
+    const float* bias;
+    const void* residual; int ldr;
+    void* aux; int ldaux;
+} lpi_gemm_desc;
+int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float alpha, int count, const lpi_gemm_desc* descs, void* stream);
+/* 1 if the last lpi_gemm_nt_grouped call of this thread ran as ONE grouped launch, 0 if it fell back to separate launches */
+int lpi_gemm_last_grouped(void);
 
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
  * x_dtype: storage type of the residual stream x — LPI_F32, or LPI_F16 in bf16 mode (statistics and arithmetic are f32 either way).

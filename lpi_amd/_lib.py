@@ -19,6 +19,13 @@ class LpiError(RuntimeError):
     pass
 
 
+class GemmDesc(ctypes.Structure):
+    """``lpi_gemm_desc`` of include/lpi_hip.h: one problem of lpi_gemm_nt_grouped (host struct, device pointers inside)."""
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int), ("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int),
+                ("C", c_void_p), ("ldc", c_int), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int), ("aux", c_void_p),
+                ("ldaux", c_int)]
+
+
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_long
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); must list EVERY symbol of include/lpi_hip.h
@@ -29,6 +36,8 @@ SIGNATURES = {
     "lpi_get_tuning": [_I],
     "lpi_gemm_last_kernel": [],
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
+    "lpi_gemm_nt_grouped": [_I, _I, _I, _F, _I, _P, _P],
+    "lpi_gemm_last_grouped": [],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
@@ -125,6 +134,26 @@ def call(name: str, *args):
     rc = fn(*conv)
     if rc != 0:
         raise LpiError(f"{name} failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+
+
+def gemm_grouped(dt: int, cdt: int, epi: int, alpha: float, problems, stream) -> bool:
+    """lpi_gemm_nt_grouped over `problems` = dicts with M, N, K, a, b, c and optional bias / residual / aux tensors.
+    Returns True if they ran as one grouped launch."""
+    lib = load()
+    arr = (GemmDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        d.M, d.N, d.K = p["M"], p["N"], p["K"]
+        d.A, d.lda = p["a"].data_ptr(), p["a"].stride(0)
+        d.B, d.ldb = p["b"].data_ptr(), p["b"].stride(0)
+        d.C, d.ldc = p["c"].data_ptr(), p["c"].stride(0)
+        bias, res, aux = p.get("bias"), p.get("residual"), p.get("aux")
+        d.bias = None if bias is None else bias.data_ptr()
+        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), res.stride(0))
+        d.aux, d.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
+    rc = lib.lpi_gemm_nt_grouped(dt, cdt, epi, float(alpha), len(problems), ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_gemm_nt_grouped failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+    return bool(lib.lpi_gemm_last_grouped())
 
 
 def launch_count() -> int:

@@ -14,10 +14,10 @@ extern "C" int lpi_gemm_last_kernel(void) { return t_last_gemm_kernel; }
 
 // tuning knobs: [0] / [1] minimum number of 256x256 tiles for the phased 256x256 GEMM kernel, bf16 / f32 operands (INT_MAX disables it).
 // f32 is MFMA-bound at either tile size, so the bigger tile only pays when its last partial round of tiles is short.
-int g_lpi_tuning[8] = {1, 1500, 0, 0, 0, 160, 1, 0};
-extern "C" int lpi_get_tuning(int key) { return (key < 0 || key >= 8) ? LPI_EINVAL : g_lpi_tuning[key]; }
+int g_lpi_tuning[16] = {1, 1500, 0, 0, 0, 160, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int lpi_get_tuning(int key) { return (key < 0 || key >= 16) ? LPI_EINVAL : g_lpi_tuning[key]; }
 extern "C" int lpi_set_tuning(int key, int value) {
-    if (key < 0 || key >= 8) return LPI_EINVAL;
+    if (key < 0 || key >= 16) return LPI_EINVAL;
     g_lpi_tuning[key] = value;
     return 0;
 }

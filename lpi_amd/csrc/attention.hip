@@ -24,7 +24,7 @@
 #include <type_traits>
 #include "common.h"
 
-extern int g_lpi_tuning[8];
+extern int g_lpi_tuning[16];
 
 namespace {
 

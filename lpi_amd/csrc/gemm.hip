@@ -284,13 +284,13 @@ bool lpi_gemm256x128_eligible(int dtype, int M, int N, int K);
 int lpi_gemm256x128_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                            const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s,
                            int group_m);
-extern int g_lpi_tuning[8];
+extern int g_lpi_tuning[16];
 
-extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                           void* C, int ldc, const float* bias, const void* residual_, int ldr, int epilogue, void* aux,
-                           int ldaux, float alpha, void* stream)
+// argument checks shared by lpi_gemm_nt and lpi_gemm_nt_grouped
+static int gemm_nt_check(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                         const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux)
 {
-    const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
+
     const int esz = dtype == LPI_F32 ? 4 : 2;
     const int csz = c_dtype == LPI_F32 ? 4 : 2;
     if (c_dtype == LPI_F16 && dtype == LPI_BF16 && (epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
@@ -304,8 +304,17 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
     if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
     if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
     if (epilogue == LPI_EPI_DQUICKGELU && !aux) return LPI_EINVAL;
+    return 0;
+}
+
+extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                           void* C, int ldc, const float* bias, const void* residual_, int ldr, int epilogue, void* aux,
+                           int ldaux, float alpha, void* stream)
+{
+    const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
+    if (int e = gemm_nt_check(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux)) return e;
+    hipStream_t s = (hipStream_t)stream;
     // Half-empty launches: fewer than tuning key 5 (default 160) 256x256 tiles -> 256x128 tiles, twice the workgroups (bf16 only:
     // the f32 path is MFMA-bound at any tile size).  Key 5 = 0 disables it.
     if (dtype != LPI_F32 && g_lpi_tuning[5] > 0 && lpi_gemm256_eligible(dtype, M, N, K) && (M / 256) * (N / 256) < g_lpi_tuning[5] &&
@@ -330,4 +339,40 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     if (dtype == LPI_F16 && c_dtype == LPI_F32)
         return dispatch_epi<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
     return LPI_ENOSYS;
+}
+
+int lpi_gemm256p_launch2(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* d, hipStream_t s);
+static thread_local int t_last_grouped = 0;
+extern "C" int lpi_gemm_last_grouped(void) { return t_last_grouped; }
+
+extern "C" int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float alpha, int count, const lpi_gemm_desc* d, void* stream)
+{
+    if (count <= 0 || !d) return LPI_EINVAL;
+    t_last_grouped = 0;
+    for (int i = 0; i < count; ++i)
+        if (int e = gemm_nt_check(dtype, c_dtype, d[i].M, d[i].N, d[i].K, d[i].A, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].ldc, d[i].bias,
+                                  (const float*)d[i].residual, d[i].ldr, epilogue, d[i].aux, d[i].ldaux)) return e;
+    // one persistent launch: two bf16 / f16 problems that the 256x256 kernel takes, with an epilogue the persistent kernel has (store-only,
+    // or a 2-byte side tile), together at least a round of tiles (tuning key 8 != 0 = never group: A/B switch)
+    bool group = count == 2 && dtype != LPI_F32 && g_lpi_tuning[2] >= 0 && g_lpi_tuning[8] == 0;
+    if (group) {
+        int tiles = 0;
+        for (int i = 0; i < 2 && group; ++i) {
+            const bool res = d[i].residual != nullptr;
+            const bool side16 = (res && c_dtype == LPI_F16) || epilogue == LPI_EPI_DQUICKGELU;
+            const bool loads = res || epilogue == LPI_EPI_DQUICKGELU;
+            group = lpi_gemm256_eligible(dtype, d[i].M, d[i].N, d[i].K) && (!loads || (side16 && g_lpi_tuning[2] != 2));
+            tiles += (d[i].M / 256) * (d[i].N / 256);
+        }
+        group = group && tiles >= 256 && (d[0].residual != nullptr) == (d[1].residual != nullptr) && (d[0].aux != nullptr) == (d[1].aux != nullptr);
+    }
+    if (group) {
+        const int rc = lpi_gemm256p_launch2(dtype, c_dtype, epilogue, alpha, d, (hipStream_t)stream);
+        if (rc == 0) t_last_grouped = 1;
+        if (rc != LPI_ENOSYS) return rc;
+    }
+    for (int i = 0; i < count; ++i)
+        if (int e = lpi_gemm_nt(dtype, c_dtype, d[i].M, d[i].N, d[i].K, d[i].A, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].ldc, d[i].bias, d[i].residual,
+                                d[i].ldr, epilogue, d[i].aux, d[i].ldaux, alpha, stream)) return e;
+    return 0;
 }

@@ -22,7 +22,7 @@
 #include "gemm256_tile.h"
 #include "gemm256x128_tile.h"
 
-extern int g_lpi_tuning[8];
+extern int g_lpi_tuning[16];
 
 namespace {
 

@@ -19,7 +19,7 @@
 // of gemm256x128_tile.h) runs after a workgroup's full tiles with its own ring.
 #include "gemm256x128_tile.h"
 
-extern int g_lpi_tuning[8];
+extern int g_lpi_tuning[16];
 
 namespace {
 
@@ -32,11 +32,27 @@ constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 =
 constexpr int STG = BUF_BYTES;            // epilogue staging = ring slot 1 (the odd K-tiles'), 64 rows x 1024 B
 constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
 
+// One GEMM of a launch.  A launch takes one or two of them (a GROUPED launch: the same operand types and epilogue kind, e.g. the
+// vision and the text tower's in_proj of the same layer): the second problem's tiles follow the first's in the virtual workgroup order
+// (from a multiple of 8, so that an id's XCD is still id & 7), i.e. they fill the first problem's last partial round of CUs and run at
+// the persistent kernel's rate instead of as a small launch of their own.
+struct PProb {
+    const void* A; const void* B; void* C; const float* bias; const void* residual; void* aux;
+    int N, K, lda, ldb, ldc, ldr, ldaux, tiles_m, tiles_n;
+    int vb0;        // first virtual workgroup id (a multiple of 8)
+    int bias_off;   // offset (floats) of its bias vector in the LDS copy (SIDE16 epilogues)
+};
+struct PGroup {
+    PProb p[2];
+    int nprob;
+    int n_full;        // virtual ids below this run as 256x256 tiles in the persistent loop (a multiple of the grid size, or all)
+    int tail_blocks;   // work items of the hybrid short last round (256x128 half tiles), 0 = none
+    int group_m;
+    float alpha;
+};
+
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-__global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
-    int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
-    TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, int n_full, int group_m, int tail_blocks)
+__global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Elem<T>::EPC;
@@ -45,10 +61,28 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int nwg = tiles_m * tiles_n;
     const int G = gridDim.x;
+    const int group_m = grp.group_m;
+    const float alpha = grp.alpha;
+    typedef typename AuxT<T>::type TA;
+    // the CURRENT problem's operands and geometry (wave-uniform; re-bound by bind() when the workgroup moves on to the next problem)
+    const T* A = nullptr; const T* B = nullptr; TC* C = nullptr;
+    const float* bias = nullptr; const float* residual = nullptr; TA* aux = nullptr;
+    int K = 0, lda = 0, ldb = 0, ldc = 0, ldr = 0, ldaux = 0, tiles_m = 1, tiles_n = 1, nwg = 0, vb0 = 0, bias_off = 0;
+    unsigned a_off = 0, b_off = 0;
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
+    auto bind = [&](int pi) {
+        const PProb& P = grp.p[pi];
+        A = (const T*)P.A; B = (const T*)P.B; C = (TC*)P.C; bias = P.bias; residual = (const float*)P.residual; aux = (TA*)P.aux;
+        K = P.K; lda = P.lda; ldb = P.ldb; ldc = P.ldc; ldr = P.ldr; ldaux = P.ldaux; tiles_m = P.tiles_m; tiles_n = P.tiles_n;
+        nwg = tiles_m * tiles_n; vb0 = P.vb0; bias_off = P.bias_off;
+        a_off = (unsigned)(((size_t)srow * lda + schunk * EPC) * sizeof(T));
+        b_off = (unsigned)(((size_t)srow * ldb + schunk * EPC) * sizeof(T));
+    };
 
-    // tile (tm, tn) of virtual workgroup id vb: the same XCD-aware order as gemm256_kernel (ids that share vb & 7 share an XCD)
+    // tile (tm, tn) of the current problem's workgroup id vb (= virtual id - vb0): the same XCD-aware order as gemm256_kernel (ids that
+    // share vb & 7 share an XCD)
     auto coords = [&](int vb, int& m0, int& n0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -64,10 +98,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     // SGPR base + 32-bit VGPR offset: the base of (tile, K-tile, half, instruction) is scalar arithmetic and a thread keeps two offsets
     // for the whole launch — with 64-bit per-lane pointers re-formed for every tile the kernel spilled, and a scratch reload is a
     // vector-memory operation that sits in the same in-order vmcnt queue as the LDS-DMA.
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((tid >> 4) & 7);
-    const unsigned a_off = (unsigned)(((size_t)srow * lda + schunk * EPC) * sizeof(T));
-    const unsigned b_off = (unsigned)(((size_t)srow * ldb + schunk * EPC) * sizeof(T));
     const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024);
     auto glds16 = [&](const T* sbase, unsigned voff, unsigned lds_addr) {
         unsigned keep;
@@ -128,7 +158,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     __builtin_amdgcn_s_barrier();                         \
     asm volatile("" ::: "memory")
 
-    const int nk = K / BK;   // even, >= 2 (checked on the host)
+    int nk = 0;              // K / BK of the current problem: even, >= 2 (checked on the host)
     // Epilogues that LOAD (residual, gelu'(u)): their loads share the in-order vmcnt queue with the LDS-DMA, so a next-tile K-tile 0
     // issued from the main loop makes the first epilogue load wait for it.  For them the eight DMA instructions of the next tile's
     // K-tile 0 are issued after pass 1 of the epilogue instead (only passes 2 and 3 queue behind them).
@@ -139,13 +169,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
     // vmcnt queue behind a DMA, and the load latency of each pass (exposed four times per tile in the one-tile kernel) is hidden.
     // The bias vector goes to LDS once per launch for the same reason.  No next-tile K prefetch for these (slot 0 is taken).
     constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
-    typedef typename AuxT<T>::type TA;
-    const char* const side_base = SIDE16 ? (RES ? reinterpret_cast<const char*>(residual) : reinterpret_cast<const char*>(aux)) : nullptr;
-    const int side_ld = RES ? ldr : ldaux;
+    const char* side_base = nullptr;
+    int side_ld = 0;
     float* const bias_lds = reinterpret_cast<float*>(smem + LDS_P);
     if constexpr (SIDE16) {
-        for (int i = tid * 4; i < N; i += NTHR * 4)
-            *reinterpret_cast<f32x4*>(bias_lds + i) = bias ? *reinterpret_cast<const f32x4*>(bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pi = 0; pi < grp.nprob; ++pi) {
+            const float* bp = grp.p[pi].bias;
+            float* dst = bias_lds + grp.p[pi].bias_off;
+            for (int i = tid * 4; i < grp.p[pi].N; i += NTHR * 4)
+                *reinterpret_cast<f32x4*>(dst + i) = bp ? *reinterpret_cast<const f32x4*>(bp + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
     }
     // pass p of the tile at (m0, n0): staging row s (0..63) = tile row mh*128 + (s>>5)*64 + ((p&1)*2 + ((s>>4)&1))*16 + (s&15); its 256
@@ -166,8 +199,28 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
         }
     };
 
-    int vb = blockIdx.x;
-    if (vb < n_full) {
+    const int n_full = grp.n_full;
+    int vbv = blockIdx.x;          // virtual id of the workgroup's next tile: blockIdx.x, + G, ...
+    bool lds_used = false;
+    for (int pi = 0; pi < grp.nprob; ++pi) {
+        bind(pi);
+        nk = K / BK;
+        if constexpr (SIDE16) {
+            side_base = RES ? reinterpret_cast<const char*>(residual) : reinterpret_cast<const char*>(aux);
+            side_ld = RES ? ldr : ldaux;
+        }
+        // this problem's 256x256 tiles of the persistent loop: virtual ids [vb0, vend); ids between two problems are padding
+        const int vend = min(vb0 + nwg, n_full);
+        if (vbv < vb0) vbv += (vb0 - vbv + G - 1) / G * G;
+        if (vbv >= vend) continue;
+        if (lds_used) {              // the previous problem's last epilogue pass may still be reading the ring slots
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        lds_used = true;
+        int vb = vbv - vb0;          // id within the problem
+        const int lend = vend - vb0;
         int m0, n0;
         coords(vb, m0, n0);
         m0 = __builtin_amdgcn_readfirstlane(m0);
@@ -180,7 +233,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
         bool first = true;
         for (;;) {
             const int nvb = vb + G;
-            const bool more_tiles = nvb < n_full;
+            const bool more_tiles = nvb < lend;
             const bool has_next = more_tiles && !LATE;       // next tile's K-tile 0 staged from the main loop
             int nm0 = 0, nn0 = 0;
             if (more_tiles) coords(nvb, nm0, nn0);
@@ -265,7 +318,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
             const int wm_e = wave_e >> 2, wn_e = wave_e & 3;
             const int ecol = n0 + lane_e * 4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SIDE16) bv = *reinterpret_cast<const f32x4*>(bias_lds + ecol);
+            if constexpr (SIDE16) bv = *reinterpret_cast<const f32x4*>(bias_lds + bias_off + ecol);
             else if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
             char* const stg = smem + STG;
 #pragma unroll
@@ -335,7 +388,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
                     if (p == 3 && more_tiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 }
             }
-            if (!more_tiles) break;
+            if (!more_tiles) { vbv = nvb + vb0; break; }
             // the staging slot is free again once every wave has read its rows: K-tile 1's three early halves of the next tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -355,22 +408,20 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(
 #undef PHASE_SYNC_IN
 #undef PHASE_SYNC_OUT
 
-    // ---- hybrid short last round: the rem = nwg - n_full leftover tiles as 2 * rem half tiles of 256x128 (mapping of gemm256_tail_kernel)
-    if (tail_blocks > 0) {
-        for (int j = blockIdx.x; j < tail_blocks; j += G) {
-            __syncthreads();      // LDS hand-over between tile bodies
+    // ---- hybrid short last round: the leftover virtual ids [n_full, ...) as two 256x128 half tiles each (mapping of gemm256_tail_kernel:
+    // work item j -> leftover id k = (j >> 4) * 8 + (j & 7), half (j >> 3) & 1, so both halves of a tile stay on one XCD)
+    if (grp.tail_blocks > 0) {
+        for (int j = blockIdx.x; j < grp.tail_blocks; j += G) {
             const int k = (j >> 4) * 8 + (j & 7), half = (j >> 3) & 1;
-            const int q = nwg >> 3, r = nwg & 7, per = n_full >> 3;
-            const int xcd = k & 7, idx = per + (k >> 3);
-            const int count = q + (xcd < r ? 1 : 0);
-            if (idx >= count) continue;
-            const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-            const int group = t / (group_m * tiles_n);
-            const int first_m = group * group_m;
-            const int gsz = min(tiles_m - first_m, group_m);
-            const int in_group = t - group * group_m * tiles_n;
-            const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-            t128::tile<T, TC, EPI, RES, SAVE_U>(tm * 256, tn * 256 + half * 128, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, smem);
+            const int v = n_full + k;
+            const int pi = (grp.nprob > 1 && v >= grp.p[1].vb0) ? 1 : 0;
+            bind(pi);
+            const int lv = v - vb0;
+            if (lv < 0 || lv >= nwg) continue;          // padding between the problems / past the last tile
+            __syncthreads();      // LDS hand-over between tile bodies
+            int m0, n0;
+            coords(lv, m0, n0);
+            t128::tile<T, TC, EPI, RES, SAVE_U>(m0, n0 + half * 128, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, smem);
         }
     }
 }
@@ -385,83 +436,106 @@ int cu_count_p() {
     return n;
 }
 
+// ---- host side: one launch for a group of 1 or 2 problems (same T / TC / epilogue kind)
+struct HostProb {
+    int M, N, K;
+    const void* A; int lda; const void* B; int ldb; void* C; int ldc; const float* bias; const float* residual; int ldr; void* aux; int ldaux;
+};
+
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-int launchp_impl(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-                 const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
 {
-    const int tm = M / T256, tn = N / T256;
-    const int nwg = tm * tn;
+    constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
     const int ncu = cu_count_p();
-    const int gm = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8;
-    // hybrid short last round as in gemm256.hip: rem <= ncu/2 leftover tiles run as half tiles (tuning key 6)
-    int rem = nwg % ncu, n_full = nwg - rem, tail_blocks = 0;
-    if (g_lpi_tuning[6] != 0 && n_full >= ncu && rem > 0 && rem <= ncu / 2 && (ncu % 8) == 0) {
-        const int q = nwg >> 3, r = nwg & 7;
-        const int max_left = q + (r ? 1 : 0) - (n_full >> 3);
-        tail_blocks = 16 * max_left;
-    } else {
-        n_full = nwg;
+    PGroup g = {};
+    g.nprob = np;
+    g.group_m = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 8;
+    g.alpha = alpha;
+    int v = 0, nsum = 0;
+    for (int i = 0; i < np; ++i) {
+        PProb& P = g.p[i];
+        const HostProb& h = hp[i];
+        P.A = h.A; P.B = h.B; P.C = h.C; P.bias = h.bias; P.residual = h.residual; P.aux = h.aux;
+        P.N = h.N; P.K = h.K; P.lda = h.lda; P.ldb = h.ldb; P.ldc = h.ldc; P.ldr = h.ldr; P.ldaux = h.ldaux;
+        P.tiles_m = h.M / T256; P.tiles_n = h.N / T256;
+        v = (v + 7) & ~7;                 // a problem starts at a multiple of 8: its ids keep id & 7 = XCD
+        P.vb0 = v;
+        v += P.tiles_m * P.tiles_n;
+        P.bias_off = nsum;
+        nsum += h.N;
+    }
+    if (SIDE16 && nsum > 8192) return LPI_ENOSYS;       // the bias vectors must fit behind the ring (the caller falls back to the one-tile kernel)
+    // hybrid short last round as in gemm256.hip: rem <= ncu/2 leftover ids run as half tiles (tuning key 6)
+    const int rem = v % ncu;
+    g.n_full = v;
+    if (g_lpi_tuning[6] != 0 && v - rem >= ncu && rem > 0 && rem <= ncu / 2 && (ncu % 8) == 0) {
+        g.n_full = v - rem;
+        g.tail_blocks = 16 * ((rem + 7) >> 3);
     }
     auto kern = gemm256p_kernel<T, TC, EPI, RES, SAVE_U>;
-    constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
-    if (SIDE16 && N > 8192) return LPI_ENOSYS;          // the bias vector must fit behind the ring (the caller falls back to the one-tile kernel)
-    const int LDS = std::max<int>(t128::LDS_BYTES, LDS_P + (SIDE16 ? N * 4 : 0));
+    const int LDS = std::max<int>(t128::LDS_BYTES, LDS_P + (SIDE16 ? nsum * 4 : 0));
     static LdsOnce once;
     if (int e = lpi_ensure_lds(once, (const void*)kern, 160 * 1024)) return e;
-    lpi_note_gemm_kernel(tail_blocks ? LPI_GEMM_K_256_TAIL : LPI_GEMM_K_256);
-    const int grid = std::min(ncu, std::max(n_full, tail_blocks));
-    LPI_LAUNCH(kern, dim3(grid), dim3(NTHR), LDS, s, M, N, K, (const T*)A, lda, (const T*)B, ldb, (TC*)C, ldc, bias, residual, ldr,
-               (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, n_full, gm, tail_blocks);
+    lpi_note_gemm_kernel(g.tail_blocks ? LPI_GEMM_K_256_TAIL : LPI_GEMM_K_256);
+    const int grid = std::min(ncu, std::max(g.n_full, g.tail_blocks));
+    LPI_LAUNCH(kern, dim3(grid), dim3(NTHR), LDS, s, g);
     LPI_CHECK_LAST();
     return 0;
 }
 
-template <typename T, typename TC, int EPI>
-int launchp(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-            const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
-{
-    if constexpr (EPI == LPI_EPI_NONE) {
-        if (residual) return launchp_impl<T, TC, EPI, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-        return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    } else {
-        if (residual) return LPI_ENOSYS;
-        if constexpr (EPI == LPI_EPI_QUICKGELU) {
-            if (aux) return launchp_impl<T, TC, EPI, false, true>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-            return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-        } else {
-            if (!aux) return LPI_EINVAL;
-            return launchp_impl<T, TC, EPI, false, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-        }
-    }
-}
-
+// run-time pointer presence -> compile-time epilogue flags; every problem of a group must agree on them
 template <typename T, typename TC>
-int dispatchp(int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-              const float* residual, int ldr, void* aux, int ldaux, float alpha, hipStream_t s)
+int dispatchp(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
 {
+    const bool res = hp[0].residual != nullptr, ax = hp[0].aux != nullptr;
+    for (int i = 1; i < np; ++i)
+        if ((hp[i].residual != nullptr) != res || (hp[i].aux != nullptr) != ax) return LPI_EINVAL;
     switch (epi) {
-    case LPI_EPI_NONE: return launchp<T, TC, LPI_EPI_NONE>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    case LPI_EPI_QUICKGELU: return launchp<T, TC, LPI_EPI_QUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    case LPI_EPI_DQUICKGELU: return launchp<T, TC, LPI_EPI_DQUICKGELU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
+    case LPI_EPI_NONE:
+        if (res) return launchp_impl<T, TC, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
+        return launchp_impl<T, TC, LPI_EPI_NONE, false, false>(hp, np, alpha, s);
+    case LPI_EPI_QUICKGELU:
+        if (res) return LPI_ENOSYS;
+        if (ax) return launchp_impl<T, TC, LPI_EPI_QUICKGELU, false, true>(hp, np, alpha, s);
+        return launchp_impl<T, TC, LPI_EPI_QUICKGELU, false, false>(hp, np, alpha, s);
+    case LPI_EPI_DQUICKGELU:
+        if (res) return LPI_ENOSYS;
+        if (!ax) return LPI_EINVAL;
+        return launchp_impl<T, TC, LPI_EPI_DQUICKGELU, false, false>(hp, np, alpha, s);
     }
     return LPI_EINVAL;
 }
 
+int launch_group(int dtype, int c_dtype, int epilogue, const HostProb* hp, int np, float alpha, hipStream_t s)
+{
+    if (dtype == LPI_BF16 && c_dtype == LPI_BF16) return dispatchp<bf16_t, bf16_t>(epilogue, hp, np, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F32) return dispatchp<bf16_t, float>(epilogue, hp, np, alpha, s);
+    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && hp[0].residual) {
+        for (int i = 1; i < np; ++i) if (!hp[i].residual) return LPI_EINVAL;
+        return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
+    }
+    if (dtype == LPI_F16 && c_dtype == LPI_F16) return dispatchp<f16_t, f16_t>(epilogue, hp, np, alpha, s);
+    if (dtype == LPI_F16 && c_dtype == LPI_F32) return dispatchp<f16_t, float>(epilogue, hp, np, alpha, s);
+    return LPI_ENOSYS;
+}
+
 }  // namespace
 
-// bf16 operands only (the f32 path is MFMA-bound: its prologue share is small and its K-tile geometry differs)
+// bf16 / f16 operands only (the f32 path is MFMA-bound: its prologue share is small and its K-tile geometry differs)
 int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                         const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s)
 {
-    if (dtype == LPI_BF16 && c_dtype == LPI_BF16)
-        return dispatchp<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_F32)
-        return dispatchp<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && residual)
-        return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F16)
-        return dispatchp<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F32)
-        return dispatchp<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, s);
-    return LPI_ENOSYS;
+    const HostProb hp = {M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux};
+    return launch_group(dtype, c_dtype, epilogue, &hp, 1, alpha, s);
+}
+
+// Two GEMMs of the same operand types and epilogue kind in ONE persistent launch (lpi_gemm_nt_grouped); both already validated and
+// eligible for the 256x256 kernel.  LPI_ENOSYS: combination not built (the caller issues them one after the other).
+int lpi_gemm256p_launch2(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* d, hipStream_t s)
+{
+    HostProb hp[2];
+    for (int i = 0; i < 2; ++i)
+        hp[i] = HostProb{d[i].M, d[i].N, d[i].K, d[i].A, d[i].lda, d[i].B, d[i].ldb, d[i].C, d[i].ldc, d[i].bias, (const float*)d[i].residual, d[i].ldr,
+                         d[i].aux, d[i].ldaux};
+    return launch_group(dtype, c_dtype, epilogue, hp, 2, alpha, s);
 }

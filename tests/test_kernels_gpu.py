@@ -546,6 +546,92 @@ def test_gemm_hybrid_tail_round(tm, N):
     assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < TOL[BF16]
 
 
+@pytest.mark.parametrize("tm0,N0,K0,tm1,N1,K1", [(90, 768, 768, 24, 512, 512),       # 270 + 8*.. ids: two problems, short last round of halves
+                                                   (50, 1536, 512, 9, 1024, 256),     # 300 + 36 tiles: the tail straddles both problems
+                                                   (64, 1024, 256, 16, 512, 1024),    # 256 + 32 tiles: the second problem is all tail
+                                                   (100, 768, 512, 60, 512, 512),     # 300 + 120 tiles, no tail: workgroups move on from problem 0 to 1
+                                                   (213, 768, 256, 59, 512, 256)])    # 639 + 118 tiles (the bench's out_proj pair, short K)
+def test_gemm_grouped_launch_equals_separate_launches(tm0, N0, K0, tm1, N1, K1):
+    """lpi_gemm_nt_grouped: two GEMMs (the two towers' projections of one layer, model.py:172-177) in ONE persistent launch give the
+    same bits as two lpi_gemm_nt launches, for every epilogue kind, and the grouped path really ran (lpi_gemm_last_grouped)."""
+    probs = []
+    for i, (tm, N, K) in enumerate(((tm0, N0, K0), (tm1, N1, K1))):
+        M = tm * 256
+        probs.append(dict(M=M, N=N, K=K, a=rnd(M, K, seed=10 + i).bfloat16().to(DEV), b=rnd(N, K, seed=20 + i, scale=0.05).bfloat16().to(DEV),
+                          bias=rnd(N, seed=30 + i).to(DEV), res16=(rnd(M, N, seed=40 + i) * 4).half().to(DEV),
+                          u0=rnd(M, N, seed=50 + i).bfloat16().to(DEV)))
+
+    def run(kind, grouped):
+        outs, descs = [], []
+        for p in probs:
+            M, N = p["M"], p["N"]
+            d = dict(M=M, N=N, K=p["K"], a=p["a"], b=p["b"])
+            if kind == "plain":
+                d.update(c=torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), bias=p["bias"])
+            elif kind == "f32out":
+                d.update(c=torch.zeros(M, N, device=DEV, dtype=torch.float32), bias=p["bias"])
+            elif kind == "f16res":
+                d.update(c=torch.zeros(M, N, device=DEV, dtype=torch.float16), bias=p["bias"], residual=p["res16"])
+            elif kind == "gelu":
+                d.update(c=torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), bias=p["bias"], aux=torch.zeros(M, N, device=DEV, dtype=torch.bfloat16))
+            elif kind == "dgelu":
+                d.update(c=torch.zeros(M, N, device=DEV, dtype=torch.bfloat16), aux=p["u0"])
+            descs.append(d)
+        epi = {"gelu": E.EPI_QUICKGELU, "dgelu": E.EPI_DQUICKGELU}.get(kind, E.EPI_NONE)
+        alpha = 0.5 if kind == "plain" else 1.0
+        if grouped:
+            cdt = {torch.bfloat16: BF16, torch.float32: F32, torch.float16: F16}[descs[0]["c"].dtype]
+            assert _lib.gemm_grouped(BF16, cdt, epi, alpha, descs, stream()), "fell back to separate launches"
+        else:
+            for d in descs:
+                E.gemm(BF16, d["a"], d["b"], d["c"], d["M"], d["N"], d["K"], bias=d.get("bias"), residual=d.get("residual"), epi=epi,
+                       aux=d.get("aux"), alpha=alpha)
+        torch.cuda.synchronize()
+        for d in descs:
+            outs.append(d["c"])
+            if kind == "gelu":
+                outs.append(d["aux"])
+        return outs
+
+    for kind in ("plain", "f32out", "f16res", "gelu", "dgelu"):
+        n0 = _lib.launch_count()
+        g = run(kind, True)
+        assert _lib.launch_count() - n0 == 1, kind
+        s = run(kind, False)
+        for x, y in zip(g, s):
+            assert torch.equal(x, y), kind
+    p = probs[1]
+    ref = 0.5 * (p["a"].double().cpu() @ p["b"].double().cpu().t()) + p["bias"].double().cpu()
+    assert relerr(run("plain", True)[1], ref) < TOL[BF16]
+    # key 8 != 0: never grouped (A/B switch) -> two launches
+    call("lpi_set_tuning", 8, 1)
+    try:
+        d = [dict(M=p["M"], N=p["N"], K=p["K"], a=p["a"], b=p["b"], c=torch.zeros(p["M"], p["N"], device=DEV, dtype=torch.bfloat16)) for p in probs]
+        assert not _lib.gemm_grouped(BF16, BF16, E.EPI_NONE, 1.0, d, stream())
+    finally:
+        call("lpi_set_tuning", 8, 0)
+
+
+def test_gemm_grouped_f16_operands_and_fallback():
+    """f16 operand mode through the grouped launch; shapes the 256x256 kernel does not take fall back to separate launches (same bits)."""
+    probs = []
+    for i, (M, N, K) in enumerate(((256 * 70, 768, 768), (256 * 20, 512, 512))):
+        probs.append(dict(M=M, N=N, K=K, a=rnd(M, K, seed=60 + i).half().to(DEV), b=rnd(N, K, seed=70 + i, scale=0.05).half().to(DEV),
+                          c=torch.zeros(M, N, device=DEV, dtype=torch.float16), bias=rnd(N, seed=80 + i).to(DEV)))
+    assert _lib.gemm_grouped(F16, F16, E.EPI_NONE, 1.0, probs, stream())
+    torch.cuda.synchronize()
+    for p in probs:
+        c = torch.zeros_like(p["c"])
+        E.gemm(F16, p["a"], p["b"], c, p["M"], p["N"], p["K"], bias=p["bias"])
+        assert torch.equal(c, p["c"])
+        assert relerr(c, p["a"].double().cpu() @ p["b"].double().cpu().t() + p["bias"].double().cpu()) < 2e-3
+    small = [dict(M=128, N=128, K=64, a=rnd(128, 64, seed=1).bfloat16().to(DEV), b=rnd(128, 64, seed=2).bfloat16().to(DEV),
+                  c=torch.zeros(128, 128, device=DEV, dtype=torch.bfloat16)) for _ in range(2)]
+    assert not _lib.gemm_grouped(BF16, BF16, E.EPI_NONE, 1.0, small, stream())
+    torch.cuda.synchronize()
+    assert relerr(small[1]["c"], small[1]["a"].double().cpu() @ small[1]["b"].double().cpu().t()) < TOL[BF16]
+
+
 # ---------------------------------------------------------------------------------------------------------------- round 2 kernels
 @pytest.mark.parametrize("n,r0,nloc", [(6, 2, 3), (256, 128, 128), (300, 44, 256)])
 def test_clip_loss_local_rows(n, r0, nloc):
