@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="run the two towers on two HIP streams (was +6.6 %% with the first kernels; -0.7 %% with the final ones: A/B switch)")
     ap.add_argument("--no-overlap", action="store_true", help="accepted for older command lines: one stream is the default")
+    ap.add_argument("--no-lockstep", action="store_true",
+                    help="run the towers one after the other instead of in lock step with grouped GEMM launches (A/B switch; same bits)")
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
@@ -184,10 +186,11 @@ class Workload:
         if self.fwd_only:
             with torch.no_grad():
                 forward_loss(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange.gather if self.exchange else None,
-                             overlap_towers=self.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes)
+                             overlap_towers=self.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes,
+                             lockstep=not a.no_lockstep)
         else:
             train_step(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange, overlap_towers=self.overlap,
-                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes)
+                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes, lockstep=not a.no_lockstep)
             self.opt.step()
 
     def run(self, steps, warmup, sync):

@@ -134,6 +134,97 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
         prof.append((e0, e1, 2.0 * mr * N * K, nbytes, kind))
 
 
+class GemmReq:
+    """A GEMM a tower wants issued: the towers' forward / backward are generators that YIELD their GEMMs instead of launching them, so
+    that a driver (run_lockstep) can launch the vision and the text tower's GEMM of the same layer op as ONE grouped launch
+    (lpi_gemm_nt_grouped).  `tag` names the op ("3.qkv", "last.kv", ...): only requests with equal tags are paired; None = never."""
+    __slots__ = ("tag", "dt", "a", "b", "c", "M", "N", "K", "kw")
+
+    def __init__(self, tag, dt, a, b, c, M, N, K, **kw):
+        self.tag, self.dt, self.a, self.b, self.c, self.M, self.N, self.K, self.kw = tag, dt, a, b, c, M, N, K, kw
+
+    def issue(self):
+        gemm(self.dt, self.a, self.b, self.c, self.M, self.N, self.K, **self.kw)
+
+
+def _cdt(c):
+    return F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
+
+
+# LPI_GROUP_TOWERS=0: the towers' GEMMs are never grouped (A/B switch; the library knob is lpi_set_tuning(8, 1))
+GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
+
+
+def _issue_pair(r0: GemmReq, r1: GemmReq):
+    """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
+    kind), else two launches — the same bits either way."""
+    k0, k1 = r0.kw, r1.kw
+    same = (GROUP_TOWERS and r0.dt == r1.dt and r0.dt != F32 and r0.c.dtype == r1.c.dtype and k0.get("epi", EPI_NONE) == k1.get("epi", EPI_NONE)
+            and (k0.get("residual") is None) == (k1.get("residual") is None) and (k0.get("aux") is None) == (k1.get("aux") is None)
+            and (k0.get("bias") is None) == (k1.get("bias") is None) and k0.get("alpha", 1.0) == k1.get("alpha", 1.0)
+            and min(r0.M, r1.M) > 256)
+    if not same:
+        r0.issue()
+        r1.issue()
+        return
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    probs = [dict(M=r.M, N=r.N, K=r.K, a=r.a, b=r.b, c=r.c, bias=r.kw.get("bias"), residual=r.kw.get("residual"), aux=r.kw.get("aux"))
+             for r in (r0, r1)]
+    _lib.gemm_grouped(r0.dt, _cdt(r0.c), k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, _stream())
+    if prof is not None:
+        e1.record()
+        fl = nb = 0.0
+        for r in (r0, r1):
+            mr = r.kw.get("m_real") or r.M
+            res, aux = r.kw.get("residual"), r.kw.get("aux")
+            fl += 2.0 * mr * r.N * r.K
+            nb += (mr * r.K + r.N * r.K) * r.a.element_size() + mr * r.N * (r.c.element_size() + (res.element_size() if res is not None else 0)
+                                                                         + (aux.element_size() if aux is not None else 0))
+        prof.append((e0, e1, fl, nb, int(_lib.load().lpi_gemm_last_kernel())))
+
+
+def run_alone(gen):
+    """Drive one tower generator: every GEMM it yields is launched at once.  Returns the generator's return value."""
+    try:
+        while True:
+            next(gen).issue()
+    except StopIteration as e:
+        return e.value
+
+
+def run_lockstep(g0, g1):
+    """Drive two tower generators in lock step: requests with EQUAL tags are issued as a pair (_issue_pair); an untagged request is
+    issued alone and only its tower advances; two different tags are issued one after the other.  Returns both return values."""
+    gens, cur, done, ret = [g0, g1], [None, None], [False, False], [None, None]
+
+    def adv(i):
+        try:
+            cur[i] = next(gens[i])
+        except StopIteration as e:
+            cur[i], done[i], ret[i] = None, True, e.value
+
+    adv(0)
+    adv(1)
+    while not (done[0] and done[1]):
+        for i in (0, 1):                 # untagged requests (and a tower whose partner has finished) run alone
+            while not done[i] and (cur[i].tag is None or done[1 - i]):
+                cur[i].issue()
+                adv(i)
+        if done[0] or done[1]:
+            continue
+        if cur[0].tag == cur[1].tag:
+            _issue_pair(cur[0], cur[1])
+        else:
+            cur[0].issue()
+            cur[1].issue()
+        adv(0)
+        adv(1)
+    return ret[0], ret[1]
+
+
 @dataclass
 class TowerSpec:
     width: int
@@ -230,8 +321,8 @@ class Tower:
         return ws
 
     # ------------------------------------------------------------------ forward
-    def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
-        """Runs the blocks over ws['x'][0]; returns the POOLED rows of the output residual stream, [Bp, d] f32: row b is token
+    def forward_gen(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
+        """GENERATOR (see GemmReq): runs the blocks over ws['x'][0], yielding its GEMMs; returns the POOLED rows of the output residual stream, [Bp, d] f32: row b is token
         pool_idx[b] of sample b (None: token 0 = CLS).  Only those rows are ever read by the heads (model.py:255,
         prompt_learner.py:61), so the last block's MLP is evaluated on them alone.
 
@@ -255,35 +346,39 @@ class Tower:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
-                gemm(dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
+                yield GemmReq(f"{i}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
                 call("lpi_pool_ln_fwd", dt, xdt, B, L, d, x_in, pool_idx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
-                gemm(dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
+                yield GemmReq(None, dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
                 call("lpi_attn_pooled_fwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
                 call("lpi_gather_rows", xdt, B, L, d, x_in, pool_idx, ws["c_xin"], s)
-                gemm(dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
+                yield GemmReq(None, dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
                 call("lpi_pool_ln_fwd", dt, F32, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
-                gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
-                gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            gemm(dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
+            yield GemmReq(f"{i}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
-            gemm(dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
+            yield GemmReq(f"{i}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 call("lpi_gather_rows", xdt, B, L, d, xmid, pool_idx, ws["c_xmid"], s)
                 call("lpi_pool_ln_fwd", dt, xdt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
-                gemm(dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
-                gemm(dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             call("lpi_layernorm_fwd", dt, xdt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
-            gemm(dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            gemm(dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
+            yield GemmReq(f"{i}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
+            yield GemmReq(f"{i}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, L, d, x_out, pool_idx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 
+    def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
+        """forward_gen driven alone: every GEMM launched as it is yielded."""
+        return run_alone(self.forward_gen(ws, prompts, prompt_bstride, depth, train, pool_idx))
+
     # ------------------------------------------------------------------ backward (dgrad only)
-    def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
-        """ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
+    def backward_gen(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
+        """GENERATOR (see GemmReq).  ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
         dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
         sp, dt, xdt, s = self.spec, self.gdt, self.xdt, _stream()        # dt: the BACKWARD's operand / storage type from here on
         adt = F16 if self.dt == F16 else dt       # attention backward: F16 = "saved q, k, v, ctx are fp16; gradients and operands bf16"
@@ -305,8 +400,8 @@ class Tower:
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 c_dx = ws["c_dx"]
                 c_dxT = ws["c_dxT"] if dt != F32 else c_dx
-                gemm(dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
-                gemm(dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
+                yield GemmReq(None, dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(None, dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, 1, s)
                 if not POOLED_ATTN:
@@ -315,11 +410,11 @@ class Tower:
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
-                gemm(dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
+                yield GemmReq(None, dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
                 call("lpi_attn_pooled_bwd", adt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
                      dqkv, 3 * d, int(sp.causal), s)
-                gemm(dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
-                gemm(dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
+                yield GemmReq(f"{i}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
+                yield GemmReq(None, dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
                 call("lpi_scatter_add_rows", dt, B, L, d, ws["c_dh"], d, pool_idx, dh, d, s)
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
                 # path of the pooled rows is added
@@ -331,11 +426,11 @@ class Tower:
                 continue
             if not (i == len(self.blocks) - 1 and POOLED_LAST):
                 du = ws["du"]
-                gemm(dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
-                gemm(dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
+                yield GemmReq(f"{i}.dproj", dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
+                yield GemmReq(f"{i}.dfc", dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
-            gemm(dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
+            yield GemmReq(f"{i}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd", adt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
                 # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
@@ -343,16 +438,20 @@ class Tower:
                 # path of those rows is already in the stream; every other row of it is left without this block's attention term.
                 pq, ph = ws["p_dqkv"], ws["p_dh"]
                 call("lpi_gather_batch_rows", dt, B, L, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
-                gemm(dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
+                yield GemmReq(f"{i}.dqkv_p", dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
                 call("lpi_layernorm_bwd_rows", dt, dt, xdt, B, L, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                      None if dt == F32 else dxT, d, 1, s)
                 continue
-            gemm(dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
+            yield GemmReq(f"{i}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, 1, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
                 call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
         return dxT
+
+    def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
+        """backward_gen driven alone."""
+        return run_alone(self.backward_gen(ws, prompts, depth, dprompts, pool_idx))
 
 
 class DualEncoder:
@@ -447,6 +546,11 @@ class DualEncoder:
     def encode_image(self, image, prompts=None, depth=1, train=False, normalise=True, return_ctx=False):
         """image [B,3,R,R] f32 (device) -> features [B,E] f32 (L2-normalised like slinet.py:122 unless normalise=False).
         return_ctx: also return the backward context (held by the autograd node, functional.EncodeImageFn)."""
+        out, ctx = run_alone(self.encode_image_gen(image, prompts, depth, train, normalise))
+        return (out, ctx) if return_ctx else out
+
+    def encode_image_gen(self, image, prompts=None, depth=1, train=False, normalise=True):
+        """GENERATOR form of encode_image (yields its GEMMs, see GemmReq); returns (features, backward context)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
         B = image.shape[0]
         image = image.to(device=self.device, dtype=torch.float32).contiguous()
@@ -461,13 +565,13 @@ class DualEncoder:
                   "pe": torch.zeros(rows, d, device=self.device), "stat": torch.zeros(2, ws["Mp"], device=self.device)}
             ws["front"] = fe
         call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
-        gemm(dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
+        yield GemmReq(None, dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
         call("lpi_vis_assemble_fwd", self.vis.xdt, B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
              ws["x"][0], fe["stat"][0], fe["stat"][1], s)
-        xo = self.vis.forward(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
+        xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        gemm(dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        yield GemmReq(None, dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
@@ -475,11 +579,14 @@ class DualEncoder:
             out.copy_(hw["feat"][:B])
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.vis.serial)
         self._vis_ctx = ctx
-        return (out, ctx) if return_ctx else out
+        return out, ctx
 
     def encode_image_backward(self, dout, ctx=None):
         """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch.
         ctx: the context encode_image(return_ctx=True) returned (default: the engine's last forward)."""
+        return run_alone(self.encode_image_backward_gen(dout, ctx))
+
+    def encode_image_backward_gen(self, dout, ctx=None):
         cfg, dt, s = self.cfg, self.gdt, _stream()         # the backward's operand / storage type
         ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._vis_ctx
         self._stale(self.vis, serial, "encode_image_backward")
@@ -491,14 +598,14 @@ class DualEncoder:
         if dt != F32:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
-        gemm(dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        yield GemmReq(None, dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
         call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
              ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
-        self.vis.backward(ws, pr, depth, dpr, None)
+        yield from self.vis.backward_gen(ws, pr, depth, dpr, None)
         call("lpi_vis_assemble_bwd", dt, B, cfg.n_patches, P, d, ws["dx"] if dt == F32 else ws["dxT"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
              ws["front"]["stat"][1], dpr[0], s)
         return dpr
@@ -507,6 +614,11 @@ class DualEncoder:
     def encode_text(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True, return_ctx=False):
         """ids [B,77] int64 (device).  prompts as in encode_image; row 0 of the prompt stack is the ctx spliced over
         positions 1..n_ctx (slinet.py:130, prompt_learner.py:155-163); use_ctx=False = extract_vector (:118-126)."""
+        out, ctx = run_alone(self.encode_text_gen(ids, prompts, depth, train, use_ctx, normalise))
+        return (out, ctx) if return_ctx else out
+
+    def encode_text_gen(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True):
+        """GENERATOR form of encode_text; returns (features, backward context)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
         B, L = ids.shape
         ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
@@ -521,9 +633,9 @@ class DualEncoder:
         call("lpi_eot_index", B, L, ids, hw["idx"], s)
         ctx = pr if (pr is not None and use_ctx) else None
         call("lpi_txt_embed_fwd", self.txt.xdt, B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
-        xo = self.txt.forward(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
+        xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        gemm(dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        yield GemmReq(None, dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
@@ -531,9 +643,12 @@ class DualEncoder:
             out.copy_(hw["feat"][:B])
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial)
         self._txt_ctx = ctx
-        return (out, ctx) if return_ctx else out
+        return out, ctx
 
     def encode_text_backward(self, dout, ctx=None):
+        return run_alone(self.encode_text_backward_gen(dout, ctx))
+
+    def encode_text_backward_gen(self, dout, ctx=None):
         cfg, dt, s = self.cfg, self.gdt, _stream()         # the backward's operand / storage type
         ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._txt_ctx
         self._stale(self.txt, serial, "encode_text_backward")
@@ -545,16 +660,29 @@ class DualEncoder:
         if dt != F32:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
-        gemm(dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        yield GemmReq(None, dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
         call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_final[0], hw["stat"][0], hw["stat"][1],
              ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
-        self.txt.backward(ws, pr, depth, dpr, hw["idx"])
+        yield from self.txt.backward_gen(ws, pr, depth, dpr, hw["idx"])
         call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
+
+
+    # ------------------------------------------------------------------ both towers in lock step
+    def encode_both(self, image, ids, vis_prompts=None, txt_prompts=None, depth=1, train=False):
+        """encode_image and encode_text with the two towers' GEMMs of the same layer op issued as ONE grouped launch
+        (lpi_gemm_nt_grouped: the text tower's tiles fill the vision tower's partial last round of CUs).  The towers are independent
+        (slinet.py:121-133 runs them one after the other), every kernel is the one encode_image / encode_text launch, so the results are
+        the same bits.  Returns ((img_f, vis_ctx), (txt_f, txt_ctx))."""
+        return run_lockstep(self.encode_image_gen(image, vis_prompts, depth, train), self.encode_text_gen(ids, txt_prompts, depth, train))
+
+    def encode_both_backward(self, dimg, dtxt, vis_ctx, txt_ctx):
+        """The two backward passes in lock step -> (dL/d vis prompts, dL/d txt prompts)."""
+        return run_lockstep(self.encode_image_backward_gen(dimg, vis_ctx), self.encode_text_backward_gen(dtxt, txt_ctx))
 
 
 def trim_token_ids(ids):

@@ -70,6 +70,36 @@ class EncodeTextFn(torch.autograd.Function):
         return None, None, dpr, None
 
 
+class EncodeBothFn(torch.autograd.Function):
+    """EncodeImageFn and EncodeTextFn as ONE node: the two independent towers (slinet.py:121-133) run in lock step so that their GEMMs
+    of the same layer op go out as one grouped launch (engine.DualEncoder.encode_both), forward and backward.  Same kernels, same bits
+    as the two separate nodes."""
+
+    @staticmethod
+    def forward(ctx, enc, image, ids, vis_prompts, txt_prompts, depth):
+        ctx.enc = enc
+        ctx.vshape, ctx.tshape = vis_prompts.shape, txt_prompts.shape
+        train = vis_prompts.requires_grad or txt_prompts.requires_grad
+        (img_f, ctx.lpi_v), (txt_f, ctx.lpi_t) = enc.encode_both(image, ids, vis_prompts.detach(), txt_prompts.detach(), depth, train=train)
+        return img_f, txt_f
+
+    @staticmethod
+    def backward(ctx, g_img, g_txt):
+        if g_img is None:
+            g_img = torch.zeros_like(ctx.lpi_v[7])
+        if g_txt is None:
+            g_txt = torch.zeros_like(ctx.lpi_t[7])
+        dv, dt = ctx.enc.encode_both_backward(g_img, g_txt, ctx.lpi_v, ctx.lpi_t)
+        outs = []
+        for dpr, shape in ((dv, ctx.vshape), (dt, ctx.tshape)):
+            if len(shape) == 4:     # stride-0 expanded [B,Lyr,P,d] view: autograd sums the broadcast itself
+                full = torch.zeros(shape, device=dpr.device)
+                full[0] = dpr
+                dpr = full
+            outs.append(dpr)
+        return None, None, None, outs[0], outs[1], None
+
+
 class ClipLossFn(torch.autograd.Function):
     """logit_scale * I @ T^T then ClipLoss (slinet.py:138-141, loss/loss.py:75-87).  With a process group the
     features are all-gathered first (dp.py) and every rank evaluates the full global loss (``local_loss=False``

@@ -8,12 +8,12 @@ from __future__ import annotations
 
 import torch
 
-from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeImageFn, EncodeTextFn
+from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeBothFn, EncodeImageFn, EncodeTextFn
 from .synth import PROMPT_NAMES
 
 
-def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = True,
-                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None):
+def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = False,
+                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True):
     """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
     Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits).
 
@@ -68,6 +68,9 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
             main.wait_stream(enc.lane(li).stream)
         img_f = outs["v"][0] if nv == 1 else torch.cat(outs["v"])
         txt_f = outs["t"][0] if ntx == 1 else torch.cat(outs["t"])
+    elif lockstep:
+        # one stream, the towers in lock step: their GEMMs of the same layer op go out as ONE grouped persistent launch
+        img_f, txt_f = EncodeBothFn.apply(enc, images, ids, vis, txt, depth)
     else:
         img_f = EncodeImageFn.apply(enc, images, vis, depth)
         txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
@@ -77,8 +80,8 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
     return losses, img_f, txt_f, vis, txt
 
 
-def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = True,
-               vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None):
+def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = False,
+               vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True):
     """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
 
     exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
@@ -87,7 +90,7 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
         factors[k].grad = None
     gather = exchange.gather if exchange is not None else None
     losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
-                                                  cu_lanes)
+                                                  cu_lanes, lockstep)
     world = exchange.world if exchange is not None else 1
     total = losses["base_loss"] + losses["alignment_loss"] / world
     total.backward()

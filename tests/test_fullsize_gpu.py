@@ -257,6 +257,34 @@ def test_throughput_modes_train_step_at_the_benchmarked_configuration(enc32, dat
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_lockstep_towers_with_grouped_gemm_launches_equal_the_sequential_towers(data, mode):
+    """The default step runs the two towers in lock step and issues their GEMMs of the same layer op as ONE grouped persistent launch
+    (lpi_gemm_nt_grouped; engine.run_lockstep).  Same kernels on the same operands: features, losses and factor gradients are the same
+    BITS as with the towers one after the other (slinet.py:121-133's order), and the grouped path really ran (fewer launches)."""
+    from lpi_amd import _lib
+    from lpi_amd.engine import trim_token_ids
+    img, _ = data
+    ids_t = torch.from_numpy(np.ascontiguousarray(trim_token_ids(synth.token_ids(B)))).to(DEV)
+    enc = DualEncoder(CFG, synth.clip_state_dict(CFG), dtype=mode, device=DEV)
+    res = {}
+    for lock in (True, False):
+        fac = factors()
+        n0 = _lib.launch_count()
+        out = train_step(enc, img, ids_t, fac, 3, lockstep=lock)
+        torch.cuda.synchronize()
+        res[lock] = ({k: v.clone() for k, v in out.items()}, {k: fac[k].grad.clone() for k in synth.PROMPT_NAMES}, _lib.launch_count() - n0)
+    for k in ("img_f", "txt_f", "base_loss", "alignment_loss"):
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    for k in synth.PROMPT_NAMES:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    saved = res[False][2] - res[True][2]
+    print(f"{mode}: {res[False][2]} launches sequential, {res[True][2]} in lock step ({saved} GEMM launches merged)")
+    assert saved >= 8 * (CFG.vision_layers - 2), saved
+    del enc
+    torch.cuda.empty_cache()
+
+
 def test_eval_shard_at_vitb16_size_matches_reference(golden):
     """north_star: 'R@1 indices bit-identical to reference on a fixed synthetic shard'.  The reference's whole evaluation
     (sprompt.py:433-646: task ids by L1 distance to keys, per-sample prompted features, N_img x N_txt score matrix, per-row rank of the

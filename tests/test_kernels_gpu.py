@@ -615,7 +615,7 @@ def test_gemm_grouped_launch_equals_separate_launches(tm0, N0, K0, tm1, N1, K1):
 def test_gemm_grouped_f16_operands_and_fallback():
     """f16 operand mode through the grouped launch; shapes the 256x256 kernel does not take fall back to separate launches (same bits)."""
     probs = []
-    for i, (M, N, K) in enumerate(((256 * 70, 768, 768), (256 * 20, 512, 512))):
+    for i, (M, N, K) in enumerate(((256 * 90, 768, 768), (256 * 20, 512, 512))):
         probs.append(dict(M=M, N=N, K=K, a=rnd(M, K, seed=60 + i).half().to(DEV), b=rnd(N, K, seed=70 + i, scale=0.05).half().to(DEV),
                           c=torch.zeros(M, N, device=DEV, dtype=torch.float16), bias=rnd(N, seed=80 + i).to(DEV)))
     assert _lib.gemm_grouped(F16, F16, E.EPI_NONE, 1.0, probs, stream())
