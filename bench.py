@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="accepted for older command lines: one stream is the default")
     ap.add_argument("--no-lockstep", action="store_true",
                     help="run the towers one after the other instead of in lock step with grouped GEMM launches (A/B switch; same bits)")
+    ap.add_argument("--no-text-pack", action="store_true",
+                    help="cut the text batch at the LONGEST caption only instead of packing every caption at its own length (A/B switch)")
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
@@ -157,7 +159,7 @@ class Workload:
         import numpy as np
         import torch
         from lpi_amd import synth
-        from lpi_amd.engine import DualEncoder, trim_token_ids
+        from lpi_amd.engine import DualEncoder, PackedIds, trim_token_ids
         self.a, self.dev, self.dtype, self.fwd_only, self.exchange = a, dev, dtype, fwd_only, exchange
         self.cfg = cfg = synth.CONFIGS[a.model]
         self.enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=dev)
@@ -168,6 +170,11 @@ class Workload:
             # token columns behind the longest caption's EOT are dead under the causal mask (engine.trim_token_ids): not computed
             ids_host = np.ascontiguousarray(trim_token_ids(ids_host))
         self.ids = torch.from_numpy(ids_host).to(dev)
+        self.text_rows = float(self.ids.shape[1])
+        if not (a.no_text_trim or a.no_text_pack):
+            # ... and so are the rows behind every caption's OWN EOT (engine.PackedIds: the text batch packed, one row per live token)
+            self.ids = PackedIds(ids_host).to(dev)
+            self.text_rows = self.ids.rows / B
         self.fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not fwd_only)
                     for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
         self.opt = torch.optim.SGD(list(self.fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
@@ -378,7 +385,7 @@ def main():
                        + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r={a.rank} P=16, "
                        + ("fwd-only + cosine matrix" if a.fwd_only else "fwd+bwd incl. DecomposedPrompt grads + SGD step"),
                        "global_batch": world * B, "image": f"{cfg.image_resolution}x{cfg.image_resolution}", "tokens": cfg.context_length,
-                       "text_rows_computed": int(wl.ids.shape[1]),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
+                       "text_rows_computed": round(wl.text_rows, 2),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
                        "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
                        "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "

@@ -151,6 +151,39 @@ int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q, int ldq, 
                         const void* dctx, int lddctx, const float* lse, void* dq, int lddq, void* dqkv, int lddqkv, int causal,
                         void* stream);
 
+/* ---- RAGGED batches (`_varlen`): samples of different lengths packed back to back --------------------------------------------
+ * The text tower is causal and read at the EOT token only (model.py:347-353, prompt_learner.py:61), so the token rows BEHIND a
+ * sample's own EOT can reach neither its feature nor any gradient: the reference computes them (every caption is padded to 77
+ * tokens, clip.py:185-221) and throws them away.  Here a batch may be packed: sample b owns rows row_start[b] .. row_start[b+1]-1 of
+ * every [rows, *] array (row_start: B + 1 int32 on the device, ascending; L_b = row_start[b+1] - row_start[b] <= L).  `L` stays the
+ * MAXIMUM length (launch geometry, the [B, H, L] layout of lse / delta, the [B, L] layout of ids).  row_start == NULL is exactly the
+ * function without the suffix (row(b, l) = b*L + l).  Row-wise kernels (LayerNorm, GEMM) need no variant: they see sum_b L_b rows.
+ * Kernels that take a per-sample token index `idx` (lpi_pool_ln_fwd/bwd, lpi_gather_rows, lpi_scatter_rows, lpi_scatter_add_rows)
+ * accept L == 0, which makes idx[b] an ABSOLUTE row index (= row_start[b] + token). */
+int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                        float* lse, int causal, void* stream);
+int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
+                        const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
+                        int causal, void* stream);
+/* idx[b] stays the token index WITHIN sample b (the causal limit) */
+int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
+                               const int32_t* idx, void* ctx, int ldctx, float* lse, int causal, void* stream);
+int lpi_attn_pooled_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
+                               const int32_t* idx, const void* dctx, int lddctx, const float* lse, void* dq, int lddq, void* dqkv,
+                               int lddqkv, int causal, void* stream);
+int lpi_layernorm_bwd_rows_varlen(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, const int32_t* row_start, int row0, int P, int d,
+                                  const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                                  float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
+int lpi_gather_batch_rows_varlen(int dtype, int B, int L, const int32_t* row_start, int row0, int P, int cols, const void* src, int ld_src,
+                                 void* dst, int ld_dst, void* stream);
+int lpi_rows_sum_over_batch_varlen(int dtype, int B, int L, const int32_t* row_start, int row0, int P, int d, const void* dx, float* out,
+                                   int accumulate, void* stream);
+int lpi_prompt_add_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, void* x, const float* prompt_l, long prompt_bstride,
+                          void* stream);
+/* ids stays the padded [B, L] matrix (clip.tokenize's output); tokens l >= L_b of sample b are not embedded */
+int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
+                             const float* pos, const float* ctx, long ctx_bstride, void* x0, void* stream);
+
 /* ---- a1: DecomposedPrompt                          replaces: models/prompts/prompts.py:38-57 -----------
  * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout; scratch: Lyr*P*r floats. */
 int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,

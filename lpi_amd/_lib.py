@@ -47,6 +47,16 @@ SIGNATURES = {
     "lpi_attn_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
+    # ragged (packed) batches: the same kernels with a row_start array (NULL = uniform length L)
+    "lpi_attn_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "lpi_attn_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
+    "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
+    "lpi_layernorm_bwd_rows_varlen": [_I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
+    "lpi_gather_batch_rows_varlen": [_I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "lpi_rows_sum_over_batch_varlen": [_I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P],
+    "lpi_prompt_add_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _L, _P],
+    "lpi_txt_embed_fwd_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _L, _P, _P],
     "lpi_scatter_add_rows": [_I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "lpi_prompt_cp_fwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P],
     "lpi_prompt_cp_bwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P],

@@ -193,12 +193,22 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                       T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    int L = Lmax, Lp = Lpmax;
+    size_t row0 = (size_t)b * Lmax;
+    if (rs) {
+        const int r = rs[b];
+        row0 = (size_t)r;
+        L = rs[b + 1] - r;
+        Lp = (L + 31) / 32 * 32;
+    }
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
-    const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
+    const T* qg = qkv + row0 * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -290,13 +300,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
                 f32x4 os[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) os[dt] = o[j][dt] * inv;
-                store_row16_t<T>(ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
-                if (qrow[j] < L && g == 0) lse[((size_t)b * H + h) * L + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
+                store_row16_t<T>(ctx + (row0 + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
+                if (qrow[j] < L && g == 0) lse[lse0 + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
             } else if (qrow[j] < L) {
-                T* dst = ctx + ((size_t)b * L + qrow[j]) * ldctx + h * HD + 4 * g;
+                T* dst = ctx + (row0 + qrow[j]) * ldctx + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, o[j][dt] * inv);
-                if (g == 0) lse[((size_t)b * H + h) * L + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
+                if (g == 0) lse[lse0 + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
             }
         }
     }
@@ -304,14 +314,24 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int L, int Lp, int H, con
 
 // ------------------------------------------------------------------------------------------------ backward A
 template <typename T, bool CAUSAL, bool SV16 = false>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                          const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                          const float* __restrict__ lse, float* __restrict__ delta,
                                                          T* __restrict__ dqkv, int lddqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    int L = Lmax, Lp = Lpmax;
+    size_t row0 = (size_t)b * Lmax;
+    if (rs) {
+        const int r = rs[b];
+        row0 = (size_t)r;
+        L = rs[b + 1] - r;
+        Lp = (L + 31) / 32 * 32;
+    }
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
-    const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
+    const T* qg = qkv + row0 * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
     stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
         for (int j = 0; j < NB; ++j) {
             qrow[j] = q0 + 16 * j + (lane & 15);
             const bool valid = qrow[j] < L;
-            const size_t grow = (size_t)b * L + qrow[j];
+            const size_t grow = row0 + qrow[j];
             load_row_chunks<T, SV16>(q[j], qg, qrow[j], ldqkv, g, valid);
             load_row_chunks<T>(dO[j], dctx + h * HD, grow, lddctx, g, valid);
             Chunk oc[AT<T>::KS];
@@ -349,8 +369,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
                 }
             }
             dl = group_sum(dl);
-            lq[j] = valid ? lse[((size_t)b * H + h) * L + qrow[j]] * LOG2E : INFINITY;     // padded queries -> P = 0
-            if (valid && g == 0) delta[((size_t)b * H + h) * L + qrow[j]] = dl;
+            lq[j] = valid ? lse[lse0 + qrow[j]] * LOG2E : INFINITY;     // padded queries -> P = 0
+            if (valid && g == 0) delta[lse0 + qrow[j]] = dl;
             dls[j] = dl * SCALE;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -389,9 +409,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
             } else if (qrow[j] < L) {
-                T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
@@ -401,13 +421,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int L, int Lp, int H, 
 
 // ------------------------------------------------------------------------------------------------ backward B
 template <typename T, bool CAUSAL, bool SV16 = false>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ dctx, int lddctx, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    int L = Lmax, Lp = Lpmax;
+    size_t row0 = (size_t)b * Lmax;
+    if (rs) {
+        const int r = rs[b];
+        row0 = (size_t)r;
+        L = rs[b + 1] - r;
+        Lp = (L + 31) / 32 * 32;
+    }
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
-    const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
+    const T* qg = qkv + row0 * ldqkv + h * HD;
     char* q_lds = smem;
     char* do_lds = smem + Lp * AT<T>::RS;
     float* lse_lds = reinterpret_cast<float*>(smem + 2 * Lp * AT<T>::RS);
@@ -421,10 +451,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
         load_row_chunks<T, SV16>(kk[j], qg + dm, kr, ldqkv, g, kr < L);
         load_row_chunks<T, SV16>(vv[j], qg + 2 * dm, kr, ldqkv, g, kr < L);
     }
-    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
-        lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;  // padded queries -> P = 0
-        dl_lds[i] = i < L ? delta[((size_t)b * H + h) * L + i] * SCALE : 0.f;
+        lse_lds[i] = i < L ? lse[lse0 + i] * LOG2E : INFINITY;  // padded queries -> P = 0
+        dl_lds[i] = i < L ? delta[lse0 + i] * SCALE : 0.f;
     }
     __syncthreads();
 
@@ -490,11 +520,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + krow[j]) * lddqkv + h * HD;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (row0 + krow[j]) * lddqkv + h * HD;
                 store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
                 store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
             } else if (krow[j] < L) {
-                T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + krow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
@@ -511,14 +541,24 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int L, int Lp, int H,
 // this one moves a third less.  Phase A (queries) produces delta into LDS and dQ; after one barrier phase B (keys) produces
 // dK, dV.  Same tile bodies, same fixed summation order as the two-pass kernels.
 template <typename T, bool CAUSAL, bool SV16 = false>
-__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int H, const T* __restrict__ qkv, int ldqkv,
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
                                                             T* __restrict__ dqkv, int lddqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
+    // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    int L = Lmax, Lp = Lpmax;
+    size_t row0 = (size_t)b * Lmax;
+    if (rs) {
+        const int r = rs[b];
+        row0 = (size_t)r;
+        L = rs[b + 1] - r;
+        Lp = (L + 31) / 32 * 32;
+    }
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
-    const T* qg = qkv + (size_t)b * L * ldqkv + h * HD;
+    const T* qg = qkv + row0 * ldqkv + h * HD;
     const int img = Lp * AT<T>::RS;
     char* q_lds = smem;
     char* k_lds = smem + img;
@@ -527,8 +567,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
     float* lse_lds = reinterpret_cast<float*>(smem + 4 * img);
     float* dl_lds = lse_lds + Lp;
     stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
-    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + (size_t)b * L * lddctx + h * HD, ldqkv, lddctx, L, Lp);
-    for (int i = threadIdx.x; i < Lp; i += blockDim.x) lse_lds[i] = i < L ? lse[((size_t)b * H + h) * L + i] * LOG2E : INFINITY;
+    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    for (int i = threadIdx.x; i < Lp; i += blockDim.x) lse_lds[i] = i < L ? lse[lse0 + i] * LOG2E : INFINITY;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -555,7 +595,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
             lds_row_chunks<T>(q[j], q_lds, qrow[j], g);
             lds_row_chunks<T>(dO[j], do_lds, qrow[j], g);
             Chunk oc[AT<T>::KS];
-            load_row_chunks<T>(oc, ctx + h * HD, (size_t)b * L + qrow[j], ldctx, g, valid);
+            load_row_chunks<T>(oc, ctx + h * HD, row0 + qrow[j], ldctx, g, valid);
             float dl = 0.f;
 #pragma unroll
             for (int ks = 0; ks < AT<T>::KS; ++ks) {
@@ -572,7 +612,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
             dls[j] = dl * SCALE;
             if (g == 0) {
                 dl_lds[qrow[j]] = valid ? dls[j] : 0.f;     // delta * scale, for phase B
-                if (valid) delta[((size_t)b * H + h) * L + qrow[j]] = dl;
+                if (valid) delta[lse0 + qrow[j]] = dl;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -609,9 +649,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
             } else if (qrow[j] < L) {
-                T* dst = dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
@@ -669,11 +709,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int L, int Lp, int 
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + ((size_t)b * L + krow[j]) * lddqkv + h * HD;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (row0 + krow[j]) * lddqkv + h * HD;
                 store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
                 store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
             } else if (krow[j] < L) {
-                T* dst = dqkv + ((size_t)b * L + krow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + krow[j]) * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
@@ -715,20 +755,20 @@ int set_lds(const void* kern, size_t bytes) {
 }
 
 template <typename T, bool CAUSAL>
-int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s) {
+int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)2 * Lp * AT<T>::RS;
     const int thr = 64 * pick_waves(L);
     int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL>, lds);
     if (e) return e;
-    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), lds, s, L, Lp, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
     LPI_CHECK_LAST();
     return 0;
 }
 
 template <typename T, bool CAUSAL, bool SV16 = false>
 int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s) {
+               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
@@ -739,7 +779,7 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     if (sizeof(T) == 2 && ldsF <= 160 * 1024 && g_lpi_tuning[3] == 0) {
         int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL, SV16>, ldsF);
         if (ef) return ef;
-        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
                    (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
         LPI_CHECK_LAST();
         return 0;
@@ -748,10 +788,10 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     if (e) return e;
     e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL, SV16>, ldsB);
     if (e) return e;
-    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
                (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
-    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
+    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
                lse, delta, (T*)dqkv, lddqkv);
     LPI_CHECK_LAST();
     return 0;
@@ -777,43 +817,50 @@ bool lpi_attn3_bwd_ok(int L, int causal);
 int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                   const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16);
 
-extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal,
-                            void* stream) {
+extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                                   float* lse, int causal, void* stream) {
+    const int* rs = row_start;      // ragged batch: the one-head-per-workgroup kernels take a per-sample length
     if (!qkv || !ctx || !lse || bad_attn(dtype, B, L, H, ldqkv) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32)
-        return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+        return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     if (dtype == LPI_F16)       // f16 operand mode: q, k, v and ctx are fp16 (the reference's own arithmetic type)
-        return causal ? fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<f16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+        return causal ? fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<f16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     if (dtype == LPI_BF16) {
         // measured (MI355X, B = 256): the persistent forward is SLOWER than two one-head workgroups per CU (112.7 vs 102.5 us at L = 213:
         // the forward is bound by dependent-chain latency at low occupancy, and 14 waves per CU hide more of it than 7 with DMA
         // double buffering), so it is opt-in (key 7 = 2)
-        if (g_lpi_tuning[7] == 2 && lpi_attn2_fwd_ok(L)) return lpi_attn2_fwd(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, s);
-        return causal ? fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s) : fwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
+        if (!rs && g_lpi_tuning[7] == 2 && lpi_attn2_fwd_ok(L)) return lpi_attn2_fwd(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, s);
+        return causal ? fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     }
     return LPI_EINVAL;
 }
 
-extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx,
-                            int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
+extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal,
+                            void* stream) {
+    return lpi_attn_fwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, lse, causal, stream);
+}
+
+extern "C" int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
+                                   const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
+    const int* rs = row_start;
     if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv) || bad_attn(dtype, B, L, H, lddqkv)) return LPI_EINVAL;
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (ldctx < H * HD || lddctx < H * HD || (ldctx * esz) % 16 || (lddctx * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32)
-        return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
-                      : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
+        return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
+                      : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
     if (dtype == LPI_F16) {     // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
                                 // q, k, v are converted on their way into LDS / registers, or in place after the LDS-DMA (persistent kernel)
-        if (g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
-        if (g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 1);
-        return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
-                      : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
+        return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
+                      : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
     }
     if (dtype == LPI_BF16) {
         // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
@@ -821,12 +868,17 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
         // the single-pass kernel is opt-in (key 7 = 4): 29 % fewer MFMAs and half the exponentials buy nothing (244.7 vs 243.1 us at L = 213,
         // B = 256) — at 7 waves per CU the backward is bound by the latency of its dependent chain (LDS read -> MFMA -> exp -> LDS -> MFMA),
         // not by matrix or vector issue
-        if (g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
-        if (g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 0);
-        return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s)
-                      : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);
+        return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
+                      : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
     }
     return LPI_EINVAL;
+}
+
+extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx,
+                            int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
+    return lpi_attn_bwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, stream);
 }

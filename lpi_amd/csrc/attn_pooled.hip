@@ -26,7 +26,7 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a
 
 template <typename T>
 __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
-    int B, int L, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
     T* __restrict__ ctx, int ldo, float* __restrict__ lse, int causal)
 {
     extern __shared__ float sm[];
@@ -37,10 +37,13 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H, d = H * DH;
     const int row = idx ? idx[b] : 0;
+    // ragged batch (rs = row starts): sample b owns rows rs[b] .. rs[b+1]-1 of qkv
+    const size_t r0 = rs ? (size_t)rs[b] : (size_t)b * Lmax;
+    const int L = rs ? rs[b + 1] - rs[b] : Lmax;
     const int nv = causal ? row + 1 : L;           // keys the query row may attend to
     const int kk = lane >> 4, g = lane & 15;
     const f32x4 q4 = Elem<T>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
-    const T* kbase = qkv + (size_t)b * L * ld + d + h * DH;
+    const T* kbase = qkv + r0 * ld + d + h * DH;
     const T* vbase = kbase + d;
     for (int j0 = wave * 4; j0 < nv; j0 += 4 * WPB) {
         const int j = j0 + kk;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
 // TS: storage type of the SAVED q / qkv (fp16 after an f16-mode forward, else T); dctx, dq, dqkv are T.  All arithmetic is f32.
 template <typename T, typename TS = T>
 __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
-    int B, int L, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
     const T* __restrict__ dctx, int ldo, const float* __restrict__ lse, T* __restrict__ dq, int lddq, T* __restrict__ dqkv, int ldg, int causal)
 {
     extern __shared__ float sm[];
@@ -87,11 +90,13 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
     const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H, d = H * DH;
     const int row = idx ? idx[b] : 0;
+    const size_t r0 = rs ? (size_t)rs[b] : (size_t)b * Lmax;      // ragged batch: see the forward
+    const int L = rs ? rs[b + 1] - rs[b] : Lmax;
     const int nv = causal ? row + 1 : L;
     const int kk = lane >> 4, g = lane & 15;
     const f32x4 q4 = Elem<TS>::ld4(q + (size_t)b * ldq + h * DH + 4 * g);
     const f32x4 o4 = Elem<T>::ld4(dctx + (size_t)b * ldo + h * DH + 4 * g);
-    const TS* kbase = qkv + (size_t)b * L * ld + d + h * DH;
+    const TS* kbase = qkv + r0 * ld + d + h * DH;
     const TS* vbase = kbase + d;
     const float ls = lse[bh];
     for (int j0 = wave * 4; j0 < nv; j0 += 4 * WPB) {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
     __syncthreads();
     const float qd = Elem<TS>::ld(q + (size_t)b * ldq + h * DH + lane);
     const float od = Elem<T>::ld(dctx + (size_t)b * ldo + h * DH + lane);
-    T* dk = dqkv + (size_t)b * L * ldg + d + h * DH + lane;
+    T* dk = dqkv + r0 * ldg + d + h * DH + lane;
     T* dv = dk + d;
     float acc = 0.f;
 #pragma unroll 4
@@ -157,9 +162,10 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int B, int L, int
 
 }  // namespace
 
-extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
-                                   void* ctx, int ldo, float* lse, int causal, void* stream)
+extern "C" int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ld,
+                                          const int* idx, void* ctx, int ldo, float* lse, int causal, void* stream)
 {
+    const int* rs = row_start;
     if (!q || !qkv || !ctx || !lse || B <= 0 || L <= 0 || H <= 0) return LPI_EINVAL;
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (ld < 3 * H * DH || ldq < H * DH || ldo < H * DH || (ld * esz) % 16 || (ldq * esz) % 16) return LPI_EINVAL;
@@ -170,13 +176,13 @@ extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(B * H), block(WAVE * WPB);
     if (dtype == LPI_F32)
-        LPI_LAUNCH((attn_pooled_fwd_kernel<float>), grid, block, lds, s, B, L, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_fwd_kernel<float>), grid, block, lds, s, B, L, rs, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
                    (float*)ctx, ldo, lse, causal);
     else if (dtype == LPI_BF16)
-        LPI_LAUNCH((attn_pooled_fwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_fwd_kernel<bf16_t>), grid, block, lds, s, B, L, rs, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
                    (bf16_t*)ctx, ldo, lse, causal);
     else if (dtype == LPI_F16)
-        LPI_LAUNCH((attn_pooled_fwd_kernel<f16_t>), grid, block, lds, s, B, L, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_fwd_kernel<f16_t>), grid, block, lds, s, B, L, rs, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
                    (f16_t*)ctx, ldo, lse, causal);
     else
         return LPI_ENOSYS;
@@ -184,10 +190,11 @@ extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q
     return 0;
 }
 
-extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
-                                   const void* dctx, int ldo, const float* lse, void* dq, int lddq, void* dqkv, int ldg, int causal,
-                                   void* stream)
+extern "C" int lpi_attn_pooled_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ld,
+                                          const int* idx, const void* dctx, int ldo, const float* lse, void* dq, int lddq, void* dqkv, int ldg,
+                                          int causal, void* stream)
 {
+    const int* rs = row_start;
     if (!q || !qkv || !dctx || !lse || !dq || !dqkv || B <= 0 || L <= 0 || H <= 0) return LPI_EINVAL;
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (ld < 3 * H * DH || ldg < 3 * H * DH || ldq < H * DH || ldo < H * DH || lddq < H * DH) return LPI_EINVAL;
@@ -199,13 +206,13 @@ extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(B * H), block(WAVE * WPB);
     if (dtype == LPI_F32)
-        LPI_LAUNCH((attn_pooled_bwd_kernel<float>), grid, block, lds, s, B, L, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_bwd_kernel<float>), grid, block, lds, s, B, L, rs, H, Lp, (const float*)q, ldq, (const float*)qkv, ld, idx,
                    (const float*)dctx, ldo, lse, (float*)dq, lddq, (float*)dqkv, ldg, causal);
     else if (dtype == LPI_BF16)
-        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t>), grid, block, lds, s, B, L, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t>), grid, block, lds, s, B, L, rs, H, Lp, (const bf16_t*)q, ldq, (const bf16_t*)qkv, ld, idx,
                    (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
     else if (dtype == LPI_F16)      // saved q / qkv are fp16 (f16-mode forward); the gradients in and out are bf16
-        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t, f16_t>), grid, block, lds, s, B, L, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
+        LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t, f16_t>), grid, block, lds, s, B, L, rs, H, Lp, (const f16_t*)q, ldq, (const f16_t*)qkv, ld, idx,
                    (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
     else
         return LPI_ENOSYS;
@@ -213,10 +220,22 @@ extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q
     return 0;
 }
 
+extern "C" int lpi_attn_pooled_fwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
+                                   void* ctx, int ldo, float* lse, int causal, void* stream)
+{
+    return lpi_attn_pooled_fwd_varlen(dtype, B, L, nullptr, H, q, ldq, qkv, ld, idx, ctx, ldo, lse, causal, stream);
+}
+extern "C" int lpi_attn_pooled_bwd(int dtype, int B, int L, int H, const void* q, int ldq, const void* qkv, int ld, const int* idx,
+                                   const void* dctx, int ldo, const float* lse, void* dq, int lddq, void* dqkv, int ldg, int causal,
+                                   void* stream)
+{
+    return lpi_attn_pooled_bwd_varlen(dtype, B, L, nullptr, H, q, ldq, qkv, ld, idx, dctx, ldo, lse, dq, lddq, dqkv, ldg, causal, stream);
+}
+
 extern "C" int lpi_scatter_add_rows(int dtype, int B, int L, int d, const void* src, int ld_src, const int* idx, void* dst, int ld_dst,
                                     void* stream)
 {
-    if (!src || !dst || B <= 0 || L <= 0 || d <= 0 || (d & 3) || ld_src < d || ld_dst < d) return LPI_EINVAL;
+    if (!src || !dst || B <= 0 || L < 0 || (L == 0 && !idx) || d <= 0 || (d & 3) || ld_src < d || ld_dst < d) return LPI_EINVAL;      // L == 0: idx holds absolute rows
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if ((ld_src * esz) % 8 || (ld_dst * esz) % 8 || (((uintptr_t)src | (uintptr_t)dst) & 7)) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;

@@ -98,12 +98,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY*
                                                     const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate,
-                                                    int mapP, int mapL, int map0) {
+                                                    int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
     const int lane = threadIdx.x & 63;
     const int crow = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (crow >= rows) return;
     // row map (mapP != 0): dy is COMPACT [B*P, d]; x / statistics / dx live at row (crow / P) * L + row0 + crow % P of the full stream
-    const int row = mapP ? (crow / mapP) * mapL + map0 + crow % mapP : crow;
+    const int row = mapP ? (map_rs ? map_rs[crow / mapP] : (crow / mapP) * mapL) + map0 + crow % mapP : crow;      // map_rs: ragged batch (row starts)
     RowT<NC> g, xr;
     const TDY* dyr = dy + (size_t)crow * lddy;
     const TX* xp = x + (size_t)row * ldx;
@@ -221,11 +221,11 @@ template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate,
-                                                        int mapP, int mapL, int map0) {
+                                                        int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
     const int hl = threadIdx.x & 31;
     const int crow = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (crow >= rows) return;
-    const int row = mapP ? (crow / mapP) * mapL + map0 + crow % mapP : crow;      // see ln_bwd_kernel
+    const int row = mapP ? (map_rs ? map_rs[crow / mapP] : (crow / mapP) * mapL) + map0 + crow % mapP : crow;      // see ln_bwd_kernel
     Row8<NC> g, xh;
     const bf16_t* dyr = dy + (size_t)crow * lddy;
     const f16_t* xr = x + (size_t)row * ldx;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, 
 // out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic: 16 waves each sum a fixed subset of the batch in order, then
 // the 16 partials are added in order.  Block = (prompt row p, 256-column chunk); lane = one float4 column.
 template <typename TS>
-__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, int P, int d, const TS* __restrict__ dx,
+__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int d, const TS* __restrict__ dx,
                                                        float* __restrict__ out, int accumulate) {
     __shared__ f32x4 part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, 
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (col < d) {
         const TS* src = dx + (size_t)(row0 + p) * d + col;
-        for (int b = wave; b < B; b += 16) s += Elem<TS>::ld4(src + (size_t)b * L * d);
+        for (int b = wave; b < B; b += 16) s += Elem<TS>::ld4(src + (rs ? (size_t)rs[b] : (size_t)b * L) * d);      // rs: ragged batch (row starts)
     }
     part[wave][lane] = s;
     __syncthreads();
@@ -371,43 +371,48 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, int row0, 
 }
 
 // dst[(b*P + p), 0:cols] = src[(b*L + row0 + p), 0:cols]  in 16-byte chunks (cols * sizeof(T) a multiple of 16)
-__global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
+__global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
                                                                uint4* __restrict__ dst, long ldd16) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)B * P * chunks) return;
     const int c = (int)(t % chunks);
     const long r = t / chunks;
-    const long srow = (r / P) * L + row0 + r % P;
+    const long srow = (rs ? (long)rs[r / P] : (r / P) * L) + row0 + r % P;
     dst[r * ldd16 + c] = src[srow * lds16 + c];
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // text front end
 template <typename TX>
-__global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, int P, int d, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int* __restrict__ rs, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
                                                        const float* __restrict__ ctx, long cbs, TX* __restrict__ x0) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, l) over the [B, L] id matrix
     if (row >= B * L) return;
     const int b = row / L, l = row % L;
+    size_t orow = row;
+    if (rs) {                                                  // ragged batch: sample b owns rows rs[b] .. rs[b+1]-1; tokens behind them are not embedded
+        if (l >= rs[b + 1] - rs[b]) return;
+        orow = (size_t)rs[b] + l;
+    }
     const float* src = (ctx && l >= 1 && l <= P) ? ctx + (size_t)b * cbs + (size_t)(l - 1) * d
                                                  : tok + (size_t)ids[row] * d;
     const float* pp = pos + (size_t)l * d;
-    TX* o = x0 + (size_t)row * d;
+    TX* o = x0 + orow * d;
     for_chunks(d, lane, [&](int, int col) {
         Elem<TX>::st4(o + col, *reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col));
     });
 }
 
 template <typename TX>
-__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, int P, int d, TX* __restrict__ x,
+__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
                                                         const float* __restrict__ pr, long pbs) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
     const int b = w / P, p = w % P;
-    TX* xr = x + ((size_t)b * L + 1 + p) * d;
+    TX* xr = x + ((rs ? (size_t)rs[b] : (size_t)b * L) + 1 + p) * d;
     const float* s = pr + (size_t)b * pbs + (size_t)p * d;
     for_chunks(d, lane, [&](int, int col) { Elem<TX>::st4(xr + col, Elem<TX>::ld4(xr + col) + *reinterpret_cast<const f32x4*>(s + col)); });
 }
@@ -606,17 +611,17 @@ extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const 
 
 static int ln_bwd_impl(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
                        const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
-                       int ldcast, int accumulate, int mapP, int mapL, int map0, void* stream) {
+                       int ldcast, int accumulate, int mapP, int mapL, int map0, const int* map_rs, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || (!dx && !dx_cast) || rows <= 0 || bad_row_dim(d) || (lddy & 3) || (ldx & 3) || (lddx & 3) || (ldcast & 3))
         return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
-#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast, accumulate, mapP, mapL, map0)
+#define LNB(TX, TDY, TC, NC) LPI_LAUNCH((ln_bwd_kernel<TX, TDY, TC, NC>), g, b, 0, S(stream), rows, d, (const TDY*)dy, lddy, (const TX*)x, ldx, gamma, mean, rstd, dx, lddx, (TC*)dx_cast, ldcast, accumulate, mapP, mapL, map0, map_rs)
 #define LNB_HBB(NC) LNB(f16_t, bf16_t, bf16_t, NC)
 #define LNB_FFF(NC) LNB(float, float, float, NC)
 #define LNB_FFB(NC) LNB(float, float, bf16_t, NC)
 #define LNB_FBB(NC) LNB(float, bf16_t, bf16_t, NC)
 #define LNB_FBF(NC) LNB(float, bf16_t, float, NC)
-#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast, accumulate, mapP, mapL, map0)
+#define LNB_H16(NC) LPI_LAUNCH(ln_bwd_h16_kernel<NC>, dim3((rows + 7) / 8), b, 0, S(stream), rows, d, (const bf16_t*)dy, lddy, (const f16_t*)x, ldx, gamma, mean, rstd, (bf16_t*)dx_cast, ldcast, accumulate, mapP, mapL, map0, map_rs)
     if (x_dtype == LPI_F16) {
         if (dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16 && !dx && !(d & 7) && !(lddy & 7) && !(ldx & 7) && !(ldcast & 7) &&
             !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx_cast) & 15))
@@ -643,17 +648,24 @@ static int ln_bwd_impl(int dy_dtype, int cast_dtype, int x_dtype, int rows, int 
 extern "C" int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy, const void* x, int ldx,
                                  const float* gamma, const float* mean, const float* rstd, float* dx, int lddx, void* dx_cast,
                                  int ldcast, int accumulate, void* stream) {
-    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, 0, 0, 0, stream);
+    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, 0, 0, 0, nullptr, stream);
 }
 
 // LayerNorm backward of P rows per sample only: dy is compact [B*P, d]; x, mean / rstd and the gradient stream are the full [B*L, .]
 // arrays, touched at rows b*L + row0 + p.  The first block's backward needs the input gradient at the prompt rows alone (nothing
 // upstream of the prompt slots is trainable: sprompt.py:230-237).
+extern "C" int lpi_layernorm_bwd_rows_varlen(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, const int32_t* row_start, int row0, int P, int d,
+                                             const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
+                                             float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream) {
+    if (B <= 0 || L <= 0 || P <= 0 || row0 < 0 || row0 + P > L) return LPI_EINVAL;
+    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, B * P, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, P, L, row0,
+                       row_start, stream);
+}
 extern "C" int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, int row0, int P, int d, const void* dy, int lddy,
                                       const void* x, int ldx, const float* gamma, const float* mean, const float* rstd, float* dx, int lddx,
                                       void* dx_cast, int ldcast, int accumulate, void* stream) {
-    if (B <= 0 || L <= 0 || P <= 0 || row0 < 0 || row0 + P > L) return LPI_EINVAL;
-    return ln_bwd_impl(dy_dtype, cast_dtype, x_dtype, B * P, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, P, L, row0, stream);
+    return lpi_layernorm_bwd_rows_varlen(dy_dtype, cast_dtype, x_dtype, B, L, nullptr, row0, P, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx,
+                                         dx_cast, ldcast, accumulate, stream);
 }
 
 extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream) {
@@ -692,26 +704,34 @@ extern "C" int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, co
     return 0;
 }
 
-extern "C" int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, const void* src, int ld_src, void* dst, int ld_dst,
-                                     void* stream) {
+extern "C" int lpi_gather_batch_rows_varlen(int dtype, int B, int L, const int32_t* row_start, int row0, int P, int cols, const void* src, int ld_src,
+                                            void* dst, int ld_dst, void* stream) {
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (!src || !dst || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || cols <= 0 || ld_src < cols || ld_dst < cols) return LPI_EINVAL;
     if ((cols * esz) % 16 || (ld_src * esz) % 16 || (ld_dst * esz) % 16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return LPI_EINVAL;
     const int chunks = cols * esz / 16;
     const long n = (long)B * P * chunks;
-    LPI_LAUNCH(gather_batch_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), B, L, row0, P, chunks, (const uint4*)src,
+    LPI_LAUNCH(gather_batch_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), B, L, row_start, row0, P, chunks, (const uint4*)src,
                (long)ld_src * esz / 16, (uint4*)dst, (long)ld_dst * esz / 16);
     LPI_CHECK_LAST();
     return 0;
 }
+extern "C" int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, const void* src, int ld_src, void* dst, int ld_dst,
+                                     void* stream) {
+    return lpi_gather_batch_rows_varlen(dtype, B, L, nullptr, row0, P, cols, src, ld_src, dst, ld_dst, stream);
+}
 
-extern "C" int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate, void* stream) {
+extern "C" int lpi_rows_sum_over_batch_varlen(int dtype, int B, int L, const int32_t* row_start, int row0, int P, int d, const void* dx, float* out,
+                                              int accumulate, void* stream) {
     if (!dx || !out || B <= 0 || P <= 0 || row0 < 0 || row0 + P > L || bad_row_dim(d)) return LPI_EINVAL;
-    if (dtype == LPI_F32) LPI_LAUNCH(rows_sum_kernel<float>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, (const float*)dx, out, accumulate);
-    else if (dtype == LPI_BF16) LPI_LAUNCH(rows_sum_kernel<bf16_t>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row0, P, d, (const bf16_t*)dx, out, accumulate);
+    if (dtype == LPI_F32) LPI_LAUNCH(rows_sum_kernel<float>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row_start, row0, P, d, (const float*)dx, out, accumulate);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(rows_sum_kernel<bf16_t>, dim3(P, (d + 255) / 256), dim3(1024), 0, S(stream), B, L, row_start, row0, P, d, (const bf16_t*)dx, out, accumulate);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
+}
+extern "C" int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate, void* stream) {
+    return lpi_rows_sum_over_batch_varlen(dtype, B, L, nullptr, row0, P, d, dx, out, accumulate, stream);
 }
 
 extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, const float* prompt0, long prompt_bstride,
@@ -726,34 +746,42 @@ extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void
     return lpi_rows_sum_over_batch(dtype, B, L, 1, P, d, dx0, dprompt, 0, stream);
 }
 
-extern "C" int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
-                                 long ctx_bstride, void* x0, void* stream) {
+extern "C" int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
+                                        const float* pos, const float* ctx, long ctx_bstride, void* x0, void* stream) {
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0);
+        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0);
+        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
+extern "C" int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
+                                 long ctx_bstride, void* x0, void* stream) {
+    return lpi_txt_embed_fwd_varlen(x_dtype, B, L, nullptr, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0, stream);
+}
 
-extern "C" int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream) {
+extern "C" int lpi_prompt_add_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, void* x, const float* prompt_l, long prompt_bstride,
+                                     void* stream) {
     if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, (float*)x, prompt_l, prompt_bstride);
+        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (float*)x, prompt_l, prompt_bstride);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, P, d, (f16_t*)x, prompt_l, prompt_bstride);
+        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (f16_t*)x, prompt_l, prompt_bstride);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
+}
+extern "C" int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream) {
+    return lpi_prompt_add_varlen(x_dtype, B, L, nullptr, P, d, x, prompt_l, prompt_bstride, stream);
 }
 
 extern "C" int lpi_pool_ln_fwd(int dtype, int x_dtype, int B, int L, int d, const void* x, const int32_t* idx, const float* gamma, const float* beta,
                                void* y, int ldy, float* mean, float* rstd, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || L <= 0 || bad_row_dim(d) || (ldy & 3)) return LPI_EINVAL;
+    if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0 || L < 0 || (L == 0 && !idx) || bad_row_dim(d) || (ldy & 3)) return LPI_EINVAL;      // L == 0: idx holds absolute rows
     dim3 g(rows_grid(B)), b(256);
     if (dtype == LPI_F32 && x_dtype == LPI_F32)
         LPI_LAUNCH((pool_ln_fwd_kernel<float, float>), g, b, 0, S(stream), B, L, d, (const float*)x, idx, gamma, beta, (float*)y, ldy, mean, rstd);
@@ -782,7 +810,7 @@ extern "C" int lpi_pool_ln_bwd(int cast_dtype, int B, int L, int d, const float*
 }
 
 extern "C" int lpi_gather_rows(int x_dtype, int B, int L, int d, const void* src, const int32_t* idx, float* dst, void* stream) {
-    if (!src || !dst || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
+    if (!src || !dst || B <= 0 || L < 0 || (L == 0 && !idx) || bad_row_dim(d)) return LPI_EINVAL;      // L == 0: idx holds absolute rows
     if (x_dtype == LPI_F32) LPI_LAUNCH(gather_rows_kernel<float>, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, (const float*)src, idx, dst);
     else if (x_dtype == LPI_F16) LPI_LAUNCH(gather_rows_kernel<f16_t>, dim3(rows_grid(B)), dim3(256), 0, S(stream), B, L, d, (const f16_t*)src, idx, dst);
     else return LPI_EINVAL;
@@ -792,7 +820,7 @@ extern "C" int lpi_gather_rows(int x_dtype, int B, int L, int d, const void* src
 
 extern "C" int lpi_scatter_rows(int cast_dtype, int B, int L, int d, const float* src, const int32_t* idx, float* dst, void* dst_cast,
                                 void* stream) {
-    if (!src || (!dst && !dst_cast) || B <= 0 || L <= 0 || bad_row_dim(d)) return LPI_EINVAL;
+    if (!src || (!dst && !dst_cast) || B <= 0 || L < 0 || (L == 0 && !idx) || bad_row_dim(d)) return LPI_EINVAL;      // L == 0: idx holds absolute rows
     dim3 g(rows_grid(B)), b(256);
     if (cast_dtype == LPI_F32) LPI_LAUNCH(scatter_rows_kernel<float>, g, b, 0, S(stream), B, L, d, src, idx, dst, (float*)dst_cast);
     else if (cast_dtype == LPI_BF16) LPI_LAUNCH(scatter_rows_kernel<bf16_t>, g, b, 0, S(stream), B, L, d, src, idx, dst, (bf16_t*)dst_cast);

@@ -265,15 +265,22 @@ class Tower:
             raise ValueError(f"prompt depth {depth} exceeds the tower's {len(self.blocks)} blocks")
 
     # ------------------------------------------------------------------ workspace
-    def workspace(self, B: int, L: int, train: bool, cap: Optional[int] = None):
+    def workspace(self, B: int, L: int, train: bool, cap: Optional[int] = None, packed=None):
         """Arena for B samples of L tokens.  It is allocated for `cap` (>= L) tokens per sample and reused for any shorter L (the
         text tower's L varies with the longest caption of the batch, see trim_token_ids): a call only re-binds L and the padded
-        row count; the [M, *] buffers are used by their first B*L rows, the [B, H, L] ones as flat storage."""
+        row count; the [M, *] buffers are used by their first M rows, the [B, H, L] ones as flat storage.
+        packed: a PackedIds (ragged batch: sample b owns rows row_start[b] .. row_start[b+1]-1, M = sum of the lengths, L = the longest)."""
+        def bind(ws, L):
+            ws["L"] = L
+            ws["M"] = B * L if packed is None else packed.rows
+            ws["Mp"] = _pad(ws["M"], 256)
+            ws["rs"] = None if packed is None else packed.row_start_dev
+            ws["pool_abs"] = None if packed is None else packed.pool_rows_dev
+            return ws
         key = (B, train)
         ws = self._ws.get(key)
         if ws is not None and ws["Lcap"] >= L:
-            ws["L"], ws["Mp"] = L, _pad(B * L, 256)
-            return ws
+            return bind(ws, L)
         self._ws.clear()   # one live shape per tower: the arena is large
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
         Lreal, L = L, max(L, cap or L)
@@ -316,9 +323,8 @@ class Tower:
             })
         if train:
             ws["du"], ws["c_du"] = ws["g"].view(TG), ws["c_g"].view(TG)
-        ws["L"], ws["Mp"] = Lreal, _pad(B * Lreal, 256)
         self._ws[key] = ws
-        return ws
+        return bind(ws, Lreal)
 
     # ------------------------------------------------------------------ forward
     def forward_gen(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
@@ -329,8 +335,10 @@ class Tower:
         prompts: f32 tensor whose element (b, layer, p, :) sits at  b*prompt_bstride + (layer*P + p)*d."""
         sp, dt, xdt, s = self.spec, self.dt, self.xdt, _stream()
         d, H = sp.width, sp.heads
-        B, L, Mp = ws["B"], ws["L"], ws["Mp"]
-        M = B * L
+        B, L, Mp, M = ws["B"], ws["L"], ws["Mp"], ws["M"]
+        rs = ws["rs"]                                  # ragged batch: row starts (device int32 [B+1]); None = B x L rows
+        # kernels that address ONE token per sample: (L, token index) or, ragged, (0, absolute row) — see include/lpi_hip.h
+        Lx, pidx = (L, pool_idx) if rs is None else (0, ws["pool_abs"])
         P = prompts.shape[-2] if prompts is not None else 0
         self._check_depth(prompts, depth)
         self.serial += 1
@@ -340,36 +348,36 @@ class Tower:
             x_out = ws["x"][i + 1 if train else (i + 1) % 2]
             xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][k]
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
-                call("lpi_prompt_add", xdt, B, L, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
+                call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
             call("lpi_layernorm_fwd", dt, xdt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
                 yield GemmReq(f"{i}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
-                call("lpi_pool_ln_fwd", dt, xdt, B, L, d, x_in, pool_idx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
+                call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, x_in, pidx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
                 yield GemmReq(None, dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
-                call("lpi_attn_pooled_fwd", dt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
-                call("lpi_gather_rows", xdt, B, L, d, x_in, pool_idx, ws["c_xin"], s)
+                call("lpi_attn_pooled_fwd_varlen", dt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
+                call("lpi_gather_rows", xdt, B, Lx, d, x_in, pidx, ws["c_xin"], s)
                 yield GemmReq(None, dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
                 call("lpi_pool_ln_fwd", dt, F32, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
                 yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             yield GemmReq(f"{i}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
-            call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
+            call("lpi_attn_fwd_varlen", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
             yield GemmReq(f"{i}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
-                call("lpi_gather_rows", xdt, B, L, d, xmid, pool_idx, ws["c_xmid"], s)
-                call("lpi_pool_ln_fwd", dt, xdt, B, L, d, xmid, pool_idx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                call("lpi_gather_rows", xdt, B, Lx, d, xmid, pidx, ws["c_xmid"], s)
+                call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, xmid, pidx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
                 yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             call("lpi_layernorm_fwd", dt, xdt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
             yield GemmReq(f"{i}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             yield GemmReq(f"{i}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
-        call("lpi_gather_rows", xdt, B, L, d, x_out, pool_idx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
+        call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 
     def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
@@ -383,8 +391,10 @@ class Tower:
         sp, dt, xdt, s = self.spec, self.gdt, self.xdt, _stream()        # dt: the BACKWARD's operand / storage type from here on
         adt = F16 if self.dt == F16 else dt       # attention backward: F16 = "saved q, k, v, ctx are fp16; gradients and operands bf16"
         d, H = sp.width, sp.heads
-        B, L, Mp = ws["B"], ws["L"], ws["Mp"]
-        M = B * L
+        B, L, Mp, M = ws["B"], ws["L"], ws["Mp"], ws["M"]
+        rs = ws["rs"]                                  # ragged batch: row starts (device int32 [B+1]); None = B x L rows
+        # kernels that address ONE token per sample: (L, token index) or, ragged, (0, absolute row) — see include/lpi_hip.h
+        Lx, pidx = (L, pool_idx) if rs is None else (0, ws["pool_abs"])
         dx, dh, dctx, dqkv = ws["dx"], ws["dh"], ws["dctx"], ws["dqkv"]
         dxT = ws["dxT"] if dt != F32 else dx          # the stream the dgrad GEMMs read; in bf16 mode also the accumulator
         P = prompts.shape[-2] if prompts is not None else 0
@@ -394,7 +404,7 @@ class Tower:
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
             if i == len(self.blocks) - 1 and not POOLED_LAST:
                 call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
-                call("lpi_scatter_rows", dt, B, L, d, ws["c_dx"], pool_idx, dx, None if dt == F32 else dxT, s)
+                call("lpi_scatter_rows", dt, B, Lx, d, ws["c_dx"], pidx, dx, None if dt == F32 else dxT, s)
             if i == len(self.blocks) - 1 and POOLED_LAST:
                 # last block: MLP backward on the pooled rows, then scatter into the (zeroed) full-size gradient stream
                 Bp, cst = ws["Bp"], ws["c_stat"]
@@ -406,23 +416,23 @@ class Tower:
                      None if dt == F32 else c_dxT, d, 1, s)
                 if not POOLED_ATTN:
                     call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
-                    call("lpi_scatter_rows", dt, B, L, d, c_dx, pool_idx, dx, None if dt == F32 else dxT, s)
+                    call("lpi_scatter_rows", dt, B, Lx, d, c_dx, pidx, dx, None if dt == F32 else dxT, s)
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
                 yield GemmReq(None, dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
-                call("lpi_attn_pooled_bwd", adt, B, L, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
+                call("lpi_attn_pooled_bwd_varlen", adt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
                      dqkv, 3 * d, int(sp.causal), s)
                 yield GemmReq(f"{i}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 yield GemmReq(None, dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
-                call("lpi_scatter_add_rows", dt, B, L, d, ws["c_dh"], d, pool_idx, dh, d, s)
+                call("lpi_scatter_add_rows", dt, B, Lx, d, ws["c_dh"], d, pidx, dh, d, s)
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
                 # path of the pooled rows is added
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                      None if dt == F32 else dxT, d, 0, s)
-                call("lpi_scatter_add_rows", dt, B, L, d, c_dxT, d, pool_idx, dxT, d, s)
+                call("lpi_scatter_add_rows", dt, B, Lx, d, c_dxT, d, pidx, dxT, d, s)
                 if prompts is not None and dprompts is not None and 0 < i < depth:
-                    call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
+                    call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
                 continue
             if not (i == len(self.blocks) - 1 and POOLED_LAST):
                 du = ws["du"]
@@ -431,22 +441,22 @@ class Tower:
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
             yield GemmReq(f"{i}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
-            call("lpi_attn_bwd", adt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
+            call("lpi_attn_bwd_varlen", adt, B, L, rs, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
                 # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
                 # CLS and token embeddings are frozen) -> in_proj dgrad and LN1 backward on the packed B*P prompt rows.  The residual
                 # path of those rows is already in the stream; every other row of it is left without this block's attention term.
                 pq, ph = ws["p_dqkv"], ws["p_dh"]
-                call("lpi_gather_batch_rows", dt, B, L, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
+                call("lpi_gather_batch_rows_varlen", dt, B, L, rs, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
                 yield GemmReq(f"{i}.dqkv_p", dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
-                call("lpi_layernorm_bwd_rows", dt, dt, xdt, B, L, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                call("lpi_layernorm_bwd_rows_varlen", dt, dt, xdt, B, L, rs, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                      None if dt == F32 else dxT, d, 1, s)
                 continue
             yield GemmReq(f"{i}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, 1, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
-                call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, dxT, dprompts[i], 0, s)
+                call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
         return dxT
 
     def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
@@ -620,6 +630,9 @@ class DualEncoder:
     def encode_text_gen(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True):
         """GENERATOR form of encode_text; returns (features, backward context)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
+        packed = ids if isinstance(ids, PackedIds) else None
+        if packed is not None:
+            ids = packed.on(self.device)
         B, L = ids.shape
         ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
         pr, pbs, P = self._prompt_args(prompts, B)
@@ -628,11 +641,13 @@ class DualEncoder:
         d = cfg.transformer_width
         if L > cfg.context_length:
             raise ValueError("more tokens than the context length")
-        ws = self.txt.workspace(B, L, train, cap=cfg.context_length)
+        if packed is not None and int(packed.lengths.min()) < self.n_ctx + 2:
+            raise ValueError("a packed caption must hold SOT, the n_ctx context slots and EOT")
+        ws = self.txt.workspace(B, L, train, cap=cfg.context_length, packed=packed)
         hw = self._head("t", B, d)
         call("lpi_eot_index", B, L, ids, hw["idx"], s)
         ctx = pr if (pr is not None and use_ctx) else None
-        call("lpi_txt_embed_fwd", self.txt.xdt, B, L, self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
+        call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
         xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         yield GemmReq(None, dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
@@ -668,7 +683,7 @@ class DualEncoder:
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
         yield from self.txt.backward_gen(ws, pr, depth, dpr, hw["idx"])
-        call("lpi_rows_sum_over_batch", dt, B, L, 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
+        call("lpi_rows_sum_over_batch_varlen", dt, B, L, ws["rs"], 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
 
 
@@ -683,6 +698,55 @@ class DualEncoder:
     def encode_both_backward(self, dimg, dtxt, vis_ctx, txt_ctx):
         """The two backward passes in lock step -> (dL/d vis prompts, dL/d txt prompts)."""
         return run_lockstep(self.encode_image_backward_gen(dimg, vis_ctx), self.encode_text_backward_gen(dtxt, txt_ctx))
+
+
+class PackedIds:
+    """Token ids of a text batch together with the PACKED row layout of the text tower: sample b owns rows row_start[b] ..
+    row_start[b+1]-1, its tokens 0 .. eot_b — the rows behind a sample's own EOT are not computed at all.
+
+    Exact dead-row elimination, per sample (trim_token_ids cuts the whole batch at the LONGEST caption; this cuts every caption at
+    its own end): under the causal mask (model.py:347-353) a position attends only to earlier ones and the tower's output is read at
+    the EOT position alone (prompt_learner.py:61), so those rows can reach neither a feature nor a gradient.  Built on the HOST,
+    where the tokenizer's output lives (prompt_learner.py:128-133): the row count and the longest caption are known without a
+    device synchronisation.  Accepted by DualEncoder.encode_text / encode_both and the autograd Functions in place of the id tensor."""
+
+    def __init__(self, ids):
+        a = np.ascontiguousarray(ids.numpy() if torch.is_tensor(ids) else np.asarray(ids))
+        if torch.is_tensor(ids) and ids.is_cuda:
+            raise ValueError("PackedIds is built from host token ids (before the upload)")
+        self.lengths = a.argmax(-1).astype(np.int64) + 1            # eot_b + 1 (ids.argmax(-1) is the EOT position, prompt_learner.py:61)
+        self.shape = (a.shape[0], int(self.lengths.max()))
+        self.ids = torch.from_numpy(np.ascontiguousarray(a[:, :self.shape[1]]).astype(np.int64))
+        rs = np.zeros(a.shape[0] + 1, dtype=np.int64)
+        np.cumsum(self.lengths, out=rs[1:])
+        self.rows = int(rs[-1])
+        self.row_start = torch.from_numpy(rs.astype(np.int32))
+        self.pool_rows = torch.from_numpy((rs[1:] - 1).astype(np.int32))       # absolute row of every sample's EOT token
+        self._dev = None
+        self.row_start_dev = self.pool_rows_dev = None
+
+    def on(self, device):
+        """Upload once (ids, row starts, pooled rows); returns the device id matrix [B, Lmax]."""
+        device = torch.device(device)
+        if self._dev is None or self._dev.device != device:
+            self._dev = self.ids.to(device)
+            self.row_start_dev = self.row_start.to(device)
+            self.pool_rows_dev = self.pool_rows.to(device)
+        return self._dev
+
+    def to(self, device):
+        self.on(device)
+        return self
+
+    def slice(self, lo, hi):
+        """The sub-batch of samples lo .. hi-1 (data-parallel shards, micro-batches)."""
+        return PackedIds(self.ids[lo:hi])
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.step not in (None, 1):
+            raise TypeError("PackedIds takes contiguous sample slices only")
+        lo, hi, _ = sl.indices(self.shape[0])
+        return self.slice(lo, hi)
 
 
 def trim_token_ids(ids):

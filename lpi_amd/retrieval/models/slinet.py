@@ -97,9 +97,11 @@ class SliNet(nn.Module):
     def _ids(self, text, pool_idx):
         ids = self.classifier_pool[pool_idx](text)
         if not ids.is_cuda and self.args.get("trim_text", True):
-            # rows behind the longest caption's EOT are dead under the causal mask (engine.trim_token_ids): exact, and free here
-            # because the tokenizer ran on the host
-            from lpi_amd.engine import trim_token_ids
+            # rows behind a caption's EOT are dead under the causal mask: exact, and free here because the tokenizer ran on the host.
+            # pack_text (default): every caption cut at its OWN end, the batch packed (engine.PackedIds); else cut at the longest one
+            from lpi_amd.engine import PackedIds, trim_token_ids
+            if self.args.get("pack_text", True):
+                return PackedIds(ids).to(self.engine.device)
             ids = trim_token_ids(ids).contiguous()
         return ids.to(self.engine.device)
 

@@ -285,6 +285,36 @@ def test_lockstep_towers_with_grouped_gemm_launches_equal_the_sequential_towers(
     torch.cuda.empty_cache()
 
 
+def test_packed_text_batch_at_the_benchmarked_configuration(data):
+    """bench.py's default text layout — every caption cut at its OWN EOT, the batch packed (engine.PackedIds; 41 instead of 59 rows
+    per caption on the synthetic batch) — against the batch cut at the longest caption, bf16, B = 256, depth 3: the same arithmetic per
+    live row, so features, losses and factor gradients agree to bf16 kernel-selection noise at most (they are usually the same bits)."""
+    from lpi_amd.engine import PackedIds, trim_token_ids
+    img, _ = data
+    ids_h = synth.token_ids(B)
+    ids_t = torch.from_numpy(np.ascontiguousarray(trim_token_ids(ids_h))).to(DEV)
+    pk = PackedIds(ids_h).to(DEV)
+    assert pk.rows < 0.8 * ids_t.numel()
+    enc = DualEncoder(CFG, synth.clip_state_dict(CFG), dtype="bf16", device=DEV)
+    res = {}
+    for tag, ids in (("trim", ids_t), ("pack", pk)):
+        fac = factors()
+        out = train_step(enc, img, ids, fac, 3)
+        torch.cuda.synchronize()
+        res[tag] = ({k: v.clone() for k, v in out.items()}, {k: fac[k].grad.clone() for k in synth.PROMPT_NAMES})
+    same = all(torch.equal(res["trim"][0][k], res["pack"][0][k]) for k in ("img_f", "txt_f", "base_loss")) and \
+        all(torch.equal(res["trim"][1][k], res["pack"][1][k]) for k in synth.PROMPT_NAMES)
+    print(f"packed text batch: {pk.rows / B:.1f} rows per caption (trimmed: {ids_t.shape[1]}); bitwise equal to the trimmed batch: {same}")
+    for k in ("img_f", "txt_f"):
+        assert float((res["trim"][0][k] - res["pack"][0][k]).abs().max()) < 1e-3, k
+    assert abs(float(res["trim"][0]["base_loss"]) - float(res["pack"][0]["base_loss"])) < 1e-3
+    for k in synth.PROMPT_NAMES:
+        a, b = res["pack"][1][k].double(), res["trim"][1][k].double()
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), k
+    del enc
+    torch.cuda.empty_cache()
+
+
 def test_eval_shard_at_vitb16_size_matches_reference(golden):
     """north_star: 'R@1 indices bit-identical to reference on a fixed synthetic shard'.  The reference's whole evaluation
     (sprompt.py:433-646: task ids by L1 distance to keys, per-sample prompted features, N_img x N_txt score matrix, per-row rank of the

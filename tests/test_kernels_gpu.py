@@ -632,6 +632,140 @@ def test_gemm_grouped_f16_operands_and_fallback():
     assert relerr(small[1]["c"], small[1]["a"].double().cpu() @ small[1]["b"].double().cpu().t()) < TOL[BF16]
 
 
+# ---------------------------------------------------------------------------------------------------------------- ragged batches
+def _ragged(B, Lmax, seed, lo):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, Lmax + 1, (B,), generator=g)
+    lens[0] = Lmax                                   # L = the longest sample
+    rs = torch.zeros(B + 1, dtype=torch.int64)
+    rs[1:] = lens.cumsum(0)
+    return lens, rs
+
+
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("B,Lmax,H,causal", [(5, 59, 2, 1), (4, 77, 1, 1), (3, 150, 2, 0), (6, 33, 1, 1)])
+def test_attention_varlen_fwd_bwd(dt, B, Lmax, H, causal):
+    """lpi_attn_*_varlen: a PACKED batch (sample b owns rows row_start[b] .. row_start[b+1]-1) vs per-sample f64 attention; rows of the
+    outputs outside every sample are never written."""
+    TDX = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+    d = H * 64
+    lens, rs = _ragged(B, Lmax, 7 * B + Lmax, 18)
+    M = int(rs[-1])
+    Mp = (M + 255) // 256 * 256
+    qkv = rnd(Mp, 3 * d, seed=31).to(TDX[dt])
+    gdt = TDX[dt] if dt != F16 else torch.bfloat16            # f16 mode: gradients are bf16
+    dctx = rnd(Mp, d, seed=32).to(gdt)
+    rs_d = rs.int().to(DEV)
+    ctx = torch.full((Mp, d), 3.0, device=DEV, dtype=TDX[dt])
+    lse = torch.zeros(B, H, Lmax, device=DEV)
+    call("lpi_attn_fwd_varlen", dt, B, Lmax, rs_d, H, qkv.to(DEV), 3 * d, ctx, d, lse, causal, stream())
+    dqkv = torch.full((Mp, 3 * d), 5.0, device=DEV, dtype=gdt)
+    delta = torch.zeros(B, H, Lmax, device=DEV)
+    call("lpi_attn_bwd_varlen", dt, B, Lmax, rs_d, H, qkv.to(DEV), 3 * d, ctx, d, dctx.to(DEV), d, lse, delta, dqkv, 3 * d, causal, stream())
+    torch.cuda.synchronize()
+    assert bool((ctx[M:] == 3.0).all()) and bool((dqkv[M:] == 5.0).all())
+    tol = {F32: 2e-5, BF16: 2e-2, F16: 3e-3}[dt]
+    gtol = {F32: 5e-5, BF16: 4e-2, F16: 4e-2}[dt]
+    for b in range(B):
+        r0, L = int(rs[b]), int(lens[b])
+        qr = qkv[r0:r0 + L].double().requires_grad_(True)
+        oref, lref = attn_ref(qr, 1, L, H, causal)
+        assert relerr(ctx[r0:r0 + L], oref.detach()) < tol, b
+        assert relerr(lse[b, :, :L], lref.detach()[0]) < (1e-5 if dt == F32 else 2e-2), b
+        oref.backward(dctx[r0:r0 + L].double())
+        assert relerr(dqkv[r0:r0 + L], qr.grad) < gtol, b
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_pooled_varlen_and_absolute_row_index(dt):
+    """The last block's single-query attention on a packed batch (lpi_attn_pooled_*_varlen) and the L == 0 convention of the
+    one-token-per-sample kernels (idx = absolute row): vs the same kernels on the equivalent uniform batch."""
+    B, Lmax, H = 5, 40, 2
+    d = H * 64
+    lens, rs = _ragged(B, Lmax, 3, 18)
+    M = int(rs[-1])
+    qkv_u = rnd(B * Lmax, 3 * d, seed=41).to(TD[dt])                      # uniform layout, rows behind a sample's end are never used
+    rows_u = torch.cat([torch.arange(int(lens[b])) + b * Lmax for b in range(B)])
+    qkv_p = qkv_u[rows_u].contiguous()                                       # the same samples packed
+    idx = (lens - 1).int()                                                   # pooled token = the last one (EOT)
+    q_rows = qkv_u[torch.arange(B) * Lmax + idx.long(), :d].contiguous().to(DEV)
+    dctx_rows = rnd(B, d, seed=42).to(TD[dt]).to(DEV)
+    outs = {}
+    for tag, qkv, rsd, L in (("u", qkv_u, None, Lmax), ("p", qkv_p, rs.int().to(DEV), Lmax)):
+        ctx = torch.zeros(B, d, device=DEV, dtype=TD[dt])
+        lse = torch.zeros(B, H, device=DEV)
+        call("lpi_attn_pooled_fwd_varlen", dt, B, L, rsd, H, q_rows, d, qkv.to(DEV), 3 * d, idx.to(DEV), ctx, d, lse, 1, stream())
+        dq = torch.zeros(B, d, device=DEV, dtype=TD[dt])
+        dqkv = torch.full((qkv.shape[0], 3 * d), 7.0, device=DEV, dtype=TD[dt])
+        call("lpi_attn_pooled_bwd_varlen", dt, B, L, rsd, H, q_rows, d, qkv.to(DEV), 3 * d, idx.to(DEV), dctx_rows, d, lse, dq, d, dqkv, 3 * d, 1,
+             stream())
+        outs[tag] = (ctx, lse, dq, dqkv)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs["u"][i], outs["p"][i]), i
+    assert torch.equal(outs["u"][3][rows_u.to(DEV)][:, d:], outs["p"][3][:, d:])
+    # one token per sample, absolute rows (L == 0): gather / pool_ln / scatter_add
+    x = rnd(M, d, seed=43).to(DEV)
+    pool_abs = (rs[1:] - 1).int().to(DEV)
+    g0 = torch.zeros(B, d, device=DEV)
+    call("lpi_gather_rows", F32, B, 0, d, x, pool_abs, g0, stream())
+    assert torch.equal(g0, x[pool_abs.long()])
+    gam, bet = rnd(d, seed=44).to(DEV), rnd(d, seed=45).to(DEV)
+    y = torch.zeros(B, d, device=DEV)
+    mean, rstd = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    call("lpi_pool_ln_fwd", F32, F32, B, 0, d, x, pool_abs, gam, bet, y, d, mean, rstd, stream())
+    ref = torch.nn.functional.layer_norm(x[pool_abs.long()].double().cpu(), (d,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    assert relerr(y, ref) < 2e-5
+    acc = torch.ones(M, d, device=DEV)
+    call("lpi_scatter_add_rows", F32, B, 0, d, g0, d, pool_abs, acc, d, stream())
+    want = torch.ones(M, d, device=DEV)
+    want[pool_abs.long()] += g0
+    assert torch.equal(acc, want)
+    assert _lib.load().lpi_gather_rows(F32, B, 0, d, x.data_ptr(), None, g0.data_ptr(), None) == -22       # L == 0 needs idx
+
+
+def test_row_kernels_varlen():
+    """txt_embed / prompt_add / rows_sum_over_batch / gather_batch_rows / layernorm_bwd_rows on a packed batch == the uniform-layout
+    kernels on the same samples (bit for bit: the per-row arithmetic is the same)."""
+    B, Lmax, P, d = 6, 30, 16, 128
+    lens, rs = _ragged(B, Lmax, 9, P + 2)
+    M = int(rs[-1])
+    rs_d = rs.int().to(DEV)
+    rows_u = torch.cat([torch.arange(int(lens[b])) + b * Lmax for b in range(B)]).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 50, (B, Lmax), generator=g)
+    tok, pos, ctxp = rnd(64, d, seed=2).to(DEV), rnd(Lmax, d, seed=3).to(DEV), rnd(P, d, seed=4).to(DEV)
+    xu = torch.zeros(B * Lmax, d, device=DEV)
+    xp = torch.full((M + 7, d), 9.0, device=DEV)
+    call("lpi_txt_embed_fwd", F32, B, Lmax, P, d, ids.to(DEV), tok, pos, ctxp, 0, xu, stream())
+    call("lpi_txt_embed_fwd_varlen", F32, B, Lmax, rs_d, P, d, ids.to(DEV), tok, pos, ctxp, 0, xp, stream())
+    assert torch.equal(xp[:M], xu[rows_u]) and bool((xp[M:] == 9.0).all())
+    pr = rnd(P, d, seed=5).to(DEV)
+    call("lpi_prompt_add", F32, B, Lmax, P, d, xu, pr, 0, stream())
+    call("lpi_prompt_add_varlen", F32, B, Lmax, rs_d, P, d, xp, pr, 0, stream())
+    assert torch.equal(xp[:M], xu[rows_u])
+    su, sp = torch.zeros(P, d, device=DEV), torch.zeros(P, d, device=DEV)
+    call("lpi_rows_sum_over_batch", F32, B, Lmax, 1, P, d, xu, su, 0, stream())
+    call("lpi_rows_sum_over_batch_varlen", F32, B, Lmax, rs_d, 1, P, d, xp, sp, 0, stream())
+    assert torch.equal(su, sp)
+    gu, gp = torch.zeros(B * P, d, device=DEV), torch.zeros(B * P, d, device=DEV)
+    call("lpi_gather_batch_rows", F32, B, Lmax, 1, P, d, xu, d, gu, d, stream())
+    call("lpi_gather_batch_rows_varlen", F32, B, Lmax, rs_d, 1, P, d, xp, d, gp, d, stream())
+    assert torch.equal(gu, gp)
+    # LayerNorm backward of the prompt rows: statistics / stream at the full layout's rows
+    gam = rnd(d, seed=6).to(DEV)
+    dy = rnd(B * P, d, seed=7).to(DEV)
+    mu_u, rs_u = torch.zeros(B * Lmax, device=DEV), torch.ones(B * Lmax, device=DEV)
+    mu_u[rows_u] = xu[rows_u].mean(1)
+    rs_u[rows_u] = (xu[rows_u].var(1, unbiased=False) + 1e-5).rsqrt()
+    dxu, dxp = torch.ones(B * Lmax, d, device=DEV), torch.ones(M, d, device=DEV)
+    call("lpi_layernorm_bwd_rows", F32, F32, F32, B, Lmax, 1, P, d, dy, d, xu, d, gam, mu_u, rs_u, dxu, d, None, d, 1, stream())
+    call("lpi_layernorm_bwd_rows_varlen", F32, F32, F32, B, Lmax, rs_d, 1, P, d, dy, d, xp, d, gam, mu_u[rows_u].contiguous(),
+         rs_u[rows_u].contiguous(), dxp, d, None, d, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dxp, dxu[rows_u])
+
+
 # ---------------------------------------------------------------------------------------------------------------- round 2 kernels
 @pytest.mark.parametrize("n,r0,nloc", [(6, 2, 3), (256, 128, 128), (300, 44, 256)])
 def test_clip_loss_local_rows(n, r0, nloc):

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from lpi_amd import _lib, synth  # noqa: E402
-from lpi_amd.engine import DualEncoder  # noqa: E402
+from lpi_amd.engine import DualEncoder, PackedIds  # noqa: E402
 from lpi_amd.step import train_step  # noqa: E402
 from oracle import lpi_oracle as O  # noqa: E402
 
@@ -21,12 +21,12 @@ def dev_factors(cfg, task=0, requires_grad=True):
     return {k: torch.from_numpy(v).to(DEV).requires_grad_(requires_grad) for k, v in f.items()}, f
 
 
-def run_hip(cfg, dtype, batch, ids, depth):
+def run_hip(cfg, dtype, batch, ids, depth, pack=False):
     enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=DEV)
     fac, fac_np = dev_factors(cfg)
     img = torch.from_numpy(synth.images(batch, cfg.image_resolution)).to(DEV)
     n0 = _lib.launch_count()
-    out = train_step(enc, img, torch.from_numpy(ids).to(DEV), fac, depth)
+    out = train_step(enc, img, PackedIds(ids).to(DEV) if pack else torch.from_numpy(ids).to(DEV), fac, depth)
     torch.cuda.synchronize()
     assert _lib.launch_count() > n0, "HIP path did not run"
     res = {k: v.cpu().numpy() for k, v in out.items()}
@@ -263,6 +263,30 @@ def test_trimming_text_rows_behind_the_longest_eot_is_exact(dtype, tol):
         assert maxerr(trim[k], full[k]) <= tol, (k, maxerr(trim[k], full[k]))
     for k in GRADS:
         assert maxerr(trim[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(trim[k], full[k]))
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-3), ("f16", 3e-4)])
+def test_packing_every_caption_at_its_own_eot_is_exact(dtype, tol):
+    """engine.PackedIds: the rows behind EVERY caption's own EOT are dead (causal mask + EOT gather), so the packed text batch — one row
+    per live token — gives the features, losses and factor gradients of the full 77-column batch (same bars as the trimming test)."""
+    cfg = synth.TINY
+    ids = synth.token_ids(6, n_ctx=16, max_len=23)
+    pk = PackedIds(ids)
+    assert pk.rows < 6 * pk.shape[1] < ids.size and pk.rows == int((ids.argmax(-1) + 1).sum())
+    full, _ = run_hip(cfg, dtype, 6, ids, 2)
+    packed, _ = run_hip(cfg, dtype, 6, ids, 2, pack=True)
+    for k in ("img_f", "txt_f", "base_loss", "alignment_loss"):
+        assert maxerr(packed[k], full[k]) <= tol, (k, maxerr(packed[k], full[k]))
+    for k in GRADS:
+        assert maxerr(packed[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(packed[k], full[k]))
+
+
+@pytest.mark.parametrize("name,depth", [("tiny_d1", 1), ("tiny_d2_patched", 2)])
+def test_packed_text_batch_vs_reference_fixture(golden, name, depth):
+    """The reference's own outputs (fixtures) reached through the packed text path, f32 parity bars."""
+    g = golden(name)
+    res, _ = run_hip(synth.TINY, "f32", 4, g["token_ids"], depth, pack=True)
+    check(res, g, tol=1e-4, gtol=1e-3, gabs=1e-4)
 
 
 def test_vitb16_fixture_through_the_f32_256x256_kernel(golden):

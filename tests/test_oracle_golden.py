@@ -125,3 +125,36 @@ def test_text_columns_behind_every_eot_are_dead_in_the_oracle():
     trim = O.train_step(ora, img, short, fac, depth=2)
     for k in full:
         assert float(np.abs(np.asarray(full[k], dtype=np.float64) - np.asarray(trim[k], dtype=np.float64)).max()) == 0.0, k
+
+
+
+def test_tokens_behind_a_captions_own_eot_are_dead_in_the_oracle():
+    """The property engine.PackedIds relies on: under the causal mask (model.py:347-353) and the EOT gather (prompt_learner.py:61) the
+    positions behind a caption's OWN EOT can reach neither its feature nor a gradient — replacing the zero padding behind every EOT
+    by arbitrary tokens (smaller than the EOT id, so ids.argmax(-1) still finds the EOT) changes nothing, exactly (f64); and
+    PackedIds lays out exactly the live rows."""
+    import numpy as np
+    import torch
+    from lpi_amd import synth
+    from lpi_amd.engine import PackedIds
+    cfg = synth.TINY
+    ora = O.Oracle(cfg, synth.clip_state_dict(cfg), dtype=torch.float64)
+    ids = synth.token_ids(5, n_ctx=16, max_len=20)
+    eot = ids.argmax(-1)
+    junk = ids.copy()
+    rng = np.random.default_rng(0)
+    for b in range(ids.shape[0]):
+        junk[b, eot[b] + 1:] = rng.integers(1, 300, size=ids.shape[1] - eot[b] - 1)
+    assert (junk.argmax(-1) == eot).all() and (junk != ids).any()
+    fac = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    img = synth.images(5, cfg.image_resolution)
+    a = O.train_step(ora, img, ids, fac, depth=2)
+    b_ = O.train_step(ora, img, junk, fac, depth=2)
+    for k in a:
+        assert float(np.abs(np.asarray(a[k], dtype=np.float64) - np.asarray(b_[k], dtype=np.float64)).max()) == 0.0, k
+    pk = PackedIds(ids)
+    assert pk.rows == int((eot + 1).sum()) and pk.shape == (5, int(eot.max()) + 1)
+    assert pk.row_start.tolist() == [0] + np.cumsum(eot + 1).tolist()
+    assert pk.pool_rows.tolist() == (np.cumsum(eot + 1) - 1).tolist()
+    assert torch.equal(pk.ids, torch.from_numpy(ids[:, :pk.shape[1]]))
+    assert pk[1:3].rows == int((eot[1:3] + 1).sum())
