@@ -265,8 +265,8 @@ def test_trimming_text_rows_behind_the_longest_eot_is_exact(dtype, tol):
         assert maxerr(trim[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(trim[k], full[k]))
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-3), ("f16", 3e-4)])
-def test_packing_every_caption_at_its_own_eot_is_exact(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,gtol", [("f32", 2e-6, 4e-5), ("bf16", 1e-3, 2e-2), ("f16", 3e-4, 2e-2)])      # f16 mode: bf16 backward
+def test_packing_every_caption_at_its_own_eot_is_exact(dtype, tol, gtol):
     """engine.PackedIds: the rows behind EVERY caption's own EOT are dead (causal mask + EOT gather), so the packed text batch — one row
     per live token — gives the features, losses and factor gradients of the full 77-column batch (same bars as the trimming test)."""
     cfg = synth.TINY
@@ -278,7 +278,7 @@ def test_packing_every_caption_at_its_own_eot_is_exact(dtype, tol):
     for k in ("img_f", "txt_f", "base_loss", "alignment_loss"):
         assert maxerr(packed[k], full[k]) <= tol, (k, maxerr(packed[k], full[k]))
     for k in GRADS:
-        assert maxerr(packed[k], full[k]) <= max(20 * tol * np.abs(full[k]).max(), 1e-9), (k, maxerr(packed[k], full[k]))
+        assert maxerr(packed[k], full[k]) <= max(gtol * np.abs(full[k]).max(), 1e-9), (k, maxerr(packed[k], full[k]))
 
 
 @pytest.mark.parametrize("name,depth", [("tiny_d1", 1), ("tiny_d2_patched", 2)])
