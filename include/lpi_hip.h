@@ -65,7 +65,10 @@ uint64_t lpi_launch_count(void);
  *              backward at every L they take (same results bit for bit), 4 the single-pass backward (non-causal; dQ summed in a
  *              different, still fixed, order).
  *   key 8      != 0: lpi_gemm_nt_grouped never groups (issues its problems one after the other; A/B switch, same bits).
- *   keys 9..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
+ *   key 9      two-workgroups-per-CU GEMM (gemm_duo.hip: 256x128 tiles, 4 waves of 128x64, 80 KiB of LDS, so that one workgroup's
+ *              epilogue runs under the other's main loop): bit mask over the epilogue kinds it is used for where the shape allows —
+ *              1 store-only (bias), 2 residual, 4 QuickGELU (+ saved u), 8 gelu'(u); 0 = never.  Same bits as the other GEMM kernels.
+ *   keys 10..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */
 
@@ -306,6 +309,7 @@ int lpi_bpe_tokenize(void* handle, const char* const* texts, int n, int context_
 #define LPI_GEMM_K_256_TAIL 2   /* gemm256_tail_kernel: 256x256 tiles, short last round as halves */
 #define LPI_GEMM_K_256X128 3    /* gemm256x128_kernel                                             */
 #define LPI_GEMM_K_SPLITK 4     /* split-K gemm_nt_kernel + splitk_reduce_kernel                  */
+#define LPI_GEMM_K_DUO 5        /* gemm_duo_kernel: 256x128 tiles, two 4-wave workgroups per CU   */
 int lpi_gemm_last_kernel(void);
 
 /* ---- CU-partitioned lanes (speed only) --------------------------------------------------------------------
