@@ -342,7 +342,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni) {
                             const int chunk = nh * 32 + wn_e * 8 + ni * 4 + lslot;
+#ifndef LPI_ABL_NO_STAGING_WRITE
                             *reinterpret_cast<f32x4*>(stg + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][(p & 1) * 2 + mi2];
+#else
+                            asm volatile("" :: "v"(acc[nh][ni][mh][(p & 1) * 2 + mi2]));      // ablation build: the accumulators stay live
+#endif
                         }
                 }
                 if constexpr (SIDE16) {
