@@ -255,6 +255,13 @@ int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, fl
  * [nloc, n] row-major, row stride ldg), from the row/column log-sum-exp vectors lpi_clip_loss_fwd_bwd left behind. */
 int lpi_clip_loss_local_grad(int n, const float* logits, int ld, const float* row_lse, const float* col_lse, float upstream,
                              int r0, int nloc, float* g, float* gt, int ldg, void* stream);
+/* `local_loss=True` form of the same loss (sprompt.py:278-283 with loss/loss.py:62-73): row-wise cross-entropy of a [rows, n] block of
+ * logits (this rank's images against ALL texts, or its texts against all images) whose row i has label label0 + i (= rank * B + i).
+ * loss_rows[i] = logsumexp(logits[i, :]) - logits[i, label0 + i]; dlogits (optional, may alias nothing) = upstream * (softmax - onehot).
+ * lpi_sum_scaled: out[0] = scale * sum(a[i] + b[i]) (b may be NULL), fixed order — the mean of the two row-loss vectors. */
+int lpi_ce_rows_fwd_bwd(int rows, int n, const float* logits, int ld, int label0, float upstream, float* loss_rows, float* dlogits,
+                        int lddl, void* stream);
+int lpi_sum_scaled(int n, const float* a, const float* b, float scale, float* out, void* stream);
 /* dst[r, 0:cols] = src[r, 0:cols], f32, row strides lds / ldd elements (packing / zero-padded operands; no framework copy kernels) */
 int lpi_zero(void* ptr, long bytes, void* stream);   /* hipMemsetAsync(ptr, 0, bytes) on `stream` */
 int lpi_copy_rows(int rows, int cols, const float* src, long lds, float* dst, long ldd, void* stream);

@@ -77,6 +77,8 @@ SIGNATURES = {
     "lpi_eot_index": [_I, _I, _P, _P, _P],
     "lpi_clip_loss_fwd_bwd": [_I, _P, _I, _F, _P, _P, _I, _P, _P, _P],
     "lpi_clip_loss_local_grad": [_I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _I, _P],
+    "lpi_ce_rows_fwd_bwd": [_I, _I, _P, _I, _I, _F, _P, _P, _I, _P],
+    "lpi_sum_scaled": [_I, _P, _P, _F, _P, _P],
     "lpi_zero": [_P, _L, _P],
     "lpi_copy_rows": [_I, _I, _P, _L, _P, _L, _P],
     "lpi_l1_task_id": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P],

@@ -483,6 +483,59 @@ extern "C" int lpi_clip_loss_local_grad(int n, const float* logits, int ld, cons
     return 0;
 }
 
+// Row-wise cross-entropy of a [rows, n] block of logits whose row i has label label0 + i — the `local_loss=True` form of the
+// contrastive loss (sprompt.py:278-283: logits_per_image = local images x ALL texts, labels offset by rank * B, loss/loss.py:62-73).
+// One wave per row: lse, the row's loss lse_i - x[i, label], and (dx != NULL) dx[i, :] = upstream * (softmax(x[i, :]) - onehot(label)).
+// dx may be x itself (the gradient overwrites the logits).
+__global__ __launch_bounds__(256) void ce_rows_kernel(int rows, int n, const float* x, int ld, int label0, float upstream,
+                                                     float* __restrict__ loss_rows, float* dx, int lddx) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* r = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, r[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += expf(r[j] - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    const int lab = label0 + row;
+    if (lane == 0) loss_rows[row] = lse - r[lab];
+    if (dx) {
+        float* d = dx + (size_t)row * lddx;
+        for (int j = lane; j < n; j += 64) d[j] = upstream * (expf(r[j] - lse) - (j == lab ? 1.f : 0.f));
+    }
+}
+// out[0] = scale * sum of v[0..n) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void sum_scaled_kernel(int n, const float* __restrict__ a, const float* __restrict__ b, float scale,
+                                                        float* __restrict__ out) {
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += a[i] + (b ? b[i] : 0.f);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] * scale;
+}
+
+extern "C" int lpi_ce_rows_fwd_bwd(int rows, int n, const float* logits, int ld, int label0, float upstream, float* loss_rows, float* dlogits,
+                                   int lddl, void* stream) {
+    if (!logits || !loss_rows || rows <= 0 || n <= 0 || ld < n || label0 < 0 || label0 + rows > n || (dlogits && lddl < n)) return LPI_EINVAL;
+    LPI_LAUNCH(ce_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, S(stream), rows, n, logits, ld, label0, upstream, loss_rows, dlogits, lddl);
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_sum_scaled(int n, const float* a, const float* b, float scale, float* out, void* stream) {
+    if (!a || !out || n <= 0) return LPI_EINVAL;
+    LPI_LAUNCH(sum_scaled_kernel, dim3(1), dim3(256), 0, S(stream), n, a, b, scale, out);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
 extern "C" int lpi_copy_rows(int rows, int cols, const float* src, long lds, float* dst, long ldd, void* stream) {
     if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return LPI_EINVAL;
     const long n = (long)rows * cols;

@@ -20,9 +20,12 @@ import torch.distributed as dist
 
 
 class Exchange:
-    def __init__(self, group=None, timing: bool = False):
+    def __init__(self, group=None, timing: bool = False, local_loss: bool = False, gather_with_grad: bool = False):
+        """local_loss / gather_with_grad: the modes of the reference's gather_features / get_logits (sprompt.py:38-82, 272-288),
+        see functional.ClipLossFn.  The default (False, False) needs no backward collective."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        self.local_loss, self.gather_with_grad = bool(local_loss), bool(gather_with_grad)
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -65,6 +68,28 @@ class Exchange:
             dist.all_gather_into_tensor(oh, h, group=self.group)
             out = oh.to(local.device)
         return out[:, :E], out[:, E:], self.rank * B
+
+    @property
+    def loss_weight(self) -> float:
+        """Weight of a rank's contrastive loss under the SUM all-reduce of the parameter gradients: 1 in the default mode (every rank
+        holds the global loss and its own rows' share of the gradient), 1/W when every rank holds a full gradient of its own loss."""
+        return 1.0 / self.world if (self.local_loss or self.gather_with_grad) else 1.0
+
+    def reduce_scatter_rows(self, dI_all: torch.Tensor, dT_all: torch.Tensor, B: int):
+        """SUM over ranks of the [W*B, E] key gradients, this rank's B rows of it: the backward of torch.distributed.nn.all_gather
+        (sprompt.py:67-69).  One fused message (image || text); reduce_scatter on RCCL, all_reduce + slice where the backend has none."""
+        E = dI_all.shape[1]
+        buf = torch.cat([dI_all, dT_all], dim=1).contiguous()
+        if self.world == 1:
+            out = buf
+        elif self.device_collectives:
+            out = torch.empty(B, 2 * E, dtype=buf.dtype, device=buf.device)
+            self._timed("reduce_scatter", lambda: dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group), buf.is_cuda)
+        else:
+            h = buf.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            out = h[self.rank * B:(self.rank + 1) * B].to(buf.device)
+        return out[:, :E].contiguous(), out[:, E:].contiguous()
 
     def allreduce_grads(self, params):
         """SUM all-reduce of the (small) prompt-factor gradients as one flat message."""

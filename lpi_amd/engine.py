@@ -819,6 +819,82 @@ def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True, r0: int = 
     return loss, logits[:n, :n], dI[:nloc], dT[:nloc]
 
 
+def _padded_rows(t, n, npad, name, ws, s):
+    """t [n, E] f32 (any row stride) as a GEMM operand with npad rows: itself if it already is one, else packed into the zero-padded ws[name]."""
+    if npad == n and _gemm_ready(t, n):
+        return t
+    E = t.shape[1]
+    buf = ws.get(name)
+    if buf is None or buf.shape != (npad, E):
+        buf = ws[name] = torch.zeros(npad, E, device=t.device)
+    tf = t if (t.dtype == torch.float32 and t.stride(1) == 1) else t.float().contiguous()
+    call("lpi_copy_rows", n, E, tf, tf.stride(0), buf, E, s)
+    return buf
+
+
+def clip_loss_local_fwd_bwd(img_all, txt_all, scale: float, r0: int, nloc: int, need_grad=True, key_grads=False):
+    """`local_loss=True` form of the contrastive loss (sprompt.py:278-283 + loss/loss.py:62-87): this rank's nloc images against ALL n
+    texts and its nloc texts against all n images, labels r0 + i; loss = (CE(logits_per_image) + CE(logits_per_text)) / 2 over the
+    nloc local rows.  Returns (loss[1], dI_q [nloc,E], dT_q [nloc,E], dI_k, dT_k): the gradients w.r.t. the LOCAL features as queries
+    (rows of the two logit blocks) and, with key_grads (`gather_with_grad=True`: the gathered features carry gradient,
+    sprompt.py:67-69), w.r.t. ALL n features as keys ([n,E] each; the caller reduce-scatters them to their owners) — else None."""
+    n, E = img_all.shape
+    if not (0 <= r0 and r0 + nloc <= n):
+        raise ValueError("local rows outside the global batch")
+    dev = img_all.device
+    s = _stream()
+    npad, lpad = _pad(n), _pad(nloc)
+    key = ("local", n, nloc, E, dev, torch.cuda.current_stream().cuda_stream)
+    ws = _LOSS_WS.get(key)
+    if ws is None:
+        z = lambda *sh: torch.zeros(*sh, device=dev)  # noqa: E731
+        ws = _LOSS_WS[key] = {"li": z(lpad, npad), "lt": z(lpad, npad), "rows": z(2, lpad), "At": z(E, npad), "Bt": z(E, npad),
+                              "git": z(npad, lpad), "gtt": z(npad, lpad), "ilt": z(E, lpad), "tlt": z(E, lpad)}
+    Ia = _padded_rows(img_all, n, npad, "Ia", ws, s)
+    Ta = _padded_rows(txt_all, n, npad, "Ta", ws, s)
+    Il = _padded_rows(img_all[r0:r0 + nloc], nloc, lpad, "Il", ws, s)
+    Tl = _padded_rows(txt_all[r0:r0 + nloc], nloc, lpad, "Tl", ws, s)
+    li, lt, rows = ws["li"], ws["lt"], ws["rows"]
+    gemm(F32, Il, Ta, li, lpad, npad, E, alpha=scale)            # logits_per_image = scale * I_loc . T_all^T
+    gemm(F32, Tl, Ia, lt, lpad, npad, E, alpha=scale)            # logits_per_text  = scale * T_loc . I_all^T
+    up = 0.5 / nloc
+    g = li if need_grad else None                                # the gradients overwrite the logit blocks
+    gt = lt if need_grad else None
+    call("lpi_ce_rows_fwd_bwd", nloc, n, li, npad, r0, up, rows[0], g, npad, s)
+    call("lpi_ce_rows_fwd_bwd", nloc, n, lt, npad, r0, up, rows[1], gt, npad, s)
+    loss = torch.empty(1, device=dev)
+    call("lpi_sum_scaled", nloc, rows[0], rows[1], up, loss, s)
+    if not need_grad:
+        return loss, None, None, None, None
+    # rows >= nloc and columns >= n of the two blocks are zero (products with the zero padding rows of the operands) and the CE kernel
+    # writes rows < nloc, columns < n only: the padded GEMMs below see zeros there
+    At, Bt = ws["At"], ws["Bt"]
+    call("lpi_transpose", F32, npad, E, Ia, Ia.stride(0), At, npad, s)
+    call("lpi_transpose", F32, npad, E, Ta, Ta.stride(0), Bt, npad, s)
+    dIq, dTq = torch.empty(lpad, E, device=dev), torch.empty(lpad, E, device=dev)
+    gemm(F32, li, Bt, dIq, lpad, E, npad, alpha=scale)           # d I_loc (queries) = scale * g  . T_all
+    gemm(F32, lt, At, dTq, lpad, E, npad, alpha=scale)           # d T_loc (queries) = scale * gt . I_all
+    if not key_grads:
+        return loss, dIq[:nloc], dTq[:nloc], None, None
+    git, gtt, ilt, tlt = ws["git"], ws["gtt"], ws["ilt"], ws["tlt"]
+    call("lpi_transpose", F32, lpad, npad, li, npad, git, lpad, s)
+    call("lpi_transpose", F32, lpad, npad, lt, npad, gtt, lpad, s)
+    call("lpi_transpose", F32, lpad, E, Il, Il.stride(0), ilt, lpad, s)
+    call("lpi_transpose", F32, lpad, E, Tl, Tl.stride(0), tlt, lpad, s)
+    dTk, dIk = torch.empty(npad, E, device=dev), torch.empty(npad, E, device=dev)
+    gemm(F32, git, ilt, dTk, npad, E, lpad, alpha=scale)         # d T_all (keys of logits_per_image) = scale * g^T  . I_loc
+    gemm(F32, gtt, tlt, dIk, npad, E, lpad, alpha=scale)         # d I_all (keys of logits_per_text)  = scale * gt^T . T_loc
+    return loss, dIq[:nloc], dTq[:nloc], dIk[:n], dTk[:n]
+
+
+def clip_loss_full_grad(img_all, txt_all, scale: float):
+    """The global loss with gradients w.r.t. ALL n features (`local_loss=False, gather_with_grad=True`, sprompt.py:67-69: every rank
+    back-propagates through every gathered feature; the caller reduce-scatters).  Returns (loss[1], dI_all [n,E], dT_all [n,E])."""
+    n = img_all.shape[0]
+    loss, _, dI, dT = clip_loss_fwd_bwd(img_all, txt_all, scale, True, 0, n)
+    return loss, dI, dT
+
+
 def score_matrix(img_feats, txt_feats):
     """The N_img x N_txt cosine score matrix of the evaluation (sprompt.py:509 `(image_feats @ text_feats.t()).t()`) and its transpose,
     through the f32 NT GEMM (exact f32 products, f32 accumulation) and lpi_transpose: -> (score_i2t [Ni, Nt], score_t2i [Nt, Ni])."""

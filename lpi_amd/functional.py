@@ -101,27 +101,49 @@ class EncodeBothFn(torch.autograd.Function):
 
 
 class ClipLossFn(torch.autograd.Function):
-    """logit_scale * I @ T^T then ClipLoss (slinet.py:138-141, loss/loss.py:75-87).  With a process group the
-    features are all-gathered first (dp.py) and every rank evaluates the full global loss (``local_loss=False``
-    semantics of the reference's dead ``gather_features``, sprompt.py:38-82)."""
+    """logit_scale * I @ T^T then ClipLoss (slinet.py:138-141, loss/loss.py:75-87).  With a process group the features are
+    all-gathered first (dp.py) in one of the four modes of the reference's dead ``gather_features`` / ``get_logits`` /
+    ``ClipLoss.get_ground_truth`` (sprompt.py:38-82, 272-288; loss/loss.py:62-73), selected on the ``dp.Exchange``:
+
+    * local_loss=False, gather_with_grad=False (default): every rank evaluates the FULL global loss and back-propagates only through
+      its own rows (sprompt.py:75-80); no backward collective.  SUM of the ranks' parameter gradients = the global-batch gradient.
+    * local_loss=True: the rank's images against all texts and its texts against all images, labels offset by rank * B; the value is the
+      rank's own mean.  Without gather_with_grad the gathered features carry no gradient (the reference's partial gradient); with it the
+      key gradients are reduce-scattered (SUM) to their owners, as ``torch.distributed.nn.all_gather``'s backward does.
+    * local_loss=False, gather_with_grad=True: the full loss with gradients through every gathered feature, reduce-scattered.
+    In the last three modes the mean over ranks of the parameter gradients is the quantity of interest, so step.py weighs the loss by
+    1/W before the SUM all-reduce."""
 
     @staticmethod
-    def forward(ctx, img_f, txt_f, scale, gather=None):
+    def forward(ctx, img_f, txt_f, scale, gather=None, exchange=None):
         if gather is not None:
             img_all, txt_all, r0 = gather(img_f.detach(), txt_f.detach())
         else:
             img_all, txt_all, r0 = img_f.detach().contiguous(), txt_f.detach().contiguous(), 0
         need = img_f.requires_grad or txt_f.requires_grad
-        loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need, r0, img_f.shape[0])     # gradients of the local rows only
+        B = img_f.shape[0]
+        ll = bool(getattr(exchange, "local_loss", False))
+        gwg = bool(getattr(exchange, "gather_with_grad", False))
+        ctx.logits = None
+        if ll:
+            loss, dI, dT, dIk, dTk = E.clip_loss_local_fwd_bwd(img_all, txt_all, scale, r0, B, need, key_grads=gwg and need)
+            if need and gwg:
+                kI, kT = exchange.reduce_scatter_rows(dIk, dTk, B)        # this rank's rows of the SUM over ranks
+                dI, dT = dI + kI, dT + kT
+        elif gwg:
+            loss, dIa, dTa = E.clip_loss_full_grad(img_all, txt_all, scale)
+            dI, dT = exchange.reduce_scatter_rows(dIa, dTa, B) if need else (None, None)
+        else:
+            loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need, r0, B)     # gradients of the local rows only
+            ctx.logits = logits
         if need:
             ctx.save_for_backward(dI, dT)
-        ctx.logits = logits
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         dI, dT = ctx.saved_tensors
-        return dI * g, dT * g, None, None
+        return dI * g, dT * g, None, None, None
 
 
 class AlignLossFn(torch.autograd.Function):

@@ -124,7 +124,9 @@ class SPrompts(BaseLearner):
         self._network.to(self._device)
         if _dist_world() > 1 and self._network.exchange is None:
             from lpi_amd.dp import Exchange
-            self._network.exchange = Exchange()
+            # the modes of the reference's gather_features (sprompt.py:38-82); the default needs no backward collective
+            self._network.exchange = Exchange(local_loss=bool(self.args.get("local_loss", False)),
+                                              gather_with_grad=bool(self.args.get("gather_with_grad", False)))
         network = self._network
         for name, param in network.named_parameters():
             param.requires_grad_(False)
@@ -152,7 +154,8 @@ class SPrompts(BaseLearner):
                 model_out = net.cal_loss(image_features, text_features, visual_prompt, textual_prompt)
                 world = net.exchange.world if net.exchange is not None else 1
                 # data-independent terms are identical on every rank: count them once under the SUM all-reduce
-                loss = sum(v if k == "base_loss" else v / world for k, v in model_out['loss'].items())
+                bw = net.exchange.loss_weight if net.exchange is not None else 1.0
+                loss = sum(v * bw if k == "base_loss" else v / world for k, v in model_out['loss'].items())
                 optimizer.zero_grad()
                 loss.backward()
                 if net.exchange is not None:

@@ -135,7 +135,7 @@ class SliNet(nn.Module):
     def cal_loss(self, image_featuers, text_features, visual_prompt, textual_prompt):
         eng = self._ensure_engine()
         gather = self.exchange.gather if self.exchange is not None else None
-        losses = {"base_loss": ClipLossFn.apply(image_featuers, text_features, eng.logit_scale_exp, gather)}
+        losses = {"base_loss": ClipLossFn.apply(image_featuers, text_features, eng.logit_scale_exp, gather, self.exchange)}
         vis, txt = self._dense(visual_prompt), self._dense(textual_prompt)
         losses["alignment_loss"] = AlignLossFn.apply(vis, txt, 0.01, 0.1)
         if self.numtask != 1:

@@ -13,7 +13,7 @@ from .synth import PROMPT_NAMES
 
 
 def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = False,
-                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True):
+                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, exchange=None):
     """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
     Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits).
 
@@ -75,7 +75,7 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
         img_f = EncodeImageFn.apply(enc, images, vis, depth)
         txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
     fn = ClipLossFn
-    base = fn.apply(img_f, txt_f, enc.logit_scale_exp, gather)
+    base = fn.apply(img_f, txt_f, enc.logit_scale_exp, gather, exchange)
     losses = {"base_loss": base, "alignment_loss": AlignLossFn.apply(vis, txt, 0.01, align_weight)}
     return losses, img_f, txt_f, vis, txt
 
@@ -90,9 +90,9 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
         factors[k].grad = None
     gather = exchange.gather if exchange is not None else None
     losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
-                                                  cu_lanes, lockstep)
+                                                  cu_lanes, lockstep, exchange)
     world = exchange.world if exchange is not None else 1
-    total = losses["base_loss"] + losses["alignment_loss"] / world
+    total = losses["base_loss"] * float(getattr(exchange, "loss_weight", 1.0)) + losses["alignment_loss"] / world
     total.backward()
     if exchange is not None:
         exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES])

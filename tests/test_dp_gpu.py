@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, q, dtype):
+def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
@@ -44,7 +44,7 @@ def _worker(rank, port, q, dtype):
         img = torch.from_numpy(synth.images(W * B, cfg.image_resolution))[rank * B:(rank + 1) * B].to(dev)
         ids = torch.from_numpy(synth.token_ids(W * B))[rank * B:(rank + 1) * B].to(dev)
         n0 = _lib.launch_count()
-        out = train_step(enc, img, ids, fac, 2, Exchange())
+        out = train_step(enc, img, ids, fac, 2, Exchange(local_loss=local_loss, gather_with_grad=gather_with_grad))
         torch.cuda.synchronize()
         assert _lib.launch_count() - n0 > 30, "the HIP kernels did not run"
         q.put((rank, float(out["base_loss"]), {k: v.grad.cpu().numpy().copy() for k, v in fac.items()}, out["img_f"].cpu().numpy()))
@@ -79,3 +79,33 @@ def test_two_process_hip_step_equals_oracle_on_global_batch():
             assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max() + 1e-6, (rank, k)
     for k in res[0][2]:      # both ranks hold the same (summed) gradients
         assert np.array_equal(res[0][2][k], res[1][2][k])
+
+
+@pytest.mark.parametrize("local_loss,gather_with_grad", [(True, True), (False, True)])
+def test_two_process_hip_step_with_gradients_through_the_gathered_features(local_loss, gather_with_grad):
+    """gather_with_grad=True (sprompt.py:67-69): the key gradients are SUM reduce-scattered to their owners (host-staged under gloo), every
+    rank weighs its loss by 1/W, and the SUM-all-reduced factor gradients are again the oracle's on the concatenated batch; with
+    local_loss=True each rank reports its OWN mean loss (their mean is the global loss)."""
+    from oracle import lpi_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q, "f32", local_loss, gather_with_grad)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(W)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = synth.TINY
+    ref = O.train_step(O.Oracle(cfg, synth.clip_state_dict(cfg)), synth.images(W * B, cfg.image_resolution), synth.token_ids(W * B),
+                       synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width), depth=2)
+    for rank, base, grads, img_f in res:
+        assert grads is not None, base
+        for k, g in grads.items():
+            r = ref["grad." + k]
+            assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max() + 1e-6, (rank, k)
+    mean_loss = float(np.mean([b for _, b, _, _ in res]))
+    assert abs(mean_loss - float(ref["base_loss"])) < 1e-4
+    if not local_loss:
+        assert all(abs(b - float(ref["base_loss"])) < 1e-4 for _, b, _, _ in res)

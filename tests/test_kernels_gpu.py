@@ -1148,3 +1148,68 @@ def test_attention_single_pass_backward(saved, B, L, H):
         e = relerr(new[0][:, sl], qr.grad[:, sl])
         assert e < 4e-2, (name, e)
     assert relerr(new[0][:, :d], old[0][:, :d].double().cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("W,B,E_", [(4, 64, 128), (2, 3, 64), (8, 128, 512)])
+def test_clip_loss_modes_of_gather_features(W, B, E_):
+    """The other three modes of the reference's dead gather_features / get_logits / get_ground_truth (sprompt.py:38-82, 272-288;
+    loss/loss.py:62-73) on W emulated ranks, against f64 autograd written the way the reference computes them:
+    local_loss (rank r: its images x all texts, its texts x all images, labels r*B + i) without and with gradients through the gathered
+    features (torch.distributed.nn.all_gather's backward = SUM reduce-scatter, emulated by summing the ranks' key gradients), and the
+    full loss with gather_with_grad."""
+    n, scale = W * B, 14.3
+    g = torch.Generator().manual_seed(W * 1000 + B)
+    feats = torch.nn.functional.normalize(torch.randn(n, 2 * E_, generator=g, dtype=torch.float64), dim=1)
+    dev = feats.float().to(DEV)
+    Ia, Ta = dev[:, :E_], dev[:, E_:]                      # row-strided views, as dp.Exchange.gather returns them
+    lab = torch.arange(B)
+
+    def ref_local(r, with_key_grads):
+        I = feats[:, :E_].clone().requires_grad_(True)
+        T = feats[:, E_:].clone().requires_grad_(True)
+        sl = slice(r * B, (r + 1) * B)
+        Iall, Tall = (I, T) if with_key_grads else (I.detach(), T.detach())
+        li = scale * I[sl] @ Tall.t()
+        lt = scale * T[sl] @ Iall.t()
+        loss = (torch.nn.functional.cross_entropy(li, lab + r * B) + torch.nn.functional.cross_entropy(lt, lab + r * B)) / 2
+        loss.backward()
+        return float(loss), I.grad, T.grad
+
+    tol = lambda ref: 1e-7 + 2e-4 * float(ref.abs().max())  # noqa: E731
+    kI, kT = torch.zeros(n, E_, dtype=torch.float64), torch.zeros(n, E_, dtype=torch.float64)
+    rI, rT = torch.zeros(n, E_, dtype=torch.float64), torch.zeros(n, E_, dtype=torch.float64)
+    q = []
+    for r in range(W):
+        sl = slice(r * B, (r + 1) * B)
+        # local_loss=True, gather_with_grad=False: queries only
+        loss, dIq, dTq, none1, none2 = E.clip_loss_local_fwd_bwd(Ia, Ta, scale, r * B, B, True, key_grads=False)
+        lref, gI, gT = ref_local(r, False)
+        assert none1 is None and none2 is None
+        assert abs(float(loss) - lref) < 2e-5 * max(1.0, abs(lref))
+        assert float((dIq.double().cpu() - gI[sl]).abs().max()) < tol(gI) and float((dTq.double().cpu() - gT[sl]).abs().max()) < tol(gT)
+        assert float(gI.abs().sum() - gI[sl].abs().sum()) == 0.0          # the reference's gradient touches the local rows only
+        # ... gather_with_grad=True: key gradients for every rank's rows
+        loss2, dIq2, dTq2, dIk, dTk = E.clip_loss_local_fwd_bwd(Ia, Ta, scale, r * B, B, True, key_grads=True)
+        assert float(loss2) == float(loss) and torch.equal(dIq2, dIq) and torch.equal(dTq2, dTq)
+        _, gI2, gT2 = ref_local(r, True)
+        kI += dIk.double().cpu()
+        kT += dTk.double().cpu()
+        rI += gI2
+        rT += gT2
+        q.append((dIq.double().cpu(), dTq.double().cpu()))
+        assert E.clip_loss_local_fwd_bwd(Ia, Ta, scale, r * B, B, False)[1] is None
+    for r in range(W):      # what rank r holds after the reduce-scatter: its query gradients + its rows of the summed key gradients
+        sl = slice(r * B, (r + 1) * B)
+        assert float((q[r][0] + kI[sl] - rI[sl]).abs().max()) < tol(rI)
+        assert float((q[r][1] + kT[sl] - rT[sl]).abs().max()) < tol(rT)
+    # the mean over ranks of the local losses is the global loss: (1/W) * summed gradients = gradient of the global loss
+    I = feats[:, :E_].clone().requires_grad_(True)
+    T = feats[:, E_:].clone().requires_grad_(True)
+    lg = scale * I @ T.t()
+    L = (torch.nn.functional.cross_entropy(lg, torch.arange(n)) + torch.nn.functional.cross_entropy(lg.t(), torch.arange(n))) / 2
+    L.backward()
+    assert float((rI / W - I.grad).abs().max()) < 1e-12 and float((rT / W - T.grad).abs().max()) < 1e-12
+    # local_loss=False, gather_with_grad=True: the full loss, gradients through every gathered feature
+    loss, dIa, dTa = E.clip_loss_full_grad(Ia, Ta, scale)
+    assert abs(float(loss) - float(L)) < 2e-5 * max(1.0, float(L))
+    assert float((dIa.double().cpu() - I.grad).abs().max()) < tol(I.grad) and float((dTa.double().cpu() - T.grad).abs().max()) < tol(T.grad)
