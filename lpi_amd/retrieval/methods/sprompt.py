@@ -9,8 +9,9 @@ What changed, and why:
     all-gathered for the global contrastive matrix and the prompt-factor gradients are SUM all-reduced (lpi_amd/dp.py) —
     the reference's multi-GPU path is dead code (README.md:13; SURVEY.md F6);
   * the per-row ``np.argsort`` rank search of ``itm_eval`` (sprompt.py:558-599) runs on the GPU (lpi_retrieval_rank);
-  * datasets: COCO is not available offline; ``args['dataset_impl'] == 'synthetic'`` (default when image_root is missing)
-    builds synthetic loaders with the same item structure.  KMeans task keys stay on the host (sklearn), as in the reference.
+  * datasets: ``args['dataset_impl']`` = 'coco' (utils/data.py's Coco / CocoEval on image_root + the two annotation files; default when
+    image_root exists) or 'synthetic' (default when image_root is missing: COCO is not available offline; loaders with the same
+    item structure).  KMeans task keys stay on the host (sklearn), as in the reference.
 """
 import collections
 import json
@@ -87,9 +88,12 @@ class SPrompts(BaseLearner):
         impl = self.args.get("dataset_impl")
         if impl is None:
             impl = "coco" if os.path.isdir(str(self.args.get("image_root", ""))) else "synthetic"
+        if impl == "coco":          # sprompt.py:163-170
+            from lpi_amd.retrieval.utils.data import Coco, CocoEval
+            return (Coco(image_root=self.args['image_root'], ann_file=self.args['annotation_train_root'], tasks=[i]),
+                    CocoEval(image_root=self.args['image_root'], ann_file=self.args['annotation_val_root'], tasks=np.arange(0, i + 1)))
         if impl != "synthetic":
-            raise NotImplementedError("COCO loading needs torchvision/PIL pipelines that are outside the hot path; pass your own "
-                                      "loaders to _train(train_loader, test_loader) or use dataset_impl='synthetic'")
+            raise ValueError(f"unknown dataset_impl {impl!r} (coco | synthetic)")
         res = self._network.clip_cfg.image_resolution
         n_train = int(self.args.get("synthetic_train_size", 4 * self.batch_size))
         n_eval = int(self.args.get("synthetic_eval_images_per_task", 16))

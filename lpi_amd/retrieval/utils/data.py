@@ -1,8 +1,14 @@
 """Dataset I/O contract of the retrieval path (utils/data.py:160-382 of the reference): train items are
 ``(image[3,224,224] f32 ImageNet-normalised, caption, 0, task)``, eval items ``(image, img_id, task)`` with the lookup tables
 ``text, image, text_cat, txt2img, img2txt`` on the dataset object.  COCO itself is not available offline, so the default
-implementation is synthetic (captions are delivered as ready token ids); ``pre_caption`` is the reference's caption
-normaliser for callers that bring real annotations."""
+implementation is synthetic (captions are delivered as ready token ids).  ``Coco`` / ``CocoEval`` read the reference's annotation
+format (a JSON list of ``{"image", "caption", "category", "image_id"}`` records, ``caption`` a string for training and a list for
+evaluation) from ``image_root`` / ``ann_file`` with PIL — the torchvision pipelines of the reference (RandomResizedCrop +
+RandomHorizontalFlip / Resize(256) + CenterCrop(224), ToTensor, ImageNet Normalize) are restated here on PIL + torch, because
+torchvision is not part of this environment.  Host-side I/O only: nothing here is on the timed path."""
+import json
+import math
+import os
 import re
 
 import numpy as np
@@ -68,3 +74,144 @@ class SyntheticCocoEval(Dataset):
     def __getitem__(self, i):
         img = torch.from_numpy(synth.normal(synth.IMAGE_SEED + 500 + self.seed, f"img{i}", (3, self.res, self.res)))
         return img, i, self.img_cat[i]
+
+
+# ---------------------------------------------------------------------------------------------- real COCO (utils/data.py:186-382)
+# task t of the 12-task protocol holds COCO super-category TASK_CATEGORIES[t] (utils/data.py:233-249, 338-353)
+TASK_CATEGORIES = (11, 6, 3, 10, 5, 12, 7, 9, 2, 8, 4, 1)
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def task_of_category(category: int) -> int:
+    """The reference's loop `for z in range(len(tasks)): if category in tasks[z]: new_category = z` (0 when absent)."""
+    return TASK_CATEGORIES.index(category) if category in TASK_CATEGORIES else 0
+
+
+def _pil():
+    try:
+        from PIL import Image
+    except ImportError as e:          # loud: there is no silent fallback to synthetic data
+        raise ImportError("the COCO datasets need Pillow (PIL) to decode images; use dataset_impl='synthetic' without it") from e
+    return Image
+
+
+def _to_normalised_tensor(img):
+    """ToTensor + Normalize(ImageNet) (utils/data.py:201-204): HWC uint8 -> CHW f32 in [0,1], then (x - mean) / std."""
+    a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+    return (a - mean) / std
+
+
+def train_transform(img, size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """RandomResizedCrop(size) + RandomHorizontalFlip + ToTensor + Normalize (utils/data.py:193-204), torch RNG: a crop of random area
+    (scale x image area) and log-uniform aspect ratio, ten attempts, else the largest centred crop inside the ratio bounds; bilinear."""
+    Image = _pil()
+    w, h = img.size
+    area = w * h
+    box = None
+    for _ in range(10):
+        target = area * float(torch.empty(1).uniform_(scale[0], scale[1]))
+        logr = float(torch.empty(1).uniform_(math.log(ratio[0]), math.log(ratio[1])))
+        ar = math.exp(logr)
+        cw, ch = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+        if 0 < cw <= w and 0 < ch <= h:
+            top = int(torch.randint(0, h - ch + 1, (1,)))
+            left = int(torch.randint(0, w - cw + 1, (1,)))
+            box = (left, top, left + cw, top + ch)
+            break
+    if box is None:
+        in_ratio = w / h
+        if in_ratio < ratio[0]:
+            cw, ch = w, int(round(w / ratio[0]))
+        elif in_ratio > ratio[1]:
+            cw, ch = int(round(h * ratio[1])), h
+        else:
+            cw, ch = w, h
+        left, top = (w - cw) // 2, (h - ch) // 2
+        box = (left, top, left + cw, top + ch)
+    img = img.crop(box).resize((size, size), Image.BILINEAR)
+    if float(torch.rand(1)) < 0.5:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)
+    return _to_normalised_tensor(img)
+
+
+def test_transform(img, resize=256, size=224):
+    """Resize(256) (shorter side, bilinear) + CenterCrop(224) + ToTensor + Normalize (utils/data.py:197-204)."""
+    Image = _pil()
+    w, h = img.size
+    if w <= h:
+        nw, nh = resize, int(resize * h / w)
+    else:
+        nw, nh = int(resize * w / h), resize
+    img = img.resize((nw, nh), Image.BILINEAR)
+    left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+    return _to_normalised_tensor(img.crop((left, top, left + size, top + size)))
+
+
+def _load(image_root, name, transform):
+    Image = _pil()
+    with Image.open(os.path.join(image_root, name)) as im:
+        return transform(im.convert("RGB"))
+
+
+class Coco(Dataset):
+    """Training pairs of the given tasks (utils/data.py:308-382): item = (image, prompt + pre_caption(caption), 0, task)."""
+
+    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, prompt='', tasks=(0,), replay_list=()):
+        _pil()
+        with open(ann_file, 'r') as f:
+            records = json.load(f)
+        cats = {TASK_CATEGORIES[int(t)] for t in tasks}
+        self.transform = transform or train_transform
+        self.image_root, self.max_words, self.prompt = image_root, max_words, prompt
+        self.img_ids = {}
+        self.annotation = []
+        for ann in records:
+            if ann['category'] in cats:
+                self.img_ids.setdefault(ann['image_id'], len(self.img_ids))
+                self.annotation.append(ann)
+        self.annotation += list(replay_list)
+
+    def __len__(self):
+        return len(self.annotation)
+
+    def __getitem__(self, index):
+        ann = self.annotation[index]
+        image = _load(self.image_root, ann['image'], self.transform)
+        return image, self.prompt + pre_caption(ann['caption'], self.max_words), 0, task_of_category(ann['category'])
+
+
+class CocoEval(Dataset):
+    """Evaluation images of tasks 0..t with every caption of every image in the lookup tables the scoring loop reads
+    (utils/data.py:186-306; sprompt.py:433-548): text, text_cat, image, txt2img, img2txt; item = (image, image index, task)."""
+
+    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, tasks=(0,)):
+        _pil()
+        with open(ann_file, 'r') as f:
+            records = json.load(f)
+        cats = {TASK_CATEGORIES[int(t)] for t in tasks}
+        # the reference's default transform is the TRAINING one (utils/data.py:206, a default-argument slip); evaluation wants the
+        # deterministic Resize + CenterCrop it defines next to it, which is the default here — pass transform=train_transform to get the slip
+        self.transform = transform or test_transform
+        self.image_root, self.max_words = image_root, max_words
+        self.ann = [a for a in records if a['category'] in cats]
+        self.text, self.text_cat, self.image = [], [], []
+        self.txt2img, self.img2txt = {}, {}
+        for img_id, ann in enumerate(self.ann):
+            self.image.append(ann['image'])
+            self.img2txt[img_id] = []
+            task = task_of_category(ann['category'])
+            for caption in ann['caption']:
+                txt_id = len(self.text)
+                self.text.append(pre_caption(caption, self.max_words))
+                self.text_cat.append(task)
+                self.img2txt[img_id].append(txt_id)
+                self.txt2img[txt_id] = img_id
+
+    def __len__(self):
+        return len(self.ann)
+
+    def __getitem__(self, index):
+        ann = self.ann[index]
+        return _load(self.image_root, ann['image'], self.transform), index, task_of_category(ann['category'])
