@@ -254,8 +254,8 @@ class Workload:
                     if all("mfma_busy_frac" in v for v in ks):
                         mfma_util = round(sum(v["mfma_busy_frac"] * v["launches"] for v in ks) / w, 4)
                     tsrc = "profiles/r02_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
-        return {"bound": "mfma", "kernel": "gemm256p_kernel / gemm256_kernel / gemm256_tail_kernel (the 256x256 GEMM: persistent for store-only epilogues, "
-                                            "one tile per workgroup for loading epilogues, the last with a short last round as half tiles)",
+        return {"bound": "mfma", "kernel": "gemm256p_kernel (the persistent 256x256 GEMM; the vision and the text tower's GEMM of the same layer op go out as ONE "
+                                            "grouped launch, a short last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
                 "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(by / len(ev)),

@@ -9,7 +9,8 @@ import os
 from ctypes import c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblpi_hip.so")
+# LPI_LIB: an alternate build of the library (tools/build_variant.sh: A/B and ablation builds for the measurement tools)
+LIB_PATH = os.environ.get("LPI_LIB") or os.path.join(_HERE, "csrc", "liblpi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU = 0, 1, 2
