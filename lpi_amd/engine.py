@@ -343,6 +343,7 @@ class Tower:
         self._check_depth(prompts, depth)
         self.serial += 1
         for i, blk in enumerate(self.blocks):
+            lt = "last" if i == len(self.blocks) - 1 else i      # GEMM tag: towers of different depth pair layer i with layer i, last with last
             k = i if train else 0
             x_in = ws["x"][i if train else i % 2]
             x_out = ws["x"][i + 1 if train else (i + 1) % 2]
@@ -354,7 +355,7 @@ class Tower:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
-                yield GemmReq(f"{i}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
+                yield GemmReq(f"{lt}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
                 call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, x_in, pidx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
                 yield GemmReq(None, dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
                 call("lpi_attn_pooled_fwd_varlen", dt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
@@ -364,9 +365,9 @@ class Tower:
                 yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            yield GemmReq(f"{i}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
+            yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             call("lpi_attn_fwd_varlen", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
-            yield GemmReq(f"{i}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
+            yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 call("lpi_gather_rows", xdt, B, Lx, d, xmid, pidx, ws["c_xmid"], s)
@@ -375,8 +376,8 @@ class Tower:
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             call("lpi_layernorm_fwd", dt, xdt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
-            yield GemmReq(f"{i}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            yield GemmReq(f"{i}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
+            yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
+            yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 
@@ -401,6 +402,8 @@ class Tower:
         self._check_depth(prompts, depth)
         for i in reversed(range(len(self.blocks))):
             blk = self.blocks[i]
+            # GEMM tag: the backward pairs the towers' layers by their distance from the END (both start at their last block)
+            lt = "last" if i == len(self.blocks) - 1 else f"r{len(self.blocks) - 1 - i}"
             x_in, xmid, qkv, ctx, lse, u, st = ws["x"][i], ws["xmid"][i], ws["qkv"][i], ws["ctx"][i], ws["lse"][i], ws["u"][i], ws["stat"][i]
             if i == len(self.blocks) - 1 and not POOLED_LAST:
                 call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
@@ -423,7 +426,7 @@ class Tower:
                 yield GemmReq(None, dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
                 call("lpi_attn_pooled_bwd_varlen", adt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
                      dqkv, 3 * d, int(sp.causal), s)
-                yield GemmReq(f"{i}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
+                yield GemmReq(f"{lt}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 yield GemmReq(None, dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
                 call("lpi_scatter_add_rows", dt, B, Lx, d, ws["c_dh"], d, pidx, dh, d, s)
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
@@ -436,11 +439,11 @@ class Tower:
                 continue
             if not (i == len(self.blocks) - 1 and POOLED_LAST):
                 du = ws["du"]
-                yield GemmReq(f"{i}.dproj", dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
-                yield GemmReq(f"{i}.dfc", dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
+                yield GemmReq(f"{lt}.dproj", dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
+                yield GemmReq(f"{lt}.dfc", dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
-            yield GemmReq(f"{i}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
+            yield GemmReq(f"{lt}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             call("lpi_attn_bwd_varlen", adt, B, L, rs, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
             if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
                 # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
@@ -448,11 +451,11 @@ class Tower:
                 # path of those rows is already in the stream; every other row of it is left without this block's attention term.
                 pq, ph = ws["p_dqkv"], ws["p_dh"]
                 call("lpi_gather_batch_rows_varlen", dt, B, L, rs, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
-                yield GemmReq(f"{i}.dqkv_p", dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
+                yield GemmReq(f"{lt}.dqkv_p", dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
                 call("lpi_layernorm_bwd_rows_varlen", dt, dt, xdt, B, L, rs, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                      None if dt == F32 else dxT, d, 1, s)
                 continue
-            yield GemmReq(f"{i}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
+            yield GemmReq(f"{lt}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                  None if dt == F32 else dxT, d, 1, s)
             if prompts is not None and dprompts is not None and 0 < i < depth:
