@@ -183,6 +183,22 @@ def test_longest_caption_and_eot_position():
     enc = DualEncoder(cfg, sd, dtype="f32", device=DEV)
     got = enc.encode_text(torch.from_numpy(ids).to(DEV), txt.float().to(DEV), depth=2).cpu().numpy()
     assert maxerr(got, ref) < 2e-5
+    # the same batch PACKED (lengths 77, 19 and a medium one: the longest and the shortest legal caption side by side), a batch of one,
+    # per-sample prompts (the evaluation's gathered prompt stacks, slinet.py:212-220) and no prompts at all (extract_textual_vector)
+    pk = PackedIds(ids)
+    assert pk.lengths.tolist()[:2] == [77, 19] and pk.rows == int(pk.lengths.sum())
+    assert maxerr(enc.encode_text(pk.to(DEV), txt.float().to(DEV), depth=2).cpu().numpy(), ref) < 2e-5
+    one = enc.encode_text(PackedIds(ids[1:2]).to(DEV), txt.float().to(DEV), depth=2).cpu().numpy()
+    assert maxerr(one, ref[1:2]) < 2e-5
+    per_sample = txt.float().unsqueeze(0).repeat(3, 1, 1, 1).to(DEV)
+    assert maxerr(enc.encode_text(pk, per_sample, depth=2).cpu().numpy(), ref) < 2e-5
+    plain = enc.encode_text(torch.from_numpy(ids).to(DEV), None).cpu().numpy()
+    assert maxerr(enc.encode_text(pk, None).cpu().numpy(), plain) < 2e-6
+    short = ids.copy()
+    short[2, :] = 0
+    short[2, :17] = [synth.SOT] + [synth.X_TOKEN] * 15 + [synth.EOT]          # no room for the 16 context slots
+    with pytest.raises(ValueError):
+        enc.encode_text(PackedIds(short), txt.float().to(DEV), depth=2)
 
 
 def test_bitwise_reproducible_gradients():
