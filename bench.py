@@ -385,7 +385,11 @@ def main():
                        + f"{a.model} dual encoder bs={B}/GPU prompt_depth={a.depth} r={a.rank} P=16, "
                        + ("fwd-only + cosine matrix" if a.fwd_only else "fwd+bwd incl. DecomposedPrompt grads + SGD step"),
                        "global_batch": world * B, "image": f"{cfg.image_resolution}x{cfg.image_resolution}", "tokens": cfg.context_length,
-                       "text_rows_computed": round(wl.text_rows, 2),   # < tokens: columns behind the longest caption's EOT are dead (causal mask) and skipped, exactly
+                       # rows per caption actually computed: the rows behind a caption's EOT are dead under the causal mask and skipped, exactly
+                       # (packed: every caption cut at its OWN EOT; --no-text-pack: at the longest one; --no-text-trim: all 77)
+                       "text_rows_computed": round(wl.text_rows, 2),
+                       "text_layout": "77 columns" if a.no_text_trim else ("cut at the longest caption" if a.no_text_pack else "packed (engine.PackedIds)"),
+                       "towers": "one after the other" if (a.no_lockstep or a.overlap or a.cu_lanes) else "lock step, GEMMs of one layer op grouped in one launch",
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
                        "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
                        "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "
