@@ -104,6 +104,9 @@ template <> struct Elem<f16_t> {
     }
 };
 
+// 4 consecutive elements of TT from 4 floats with a STREAMING (non-temporal) store: for tensors that are not read again soon
+template <typename TT> __device__ __forceinline__ void st4_nt(TT* p, f32x4 v);
+template <> __device__ __forceinline__ void st4_nt<float>(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 // 16-byte fragment chunk as it sits in a lane's registers
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 union Chunk {
@@ -143,6 +146,18 @@ template <> __device__ __forceinline__ uint32_t pack2_t<f16_t>(float a, float b)
     typedef __attribute__((ext_vector_type(2))) _Float16 h2_;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, h2_));
 }
+template <> __device__ __forceinline__ void st4_nt<bf16_t>(bf16_t* p, f32x4 v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+    u32x2_ w;
+    w[0] = pack2_t<bf16_t>(v[0], v[1]); w[1] = pack2_t<bf16_t>(v[2], v[3]);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_*>(p));
+}
+template <> __device__ __forceinline__ void st4_nt<f16_t>(f16_t* p, f32x4 v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+    u32x2_ w;
+    w[0] = pack2_t<f16_t>(v[0], v[1]); w[1] = pack2_t<f16_t>(v[2], v[3]);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_*>(p));
+}
 // element e (0..7) of a chunk of T as float
 template <typename T> __device__ __forceinline__ float chunk_elem(const Chunk& c, int e);
 template <> __device__ __forceinline__ float chunk_elem<bf16_t>(const Chunk& c, int e) { return (float)c.h[e]; }
@@ -173,7 +188,12 @@ __device__ __forceinline__ void store_row16_t(T16* row_ptr, const f32x4 (&o)[4],
         const uint32_t y0 = pk(o[2 * p + 1][0], o[2 * p + 1][1]), y1 = pk(o[2 * p + 1][2], o[2 * p + 1][3]);
         const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);      // {x rows 0,2 | y rows 0,2 -> x rows 1,3}, {x rows 1,3 -> y rows 0,2 | y rows 1,3}
         const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+#ifdef LPI_NT_ATTN
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+        if (valid) __builtin_nontemporal_store((u32x4_){r0[0], r1[0], r0[1], r1[1]}, reinterpret_cast<u32x4_*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8));
+#else
         if (valid) *reinterpret_cast<uint4*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+#endif
     }
 }
 

@@ -381,7 +381,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         } else {
                             o += Elem<TC>::ld4(reinterpret_cast<const TC*>(sp));
                         }
-                        Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                        // streaming store, as gemm_epilogue_store (a RUN-TIME choice per problem was tried: the duplicated store
+                        // loops spilled 60 bytes per lane in the QuickGELU instantiations and the step lost 7 %)
+                        if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                        else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
                     } else {
                         gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
                     }

@@ -10,7 +10,15 @@ template <> struct AuxT<f16_t> { typedef bf16_t type; };
 // RES (residual present) and SAVE_U (QuickGELU pre-activation wanted) are COMPILE-TIME: a run-time "pointer or not" test per
 // element makes hipcc branch around every load and wait vmcnt(0) each time — 32 serial HBM round trips per lane
 // (cdna_hip_programming.md, "Three .s-level traps" (c)).  Without branches the unrolled loads are batched.
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true>
+// NTC: the output C is stored with a STREAMING (non-temporal) store.  Measured on the whole step: +3.2 % with every GEMM output streamed
+// (26.19 -> 25.37 ms: the outputs are 84-335 MB, the next kernel reads them through L2 misses either way, and without write-allocated
+// lines the A / B tiles of the running GEMM stay in the XCD L2); the persistent kernel chooses per problem (gemm256p.hip).
+#ifndef LPI_NO_NT_C
+#define LPI_NTC_DEFAULT true
+#else
+#define LPI_NTC_DEFAULT false
+#endif
+template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true, bool NTC = LPI_NTC_DEFAULT>
 __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
                                                     const float* __restrict__ residual, int ldr, typename AuxT<T>::type* __restrict__ aux,
                                                     int ldaux) {
@@ -48,7 +56,8 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
         else v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
     }
 #ifndef LPI_ABL_NO_GLOBAL_STORE
-    Elem<TC>::st4(C + (size_t)row * ldc + col, v);
+    if constexpr (NTC) st4_nt<TC>(C + (size_t)row * ldc + col, v);
+    else Elem<TC>::st4(C + (size_t)row * ldc + col, v);
 #else
     if (v[0] == 12345.678f) Elem<TC>::st4(C + (size_t)row * ldc + col, v);      // ablation build: keeps the arithmetic alive, stores nothing
 #endif
