@@ -106,7 +106,35 @@ template <> struct Elem<f16_t> {
 
 // 4 consecutive elements of TT from 4 floats with a STREAMING (non-temporal) store: for tensors that are not read again soon
 template <typename TT> __device__ __forceinline__ void st4_nt(TT* p, f32x4 v);
-template <> __device__ __forceinline__ void st4_nt<float>(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+// LPI_ST_POLICY (A/B builds): 0 = `nt` (default), 1 = `sc1`, 2 = `sc0 sc1`, 3 = `nt sc1`, 4 = `sc0`  — the cache-policy bits of the streaming store
+#ifndef LPI_ST_POLICY
+#define LPI_ST_POLICY 0
+#endif
+#if LPI_ST_POLICY == 1
+#define LPI_ST_BITS "sc1"
+#elif LPI_ST_POLICY == 2
+#define LPI_ST_BITS "sc0 sc1"
+#elif LPI_ST_POLICY == 3
+#define LPI_ST_BITS "nt sc1"
+#elif LPI_ST_POLICY == 4
+#define LPI_ST_BITS "sc0"
+#endif
+__device__ __forceinline__ void st_stream8(void* p, unsigned w0, unsigned w1) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+#if LPI_ST_POLICY == 0
+    __builtin_nontemporal_store((u32x2_){w0, w1}, reinterpret_cast<u32x2_*>(p));
+#else
+    const u32x2_ w = {w0, w1};
+    asm volatile("global_store_dwordx2 %0, %1, off " LPI_ST_BITS :: "v"(p), "v"(w) : "memory");
+#endif
+}
+template <> __device__ __forceinline__ void st4_nt<float>(float* p, f32x4 v) {
+#if LPI_ST_POLICY == 0
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off " LPI_ST_BITS :: "v"(p), "v"(v) : "memory");
+#endif
+}
 // 16-byte fragment chunk as it sits in a lane's registers
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 union Chunk {
@@ -146,18 +174,8 @@ template <> __device__ __forceinline__ uint32_t pack2_t<f16_t>(float a, float b)
     typedef __attribute__((ext_vector_type(2))) _Float16 h2_;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f2_){a, b}, h2_));
 }
-template <> __device__ __forceinline__ void st4_nt<bf16_t>(bf16_t* p, f32x4 v) {
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
-    u32x2_ w;
-    w[0] = pack2_t<bf16_t>(v[0], v[1]); w[1] = pack2_t<bf16_t>(v[2], v[3]);
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_*>(p));
-}
-template <> __device__ __forceinline__ void st4_nt<f16_t>(f16_t* p, f32x4 v) {
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
-    u32x2_ w;
-    w[0] = pack2_t<f16_t>(v[0], v[1]); w[1] = pack2_t<f16_t>(v[2], v[3]);
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_*>(p));
-}
+template <> __device__ __forceinline__ void st4_nt<bf16_t>(bf16_t* p, f32x4 v) { st_stream8(p, pack2_t<bf16_t>(v[0], v[1]), pack2_t<bf16_t>(v[2], v[3])); }
+template <> __device__ __forceinline__ void st4_nt<f16_t>(f16_t* p, f32x4 v) { st_stream8(p, pack2_t<f16_t>(v[0], v[1]), pack2_t<f16_t>(v[2], v[3])); }
 // element e (0..7) of a chunk of T as float
 template <typename T> __device__ __forceinline__ float chunk_elem(const Chunk& c, int e);
 template <> __device__ __forceinline__ float chunk_elem<bf16_t>(const Chunk& c, int e) { return (float)c.h[e]; }

@@ -29,15 +29,7 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
         if constexpr (SAVE_U) {
 #ifndef LPI_NO_NT_SAVE_U      /* A/B switch: -DLPI_NO_NT_SAVE_U keeps the default cache policy (26.23 -> 26.12 ms per step with the streaming store) */
             // u is written here and read again only by the backward, a whole forward later: a streaming (non-temporal) store
-            if constexpr (sizeof(TA) == 2) {
-                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-                u32x2 w;
-                w[0] = pack2_t<TA>(v[0], v[1]);
-                w[1] = pack2_t<TA>(v[2], v[3]);
-                __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(aux + (size_t)row * ldaux + col));
-            } else {
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(aux + (size_t)row * ldaux + col));
-            }
+            st4_nt<TA>(aux + (size_t)row * ldaux + col, v);
 #else
             Elem<TA>::st4(aux + (size_t)row * ldaux + col, v);
 #endif
