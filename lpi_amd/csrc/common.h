@@ -293,6 +293,22 @@ __device__ __forceinline__ float fast_sigmoid1702(float u) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * u));
 #endif
 }
+// The same for four values with the multiplies and adds as packed f32 operations (v_pk_mul_f32 / v_pk_add_f32: two lanes of work per issue slot;
+// the exponential and the reciprocal have no packed form) and -1.702 * log2(e) folded into one constant: the QuickGELU / gelu' epilogues of the
+// K = 768 GEMMs are bound by exactly these vector instructions (128 elements per lane per 256x256 tile).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ f32x4 fast_sigmoid1702_x4(f32x4 u) {
+    constexpr float K = -1.702f * 1.4426950408889634f;
+    const f32x2_t t0 = (f32x2_t){u[0], u[1]} * K, t1 = (f32x2_t){u[2], u[3]} * K;
+    const f32x2_t d0 = (f32x2_t){__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} + 1.0f;
+    const f32x2_t d1 = (f32x2_t){__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} + 1.0f;
+    return f32x4{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1]), __builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
+}
+__device__ __forceinline__ f32x4 quick_gelu_x4(f32x4 u) { return u * fast_sigmoid1702_x4(u); }
+__device__ __forceinline__ f32x4 quick_gelu_grad_x4(f32x4 u) {
+    const f32x4 s = fast_sigmoid1702_x4(u);
+    return s * (1.0f + (1.702f * u) * (1.0f - s));
+}
 __device__ __forceinline__ float quick_gelu(float u) { return u * fast_sigmoid1702(u); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
     const float s = fast_sigmoid1702(u);

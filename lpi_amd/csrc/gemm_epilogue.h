@@ -35,12 +35,20 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
 #endif
         }
 #endif
+#if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)      /* A/B: the one-value-at-a-time form */
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+#else
+        v = quick_gelu_x4(v);
+#endif
     } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
         f32x4 u = Elem<TA>::ld4(aux + (size_t)row * ldaux + col);
+#if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
+#else
+        v *= quick_gelu_grad_x4(u);
+#endif
     }
     if constexpr (RES) {
         // the residual stream has C's storage type when C is fp16 (bf16 mode), f32 otherwise; ldr counts elements of that type
