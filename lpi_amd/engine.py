@@ -648,10 +648,14 @@ class DualEncoder:
             raise ValueError("a packed caption must hold SOT, the n_ctx context slots and EOT")
         ws = self.txt.workspace(B, L, train, cap=cfg.context_length, packed=packed)
         hw = self._head("t", B, d)
-        call("lpi_eot_index", B, L, ids, hw["idx"], s)
+        if packed is not None:       # the EOT positions came with the packed layout (host side): no argmax kernel
+            eot_idx = packed.eot_dev
+        else:
+            eot_idx = hw["idx"]
+            call("lpi_eot_index", B, L, ids, eot_idx, s)
         ctx = pr if (pr is not None and use_ctx) else None
         call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
-        xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, hw["idx"])      # pooled (EOT) rows [Bp, d]
+        xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx)      # pooled (EOT) rows [Bp, d]
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         yield GemmReq(None, dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
@@ -659,7 +663,7 @@ class DualEncoder:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
         else:
             out.copy_(hw["feat"][:B])
-        ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial)
+        ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial, eot_idx)
         self._txt_ctx = ctx
         return out, ctx
 
@@ -668,7 +672,7 @@ class DualEncoder:
 
     def encode_text_backward_gen(self, dout, ctx=None):
         cfg, dt, s = self.cfg, self.gdt, _stream()         # the backward's operand / storage type
-        ws, pr, pbs, P, depth, B, L, out, serial = ctx if ctx is not None else self._txt_ctx
+        ws, pr, pbs, P, depth, B, L, out, serial, eot_idx = ctx if ctx is not None else self._txt_ctx
         self._stale(self.txt, serial, "encode_text_backward")
         d, E = cfg.transformer_width, cfg.embed_dim
         hw = self._head("t", B, d)
@@ -685,7 +689,7 @@ class DualEncoder:
             return None
         Lyr = pr.shape[-3]
         dpr = torch.zeros(Lyr, P, d, device=self.device)
-        yield from self.txt.backward_gen(ws, pr, depth, dpr, hw["idx"])
+        yield from self.txt.backward_gen(ws, pr, depth, dpr, eot_idx)
         call("lpi_rows_sum_over_batch_varlen", dt, B, L, ws["rs"], 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
 
@@ -725,8 +729,9 @@ class PackedIds:
         self.rows = int(rs[-1])
         self.row_start = torch.from_numpy(rs.astype(np.int32))
         self.pool_rows = torch.from_numpy((rs[1:] - 1).astype(np.int32))       # absolute row of every sample's EOT token
+        self.eot = torch.from_numpy((self.lengths - 1).astype(np.int32))       # ... and its index within the sample (= ids.argmax(-1))
         self._dev = None
-        self.row_start_dev = self.pool_rows_dev = None
+        self.row_start_dev = self.pool_rows_dev = self.eot_dev = None
 
     def on(self, device):
         """Upload once (ids, row starts, pooled rows); returns the device id matrix [B, Lmax]."""
@@ -735,6 +740,7 @@ class PackedIds:
             self._dev = self.ids.to(device)
             self.row_start_dev = self.row_start.to(device)
             self.pool_rows_dev = self.pool_rows.to(device)
+            self.eot_dev = self.eot.to(device)
         return self._dev
 
     def to(self, device):
