@@ -39,8 +39,9 @@ extern "C" {
 
 /* epilogue selectors of lpi_gemm_nt */
 #define LPI_EPI_NONE 0        /* C = alpha*acc (+bias) (+residual)                                     */
-#define LPI_EPI_QUICKGELU 1   /* u = acc+bias; aux = u (if aux); C = u*sigmoid(1.702u)   model.py:163-165 */
-#define LPI_EPI_DQUICKGELU 2  /* C = acc * d/du[u*sigmoid(1.702u)] with u = aux          (backward)     */
+#define LPI_EPI_QUICKGELU 1   /* u = acc+bias; C = u*sigmoid(1.702u) (model.py:163-165); aux (if given) = d/du[u*sigmoid(1.702u)] — the
+                               * DERIVATIVE, evaluated here from the same sigmoid and saved for the backward                          */
+#define LPI_EPI_DQUICKGELU 2  /* C = acc * aux, aux = the derivative the forward saved          (backward of the activation)          */
 
 int lpi_version(void);
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */

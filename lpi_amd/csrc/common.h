@@ -305,6 +305,12 @@ __device__ __forceinline__ f32x4 fast_sigmoid1702_x4(f32x4 u) {
     return f32x4{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1]), __builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
 }
 __device__ __forceinline__ f32x4 quick_gelu_x4(f32x4 u) { return u * fast_sigmoid1702_x4(u); }
+// value and derivative from ONE sigmoid: g = u s, g' = s (1 + 1.702 u (1 - s))
+__device__ __forceinline__ void quick_gelu_both_x4(f32x4 u, f32x4& g, f32x4& dg) {
+    const f32x4 s = fast_sigmoid1702_x4(u);
+    g = u * s;
+    dg = s * (1.0f + (1.702f * u) * (1.0f - s));
+}
 __device__ __forceinline__ f32x4 quick_gelu_grad_x4(f32x4 u) {
     const f32x4 s = fast_sigmoid1702_x4(u);
     return s * (1.0f + (1.702f * u) * (1.0f - s));

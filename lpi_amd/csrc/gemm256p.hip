@@ -376,12 +376,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         const char* sp = smem + (p & 1) * 32768 + s_row * 512 + lane_e * 8;
                         if constexpr (EPI == LPI_EPI_DQUICKGELU) {
                             const f32x4 u = Elem<TA>::ld4(reinterpret_cast<const TA*>(sp));
-#ifdef LPI_SCALAR_GELU
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] *= quick_gelu_grad(u[j]);
-#else
-                            o *= quick_gelu_grad_x4(u);
-#endif
+                            o *= u;      // the side tile holds gelu'(u) (gemm_epilogue.h)
                         } else {
                             o += Elem<TC>::ld4(reinterpret_cast<const TC*>(sp));
                         }

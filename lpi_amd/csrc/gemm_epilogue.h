@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-// Storage type of the saved QuickGELU pre-activation u (`aux`): the operand type, except in f16 operand mode, where u is kept in bf16 —
+// Storage type of what the QuickGELU epilogue saves for the backward (`aux` = gelu'(u)): the operand type, except in f16 operand mode, where it is kept in bf16 —
 // it is read only by the BACKWARD's gelu'(u) epilogue, whose operands (gradients) are bf16 (they do not fit fp16's range).
 template <typename T> struct AuxT { typedef T type; };
 template <> struct AuxT<f16_t> { typedef bf16_t type; };
@@ -25,30 +25,31 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
     typedef typename AuxT<T>::type TA;
     f32x4 v = acc * alpha + bv;
     if constexpr (EPI == LPI_EPI_QUICKGELU) {
-#ifndef LPI_ABL_NO_GLOBAL_STORE
+        // aux (if wanted) receives the DERIVATIVE gelu'(u) = s (1 + 1.702 u (1 - s)), not u: the backward's d c_proj epilogue then is a plain
+        // multiply.  gelu' shares this epilogue's sigmoid, and this epilogue's vector work hides behind its two output stores, whereas the
+        // backward's gelu'(u) evaluation was exposed (5 us of 27 per 256x256 tile of the d c_proj GEMM).
         if constexpr (SAVE_U) {
-#ifndef LPI_NO_NT_SAVE_U      /* A/B switch: -DLPI_NO_NT_SAVE_U keeps the default cache policy (26.23 -> 26.12 ms per step with the streaming store) */
-            // u is written here and read again only by the backward, a whole forward later: a streaming (non-temporal) store
-            st4_nt<TA>(aux + (size_t)row * ldaux + col, v);
-#else
-            Elem<TA>::st4(aux + (size_t)row * ldaux + col, v);
-#endif
-        }
-#endif
-#if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)      /* A/B: the one-value-at-a-time form */
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
-#else
-        v = quick_gelu_x4(v);
-#endif
-    } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
-        f32x4 u = Elem<TA>::ld4(aux + (size_t)row * ldaux + col);
+            f32x4 g, dg;
 #if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(u[j]);
+            for (int j = 0; j < 4; ++j) { g[j] = quick_gelu(v[j]); dg[j] = quick_gelu_grad(v[j]); }
 #else
-        v *= quick_gelu_grad_x4(u);
+            quick_gelu_both_x4(v, g, dg);
 #endif
+#ifndef LPI_ABL_NO_GLOBAL_STORE
+            st4_nt<TA>(aux + (size_t)row * ldaux + col, dg);      // read again only by the backward, a whole forward later: streaming store
+#endif
+            v = g;
+        } else {
+#if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)      /* A/B: the one-value-at-a-time form */
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+#else
+            v = quick_gelu_x4(v);
+#endif
+        }
+    } else if constexpr (EPI == LPI_EPI_DQUICKGELU) {
+        v *= Elem<TA>::ld4(aux + (size_t)row * ldaux + col);      // aux = gelu'(u), saved by the forward's QuickGELU epilogue
     }
     if constexpr (RES) {
         // the residual stream has C's storage type when C is fp16 (bf16 mode), f32 otherwise; ldr counts elements of that type

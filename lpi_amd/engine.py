@@ -287,7 +287,7 @@ class Tower:
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         Bp = _pad(B)
         T, TX, TG = _TORCH_DT[self.dt], _TORCH_DT[self.xdt], _TORCH_DT[self.gdt]
-        TU = TG if self.dt == F16 else T      # the saved QuickGELU pre-activation: read by the backward only (gemm_epilogue.h, AuxT)
+        TU = TG if self.dt == F16 else T      # the saved QuickGELU DERIVATIVE gelu'(u) ("u" buffers): read by the backward only (gemm_epilogue.h, AuxT)
         dev = self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
         keep = nl if train else 1

@@ -29,6 +29,12 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def gelu_grad_ref(u):
+    """d/du [u sigmoid(1.702 u)] (model.py:163-165) — what LPI_EPI_QUICKGELU saves in `aux` for the backward."""
+    sg = torch.sigmoid(1.702 * u)
+    return sg * (1 + 1.702 * u * (1 - sg))
+
+
 def test_library_loaded_and_counts():
     n0 = _lib.launch_count()
     a = torch.zeros(128, 32, device=DEV)
@@ -62,20 +68,19 @@ def test_gemm_epilogues(dt):
     E.gemm(dt, a.to(DEV), b.to(DEV), c, M, N, K, bias=bias.to(DEV), residual=res.to(DEV))
     ref = a.double() @ b.double().t() + bias.double() + res.double()
     assert relerr(c, ref) < TOL[dt]
-    # QuickGELU with saved pre-activation
+    # QuickGELU; aux receives the DERIVATIVE gelu'(u) for the backward
     g = torch.zeros(M, N, device=DEV, dtype=TD[dt])
     u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
     E.gemm(dt, a.to(DEV), b.to(DEV), g, M, N, K, bias=bias.to(DEV), epi=E.EPI_QUICKGELU, aux=u)
     uref = a.double() @ b.double().t() + bias.double()
-    assert relerr(u, uref) < TOL[dt]
+    assert relerr(u, gelu_grad_ref(uref)) < TOL[dt]
     assert relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
-    # gelu' epilogue reads the (rounded) saved u
+    # the backward's epilogue multiplies by the (rounded) saved derivative
     du = torch.zeros(M, N, device=DEV, dtype=TD[dt])
     E.gemm(dt, a.to(DEV), b.to(DEV), du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u)
-    ud = u.double().cpu()
-    sg = torch.sigmoid(1.702 * ud)
-    ref = (a.double() @ b.double().t()) * (sg * (1 + 1.702 * ud * (1 - sg)))
+    ref = (a.double() @ b.double().t()) * u.double().cpu()
     assert relerr(du, ref) < TOL[dt]
+    assert relerr(du, (a.double() @ b.double().t()) * gelu_grad_ref(uref)) < 2 * TOL[dt]
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
@@ -99,12 +104,10 @@ def test_gemm256_kernel(dt, M, N, K):
         u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
         E.gemm(dt, a.to(DEV), b.to(DEV), g, M, N, K, bias=bias.to(DEV), epi=E.EPI_QUICKGELU, aux=u)
         uref = ab + bias.double()
-        assert relerr(u, uref) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
+        assert relerr(u, gelu_grad_ref(uref)) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
         du = torch.zeros(M, N, device=DEV, dtype=TD[dt])
         E.gemm(dt, a.to(DEV), b.to(DEV), du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u)
-        ud = u.double().cpu()
-        sg = torch.sigmoid(1.702 * ud)
-        assert relerr(du, ab * (sg * (1 + 1.702 * ud * (1 - sg)))) < TOL[dt]
+        assert relerr(du, ab * u.double().cpu()) < TOL[dt]
     finally:
         call("lpi_set_tuning", 0, 1)
         call("lpi_set_tuning", 1, 1500)
@@ -451,11 +454,9 @@ def test_gemm_splitk_all_epilogues(dt, M, N, K, ks):
     u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
     g = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, epi=E.EPI_QUICKGELU, aux=u)
     uref = ab + bias.double()
-    assert relerr(u, uref) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
+    assert relerr(u, gelu_grad_ref(uref)) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
     du = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), epi=E.EPI_DQUICKGELU, aux=u)
-    ud = u.double().cpu()
-    sg = torch.sigmoid(1.702 * ud)
-    assert relerr(du, ab * (sg * (1 + 1.702 * ud * (1 - sg)))) < TOL[dt]
+    assert relerr(du, ab * u.double().cpu()) < TOL[dt]
     with pytest.raises(_lib.LpiError):      # K must split into whole K tiles
         call("lpi_gemm_nt_splitk", dt, F32 if dt == F32 else BF16, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None, None, 0, 0, None, 0, 1.0,
              7, scratch, stream())
@@ -1018,7 +1019,7 @@ def test_gemm_f16_operands_all_epilogues():
             u = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
             E.gemm(F16, a.to(DEV), b.to(DEV), g, M, N, K, bias=bias.to(DEV), epi=E.EPI_QUICKGELU, aux=u)
             uref = ab + bias.double()
-            assert relerr(u, uref) < TOL[BF16] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < 2e-3
+            assert relerr(u, gelu_grad_ref(uref)) < TOL[BF16] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < 2e-3
         finally:
             for k, v in ((0, 1), (5, 160), (2, 0)):
                 call("lpi_set_tuning", k, v)
