@@ -169,6 +169,12 @@ int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H
 int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
                         const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
                         int causal, void* stream);
+/* The same backward when only the FIRST `rows_needed` token rows of dqkv are wanted (the first block: nothing upstream of the prompt slots
+ * 1 .. P is trainable, sprompt.py:230-237, so only dQ / dK / dV of rows < 1 + P are read): delta is produced for every row, the rows of dqkv
+ * behind rows_needed MAY be left unwritten (the 2-byte kernels skip whole 32-row blocks behind it; rows_needed >= L is lpi_attn_bwd_varlen). */
+int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,
+                        int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal,
+                        void* stream);
 /* idx[b] stays the token index WITHIN sample b (the causal limit) */
 int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
                                const int32_t* idx, void* ctx, int ldctx, float* lse, int causal, void* stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     # ragged (packed) batches: the same kernels with a row_start array (NULL = uniform length L)
     "lpi_attn_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "lpi_attn_bwd_prefix": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
     "lpi_layernorm_bwd_rows_varlen": [_I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],

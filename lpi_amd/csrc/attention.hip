@@ -544,7 +544,7 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int lddqkv) {
+                                                            T* __restrict__ dqkv, int lddqkv, int rows_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
@@ -640,6 +640,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
                 }
             mma_transposed<T>(dq, kt0 + kb * AT<T>::RS, s0, s1);
         };
+        if (q0 >= rows_hi) continue;      // rows_hi: only dQ / dK / dV of token rows < rows_hi are wanted (delta above is needed for every row)
         const int qlast = q0 + 16 * NB - 1;
         const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
         const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
     __syncthreads();   // every row < Lp of dl_lds was written: the waves' 32-row spans tile [0, Lp)
 
     // ---- phase B: a wave owns NB x 16 keys -> dK, dV
-    for (int k0 = wave * 16 * NB; k0 < L; k0 += nw * 16 * NB) {
+    for (int k0 = wave * 16 * NB; k0 < min(L, rows_hi); k0 += nw * 16 * NB) {
         int krow[NB];
         Chunk kk[NB][AT<T>::KS], vv[NB][AT<T>::KS];
         f32x4 dk[NB][4], dv[NB][4];
@@ -768,7 +769,7 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
 
 template <typename T, bool CAUSAL, bool SV16 = false>
 int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr) {
+               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr, int rows_hi = 1 << 30) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
@@ -780,7 +781,7 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
         int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL, SV16>, ldsF);
         if (ef) return ef;
         LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi);
         LPI_CHECK_LAST();
         return 0;
     }
@@ -811,7 +812,7 @@ bool lpi_attn2_fwd_ok(int L);
 bool lpi_attn2_bwd_ok(int L);
 int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal, hipStream_t s);
 int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16);
+                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16, int rows_hi);
 // third generation: ONE pass per head (dK, dV and dQ from one evaluation of S, P, dP, dS; key 7 = 0 default where it applies, 4 forces it)
 bool lpi_attn3_bwd_ok(int L, int causal);
 int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
@@ -842,25 +843,28 @@ extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int
     return lpi_attn_fwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, lse, causal, stream);
 }
 
-extern "C" int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
-                                   const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
+extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,
+                                   int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal,
+                                   void* stream) {
     const int* rs = row_start;
+    if (rows_needed <= 0) return LPI_EINVAL;
+    const int rows_hi = rows_needed >= L ? (1 << 30) : rows_needed;      // the 2-byte kernels skip the 32-row blocks behind it; f32 computes all
     if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv) || bad_attn(dtype, B, L, H, lddqkv)) return LPI_EINVAL;
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (ldctx < H * HD || lddctx < H * HD || (ldctx * esz) % 16 || (lddctx * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F32)
-        return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
-                      : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
+        return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
+                      : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     if (dtype == LPI_F16) {     // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
                                 // q, k, v are converted on their way into LDS / registers, or in place after the LDS-DMA (persistent kernel)
-        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 1);
-        return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
-                      : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
+            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 1, rows_hi);
+        return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
+                      : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     }
     if (dtype == LPI_BF16) {
         // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
@@ -868,14 +872,19 @@ extern "C" int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_s
         // the single-pass kernel is opt-in (key 7 = 4): 29 % fewer MFMAs and half the exponentials buy nothing (244.7 vs 243.1 us at L = 213,
         // B = 256) — at 7 waves per CU the backward is bound by the latency of its dependent chain (LDS read -> MFMA -> exp -> LDS -> MFMA),
         // not by matrix or vector issue
-        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
+        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 0);
-        return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs)
-                      : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs);
+            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 0, rows_hi);
+        return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
+                      : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     }
     return LPI_EINVAL;
+}
+
+extern "C" int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
+                                   const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
+    return lpi_attn_bwd_prefix(dtype, B, L, row_start, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, stream);
 }
 
 extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx,

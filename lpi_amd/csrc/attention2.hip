@@ -291,7 +291,7 @@ template <bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, int total, const T* __restrict__ qkv, int ldqkv,
                                                        const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                        const float* __restrict__ lse, float* __restrict__ delta,
-                                                       T* __restrict__ dqkv, int lddqkv) {
+                                                       T* __restrict__ dqkv, int lddqkv, int rows_hi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -309,6 +309,9 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
     const float c = SCALE * LOG2E;
     const int q0 = wave * 16 * NB;          // this wave's 32 rows (queries in phase A, keys in phase B): Lp <= 32 * waves
     const bool has_rows = q0 < L;
+    // rows_hi: only dQ / dK / dV of token rows < rows_hi are wanted (the first block's backward needs the prompt rows alone); a wave
+    // whose 32 rows lie behind them computes delta for its queries (phase B needs every row's) and skips both tile loops and stores
+    const bool work = has_rows && q0 < rows_hi;
 
     zero_pad_rows(smem, 4, L, Lp);
     auto head_ptr = [&](int bh) { return qkv + (size_t)(bh / H) * L * ldqkv + (bh % H) * HD; };
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (has_rows) {
+        if (work) {
             auto tile = [&](int kb, auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
                 f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
                 dl_lds[qrow[j]] = valid ? dls[j] : 0.f;     // delta * scale, for phase B
                 if (valid) delta[((size_t)b * H + h) * L + qrow[j]] = dlt[j];
             }
-            store_row_bf16_t(dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, valid);
+            store_row_bf16_t(dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, valid && work);
         }
         LPI_BARRIER();            // B1: Q, dO, lse, delta images complete and visible
         if constexpr (SV16) {
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
             prefetch_own(own, nbh);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (has_rows) {
+        if (work) {
             const int k0w = q0;
             int krow[NB];
 #pragma unroll
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
             for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
         }
         LPI_WAIT_VM0();           // next head's K, V images and own rows landed (they had phase B); BEFORE the dK / dV stores
-        if (has_rows) {
+        if (work) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int kr = q0 + 16 * j + (lane & 15);
@@ -776,7 +779,7 @@ int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
 }
 
 int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16) {
+                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16, int rows_hi) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)4 * Lp * RB + (size_t)2 * Lp * sizeof(float);
     const int thr = 64 * ((Lp + 31) / 32);       // one 32-row block per wave
@@ -788,7 +791,7 @@ int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
     do {                                                                                                                                 \
         if (int e = set_lds2(O, (const void*)attn_bwd2_kernel<C, S>)) return e;                                                          \
         LPI_LAUNCH((attn_bwd2_kernel<C, S>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, \
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);                                                                \
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi);                                                       \
     } while (0)
     if (causal && saved_f16) BWD2(true, true, o3);
     else if (causal) BWD2(true, false, o1);

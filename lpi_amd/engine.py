@@ -444,8 +444,11 @@ class Tower:
                 call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
                      None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
             yield GemmReq(f"{lt}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
-            call("lpi_attn_bwd_varlen", adt, B, L, rs, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d, int(sp.causal), s)
-            if i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1:
+            l0_rows = i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1
+            # first block: only dQ / dK / dV of the prompt rows 1 .. P are read below -> the attention backward skips the row blocks behind them
+            call("lpi_attn_bwd_prefix", adt, B, L, rs, (1 + P) if l0_rows else L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d,
+                 int(sp.causal), s)
+            if l0_rows:
                 # first block: dL/dx_0 is read at the prompt rows 1..P only (vis_assemble_bwd / rows_sum_over_batch below; the patch,
                 # CLS and token embeddings are frozen) -> in_proj dgrad and LN1 backward on the packed B*P prompt rows.  The residual
                 # path of those rows is already in the stream; every other row of it is left without this block's attention term.

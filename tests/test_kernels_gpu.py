@@ -679,6 +679,41 @@ def test_gemm_two_workgroups_per_cu_kernel_equals_the_default_kernels(tm, N, K):
         assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < (TOL[BF16] if dt == BF16 else 2e-3)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("B,L,H,causal,ragged", [(2, 213, 3, 0, False), (4, 59, 2, 1, True), (3, 77, 2, 1, False), (2, 197, 1, 0, False)])
+def test_attention_backward_of_a_row_prefix(dt, B, L, H, causal, ragged):
+    """lpi_attn_bwd_prefix: the first block's backward needs dQ / dK / dV of the prompt rows 1 .. 16 only.  Rows < 17 must equal the full
+    backward bit for bit (delta too, for every row); what lies behind them may stay unwritten."""
+    TDX = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+    d = H * 64
+    if ragged:
+        lens, rs = _ragged(B, L, 5, 18)
+        rs_d = rs.int().to(DEV)
+        M = int(rs[-1])
+        starts = [int(rs[b]) for b in range(B)]
+    else:
+        rs_d, M, starts = None, B * L, [b * L for b in range(B)]
+    gdt = TDX[dt] if dt != F16 else torch.bfloat16
+    qkv = rnd(M, 3 * d, seed=61).to(TDX[dt]).to(DEV)
+    dctx = rnd(M, d, seed=62).to(gdt).to(DEV)
+    ctx = torch.zeros(M, d, device=DEV, dtype=TDX[dt])
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd_varlen", dt, B, L, rs_d, H, qkv, 3 * d, ctx, d, lse, causal, stream())
+    full = torch.zeros(M, 3 * d, device=DEV, dtype=gdt)
+    part = torch.full((M, 3 * d), 9.0, device=DEV, dtype=gdt)
+    dl_f, dl_p = torch.zeros(B, H, L, device=DEV), torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_bwd_varlen", dt, B, L, rs_d, H, qkv, 3 * d, ctx, d, dctx, d, lse, dl_f, full, 3 * d, causal, stream())
+    call("lpi_attn_bwd_prefix", dt, B, L, rs_d, 17, H, qkv, 3 * d, ctx, d, dctx, d, lse, dl_p, part, 3 * d, causal, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dl_f, dl_p)
+    for r0 in starts:
+        assert torch.equal(part[r0:r0 + 17], full[r0:r0 + 17])
+    if dt != F32 and L > 64:      # the 2-byte kernels really skipped the blocks behind the prefix
+        assert bool((part[starts[0] + 64:starts[0] + L] == 9.0).all())
+    assert _lib.load().lpi_attn_bwd_prefix(dt, B, L, None, 0, H, qkv.data_ptr(), 3 * d, ctx.data_ptr(), d, dctx.data_ptr(), d, lse.data_ptr(),
+                                           dl_p.data_ptr(), part.data_ptr(), 3 * d, causal, None) == -22
+
+
 # ---------------------------------------------------------------------------------------------------------------- ragged batches
 def _ragged(B, Lmax, seed, lo):
     g = torch.Generator().manual_seed(seed)
