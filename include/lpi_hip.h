@@ -126,6 +126,28 @@ int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, in
 int lpi_layernorm_bwd(int dy_dtype, int cast_dtype, int x_dtype, int rows, int d, const void* dy, int lddy,
                       const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                       float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
+/* TWO LayerNorms in one launch — the vision and the text tower's LayerNorm of the same layer (two independent nn.LayerNorm calls of two
+ * independent towers, model.py:154-160): the text tower's alone is a few-microsecond kernel that is mostly launch ramp.  `d` points to two
+ * descriptors in HOST memory; with the bf16 / f16 operand types over the fp16 residual stream they run as one kernel, any other combination
+ * as two lpi_layernorm_fwd / _bwd calls (same results either way). */
+typedef struct lpi_ln_fwd_desc {
+    int rows, d;
+    const void* x; int ldx;
+    const float* gamma; const float* beta;
+    void* y; int ldy;
+    float* mean; float* rstd;
+} lpi_ln_fwd_desc;
+typedef struct lpi_ln_bwd_desc {
+    int rows, d;
+    const void* dy; int lddy;
+    const void* x; int ldx;
+    const float* gamma; const float* mean; const float* rstd;
+    float* dx; int lddx;
+    void* dx_cast; int ldcast;
+    int accumulate;
+} lpi_ln_bwd_desc;
+int lpi_layernorm_fwd_pair(int dtype, int x_dtype, const lpi_ln_fwd_desc* d, void* stream);
+int lpi_layernorm_bwd_pair(int dy_dtype, int cast_dtype, int x_dtype, const lpi_ln_bwd_desc* d, void* stream);
 /* The same backward for P rows per sample only (the first block: nothing upstream of the prompt slots is trainable, sprompt.py:230-237):
  * dy is compact [B*P, d]; x, mean/rstd and the gradient stream are the full [B*L, .] arrays, touched at rows b*L + row0 + p. */
 int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, int row0, int P, int d, const void* dy, int lddy,

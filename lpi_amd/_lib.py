@@ -42,6 +42,8 @@ SIGNATURES = {
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
+    "lpi_layernorm_fwd_pair": [_I, _I, _P, _P],
+    "lpi_layernorm_bwd_pair": [_I, _I, _I, _P, _P],
     "lpi_layernorm_bwd_rows": [_I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "lpi_gather_batch_rows": [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "lpi_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P],
@@ -148,6 +150,41 @@ def call(name: str, *args):
     rc = fn(*conv)
     if rc != 0:
         raise LpiError(f"{name} failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+
+
+class LnFwdDesc(ctypes.Structure):
+    """``lpi_ln_fwd_desc``"""
+    _fields_ = [("rows", c_int), ("d", c_int), ("x", c_void_p), ("ldx", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("y", c_void_p),
+                ("ldy", c_int), ("mean", c_void_p), ("rstd", c_void_p)]
+
+
+class LnBwdDesc(ctypes.Structure):
+    """``lpi_ln_bwd_desc``"""
+    _fields_ = [("rows", c_int), ("d", c_int), ("dy", c_void_p), ("lddy", c_int), ("x", c_void_p), ("ldx", c_int), ("gamma", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("dx", c_void_p), ("lddx", c_int), ("dx_cast", c_void_p), ("ldcast", c_int),
+                ("accumulate", c_int)]
+
+
+def layernorm_fwd_pair(dt, xdt, a, b, stream):
+    """Two lpi_layernorm_fwd argument tuples (rows, d, x, ldx, gamma, beta, y, ldy, mean, rstd) in one launch."""
+    arr = (LnFwdDesc * 2)()
+    for q, t in zip(arr, (a, b)):
+        q.rows, q.d, q.x, q.ldx, q.gamma, q.beta, q.y, q.ldy, q.mean, q.rstd = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), _ptr(t[5]), _ptr(t[6]), t[7],
+                                                                               _ptr(t[8]), _ptr(t[9]))
+    rc = load().lpi_layernorm_fwd_pair(dt, xdt, ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_layernorm_fwd_pair failed with code {rc}")
+
+
+def layernorm_bwd_pair(dydt, cdt, xdt, a, b, stream):
+    """Two lpi_layernorm_bwd argument tuples (rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate)."""
+    arr = (LnBwdDesc * 2)()
+    for q, t in zip(arr, (a, b)):
+        (q.rows, q.d, q.dy, q.lddy, q.x, q.ldx, q.gamma, q.mean, q.rstd, q.dx, q.lddx, q.dx_cast, q.ldcast, q.accumulate) = (
+            t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), _ptr(t[7]), _ptr(t[8]), _ptr(t[9]), t[10], _ptr(t[11]), t[12], t[13])
+    rc = load().lpi_layernorm_bwd_pair(dydt, cdt, xdt, ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_layernorm_bwd_pair failed with code {rc}")
 
 
 def gemm_grouped(dt: int, cdt: int, epi: int, alpha: float, problems, stream) -> bool:

@@ -200,12 +200,12 @@ __device__ __forceinline__ void st8(f16_t* p, const float (&v)[8]) {
 #endif
 }
 
-template <int NC, typename TY = bf16_t>
-__global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const f16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, TY* __restrict__ y, int ldy,
-                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+template <int NC, typename TY>
+__device__ __forceinline__ void ln_fwd_h16_body(int blk, int rows, int d, const f16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, TY* __restrict__ y, int ldy,
+                                                float* __restrict__ mean, float* __restrict__ rstd) {
     const int hl = threadIdx.x & 31;
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int row = blk * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
     Row8<NC> r;
     const f16_t* xr = x + (size_t)row * ldx;
@@ -233,15 +233,32 @@ __global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const 
     });
     if (hl == 0) { mean[row] = mu; rstd[row] = rs; }
 }
+template <int NC, typename TY = bf16_t>
+__global__ __launch_bounds__(256) void ln_fwd_h16_kernel(int rows, int d, const f16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TY* __restrict__ y, int ldy,
+                                                        float* __restrict__ mean, float* __restrict__ rstd) {
+    ln_fwd_h16_body<NC, TY>(blockIdx.x, rows, d, x, ldx, gamma, beta, y, ldy, mean, rstd);
+}
+// TWO LayerNorms in one launch (the vision and the text tower's LayerNorm of the same layer: the text one alone is a 4-5 us kernel for
+// 16 MB of traffic — mostly launch ramp): blocks [0, nb0) run problem 0, the rest problem 1.
+struct LnFwdP {
+    int rows, d, ldx, ldy;
+    const f16_t* x; const float* gamma; const float* beta; void* y; float* mean; float* rstd;
+};
+template <int NC0, int NC1, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_h16_pair_kernel(LnFwdP p0, LnFwdP p1, int nb0) {
+    if ((int)blockIdx.x < nb0) ln_fwd_h16_body<NC0, TY>(blockIdx.x, p0.rows, p0.d, p0.x, p0.ldx, p0.gamma, p0.beta, (TY*)p0.y, p0.ldy, p0.mean, p0.rstd);
+    else ln_fwd_h16_body<NC1, TY>(blockIdx.x - nb0, p1.rows, p1.d, p1.x, p1.ldx, p1.gamma, p1.beta, (TY*)p1.y, p1.ldy, p1.mean, p1.rstd);
+}
 
 // dx_stream (bf16, in/out) += LN'(dy): the bf16-mode backward with the fp16 saved input
 template <int NC>
-__global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
-                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate,
-                                                        int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
+__device__ __forceinline__ void ln_bwd_h16_body(int blk, int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
+                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate,
+                                                int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
     const int hl = threadIdx.x & 31;
-    const int crow = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int crow = blk * 8 + (threadIdx.x >> 5);
     if (crow >= rows) return;
     const int row = mapP ? (map_rs ? map_rs[crow / mapP] : (crow / mapP) * mapL) + map0 + crow % mapP : crow;      // see ln_bwd_kernel
     Row8<NC> g, xh;
@@ -276,6 +293,25 @@ __global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const 
         for (int j = 0; j < 8; ++j) acc[j] += (g.v[i][j] - c1 - xh.v[i][j] * c2) * rs;
         st8(o + col, acc);
     });
+}
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_h16_kernel(int rows, int d, const bf16_t* __restrict__ dy, int lddy, const f16_t* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, bf16_t* __restrict__ dxs, int ldcast, int accumulate,
+                                                        int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
+    ln_bwd_h16_body<NC>(blockIdx.x, rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dxs, ldcast, accumulate, mapP, mapL, map0, map_rs);
+}
+struct LnBwdP {
+    int rows, d, lddy, ldx, ldcast, accumulate;
+    const bf16_t* dy; const f16_t* x; const float* gamma; const float* mean; const float* rstd; bf16_t* dxs;
+};
+template <int NC0, int NC1>
+__global__ __launch_bounds__(256) void ln_bwd_h16_pair_kernel(LnBwdP p0, LnBwdP p1, int nb0) {
+    if ((int)blockIdx.x < nb0)
+        ln_bwd_h16_body<NC0>(blockIdx.x, p0.rows, p0.d, p0.dy, p0.lddy, p0.x, p0.ldx, p0.gamma, p0.mean, p0.rstd, p0.dxs, p0.ldcast, p0.accumulate, 0, 0, 0, nullptr);
+    else
+        ln_bwd_h16_body<NC1>(blockIdx.x - nb0, p1.rows, p1.d, p1.dy, p1.lddy, p1.x, p1.ldx, p1.gamma, p1.mean, p1.rstd, p1.dxs, p1.ldcast, p1.accumulate, 0, 0, 0,
+                             nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -684,6 +720,96 @@ extern "C" int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype,
                                       void* dx_cast, int ldcast, int accumulate, void* stream) {
     return lpi_layernorm_bwd_rows_varlen(dy_dtype, cast_dtype, x_dtype, B, L, nullptr, row0, P, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx,
                                          dx_cast, ldcast, accumulate, stream);
+}
+
+// ---- two LayerNorms in one launch (lpi_layernorm_fwd_pair / _bwd_pair): the half-wave 16-byte kernels only; anything else runs as two launches
+static int nc_of(int d) { const int n = (d + 255) / 256; return n <= 4 ? n : 0; }
+static bool ln_h16_ok(int d, int ld0, int ld1, const void* p0, const void* p1) {
+    return !(d & 7) && !(ld0 & 7) && !(ld1 & 7) && !(((uintptr_t)p0 | (uintptr_t)p1) & 15) && nc_of(d) != 0;
+}
+template <typename TY>
+static int ln_fwd_pair_launch(const LnFwdP& a, const LnFwdP& b, hipStream_t s) {
+    const int nb0 = (a.rows + 7) / 8, nb1 = (b.rows + 7) / 8;
+    const int n0 = nc_of(a.d), n1 = nc_of(b.d);
+#define LNP(A, B) LPI_LAUNCH((ln_fwd_h16_pair_kernel<A, B, TY>), dim3(nb0 + nb1), dim3(256), 0, s, a, b, nb0); LPI_CHECK_LAST(); return 0
+    switch (n0 * 8 + n1) {
+    case 1 * 8 + 1: LNP(1, 1);
+    case 2 * 8 + 1: LNP(2, 1);
+    case 2 * 8 + 2: LNP(2, 2);
+    case 3 * 8 + 1: LNP(3, 1);
+    case 3 * 8 + 2: LNP(3, 2);
+    case 3 * 8 + 3: LNP(3, 3);
+    case 4 * 8 + 1: LNP(4, 1);
+    case 4 * 8 + 2: LNP(4, 2);
+    case 4 * 8 + 3: LNP(4, 3);
+    case 4 * 8 + 4: LNP(4, 4);
+    }
+#undef LNP
+    return LPI_ENOSYS;
+}
+extern "C" int lpi_layernorm_fwd_pair(int dtype, int x_dtype, const lpi_ln_fwd_desc* d, void* stream) {
+    if (!d) return LPI_EINVAL;
+    for (int i = 0; i < 2; ++i)
+        if (!d[i].x || !d[i].gamma || !d[i].beta || !d[i].y || !d[i].mean || !d[i].rstd || d[i].rows <= 0 || bad_row_dim(d[i].d)) return LPI_EINVAL;
+    const bool fast = x_dtype == LPI_F16 && (dtype == LPI_BF16 || dtype == LPI_F16) && ln_h16_ok(d[0].d, d[0].ldx, d[0].ldy, d[0].x, d[0].y) &&
+                      ln_h16_ok(d[1].d, d[1].ldx, d[1].ldy, d[1].x, d[1].y);
+    if (fast) {
+        const int o = nc_of(d[0].d) >= nc_of(d[1].d) ? 0 : 1;      // the wider row first (the instantiated pairs have NC0 >= NC1)
+        LnFwdP p[2];
+        for (int i = 0; i < 2; ++i) {
+            const lpi_ln_fwd_desc& q = d[i ^ o];
+            p[i] = LnFwdP{q.rows, q.d, q.ldx, q.ldy, (const f16_t*)q.x, q.gamma, q.beta, q.y, q.mean, q.rstd};
+        }
+        const int rc = dtype == LPI_BF16 ? ln_fwd_pair_launch<bf16_t>(p[0], p[1], S(stream)) : ln_fwd_pair_launch<f16_t>(p[0], p[1], S(stream));
+        if (rc != LPI_ENOSYS) return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (int e = lpi_layernorm_fwd(dtype, x_dtype, d[i].rows, d[i].d, d[i].x, d[i].ldx, d[i].gamma, d[i].beta, d[i].y, d[i].ldy, d[i].mean, d[i].rstd, stream))
+            return e;
+    return 0;
+}
+static int ln_bwd_pair_launch(const LnBwdP& a, const LnBwdP& b, hipStream_t s) {
+    const int nb0 = (a.rows + 7) / 8, nb1 = (b.rows + 7) / 8;
+    const int n0 = nc_of(a.d), n1 = nc_of(b.d);
+#define LNP(A, B) LPI_LAUNCH((ln_bwd_h16_pair_kernel<A, B>), dim3(nb0 + nb1), dim3(256), 0, s, a, b, nb0); LPI_CHECK_LAST(); return 0
+    switch (n0 * 8 + n1) {
+    case 1 * 8 + 1: LNP(1, 1);
+    case 2 * 8 + 1: LNP(2, 1);
+    case 2 * 8 + 2: LNP(2, 2);
+    case 3 * 8 + 1: LNP(3, 1);
+    case 3 * 8 + 2: LNP(3, 2);
+    case 3 * 8 + 3: LNP(3, 3);
+    case 4 * 8 + 1: LNP(4, 1);
+    case 4 * 8 + 2: LNP(4, 2);
+    case 4 * 8 + 3: LNP(4, 3);
+    case 4 * 8 + 4: LNP(4, 4);
+    }
+#undef LNP
+    return LPI_ENOSYS;
+}
+extern "C" int lpi_layernorm_bwd_pair(int dy_dtype, int cast_dtype, int x_dtype, const lpi_ln_bwd_desc* d, void* stream) {
+    if (!d) return LPI_EINVAL;
+    for (int i = 0; i < 2; ++i)
+        if (!d[i].dy || !d[i].x || !d[i].gamma || !d[i].mean || !d[i].rstd || (!d[i].dx && !d[i].dx_cast) || d[i].rows <= 0 || bad_row_dim(d[i].d))
+            return LPI_EINVAL;
+    bool fast = x_dtype == LPI_F16 && dy_dtype == LPI_BF16 && cast_dtype == LPI_BF16;
+    for (int i = 0; i < 2 && fast; ++i)
+        fast = !d[i].dx && d[i].dx_cast && ln_h16_ok(d[i].d, d[i].lddy, d[i].ldx, d[i].dy, d[i].x) && !(d[i].ldcast & 7) && !(((uintptr_t)d[i].dx_cast) & 15);
+    if (fast) {
+        const int o = nc_of(d[0].d) >= nc_of(d[1].d) ? 0 : 1;
+        LnBwdP p[2];
+        for (int i = 0; i < 2; ++i) {
+            const lpi_ln_bwd_desc& q = d[i ^ o];
+            p[i] = LnBwdP{q.rows, q.d, q.lddy, q.ldx, q.ldcast, q.accumulate, (const bf16_t*)q.dy, (const f16_t*)q.x, q.gamma, q.mean, q.rstd, (bf16_t*)q.dx_cast};
+        }
+        const int rc = ln_bwd_pair_launch(p[0], p[1], S(stream));
+        if (rc != LPI_ENOSYS) return rc;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (int e = lpi_layernorm_bwd(dy_dtype, cast_dtype, x_dtype, d[i].rows, d[i].d, d[i].dy, d[i].lddy, d[i].x, d[i].ldx, d[i].gamma, d[i].mean, d[i].rstd,
+                                      d[i].dx, d[i].lddx, d[i].dx_cast, d[i].ldcast, d[i].accumulate, stream))
+            return e;
+    return 0;
 }
 
 extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream) {

@@ -147,17 +147,38 @@ class GemmReq:
         gemm(self.dt, self.a, self.b, self.c, self.M, self.N, self.K, **self.kw)
 
 
+class LnReq:
+    """A LayerNorm a tower wants issued (forward: kind "fwd", args of lpi_layernorm_fwd after the two dtypes; backward: "bwd", args of
+    lpi_layernorm_bwd after the three dtypes).  Yielded like a GemmReq so that the two towers' LayerNorms of the same layer go out as
+    ONE launch (lpi_layernorm_fwd_pair / _bwd_pair): the text tower's alone is a few-microsecond kernel that is mostly launch ramp."""
+    __slots__ = ("tag", "kind", "dts", "args")
+
+    def __init__(self, tag, kind, dts, *args):
+        self.tag, self.kind, self.dts, self.args = tag, kind, dts, args
+
+    def issue(self):
+        call("lpi_layernorm_fwd" if self.kind == "fwd" else "lpi_layernorm_bwd", *self.dts, *self.args, _stream())
+
+
 def _cdt(c):
     return F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
 
 
 # LPI_GROUP_TOWERS=0: the towers' GEMMs are never grouped (A/B switch; the library knob is lpi_set_tuning(8, 1))
 GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
+GROUP_LN = _os.environ.get("LPI_GROUP_LN", "1") != "0"      # ... the towers' LayerNorms of one layer as one launch (A/B switch)
 
 
 def _issue_pair(r0: GemmReq, r1: GemmReq):
     """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
     kind), else two launches — the same bits either way."""
+    if isinstance(r0, LnReq) or isinstance(r1, LnReq):
+        if GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts:
+            (_lib.layernorm_fwd_pair if r0.kind == "fwd" else _lib.layernorm_bwd_pair)(*r0.dts, r0.args, r1.args, _stream())
+        else:
+            r0.issue()
+            r1.issue()
+        return
     k0, k1 = r0.kw, r1.kw
     same = (GROUP_TOWERS and r0.dt == r1.dt and r0.dt != F32 and r0.c.dtype == r1.c.dtype and k0.get("epi", EPI_NONE) == k1.get("epi", EPI_NONE)
             and (k0.get("residual") is None) == (k1.get("residual") is None) and (k0.get("aux") is None) == (k1.get("aux") is None)
@@ -350,7 +371,7 @@ class Tower:
             xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][k]
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
                 call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
-            call("lpi_layernorm_fwd", dt, xdt, M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], s)
+            yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1])
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
@@ -375,7 +396,7 @@ class Tower:
                 yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            call("lpi_layernorm_fwd", dt, xdt, M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], s)
+            yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
             yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
@@ -431,8 +452,8 @@ class Tower:
                 call("lpi_scatter_add_rows", dt, B, Lx, d, ws["c_dh"], d, pidx, dh, d, s)
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
                 # path of the pooled rows is added
-                call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
-                     None if dt == F32 else dxT, d, 0, s)
+                yield LnReq(f"{lt}.dln1", "bwd", (dt, dt, xdt), M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                            None if dt == F32 else dxT, d, 0)
                 call("lpi_scatter_add_rows", dt, B, Lx, d, c_dxT, d, pidx, dxT, d, s)
                 if prompts is not None and dprompts is not None and 0 < i < depth:
                     call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
@@ -441,8 +462,8 @@ class Tower:
                 du = ws["du"]
                 yield GemmReq(f"{lt}.dproj", dt, dxT, blk["proj"].wt, du, Mp, 4 * d, d, epi=EPI_DQUICKGELU, aux=u, m_real=M)          # d c_proj, * gelu'
                 yield GemmReq(f"{lt}.dfc", dt, du, blk["fc"].wt, dh, Mp, d, 4 * d, m_real=M)                                         # d c_fc
-                call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
-                     None if dt == F32 else dxT, d, 1, s)      # dx is None in bf16 mode: dxT accumulates in place
+                yield LnReq(f"{lt}.dln2", "bwd", (dt, dt, xdt), M, d, dh, d, xmid, d, blk["ln_2.w"], st[2], st[3], dx, d,
+                            None if dt == F32 else dxT, d, 1)      # dx is None in bf16 mode: dxT accumulates in place
             yield GemmReq(f"{lt}.dout", dt, dxT, blk["out"].wt, dctx, Mp, d, d, m_real=M)                                         # d out_proj
             l0_rows = i == 0 and L0_PROMPT_ROWS and prompts is not None and 0 < P <= 32 and len(self.blocks) > 1
             # first block: only dQ / dK / dV of the prompt rows 1 .. P are read below -> the attention backward skips the row blocks behind them
@@ -459,8 +480,8 @@ class Tower:
                      None if dt == F32 else dxT, d, 1, s)
                 continue
             yield GemmReq(f"{lt}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
-            call("lpi_layernorm_bwd", dt, dt, xdt, M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
-                 None if dt == F32 else dxT, d, 1, s)
+            yield LnReq(f"{lt}.dln1", "bwd", (dt, dt, xdt), M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                        None if dt == F32 else dxT, d, 1)
             if prompts is not None and dprompts is not None and 0 < i < depth:
                 call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
         return dxT

@@ -1249,3 +1249,57 @@ def test_clip_loss_modes_of_gather_features(W, B, E_):
     loss, dIa, dTa = E.clip_loss_full_grad(Ia, Ta, scale)
     assert abs(float(loss) - float(L)) < 2e-5 * max(1.0, float(L))
     assert float((dIa.double().cpu() - I.grad).abs().max()) < tol(I.grad) and float((dTa.double().cpu() - T.grad).abs().max()) < tol(T.grad)
+
+
+@pytest.mark.parametrize("d0,d1", [(768, 512), (512, 768), (1024, 768), (256, 256)])
+def test_layernorm_pair_launch_equals_two_launches(d0, d1):
+    """lpi_layernorm_fwd_pair / _bwd_pair (the two towers' LayerNorm of one layer in ONE launch) against the single launches: same bits,
+    bf16 and f16 operand types over the fp16 stream; other type combinations fall back to two launches."""
+    R0, R1 = 1000, 333
+    outs = {}
+    for dt, tdt in ((BF16, torch.bfloat16), (F16, torch.float16)):
+        pr = []
+        for i, (rows, d) in enumerate(((R0, d0), (R1, d1))):
+            pr.append(dict(rows=rows, d=d, x=(rnd(rows, d, seed=90 + i) * 3).half().to(DEV), g=rnd(d, seed=92 + i).to(DEV), b=rnd(d, seed=94 + i).to(DEV),
+                           dy=rnd(rows, d, seed=96 + i).bfloat16().to(DEV), st=(rnd(rows, d, seed=98 + i)).bfloat16().to(DEV)))
+        res = {}
+        for mode in ("pair", "single"):
+            ys, sts, dxs = [], [], []
+            args_f, args_b = [], []
+            for p in pr:
+                y = torch.zeros(p["rows"], p["d"], device=DEV, dtype=tdt)
+                mean, rstd = torch.zeros(p["rows"], device=DEV), torch.zeros(p["rows"], device=DEV)
+                args_f.append((p["rows"], p["d"], p["x"], p["d"], p["g"], p["b"], y, p["d"], mean, rstd))
+                ys.append(y)
+                sts.append((mean, rstd))
+            if mode == "pair":
+                _lib.layernorm_fwd_pair(dt, F16, args_f[0], args_f[1], stream())
+            else:
+                for a in args_f:
+                    call("lpi_layernorm_fwd", dt, F16, *a, stream())
+            if dt == BF16:
+                for p, (mean, rstd) in zip(pr, sts):
+                    dx = p["st"].clone()
+                    args_b.append((p["rows"], p["d"], p["dy"], p["d"], p["x"], p["d"], p["g"], mean, rstd, None, p["d"], dx, p["d"], 1))
+                    dxs.append(dx)
+                if mode == "pair":
+                    _lib.layernorm_bwd_pair(BF16, BF16, F16, args_b[0], args_b[1], stream())
+                else:
+                    for a in args_b:
+                        call("lpi_layernorm_bwd", BF16, BF16, F16, *a, stream())
+            torch.cuda.synchronize()
+            res[mode] = (ys, sts, dxs)
+        for a, b in zip(res["pair"][0] + [t for st in res["pair"][1] for t in st] + res["pair"][2],
+                        res["single"][0] + [t for st in res["single"][1] for t in st] + res["single"][2]):
+            assert torch.equal(a, b)
+        x0 = pr[0]["x"].double().cpu()
+        ref = torch.nn.functional.layer_norm(x0, (d0,), pr[0]["g"].double().cpu(), pr[0]["b"].double().cpu(), 1e-5)
+        assert relerr(res["pair"][0][0], ref) < (2e-2 if dt == BF16 else 3e-3)
+    # f32 operands: two launches behind the same entry point
+    x = rnd(64, 256, seed=1).to(DEV)
+    g, b = rnd(256, seed=2).to(DEV), rnd(256, seed=3).to(DEV)
+    y0, y1 = torch.zeros(64, 256, device=DEV), torch.zeros(64, 256, device=DEV)
+    m, r = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    _lib.layernorm_fwd_pair(F32, F32, (64, 256, x, 256, g, b, y0, 256, m, r), (64, 256, x, 256, g, b, y1, 256, m, r), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and relerr(y0, torch.nn.functional.layer_norm(x.double().cpu(), (256,), g.double().cpu(), b.double().cpu(), 1e-5)) < 2e-5
