@@ -191,6 +191,18 @@ int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H
 int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,
                         const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
                         int causal, void* stream);
+/* TWO attention forwards in one launch — the vision and the text tower's of the same layer (two independent nn.MultiheadAttention calls,
+ * model.py:183-185): the text tower's alone is a ~15 us chain of dependent memory round trips with the chip nearly idle.  `d`: two descriptors
+ * in HOST memory (row_start may be NULL).  bf16 / f16 operands run as one kernel, f32 as two launches; same results either way. */
+typedef struct lpi_attn_fwd_desc {
+    int B, L, H;
+    const int32_t* row_start;
+    const void* qkv; int ldqkv;
+    void* ctx; int ldctx;
+    float* lse;
+    int causal;
+} lpi_attn_fwd_desc;
+int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 /* The same backward when only the FIRST `rows_needed` token rows of dqkv are wanted (the first block: nothing upstream of the prompt slots
  * 1 .. P is trainable, sprompt.py:230-237, so only dQ / dK / dV of rows < 1 + P are read): delta is produced for every row, the rows of dqkv
  * behind rows_needed MAY be left unwritten (the 2-byte kernels skip whole 32-row blocks behind it; rows_needed >= L is lpi_attn_bwd_varlen). */

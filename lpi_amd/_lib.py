@@ -53,6 +53,7 @@ SIGNATURES = {
     # ragged (packed) batches: the same kernels with a row_start array (NULL = uniform length L)
     "lpi_attn_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    "lpi_attn_fwd_pair": [_I, _P, _P],
     "lpi_attn_bwd_prefix": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
@@ -163,6 +164,23 @@ class LnBwdDesc(ctypes.Structure):
     _fields_ = [("rows", c_int), ("d", c_int), ("dy", c_void_p), ("lddy", c_int), ("x", c_void_p), ("ldx", c_int), ("gamma", c_void_p),
                 ("mean", c_void_p), ("rstd", c_void_p), ("dx", c_void_p), ("lddx", c_int), ("dx_cast", c_void_p), ("ldcast", c_int),
                 ("accumulate", c_int)]
+
+
+class AttnFwdDesc(ctypes.Structure):
+    """``lpi_attn_fwd_desc``"""
+    _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("row_start", c_void_p), ("qkv", c_void_p), ("ldqkv", c_int), ("ctx", c_void_p),
+                ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int)]
+
+
+def attn_fwd_pair(dt, a, b, stream):
+    """Two argument tuples (B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal) of lpi_attn_fwd_varlen in one launch."""
+    arr = (AttnFwdDesc * 2)()
+    for q, t in zip(arr, (a, b)):
+        q.B, q.L, q.row_start, q.H, q.qkv, q.ldqkv, q.ctx, q.ldctx, q.lse, q.causal = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), t[7],
+                                                                                     _ptr(t[8]), t[9])
+    rc = load().lpi_attn_fwd_pair(dt, ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_attn_fwd_pair failed with code {rc}")
 
 
 def layernorm_fwd_pair(dt, xdt, a, b, stream):

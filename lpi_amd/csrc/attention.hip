@@ -193,10 +193,9 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, bool CAUSAL>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
-                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+__device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
+                                              T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
+    const int b = bh / H, h = bh % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
     int L = Lmax, Lp = Lpmax;
     size_t row0 = (size_t)b * Lmax;
@@ -310,6 +309,27 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, cons
             }
         }
     }
+}
+
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
+                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attn_fwd_body<T, CAUSAL>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse);
+}
+// TWO attention forwards in one launch (the vision tower's and the text tower's of the same layer): workgroups [0, nb0) run problem 0, the
+// rest problem 1.  The text tower's forward alone is a 15 us kernel — a chain of dependent HBM round trips with the chip nearly idle; here its
+// workgroups fill in behind the vision tower's.  The launch takes the larger thread count and LDS size of the two.
+template <typename T>
+struct AttnFwdP {
+    int L, Lp, H, ldqkv, ldctx;
+    const int* rs; const T* qkv; T* ctx; float* lse;
+};
+template <typename T, bool C0, bool C1>
+__global__ __launch_bounds__(512) void attn_fwd_pair_kernel(AttnFwdP<T> p0, AttnFwdP<T> p1, int nb0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse);
+    else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse);
 }
 
 // ------------------------------------------------------------------------------------------------ backward A
@@ -841,6 +861,48 @@ extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_s
 extern "C" int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal,
                             void* stream) {
     return lpi_attn_fwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, lse, causal, stream);
+}
+
+// two forwards (2-byte operand types) in one launch; any other case runs as two launches
+template <typename T>
+static int fwd_pair_launch(const lpi_attn_fwd_desc* d, hipStream_t s) {
+    AttnFwdP<T> p[2];
+    size_t lds = 0;
+    int thr = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int Lp = (d[i].L + 31) / 32 * 32;
+        p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse};
+        lds = std::max(lds, (size_t)2 * Lp * AT<T>::RS);
+        thr = std::max(thr, 64 * pick_waves(d[i].L));
+    }
+    const int nb0 = d[0].B * d[0].H, nb1 = d[1].B * d[1].H;
+#define FP(C0, C1)                                                                                                              \
+    do {                                                                                                                        \
+        if (int e = set_lds((const void*)attn_fwd_pair_kernel<T, C0, C1>, lds)) return e;                                       \
+        LPI_LAUNCH((attn_fwd_pair_kernel<T, C0, C1>), dim3(nb0 + nb1), dim3(thr), lds, s, p[0], p[1], nb0);                     \
+    } while (0)
+    if (d[0].causal && d[1].causal) FP(true, true);
+    else if (d[0].causal) FP(true, false);
+    else if (d[1].causal) FP(false, true);
+    else FP(false, false);
+#undef FP
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                                   float* lse, int causal, void* stream);
+extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream) {
+    if (!d) return LPI_EINVAL;
+    for (int i = 0; i < 2; ++i) {
+        if (!d[i].qkv || !d[i].ctx || !d[i].lse || bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv) || d[i].ldctx < d[i].H * HD || (d[i].ldctx & 7)) return LPI_EINVAL;
+        if (((uintptr_t)d[i].qkv | (uintptr_t)d[i].ctx) & 15) return LPI_EINVAL;
+    }
+    if (dtype == LPI_BF16 && g_lpi_tuning[7] != 2) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
+    if (dtype == LPI_F16) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
+    for (int i = 0; i < 2; ++i)
+        if (int e = lpi_attn_fwd_varlen(dtype, d[i].B, d[i].L, d[i].row_start, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, d[i].causal, stream))
+            return e;
+    return 0;
 }
 
 extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,

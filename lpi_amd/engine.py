@@ -147,6 +147,17 @@ class GemmReq:
         gemm(self.dt, self.a, self.b, self.c, self.M, self.N, self.K, **self.kw)
 
 
+class AttnFwdReq:
+    """An attention forward a tower wants issued (args of lpi_attn_fwd_varlen after the dtype): the two towers' go out as one launch."""
+    __slots__ = ("tag", "dt", "args")
+
+    def __init__(self, tag, dt, *args):
+        self.tag, self.dt, self.args = tag, dt, args
+
+    def issue(self):
+        call("lpi_attn_fwd_varlen", self.dt, *self.args, _stream())
+
+
 class LnReq:
     """A LayerNorm a tower wants issued (forward: kind "fwd", args of lpi_layernorm_fwd after the two dtypes; backward: "bwd", args of
     lpi_layernorm_bwd after the three dtypes).  Yielded like a GemmReq so that the two towers' LayerNorms of the same layer go out as
@@ -167,11 +178,19 @@ def _cdt(c):
 # LPI_GROUP_TOWERS=0: the towers' GEMMs are never grouped (A/B switch; the library knob is lpi_set_tuning(8, 1))
 GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
 GROUP_LN = _os.environ.get("LPI_GROUP_LN", "1") != "0"      # ... the towers' LayerNorms of one layer as one launch (A/B switch)
+GROUP_ATTN = _os.environ.get("LPI_GROUP_ATTN", "1") != "0"  # ... and their attention forwards
 
 
 def _issue_pair(r0: GemmReq, r1: GemmReq):
     """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
     kind), else two launches — the same bits either way."""
+    if isinstance(r0, AttnFwdReq) or isinstance(r1, AttnFwdReq):
+        if GROUP_TOWERS and GROUP_ATTN and isinstance(r0, AttnFwdReq) and isinstance(r1, AttnFwdReq) and r0.dt == r1.dt and r0.dt != F32:
+            _lib.attn_fwd_pair(r0.dt, r0.args, r1.args, _stream())
+        else:
+            r0.issue()
+            r1.issue()
+        return
     if isinstance(r0, LnReq) or isinstance(r1, LnReq):
         if GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts:
             (_lib.layernorm_fwd_pair if r0.kind == "fwd" else _lib.layernorm_bwd_pair)(*r0.dts, r0.args, r1.args, _stream())
@@ -387,7 +406,7 @@ class Tower:
                 yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
-            call("lpi_attn_fwd_varlen", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), s)
+            yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal))
             yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]

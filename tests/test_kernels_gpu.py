@@ -1303,3 +1303,40 @@ def test_layernorm_pair_launch_equals_two_launches(d0, d1):
     _lib.layernorm_fwd_pair(F32, F32, (64, 256, x, 256, g, b, y0, 256, m, r), (64, 256, x, 256, g, b, y1, 256, m, r), stream())
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and relerr(y0, torch.nn.functional.layer_norm(x.double().cpu(), (256,), g.double().cpu(), b.double().cpu(), 1e-5)) < 2e-5
+
+
+@pytest.mark.parametrize("dt", [BF16, F16, F32])
+def test_attention_forward_pair_launch_equals_two_launches(dt):
+    """lpi_attn_fwd_pair: the vision tower's (non-causal, uniform length) and the text tower's (causal, packed batch) attention forward of one
+    layer in ONE launch: same bits as the two launches (f32 runs as two launches behind the same entry point)."""
+    TDX = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
+    Bv, Lv, Hv = 3, 213, 3
+    Bt, Lt, Ht = 5, 59, 2
+    lens, rs = _ragged(Bt, Lt, 11, 18)
+    rs_d = rs.int().to(DEV)
+    Mt = int(rs[-1])
+    qv = rnd(Bv * Lv, 3 * Hv * 64, seed=71).to(TDX[dt]).to(DEV)
+    qt = rnd(Mt, 3 * Ht * 64, seed=72).to(TDX[dt]).to(DEV)
+    res = {}
+    for mode in ("pair", "single"):
+        cv, ct = torch.zeros(Bv * Lv, Hv * 64, device=DEV, dtype=TDX[dt]), torch.zeros(Mt, Ht * 64, device=DEV, dtype=TDX[dt])
+        lv, lt_ = torch.zeros(Bv, Hv, Lv, device=DEV), torch.zeros(Bt, Ht, Lt, device=DEV)
+        a = (Bv, Lv, None, Hv, qv, 3 * Hv * 64, cv, Hv * 64, lv, 0)
+        b = (Bt, Lt, rs_d, Ht, qt, 3 * Ht * 64, ct, Ht * 64, lt_, 1)
+        if mode == "pair":
+            n0 = _lib.launch_count()
+            _lib.attn_fwd_pair(dt, a, b, stream())
+            assert _lib.launch_count() - n0 == (2 if dt == F32 else 1)
+        else:
+            call("lpi_attn_fwd_varlen", dt, *a, stream())
+            call("lpi_attn_fwd_varlen", dt, *b, stream())
+        torch.cuda.synchronize()
+        res[mode] = (cv, ct, lv, lt_)
+    for x, y in zip(res["pair"], res["single"]):
+        assert torch.equal(x, y)
+    # and the other order (text first)
+    cv, ct = torch.zeros_like(res["pair"][0]), torch.zeros_like(res["pair"][1])
+    lv, lt_ = torch.zeros_like(res["pair"][2]), torch.zeros_like(res["pair"][3])
+    _lib.attn_fwd_pair(dt, (Bt, Lt, rs_d, Ht, qt, 3 * Ht * 64, ct, Ht * 64, lt_, 1), (Bv, Lv, None, Hv, qv, 3 * Hv * 64, cv, Hv * 64, lv, 0), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(cv, res["single"][0]) and torch.equal(ct, res["single"][1])
