@@ -114,6 +114,12 @@ int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float alpha, int c
 /* 1 if the last lpi_gemm_nt_grouped call of this thread ran as ONE grouped launch, 0 if it fell back to separate launches */
 int lpi_gemm_last_grouped(void);
 
+/* TWO few-row GEMMs (lpi_gemm_nt_splitk) in one pair of launches — the two towers' GEMM of the same op on the pooled rows of the last block
+ * / the heads: each alone is a ~7 us partial-tile launch plus a ~6 us reduction.  Same operand types and epilogue kind; ksplit[i], scratch_i
+ * (>= ksplit[i]*M_i*N_i floats) per problem.  Same bits as two lpi_gemm_nt_splitk calls. */
+int lpi_gemm_nt_splitk_pair(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* descs, const int* ksplit,
+                            float* scratch0, float* scratch1, void* stream);
+
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
  * x_dtype: storage type of the residual stream x — LPI_F32, or LPI_F16 in bf16 mode (statistics and arithmetic are f32 either way).
  * fwd: y[r,:] = (x[r,:]-mean)*rstd*gamma+beta for r < rows; x `x_dtype` [rows,d] (row stride ldx), y `dtype`.

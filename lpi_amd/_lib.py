@@ -39,6 +39,7 @@ SIGNATURES = {
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
     "lpi_gemm_nt_grouped": [_I, _I, _I, _F, _I, _P, _P],
     "lpi_gemm_last_grouped": [],
+    "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
@@ -223,6 +224,25 @@ def gemm_grouped(dt: int, cdt: int, epi: int, alpha: float, problems, stream) ->
     if rc != 0:
         raise LpiError(f"lpi_gemm_nt_grouped failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
     return bool(lib.lpi_gemm_last_grouped())
+
+
+def gemm_splitk_pair(dt: int, cdt: int, epi: int, alpha: float, problems, ksplits, scratches, stream):
+    """lpi_gemm_nt_splitk_pair over two `problems` (dicts as for gemm_grouped)."""
+    arr = (GemmDesc * 2)()
+    for d, p in zip(arr, problems):
+        d.M, d.N, d.K = p["M"], p["N"], p["K"]
+        d.A, d.lda = p["a"].data_ptr(), p["a"].stride(0)
+        d.B, d.ldb = p["b"].data_ptr(), p["b"].stride(0)
+        d.C, d.ldc = p["c"].data_ptr(), p["c"].stride(0)
+        bias, res, aux = p.get("bias"), p.get("residual"), p.get("aux")
+        d.bias = None if bias is None else bias.data_ptr()
+        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), res.stride(0))
+        d.aux, d.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
+    ks = (c_int * 2)(*ksplits)
+    rc = load().lpi_gemm_nt_splitk_pair(dt, cdt, epi, float(alpha), ctypes.cast(arr, c_void_p), ctypes.cast(ks, c_void_p), scratches[0].data_ptr(),
+                                        scratches[1].data_ptr(), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_gemm_nt_splitk_pair failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
 
 
 def launch_count() -> int:

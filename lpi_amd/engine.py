@@ -179,6 +179,7 @@ def _cdt(c):
 GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
 GROUP_LN = _os.environ.get("LPI_GROUP_LN", "1") != "0"      # ... the towers' LayerNorms of one layer as one launch (A/B switch)
 GROUP_ATTN = _os.environ.get("LPI_GROUP_ATTN", "1") != "0"  # ... and their attention forwards
+GROUP_SPLITK = _os.environ.get("LPI_GROUP_SPLITK", "1") != "0"  # ... and their few-row (split-K) GEMMs
 
 
 def _issue_pair(r0: GemmReq, r1: GemmReq):
@@ -202,8 +203,12 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
     same = (GROUP_TOWERS and r0.dt == r1.dt and r0.dt != F32 and r0.c.dtype == r1.c.dtype and k0.get("epi", EPI_NONE) == k1.get("epi", EPI_NONE)
             and (k0.get("residual") is None) == (k1.get("residual") is None) and (k0.get("aux") is None) == (k1.get("aux") is None)
             and (k0.get("bias") is None) == (k1.get("bias") is None) and k0.get("alpha", 1.0) == k1.get("alpha", 1.0)
-            and min(r0.M, r1.M) > 256)
-    if not same:
+            )
+    cdt = _cdt(r0.c)
+    # few-row GEMMs (pooled rows of the last block, heads): the two split-K launch pairs as one (lpi_gemm_nt_splitk_pair)
+    ks = [_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)] if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16)) else [0, 0]
+    few = bool(ks[0] and ks[1])
+    if not same or not (few or min(r0.M, r1.M) > 256):
         r0.issue()
         r1.issue()
         return
@@ -213,7 +218,12 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
         e0.record()
     probs = [dict(M=r.M, N=r.N, K=r.K, a=r.a, b=r.b, c=r.c, bias=r.kw.get("bias"), residual=r.kw.get("residual"), aux=r.kw.get("aux"))
              for r in (r0, r1)]
-    _lib.gemm_grouped(r0.dt, _cdt(r0.c), k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, _stream())
+    if few:
+        n0 = (ks[0] * r0.M * r0.N + 63) // 64 * 64
+        buf = _splitk_scratch(r0.c.device, n0 + ks[1] * r1.M * r1.N)
+        _lib.gemm_splitk_pair(r0.dt, cdt, k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, ks, (buf, buf[n0:]), _stream())
+    else:
+        _lib.gemm_grouped(r0.dt, cdt, k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, _stream())
     if prof is not None:
         e1.record()
         fl = nb = 0.0
@@ -397,13 +407,13 @@ class Tower:
                 wq, bq = blk["qkv"].w, blk["qkv"].b
                 yield GemmReq(f"{lt}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
                 call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, x_in, pidx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
-                yield GemmReq(None, dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
+                yield GemmReq(f"{lt}.cq", dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
                 call("lpi_attn_pooled_fwd_varlen", dt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
                 call("lpi_gather_rows", xdt, B, Lx, d, x_in, pidx, ws["c_xin"], s)
-                yield GemmReq(None, dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
+                yield GemmReq(f"{lt}.cout", dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
                 call("lpi_pool_ln_fwd", dt, F32, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
-                yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
-                yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal))
@@ -412,8 +422,8 @@ class Tower:
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 call("lpi_gather_rows", xdt, B, Lx, d, xmid, pidx, ws["c_xmid"], s)
                 call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, xmid, pidx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
-                yield GemmReq(None, dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
-                yield GemmReq(None, dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
+                yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
             yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
             yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
@@ -453,8 +463,8 @@ class Tower:
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 c_dx = ws["c_dx"]
                 c_dxT = ws["c_dxT"] if dt != F32 else c_dx
-                yield GemmReq(None, dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
-                yield GemmReq(None, dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
+                yield GemmReq(f"{lt}.cdproj", dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
+                yield GemmReq(f"{lt}.cdfc", dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
                 call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
                      None if dt == F32 else c_dxT, d, 1, s)
                 if not POOLED_ATTN:
@@ -463,11 +473,11 @@ class Tower:
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
-                yield GemmReq(None, dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
+                yield GemmReq(f"{lt}.cdout", dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
                 call("lpi_attn_pooled_bwd_varlen", adt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
                      dqkv, 3 * d, int(sp.causal), s)
                 yield GemmReq(f"{lt}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
-                yield GemmReq(None, dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
+                yield GemmReq(f"{lt}.cdq", dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
                 call("lpi_scatter_add_rows", dt, B, Lx, d, ws["c_dh"], d, pidx, dh, d, s)
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
                 # path of the pooled rows is added
@@ -627,7 +637,7 @@ class DualEncoder:
         xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        yield GemmReq(None, dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        yield GemmReq("head", dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
@@ -654,7 +664,7 @@ class DualEncoder:
         if dt != F32:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
-        yield GemmReq(None, dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        yield GemmReq("dhead", dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
         call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
              ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:
@@ -700,7 +710,7 @@ class DualEncoder:
         call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
         xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx)      # pooled (EOT) rows [Bp, d]
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        yield GemmReq(None, dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
+        yield GemmReq("head", dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)
         if normalise:
             call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
@@ -725,7 +735,7 @@ class DualEncoder:
         if dt != F32:
             call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
             dfe = hw["dfeatT"]
-        yield GemmReq(None, dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
+        yield GemmReq("dhead", dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
         call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_final[0], hw["stat"][0], hw["stat"][1],
              ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
         if pr is None:

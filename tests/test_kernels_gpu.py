@@ -462,6 +462,53 @@ def test_gemm_splitk_all_epilogues(dt, M, N, K, ks):
              7, scratch, stream())
 
 
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+def test_gemm_splitk_pair_equals_two_launches(dt):
+    """lpi_gemm_nt_splitk_pair (the two towers' few-row GEMMs in one pair of launches): bit for bit the two lpi_gemm_nt_splitk results,
+    for problems of different shapes and slice counts and every epilogue; mismatched operand sets are refused."""
+    shapes = [((256, 768, 768, 6), (256, 512, 512, 4)), ((256, 3072, 768, 3), (256, 2048, 512, 2)), ((128, 768, 3072, 24), (256, 512, 2048, 16))]
+    td = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+    cds = [td] if dt == F32 else [td, torch.float32]
+    for (s0, s1) in shapes:
+        ops = []
+        for j, (M, N, K, ks) in enumerate((s0, s1)):
+            ops.append(dict(M=M, N=N, K=K, ks=ks, a=rnd(M, K, seed=10 + j).to(td).to(DEV), b=rnd(N, K, seed=20 + j, scale=0.05).to(td).to(DEV),
+                            bias=rnd(N, seed=30 + j).to(DEV), res=rnd(M, N, seed=40 + j).to(DEV),
+                            scr=torch.empty(ks * M * N, device=DEV)))
+        auxt = torch.bfloat16 if dt == F16 else td
+        for ctd in cds:
+            cdt = F32 if ctd == torch.float32 else dt
+            cases = [(E.EPI_NONE, True, False, False), (E.EPI_NONE, False, False, False), (E.EPI_QUICKGELU, True, False, True),
+                     (E.EPI_QUICKGELU, True, False, False), (E.EPI_DQUICKGELU, False, False, True)]
+            if ctd == torch.float32:
+                cases.append((E.EPI_NONE, True, True, False))
+            for epi, use_bias, use_res, use_aux in cases:
+                ref, refaux, got, gotaux, probs = [], [], [], [], []
+                for o in ops:
+                    M, N, K = o["M"], o["N"], o["K"]
+                    aux0 = (rnd(M, N, seed=50).to(auxt).to(DEV) if epi == E.EPI_DQUICKGELU else torch.zeros(M, N, dtype=auxt, device=DEV)) if use_aux else None
+                    c = torch.zeros(M, N, dtype=ctd, device=DEV)
+                    ax = None if aux0 is None else aux0.clone()
+                    call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, o["a"], K, o["b"], K, c, N, o["bias"] if use_bias else None,
+                         o["res"] if use_res else None, N if use_res else 0, epi, ax, N if use_aux else 0, 0.75, o["ks"], o["scr"], stream())
+                    ref.append(c)
+                    refaux.append(ax)
+                    c2 = torch.zeros(M, N, dtype=ctd, device=DEV)
+                    ax2 = None if aux0 is None else aux0.clone()
+                    got.append(c2)
+                    gotaux.append(ax2)
+                    probs.append(dict(M=M, N=N, K=K, a=o["a"], b=o["b"], c=c2, bias=o["bias"] if use_bias else None,
+                                      residual=o["res"] if use_res else None, aux=ax2))
+                _lib.gemm_splitk_pair(dt, cdt, epi, 0.75, probs, [o["ks"] for o in ops], [o["scr"] for o in ops], stream())
+                for r, g, ra, ga in zip(ref, got, refaux, gotaux):
+                    assert torch.equal(r, g), (dt, s0, s1, epi, use_bias, use_res, use_aux)
+                    if ra is not None:
+                        assert torch.equal(ra, ga)
+    probs[1]["aux"] = None            # one problem with aux, one without
+    with pytest.raises(_lib.LpiError):
+        _lib.gemm_splitk_pair(dt, cdt, E.EPI_DQUICKGELU, 1.0, probs, [o["ks"] for o in ops], [o["scr"] for o in ops], stream())
+
+
 def test_gemm_256x128_tiles_for_half_empty_launches():
     """Launches with 16..159 256x256 tiles go to the 256x128-tile kernel (twice the workgroups): every epilogue, bit for bit the
     results of the 256x256 kernel (tuning key 5 = 0 disables the rule)."""
