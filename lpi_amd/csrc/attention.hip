@@ -23,6 +23,7 @@
 // k-group g = l >> 4 of each operand as one 16-byte chunk; it receives column (l & 15), rows 4g..4g+3.
 #include <type_traits>
 #include "common.h"
+#include "attn_softmax.h"
 
 extern int g_lpi_tuning[16];
 
@@ -64,7 +65,11 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
             const int i = base + j * nt, row = i / NCH, c = i % NCH;
             v0[j] = make_uint4(0, 0, 0, 0);
             v1[j] = make_uint4(0, 0, 0, 0);
+#ifdef LPI_ABL_ATTN_NOLOAD          /* ablation build: K, V images of zeros, no global loads */
+            if (i < n && row < L && ld0 == 12345) {
+#else
             if (i < n && row < L) {
+#endif
                 v0[j] = *reinterpret_cast<const uint4*>(g0 + (size_t)row * ld0 + c * Elem<T>::EPC);
                 v1[j] = *reinterpret_cast<const uint4*>(g1 + (size_t)row * ld1 + c * Elem<T>::EPC);
             }
@@ -249,39 +254,7 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
             f32x4 s0[NB], s1[NB];
             mma_lds_rows<T>(s0, kp, q);
             mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if constexpr (MASKED) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) s0[j][r] = -INFINITY;
-                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) s1[j][r] = -INFINITY;
-                    }
-                }
-                float mt = fmaxf(fmaxf(fmaxf(s0[j][0], s0[j][1]), fmaxf(s0[j][2], s0[j][3])),
-                                 fmaxf(fmaxf(s1[j][0], s1[j][1]), fmaxf(s1[j][2], s1[j][3])));
-                mt = group_max(mt) * c;
-                const float mn = fmaxf(m[j], mt);
-                const float msafe = (MASKED && mn == -INFINITY) ? 0.f : mn;   // fully masked so far (padded / causal-early rows)
-                const float alpha = fast_exp2(m[j] - msafe);
-                float ps = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s0[j][r] = fast_exp2(fmaf(s0[j][r], c, -msafe));
-                    s1[j][r] = fast_exp2(fmaf(s1[j][r], c, -msafe));
-                    ps += s0[j][r] + s1[j][r];
-                }
-                lsum[j] = fmaf(lsum[j], alpha, ps);
-                m[j] = mn;
-                // rescale the running output only when some lane's maximum moved (wave-uniform test; x * 1.0f is exact, so skipping it
-                // changes no bit): after the first tiles of a row the maximum rarely changes, and these 16 multiplies are a quarter
-                // of the tile's vector instructions
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[j][i] *= alpha;
-                }
-            }
+            attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
             mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
         };
         const int qlast = q0 + 16 * NB - 1;
@@ -289,6 +262,10 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         // unmasked tiles: every key < L and (causal) every key <= the smallest query of the blocks
         const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
         int kb = 0;
+#ifdef LPI_ABL_ATTN_NOCOMPUTE      /* ablation build: loads, staging and stores only */
+        kb = kend - 32;
+        if (qg == nullptr)
+#endif
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
 #pragma unroll

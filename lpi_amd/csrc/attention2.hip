@@ -22,6 +22,7 @@
 // Rows [L, Lp) of every image are zeroed once per launch and never written again (the DMA is EXEC-masked there).
 #include <type_traits>
 #include "common.h"
+#include "attn_softmax.h"
 
 extern int g_lpi_tuning[16];
 
@@ -67,7 +68,11 @@ __device__ __forceinline__ void stage_dma(unsigned img, const T* g, int ld, int 
     const int r8 = lane >> 3, pc = lane & 7;
     for (int blk = wave; blk * 8 < L; blk += nw) {
         const int row = blk * 8 + r8;
+#if defined(LPI_ABL_ATTN_NOLOAD) || defined(LPI_ABL_ATTN_NODMA)      /* ablation build: no global reads (images keep their zeros) */
+        if (row < L && ld == 12345) glds16(g + (size_t)row * ld + ((pc ^ (row & 6)) << 3), img + blk * 1024);
+#else
         if (row < L) glds16(g + (size_t)row * ld + ((pc ^ (row & 6)) << 3), img + blk * 1024);
+#endif
     }
 }
 
@@ -97,7 +102,11 @@ __device__ __forceinline__ void glb_rows(Chunk (&q)[KS], const T* g, size_t row,
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         q[ks].u = make_uint4(0, 0, 0, 0);
+#if defined(LPI_ABL_ATTN_NOLOAD) || defined(LPI_ABL_ATTN_NOOWN)
+        if (valid && ld == 12345) q[ks].u = *reinterpret_cast<const uint4*>(g + row * ld + (grp + 4 * ks) * 8);
+#else
         if (valid) q[ks].u = *reinterpret_cast<const uint4*>(g + row * ld + (grp + 4 * ks) * 8);
+#endif
     }
 }
 
@@ -225,34 +234,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(int L, int Lp, int H, in
                 f32x4 s0[NB], s1[NB];
                 mma_rows(s0, k_lds + kb * RB, off, q);
                 mma_rows(s1, k_lds + (kb + 16) * RB, off, q);
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if constexpr (MASKED) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                            if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) s0[j][r] = -INFINITY;
-                            if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) s1[j][r] = -INFINITY;
-                        }
-                    }
-                    float mt = fmaxf(fmaxf(fmaxf(s0[j][0], s0[j][1]), fmaxf(s0[j][2], s0[j][3])),
-                                     fmaxf(fmaxf(s1[j][0], s1[j][1]), fmaxf(s1[j][2], s1[j][3])));
-                    mt = grp_max(mt) * c;
-                    const float mn = fmaxf(m[j], mt);
-                    const float msafe = (MASKED && mn == -INFINITY) ? 0.f : mn;
-                    const float alpha = exp2_fast(m[j] - msafe);
-                    float ps = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        s0[j][r] = exp2_fast(fmaf(s0[j][r], c, -msafe));
-                        s1[j][r] = exp2_fast(fmaf(s1[j][r], c, -msafe));
-                        ps += s0[j][r] + s1[j][r];
-                    }
-                    lsum[j] = fmaf(lsum[j], alpha, ps);
-                    m[j] = mn;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[j][i] *= alpha;
-                }
+                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
                 mma_tr(o, v_lds + kb * RB, off, s0, s1);
             };
             const int qlast = q0 + 16 * NB - 1;
@@ -287,7 +269,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(int L, int Lp, int H, in
 // SV16: the saved qkv / ctx are fp16 (f16-mode forward); dctx, dqkv and the MFMA operands are bf16.  LDS-DMA cannot convert, so the K, V
 // and Q images are converted IN PLACE once they have landed (each thread its own 16-byte chunks: no hazard), the wave's own Q rows in
 // registers; O is only dotted with dO.
-template <bool CAUSAL, bool SV16 = false>
+// OIMG: the head's O rows (for delta) come through a fifth LDS image, by LDS-DMA with the K, V images, instead of a register prefetch: with
+// them the prefetch state pushed phase B over the 256-register budget, and the reloads of the spilled lane addresses made the compiler wait
+// vmcnt(0) — i.e. for the next head's whole K, V DMA — in front of phase B (ablation: profiles/r02_gemm_experiments.md, attention section).
+template <bool CAUSAL, bool SV16, bool OIMG>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, int total, const T* __restrict__ qkv, int ldqkv,
                                                        const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                        const float* __restrict__ lse, float* __restrict__ delta,
@@ -303,7 +288,9 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
     char* const k_lds = smem + img;
     char* const v_lds = smem + 2 * img;
     char* const do_lds = smem + 3 * img;
-    float* const lse_lds = reinterpret_cast<float*>(smem + 4 * img);
+    constexpr int NIMG = OIMG ? 5 : 4;
+    char* const o_lds = smem + 4 * img;       // OIMG only
+    float* const lse_lds = reinterpret_cast<float*>(smem + NIMG * img);
     float* const dl_lds = lse_lds + Lp;
     const RdOff off = make_offsets(lane);
     const float c = SCALE * LOG2E;
@@ -312,29 +299,45 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
     // rows_hi: only dQ / dK / dV of token rows < rows_hi are wanted (the first block's backward needs the prompt rows alone); a wave
     // whose 32 rows lie behind them computes delta for its queries (phase B needs every row's) and skips both tile loops and stores
     const bool work = has_rows && q0 < rows_hi;
+#ifdef LPI_ABL_ATTN_NOSTORE     /* ablation build: no result stores */
+    const bool ABL_ST = lddqkv == 12345;
+#else
+    constexpr bool ABL_ST = true;
+#endif
+#ifdef LPI_ABL_ATTN_NOCOMPUTE   /* ablation build: loads, barriers and stores only */
+    const bool comp = work && lddqkv == 12345;
+#else
+    const bool comp = work;
+#endif
 
-    zero_pad_rows(smem, 4, L, Lp);
+    zero_pad_rows(smem, NIMG, L, Lp);
     auto head_ptr = [&](int bh) { return qkv + (size_t)(bh / H) * L * ldqkv + (bh % H) * HD; };
 
     // the wave's own rows of Q, dO, O (phase A operands) and their log-sum-exp, fetched one head ahead
     struct Own {
-        Chunk q[NB][KS], d[NB][KS], o[NB][KS];
+        Chunk q[NB][KS], d[NB][KS], o[OIMG ? 1 : NB][KS];
         float lq[NB], lse_t;
     };
     auto prefetch_own = [&](Own& w, int bh) {
         const int b = bh / H, h = bh % H;
         const T* qg = head_ptr(bh);
+        // the lane's row / chunk indices are re-derived from an opaque copy of the lane id at every call: hoisted to kernel entry (they are
+        // loop invariant) the 64-bit lane addresses are SPILLED around the tile loops, and a spill reload waits vmcnt(0), i.e. for the
+        // next head's whole K / V DMA, in front of phase B
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int gl = ln >> 4;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int qr = q0 + 16 * j + (lane & 15);
+            const int qr = q0 + 16 * j + (ln & 15);
             const bool valid = qr < L;
             const size_t grow = (size_t)b * L + qr;
-            glb_rows(w.q[j], qg, qr, ldqkv, g, valid);
-            glb_rows(w.d[j], dctx + h * HD, grow, lddctx, g, valid);
-            glb_rows(w.o[j], ctx + h * HD, grow, ldctx, g, valid);
+            glb_rows(w.q[j], qg, qr, ldqkv, gl, valid);
+            glb_rows(w.d[j], dctx + h * HD, grow, lddctx, gl, valid);
+            if constexpr (!OIMG) glb_rows(w.o[j], ctx + h * HD, grow, ldctx, gl, valid);
             w.lq[j] = valid ? lse[((size_t)b * H + h) * L + qr] : INFINITY;       // raw (natural-log) value; padded queries -> P = 0
         }
-        const int i = threadIdx.x;
+        const int i = wave * 64 + ln;
         w.lse_t = (i < L) ? lse[((size_t)b * H + h) * L + i] : INFINITY;          // thread i carries row i of the head's lse vector
     };
 
@@ -345,6 +348,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
         const T* qg = head_ptr(bh);
         stage_dma(lds0 + img, qg + dm, ldqkv, L, wave, nw, lane);
         stage_dma(lds0 + 2 * img, qg + 2 * dm, ldqkv, L, wave, nw, lane);
+        if constexpr (OIMG) stage_dma(lds0 + 4 * img, ctx + (size_t)(bh / H) * L * ldctx + (bh % H) * HD, ldctx, L, wave, nw, lane);
     }
     LPI_WAIT_VM0();
     __syncthreads();
@@ -362,6 +366,18 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
                 for (int ks = 0; ks < KS; ++ks) chunk_f16_to_bf16(own.q[j][ks]);
             LPI_BARRIER();
         }
+        // The compiler waits for the prefetched own rows (vmcnt(0): it cannot count the LDS-DMA issued from inline asm) at their first use.
+        // Make that first use HERE, before this head's Q / dO DMA is issued — where the wait is already satisfied by the vmcnt(0) that ended
+        // the last phase B — and not at the top of phase A, where it waited for the whole DMA that phase A is meant to run under.
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                asm volatile("" ::"v"(own.q[j][ks].u.x), "v"(own.q[j][ks].u.y), "v"(own.q[j][ks].u.z), "v"(own.q[j][ks].u.w),
+                             "v"(own.d[j][ks].u.x), "v"(own.d[j][ks].u.y), "v"(own.d[j][ks].u.z), "v"(own.d[j][ks].u.w));
+                if constexpr (!OIMG) asm volatile("" ::"v"(own.o[OIMG ? 0 : j][ks].u.x), "v"(own.o[OIMG ? 0 : j][ks].u.y), "v"(own.o[OIMG ? 0 : j][ks].u.z), "v"(own.o[OIMG ? 0 : j][ks].u.w));
+            }
+        asm volatile("" ::"v"(own.lq[0]), "v"(own.lq[1]), "v"(own.lse_t));
         // Q, dO of THIS head -> their images (free since the previous head's phase B), landing under phase A
         stage_dma(lds0, qg, ldqkv, L, wave, nw, lane);
         stage_dma(lds0 + 3 * img, dctx + (size_t)b * L * lddctx + h * HD, lddctx, L, wave, nw, lane);
@@ -376,10 +392,16 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
         for (int j = 0; j < NB; ++j) {
             qrow[j] = q0 + 16 * j + (lane & 15);
             float dl = 0.f;
+            Chunk oc[KS];
+            if constexpr (OIMG) lds_rows(oc, o_lds, q0 + 16 * j, off);
+            else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) oc[ks] = own.o[OIMG ? 0 : j][ks];
+            }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)own.o[j][ks].hh[e] : (float)own.o[j][ks].h[e]) * (float)own.d[j][ks].h[e];
+                for (int e = 0; e < 8; ++e) dl += (SV16 ? (float)oc[ks].hh[e] : (float)oc[ks].h[e]) * (float)own.d[j][ks].h[e];
             dl = grp_sum(dl);
             dlt[j] = dl;
             lq[j] = own.lq[j] * LOG2E;
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (work) {
+        if (comp) {
             auto tile = [&](int kb, auto masked_tag) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
                 f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
                 dl_lds[qrow[j]] = valid ? dls[j] : 0.f;     // delta * scale, for phase B
                 if (valid) delta[((size_t)b * H + h) * L + qrow[j]] = dlt[j];
             }
-            store_row_bf16_t(dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, valid && work);
+            store_row_bf16_t(dqkv + ((size_t)b * L + qrow[j]) * lddqkv + h * HD, dq[j], g, valid && work && ABL_ST);
         }
         LPI_BARRIER();            // B1: Q, dO, lse, delta images complete and visible
         if constexpr (SV16) {
@@ -449,10 +471,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
             const T* ng = head_ptr(nbh);
             stage_dma(lds0 + img, ng + dm, ldqkv, L, wave, nw, lane);
             stage_dma(lds0 + 2 * img, ng + 2 * dm, ldqkv, L, wave, nw, lane);
+            if constexpr (OIMG) stage_dma(lds0 + 4 * img, ctx + (size_t)(nbh / H) * L * ldctx + (nbh % H) * HD, ldctx, L, wave, nw, lane);
             prefetch_own(own, nbh);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (work) {
+        if (comp) {
             const int k0w = q0;
             int krow[NB];
 #pragma unroll
@@ -498,8 +521,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(int L, int Lp, int H, in
             for (int j = 0; j < NB; ++j) {
                 const int kr = q0 + 16 * j + (lane & 15);
                 T* dst = dqkv + ((size_t)b * L + kr) * lddqkv + h * HD;
-                store_row_bf16_t(dst + dm, dk[j], g, kr < L);
-                store_row_bf16_t(dst + 2 * dm, dv[j], g, kr < L);
+                store_row_bf16_t(dst + dm, dk[j], g, kr < L && ABL_ST);
+                store_row_bf16_t(dst + 2 * dm, dv[j], g, kr < L && ABL_ST);
             }
         }
         LPI_BARRIER();            // B3: phase B's reads of the Q / dO / lse / delta images are done; the next K, V images are visible
@@ -781,22 +804,28 @@ int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
 int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                   const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16, int rows_hi) {
     const int Lp = (L + 31) / 32 * 32;
-    const size_t lds = (size_t)4 * Lp * RB + (size_t)2 * Lp * sizeof(float);
+    const bool oimg = (size_t)5 * Lp * RB + (size_t)2 * Lp * sizeof(float) <= 160 * 1024 && g_lpi_tuning[10] == 0;      // key 10 = 1: O rows by register prefetch (A/B)
+    const size_t lds = (size_t)(oimg ? 5 : 4) * Lp * RB + (size_t)2 * Lp * sizeof(float);
     const int thr = 64 * ((Lp + 31) / 32);       // one 32-row block per wave
     const int total = B * H;
     const int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
     const int grid = std::min(total, cu_count() * per_cu);
-    static LdsOnce o0, o1, o2, o3;
-#define BWD2(C, S, O)                                                                                                                    \
-    do {                                                                                                                                 \
-        if (int e = set_lds2(O, (const void*)attn_bwd2_kernel<C, S>)) return e;                                                          \
-        LPI_LAUNCH((attn_bwd2_kernel<C, S>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, \
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi);                                                       \
+    static LdsOnce o0, o1, o2, o3, o4, o5, o6, o7;
+#define BWD2(C, S, I, O)                                                                                                                    \
+    do {                                                                                                                                    \
+        if (int e = set_lds2(O, (const void*)attn_bwd2_kernel<C, S, I>)) return e;                                                          \
+        LPI_LAUNCH((attn_bwd2_kernel<C, S, I>), dim3(grid), dim3(thr), lds, s, L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, \
+                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi);                                                          \
     } while (0)
-    if (causal && saved_f16) BWD2(true, true, o3);
-    else if (causal) BWD2(true, false, o1);
-    else if (saved_f16) BWD2(false, true, o2);
-    else BWD2(false, false, o0);
+    if (oimg) {
+        if (causal && saved_f16) BWD2(true, true, true, o4);
+        else if (causal) BWD2(true, false, true, o5);
+        else if (saved_f16) BWD2(false, true, true, o6);
+        else BWD2(false, false, true, o7);
+    } else if (causal && saved_f16) BWD2(true, true, false, o3);
+    else if (causal) BWD2(true, false, false, o1);
+    else if (saved_f16) BWD2(false, true, false, o2);
+    else BWD2(false, false, false, o0);
 #undef BWD2
     LPI_CHECK_LAST();
     return 0;

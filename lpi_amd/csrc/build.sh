@@ -7,8 +7,10 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 mkdir -p build
 pids=()
 for f in api gemm gemm256 gemm256p gemm256x128 gemm_duo attention attention2 attn_pooled rowops loss bpe; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_epilogue.h -nt build/$f.o ] || [ unicode_ln.h -nt build/$f.o ] || [ gemm256_tile.h -nt build/$f.o ] || [ gemm256x128_tile.h -nt build/$f.o ] || [ ../../include/lpi_hip.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ gemm_epilogue.h -nt build/$f.o ] || [ attn_softmax.h -nt build/$f.o ] || [ unicode_ln.h -nt build/$f.o ] || [ gemm256_tile.h -nt build/$f.o ] || [ gemm256x128_tile.h -nt build/$f.o ] || [ ../../include/lpi_hip.h -nt build/$f.o ]; then
+    extra=""
+    case $f in attention|attention2) extra="-fno-honor-nans";; esac      # see attn_softmax.h (attn_max3)
+    $HIPCC $FLAGS $extra -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done

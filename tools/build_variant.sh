@@ -8,7 +8,9 @@ mkdir -p build_var
 objs=""
 for f in api gemm gemm256 gemm256p gemm256x128 gemm_duo attention attention2 attn_pooled rowops loss bpe; do
   if [[ "$srcs" == *",$f,"* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable "$@" -c $f.hip -o build_var/${f}_$suffix.o &
+    extra=""
+    case $f in attention|attention2) extra="-fno-honor-nans";; esac
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable $extra "$@" -c $f.hip -o build_var/${f}_$suffix.o &
     objs="$objs build_var/${f}_$suffix.o"
   else
     objs="$objs build/$f.o"
