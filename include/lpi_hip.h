@@ -42,6 +42,12 @@ extern "C" {
 #define LPI_EPI_QUICKGELU 1   /* u = acc+bias; C = u*sigmoid(1.702u) (model.py:163-165); aux (if given) = d/du[u*sigmoid(1.702u)] — the
                                * DERIVATIVE, evaluated here from the same sigmoid and saved for the backward                          */
 #define LPI_EPI_DQUICKGELU 2  /* C = acc * aux, aux = the derivative the forward saved          (backward of the activation)          */
+#define LPI_EPI_LN 3          /* LayerNorm FOLDED into the GEMM: A is the LayerNorm's INPUT x, B = gamma o W (columns scaled), and
+                               * C = rstd[row] * (alpha*acc - mean[row] * c1[col]) + bias[col], c1[n] = sum_k B[n,k], bias = W beta + b — i.e.
+                               * LN(x) W^T + b without ever writing LN(x) (model.py:172-177: ln_1 -> attn in_proj, ln_2 -> c_fc).  `residual`
+                               * carries the LN operand block (f32): mean[ldr] | rstd[ldr] | c1[N] (ldr >= M, a multiple of 4). */
+#define LPI_EPI_LN_QUICKGELU 4 /* ... followed by the QuickGELU epilogue (aux as for LPI_EPI_QUICKGELU).  Both: bf16 / f16 operands, shapes the
+                               * persistent 256x256 kernel takes (LPI_ENOSYS otherwise: the caller runs LayerNorm + GEMM). */
 
 int lpi_version(void);
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
@@ -114,6 +120,9 @@ int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float alpha, int c
 /* 1 if the last lpi_gemm_nt_grouped call of this thread ran as ONE grouped launch, 0 if it fell back to separate launches */
 int lpi_gemm_last_grouped(void);
 
+/* 1 if lpi_gemm_nt / lpi_gemm_nt_grouped take the LayerNorm-fold epilogues (LPI_EPI_LN, LPI_EPI_LN_QUICKGELU) for this operand type and shape */
+int lpi_gemm_ln_supported(int dtype, int M, int N, int K);
+
 /* TWO few-row GEMMs (lpi_gemm_nt_splitk) in one pair of launches — the two towers' GEMM of the same op on the pooled rows of the last block
  * / the heads: each alone is a ~7 us partial-tile launch plus a ~6 us reduction.  Same operand types and epilogue kind; ksplit[i], scratch_i
  * (>= ksplit[i]*M_i*N_i floats) per problem.  Same bits as two lpi_gemm_nt_splitk calls. */
@@ -152,6 +161,8 @@ typedef struct lpi_ln_bwd_desc {
     void* dx_cast; int ldcast;
     int accumulate;
 } lpi_ln_bwd_desc;
+/* y = NULL (both problems of a pair): the row statistics only — mean / rstd are written, nothing else (fp16 stream; gamma / beta unused).  Used
+ * with the LayerNorm-fold GEMM epilogues (LPI_EPI_LN), which apply the normalisation themselves; also accepted by lpi_layernorm_fwd. */
 int lpi_layernorm_fwd_pair(int dtype, int x_dtype, const lpi_ln_fwd_desc* d, void* stream);
 int lpi_layernorm_bwd_pair(int dy_dtype, int cast_dtype, int x_dtype, const lpi_ln_bwd_desc* d, void* stream);
 /* The same backward for P rows per sample only (the first block: nothing upstream of the prompt slots is trainable, sprompt.py:230-237):

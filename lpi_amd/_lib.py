@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LPI_LIB") or os.path.join(_HERE, "csrc", "liblpi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU = 0, 1, 2
+EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU = 0, 1, 2, 3, 4
 
 
 class LpiError(RuntimeError):
@@ -39,6 +39,7 @@ SIGNATURES = {
     "lpi_gemm_nt": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
     "lpi_gemm_nt_grouped": [_I, _I, _I, _F, _I, _P, _P],
     "lpi_gemm_last_grouped": [],
+    "lpi_gemm_ln_supported": [_I, _I, _I, _I],
     "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
@@ -218,7 +219,7 @@ def gemm_grouped(dt: int, cdt: int, epi: int, alpha: float, problems, stream) ->
         d.C, d.ldc = p["c"].data_ptr(), p["c"].stride(0)
         bias, res, aux = p.get("bias"), p.get("residual"), p.get("aux")
         d.bias = None if bias is None else bias.data_ptr()
-        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), res.stride(0))
+        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), p.get("ldr") or res.stride(0))
         d.aux, d.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
     rc = lib.lpi_gemm_nt_grouped(dt, cdt, epi, float(alpha), len(problems), ctypes.cast(arr, c_void_p), stream)
     if rc != 0:

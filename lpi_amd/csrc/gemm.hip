@@ -393,6 +393,8 @@ extern "C" int lpi_gemm_nt_splitk_pair(int dtype, int c_dtype, int epilogue, flo
 }
 
 bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
+int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
 bool lpi_gemm_duo_eligible(int dtype, int M, int N, int K);
 int lpi_gemm_duo_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                         const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
@@ -413,13 +415,19 @@ static int gemm_nt_check(int dtype, int c_dtype, int M, int N, int K, const void
     const int csz = c_dtype == LPI_F32 ? 4 : 2;
     if (c_dtype == LPI_F16 && dtype == LPI_BF16 && (epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
     if (c_dtype == LPI_F16 && dtype == LPI_F32) return LPI_ENOSYS;
-    if (c_dtype == LPI_BF16 && dtype == LPI_F16) return LPI_ENOSYS;      // f16 operands write f16 or f32
+    const bool ln = epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU;
+    if (c_dtype == LPI_BF16 && dtype == LPI_F16 && !ln) return LPI_ENOSYS;      // f16 operands write f16 or f32 (bf16: the LN-fold GEMMs of bf16 mode)
+    if (ln) {      // LayerNorm folded into the GEMM: residual = mean[ldr] | rstd[ldr] | c1[N] (f32)
+        if (dtype == LPI_F32 || c_dtype == LPI_F32) return LPI_ENOSYS;
+        if (!residual || !bias || ldr < M || (ldr & 3) || ((uintptr_t)residual & 15)) return LPI_EINVAL;
+        if (epilogue == LPI_EPI_LN && aux) return LPI_EINVAL;
+    }
     const int bk = ROW_BYTES / esz;
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return LPI_EINVAL;
     if (M % BM || N % BN || K % bk) return LPI_EINVAL;
     if ((lda * esz) % 16 || (ldb * esz) % 16 || (ldc * csz) % 8 || lda < K || ldb < K || ldc < N) return LPI_EINVAL;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) return LPI_EINVAL;
-    if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
+    if (residual && !ln && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
     if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
     if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
     if (epilogue == LPI_EPI_DQUICKGELU && !aux) return LPI_EINVAL;
@@ -433,6 +441,10 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
     if (int e = gemm_nt_check(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux)) return e;
     hipStream_t s = (hipStream_t)stream;
+    if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) {      // only the persistent 256x256 kernel has the LN-fold epilogues
+        if (!lpi_gemm256_eligible(dtype, M, N, K)) return LPI_ENOSYS;
+        return lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
+    }
     // two workgroups per CU (gemm_duo.hip) for the epilogue kinds selected by tuning key 9
     if (g_lpi_tuning[9] != 0 && lpi_gemm_duo_eligible(dtype, M, N, K) && (M / 256) * (N / 128) >= 512) {
         const int kind = epilogue == LPI_EPI_QUICKGELU ? 4 : epilogue == LPI_EPI_DQUICKGELU ? 8 : residual ? 2 : 1;
@@ -467,6 +479,12 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     return LPI_ENOSYS;
 }
 
+// 1 if lpi_gemm_nt takes LPI_EPI_LN / LPI_EPI_LN_QUICKGELU for this operand type and shape (the persistent 256x256 kernel's shapes), else 0
+extern "C" int lpi_gemm_ln_supported(int dtype, int M, int N, int K)
+{
+    return (dtype == LPI_F16 || dtype == LPI_BF16) && M > 0 && N > 0 && K > 0 && lpi_gemm256_eligible(dtype, M, N, K) ? 1 : 0;
+}
+
 int lpi_gemm256p_launch2(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* d, hipStream_t s);
 static thread_local int t_last_grouped = 0;
 extern "C" int lpi_gemm_last_grouped(void) { return t_last_grouped; }
@@ -484,7 +502,7 @@ extern "C" int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float a
     if (group) {
         int tiles = 0;
         for (int i = 0; i < 2 && group; ++i) {
-            const bool res = d[i].residual != nullptr;
+            const bool res = d[i].residual != nullptr && epilogue != LPI_EPI_LN && epilogue != LPI_EPI_LN_QUICKGELU;      // LN block: not a tile
             const bool side16 = (res && c_dtype == LPI_F16) || epilogue == LPI_EPI_DQUICKGELU;
             const bool loads = res || epilogue == LPI_EPI_DQUICKGELU;
             group = lpi_gemm256_eligible(dtype, d[i].M, d[i].N, d[i].K) && (!loads || (side16 && g_lpi_tuning[2] != 2));

@@ -65,6 +65,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     const int group_m = grp.group_m;
     const float alpha = grp.alpha;
     typedef typename AuxT<T>::type TA;
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    constexpr bool LNE = EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU;
     // the CURRENT problem's operands and geometry (wave-uniform; re-bound by bind() when the workgroup moves on to the next problem)
     const T* A = nullptr; const T* B = nullptr; TC* C = nullptr;
     const float* bias = nullptr; const float* residual = nullptr; TA* aux = nullptr;
@@ -325,6 +327,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SIDE16) bv = *reinterpret_cast<const f32x4*>(bias_lds + bias_off + ecol);
             else if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
+            f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f};      // LayerNorm-fold epilogues: c1 sits behind the two statistics vectors
+            if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) c1v = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + ecol);
             char* const stg = smem + STG;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -338,6 +342,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                     // pass 2 was the last reader of half 0 = the A0 | A1 halves of ring slot 0: the next tile's K-tile 0 A rows (the ones
                     // that come from HBM; the B rows are weights and sit in L2) get a pass of head start
                     if (p == 3 && more_tiles) { stage_A(nm0, 0, 0, 0); stage_A(nm0, 0, 1, 0); }
+                }
+                // LayerNorm-fold epilogues: mean and 1/std of this wave's 8 rows of the pass (consecutive rows) by two scalar loads, issued
+                // here and waited for with the staging writes below.  (Left to the compiler they were per-row VECTOR loads of a uniform
+                // address, each followed by vmcnt(0): a memory round trip per row that also drains the LDS-DMA queue.)
+                f32x8 mu8, rs8;
+                if constexpr (LNE) {
+                    const int sr0 = wave_e * 8;
+                    const int trow0 = mh * 128 + (sr0 >> 5) * 64 + ((p & 1) * 2 + ((sr0 >> 4) & 1)) * 16 + (sr0 & 15);
+                    const float* pm = residual + (m0 + trow0);
+                    const float* pr = pm + ldr;
+                    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0" : "=&s"(mu8), "=&s"(rs8) : "s"(pm), "s"(pr));
                 }
 #pragma unroll
                 for (int mi2 = 0; mi2 < 2; ++mi2) {
@@ -362,7 +377,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                     else if (p == 3 && !more_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // p == 3 with a next tile: stores(2) + its 4 A-row DMA instructions
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (LNE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mu8), "+s"(rs8) : : "memory");      // the statistics are used after this wait
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -382,10 +398,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         }
                         // streaming store, as gemm_epilogue_store (a RUN-TIME choice per problem was tried: the duplicated store
                         // loops spilled 60 bytes per lane in the QuickGELU instantiations and the step lost 7 %)
+#ifdef LPI_NO_NT_SIDE16C          /* A/B: the residual-stream outputs (read next by a LayerNorm) with plain stores */
+                        if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+#else
                         if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+#endif
                         else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
                     } else {
-                        gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+                        gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, LNE ? mu8[rr] : 0.f,
+                                                                     LNE ? rs8[rr] : 1.f);
                     }
                 }
                 // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
@@ -517,8 +538,27 @@ int dispatchp(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
     return LPI_EINVAL;
 }
 
+// LayerNorm-fold epilogues (LPI_EPI_LN / LPI_EPI_LN_QUICKGELU): `residual` is the LN operand block, never a residual tile
+template <typename T, typename TC>
+int dispatchp_ln(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
+{
+    const bool ax = hp[0].aux != nullptr;
+    for (int i = 0; i < np; ++i)
+        if (!hp[i].residual || (hp[i].aux != nullptr) != ax) return LPI_EINVAL;
+    if (epi == LPI_EPI_LN) return ax ? LPI_EINVAL : launchp_impl<T, TC, LPI_EPI_LN, false, false>(hp, np, alpha, s);
+    if (ax) return launchp_impl<T, TC, LPI_EPI_LN_QUICKGELU, false, true>(hp, np, alpha, s);
+    return launchp_impl<T, TC, LPI_EPI_LN_QUICKGELU, false, false>(hp, np, alpha, s);
+}
+
 int launch_group(int dtype, int c_dtype, int epilogue, const HostProb* hp, int np, float alpha, hipStream_t s)
 {
+    if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) {
+        // A = the fp16 residual stream (bf16 mode keeps it fp16 too), B = gamma o W in fp16; C in the mode's storage type
+        if (dtype == LPI_F16 && c_dtype == LPI_BF16) return dispatchp_ln<f16_t, bf16_t>(epilogue, hp, np, alpha, s);
+        if (dtype == LPI_F16 && c_dtype == LPI_F16) return dispatchp_ln<f16_t, f16_t>(epilogue, hp, np, alpha, s);
+        if (dtype == LPI_BF16 && c_dtype == LPI_BF16) return dispatchp_ln<bf16_t, bf16_t>(epilogue, hp, np, alpha, s);
+        return LPI_ENOSYS;
+    }
     if (dtype == LPI_BF16 && c_dtype == LPI_BF16) return dispatchp<bf16_t, bf16_t>(epilogue, hp, np, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F32) return dispatchp<bf16_t, float>(epilogue, hp, np, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && hp[0].residual) {

@@ -123,6 +123,8 @@ __device__ __forceinline__ void tile(int m0, int n0, int K, const T* __restrict_
     const int ecol = n0 + (lane & 31) * 4;
     f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + ecol);
+    f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f};      // LayerNorm-fold epilogues: c1 sits behind the two statistics vectors (include/lpi_hip.h)
+    if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) c1v = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + ecol);
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
         if (ph) __builtin_amdgcn_s_barrier();
@@ -139,7 +141,9 @@ __device__ __forceinline__ void tile(int m0, int n0, int K, const T* __restrict_
         for (int rr = 0; rr < 8; ++rr) {
             const int r = r0 + 2 * rr;
             const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * ERS + (lane & 31) * 16);
-            gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + ph * 128 + r, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
+            float mu = 0.f, rs = 1.f;
+            if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) { mu = residual[m0 + ph * 128 + r]; rs = residual[(size_t)ldr + m0 + ph * 128 + r]; }
+            gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + ph * 128 + r, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, mu, rs);
         }
     }
 }

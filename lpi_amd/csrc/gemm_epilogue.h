@@ -21,10 +21,17 @@ template <> struct AuxT<f16_t> { typedef bf16_t type; };
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true, bool NTC = LPI_NTC_DEFAULT>
 __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
                                                     const float* __restrict__ residual, int ldr, typename AuxT<T>::type* __restrict__ aux,
-                                                    int ldaux) {
+                                                    int ldaux, f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f}, float ln_mu = 0.f, float ln_rs = 1.f) {
     typedef typename AuxT<T>::type TA;
-    f32x4 v = acc * alpha + bv;
-    if constexpr (EPI == LPI_EPI_QUICKGELU) {
+    f32x4 v;
+    if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) {
+        // LayerNorm folded into the GEMM (include/lpi_hip.h): c1v = this lane's four c1 values, (ln_mu, ln_rs) = the row's mean and 1/std —
+        // the caller loads them (`residual` = mean[ldr] | rstd[ldr] | c1[N]): the persistent kernel with scalar loads, eight rows at a time.
+        v = (acc * alpha - ln_mu * c1v) * ln_rs + bv;
+    } else {
+        v = acc * alpha + bv;
+    }
+    if constexpr (EPI == LPI_EPI_QUICKGELU || EPI == LPI_EPI_LN_QUICKGELU) {
         // aux (if wanted) receives the DERIVATIVE gelu'(u) = s (1 + 1.702 u (1 - s)), not u: the backward's d c_proj epilogue then is a plain
         // multiply.  gelu' shares this epilogue's sigmoid, and this epilogue's vector work hides behind its two output stores, whereas the
         // backward's gelu'(u) evaluation was exposed (5 us of 27 per 256x256 tile of the d c_proj GEMM).

@@ -9,6 +9,7 @@
 // One 64-lane wave owns one row of d floats and keeps it in registers (float4 per lane per 256 columns), so each
 // row is read once and written once; reductions are wave shuffles; 4 rows per 256-thread block; every access is a
 // 16-byte coalesced load/store.  These kernels are bounded by HBM bandwidth, not by the matrix cores.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -222,15 +223,17 @@ __device__ __forceinline__ void ln_fwd_h16_body(int blk, int rows, int d, const 
         for (int j = 0; j < 8; ++j) { const float c = r.v[i][j] - mu; ss += c * c; }
     });
     const float rs = 1.0f / sqrtf(half_sum(ss) / (float)d + LN_EPS);
-    TY* yr = y + (size_t)row * ldy;
-    for_chunks8<NC>(d, hl, [&](int i, int col) {
-        float g[8], b[8], o[8];
-        ld8(gamma + col, g);
-        ld8(beta + col, b);
+    if constexpr (!std::is_void<TY>::value) {      // TY = void: the statistics only (the LayerNorm itself is folded into the next GEMM, LPI_EPI_LN)
+        TY* yr = y + (size_t)row * ldy;
+        for_chunks8<NC>(d, hl, [&](int i, int col) {
+            float g[8], b[8], o[8];
+            ld8(gamma + col, g);
+            ld8(beta + col, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (r.v[i][j] - mu) * rs * g[j] + b[j];
-        st8(yr + col, o);
-    });
+            for (int j = 0; j < 8; ++j) o[j] = (r.v[i][j] - mu) * rs * g[j] + b[j];
+            st8(yr + col, o);
+        });
+    }
     if (hl == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 template <int NC, typename TY = bf16_t>
@@ -629,8 +632,20 @@ inline int rows_grid(long rows) { return (int)((rows + 3) / 4); }
         else { CALL(8); }                          \
     } while (0)
 
+static int nc_of(int d) { const int n = (d + 255) / 256; return n <= 4 ? n : 0; }
+static bool ln_h16_ok(int d, int ld0, int ld1, const void* p0, const void* p1) {
+    return !(d & 7) && !(ld0 & 7) && !(ld1 & 7) && !(((uintptr_t)p0 | (uintptr_t)p1) & 15) && nc_of(d) != 0;
+}
 extern "C" int lpi_layernorm_fwd(int dtype, int x_dtype, int rows, int d, const void* x, int ldx, const float* gamma, const float* beta,
                                  void* y, int ldy, float* mean, float* rstd, void* stream) {
+    if (!y) {      // statistics only (fp16 stream): mean / rstd of every row, nothing else written
+        if (!x || !mean || !rstd || rows <= 0 || bad_row_dim(d) || x_dtype != LPI_F16 || !ln_h16_ok(d, ldx, 0, x, nullptr)) return LPI_EINVAL;
+#define LNS(NC) LPI_LAUNCH((ln_fwd_h16_kernel<NC, void>), dim3((rows + 7) / 8), dim3(256), 0, S(stream), rows, d, (const f16_t*)x, ldx, gamma, beta, (void*)nullptr, 0, mean, rstd)
+        LN_NC_SWITCH(d, LNS);
+#undef LNS
+        LPI_CHECK_LAST();
+        return 0;
+    }
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || bad_row_dim(d) || (ldx & 3) || (ldy & 3)) return LPI_EINVAL;
     dim3 g(rows_grid(rows)), b(256);
 #define LNF(TX, TY, NC) LPI_LAUNCH((ln_fwd_kernel<TX, TY, NC>), g, b, 0, S(stream), rows, d, (const TX*)x, ldx, gamma, beta, (TY*)y, ldy, mean, rstd)
@@ -723,10 +738,6 @@ extern "C" int lpi_layernorm_bwd_rows(int dy_dtype, int cast_dtype, int x_dtype,
 }
 
 // ---- two LayerNorms in one launch (lpi_layernorm_fwd_pair / _bwd_pair): the half-wave 16-byte kernels only; anything else runs as two launches
-static int nc_of(int d) { const int n = (d + 255) / 256; return n <= 4 ? n : 0; }
-static bool ln_h16_ok(int d, int ld0, int ld1, const void* p0, const void* p1) {
-    return !(d & 7) && !(ld0 & 7) && !(ld1 & 7) && !(((uintptr_t)p0 | (uintptr_t)p1) & 15) && nc_of(d) != 0;
-}
 template <typename TY>
 static int ln_fwd_pair_launch(const LnFwdP& a, const LnFwdP& b, hipStream_t s) {
     const int nb0 = (a.rows + 7) / 8, nb1 = (b.rows + 7) / 8;
@@ -749,6 +760,22 @@ static int ln_fwd_pair_launch(const LnFwdP& a, const LnFwdP& b, hipStream_t s) {
 }
 extern "C" int lpi_layernorm_fwd_pair(int dtype, int x_dtype, const lpi_ln_fwd_desc* d, void* stream) {
     if (!d) return LPI_EINVAL;
+    if (!d[0].y && !d[1].y) {      // statistics only, both problems (y = NULL): see lpi_layernorm_fwd
+        for (int i = 0; i < 2; ++i)
+            if (!d[i].x || !d[i].mean || !d[i].rstd || d[i].rows <= 0 || bad_row_dim(d[i].d) || x_dtype != LPI_F16 || !ln_h16_ok(d[i].d, d[i].ldx, 0, d[i].x, nullptr))
+                return LPI_EINVAL;
+        const int o = nc_of(d[0].d) >= nc_of(d[1].d) ? 0 : 1;
+        LnFwdP p[2];
+        for (int i = 0; i < 2; ++i) {
+            const lpi_ln_fwd_desc& q = d[i ^ o];
+            p[i] = LnFwdP{q.rows, q.d, q.ldx, 0, (const f16_t*)q.x, q.gamma, q.beta, nullptr, q.mean, q.rstd};
+        }
+        const int rc = ln_fwd_pair_launch<void>(p[0], p[1], S(stream));
+        if (rc != LPI_ENOSYS) return rc;
+        for (int i = 0; i < 2; ++i)
+            if (int e = lpi_layernorm_fwd(dtype, x_dtype, d[i].rows, d[i].d, d[i].x, d[i].ldx, d[i].gamma, d[i].beta, nullptr, 0, d[i].mean, d[i].rstd, stream)) return e;
+        return 0;
+    }
     for (int i = 0; i < 2; ++i)
         if (!d[i].x || !d[i].gamma || !d[i].beta || !d[i].y || !d[i].mean || !d[i].rstd || d[i].rows <= 0 || bad_row_dim(d[i].d)) return LPI_EINVAL;
     const bool fast = x_dtype == LPI_F16 && (dtype == LPI_BF16 || dtype == LPI_F16) && ln_h16_ok(d[0].d, d[0].ldx, d[0].ldy, d[0].x, d[0].y) &&

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_DQUICKGELU, EPI_NONE, EPI_QUICKGELU, F16, F32, call
+from ._lib import BF16, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU, EPI_NONE, EPI_QUICKGELU, F16, F32, call
 from .synth import ClipConfig
 
 import os as _os
@@ -78,6 +78,24 @@ class Linear:
         self.b = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
 
 
+class LnLinear:
+    """LayerNorm FOLDED into the frozen Linear behind it (LPI_EPI_LN, include/lpi_hip.h): LN(x) W^T + b = rstd (x (gamma o W)^T - mean c1) + c2 with
+    c1[n] = sum_k (gamma o W)[n,k] (of the ROUNDED fp16 operand, so that the mean term cancels exactly) and c2 = W beta + b.  The GEMM then reads
+    the fp16 residual stream itself; LN(x) is never written (model.py:172-177: ln_1 -> in_proj, ln_2 -> c_fc; weights are frozen, so nothing
+    downstream needs LN(x) either).  Operands are fp16 in bf16 mode too: x is the fp16 stream, and an fp16 gamma o W keeps three more bits."""
+
+    def __init__(self, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, device):
+        w = w.to(device=device, dtype=torch.float64)
+        g, be = gamma.to(device=device, dtype=torch.float64), beta.to(device=device, dtype=torch.float64)
+        self.w = (w * g[None, :]).to(torch.float16).contiguous()
+        self.c1 = self.w.double().sum(dim=1).float().contiguous()
+        self.c2 = (w @ be + b.to(device=device, dtype=torch.float64)).float().contiguous()
+
+
+# LPI_LN_FOLD=0: LayerNorm as its own kernel in front of in_proj / c_fc (A/B switch; f32 mode always)
+LN_FOLD = _os.environ.get("LPI_LN_FOLD", "1") != "0"
+
+
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
 # (start, end, algorithmic_flops) is appended: bench.py's live roofline measurement of the dominant kernel.
 GEMM_PROFILE = None
@@ -108,7 +126,7 @@ def _splitk_scratch(device, floats):
     return buf
 
 
-def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None):
+def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None, ldr=None):
     """c[M,N] = epi(alpha * a[M,K] @ b[N,K]^T + bias) + residual   (all row-major, contiguous rows).
     m_real: un-padded row count, used only for algorithmic-FLOP accounting."""
     cdt = F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
@@ -116,22 +134,39 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) else 0
+    if ldr is None:
+        ldr = residual.stride(0) if residual is not None else 0
+    ln = epi in (EPI_LN, EPI_LN_QUICKGELU)      # `residual` is the LN operand block then (include/lpi_hip.h), ldr its vector stride
+    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) and not ln else 0
     if ks:
         call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
-             residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
+             ldr, epi, aux, aux.stride(0) if aux is not None else 0,
              float(alpha), ks, _splitk_scratch(c.device, ks * M * N), _stream())
     else:
         call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
-             residual.stride(0) if residual is not None else 0, epi, aux, aux.stride(0) if aux is not None else 0,
+             ldr, epi, aux, aux.stride(0) if aux is not None else 0,
              float(alpha), _stream())
     if prof is not None:
         e1.record()
         mr = m_real or M
-        nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None else 0)
+        nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None and not ln else 0)
                                                                  + (aux.element_size() if aux is not None else 0))
         kind = int(_lib.load().lpi_gemm_last_kernel())      # LPI_GEMM_K_*: which kernel the dispatcher launched (same host thread)
         prof.append((e0, e1, 2.0 * mr * N * K, nbytes, kind))
+
+
+_LN_FOLD_OK = {}
+
+
+def _ln_fold_ok(Mp, d):
+    """True if the persistent 256x256 kernel (the one with the LN-fold epilogues) takes the in_proj / c_fc GEMMs of a [Mp, d] stream."""
+    key = (Mp, d)
+    ok = _LN_FOLD_OK.get(key)
+    if ok is None:
+        lib = _lib.load()
+        ok = _LN_FOLD_OK[key] = bool(lib.lpi_gemm_ln_supported(F16, Mp, 2 * d, d) and lib.lpi_gemm_ln_supported(F16, Mp, 3 * d, d)
+                                     and lib.lpi_gemm_ln_supported(F16, Mp, 4 * d, d))
+    return ok
 
 
 class GemmReq:
@@ -193,7 +228,9 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             r1.issue()
         return
     if isinstance(r0, LnReq) or isinstance(r1, LnReq):
-        if GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts:
+        stats_only = [r.kind == "fwd" and r.args[6] is None for r in (r0, r1) if isinstance(r, LnReq)]      # one tower folds its LayerNorms, the other not
+        if (GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts
+                and stats_only[0] == stats_only[1]):
             (_lib.layernorm_fwd_pair if r0.kind == "fwd" else _lib.layernorm_bwd_pair)(*r0.dts, r0.args, r1.args, _stream())
         else:
             r0.issue()
@@ -206,7 +243,8 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             )
     cdt = _cdt(r0.c)
     # few-row GEMMs (pooled rows of the last block, heads): the two split-K launch pairs as one (lpi_gemm_nt_splitk_pair)
-    ks = [_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)] if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16)) else [0, 0]
+    ks = ([_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)]
+          if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU)) else [0, 0])
     few = bool(ks[0] and ks[1])
     if not same or not (few or min(r0.M, r1.M) > 256):
         r0.issue()
@@ -216,8 +254,9 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    probs = [dict(M=r.M, N=r.N, K=r.K, a=r.a, b=r.b, c=r.c, bias=r.kw.get("bias"), residual=r.kw.get("residual"), aux=r.kw.get("aux"))
+    probs = [dict(M=r.M, N=r.N, K=r.K, a=r.a, b=r.b, c=r.c, bias=r.kw.get("bias"), residual=r.kw.get("residual"), aux=r.kw.get("aux"), ldr=r.kw.get("ldr"))
              for r in (r0, r1)]
+    ln = k0.get("epi", EPI_NONE) in (EPI_LN, EPI_LN_QUICKGELU)
     if few:
         n0 = (ks[0] * r0.M * r0.N + 63) // 64 * 64
         buf = _splitk_scratch(r0.c.device, n0 + ks[1] * r1.M * r1.N)
@@ -229,7 +268,7 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
         fl = nb = 0.0
         for r in (r0, r1):
             mr = r.kw.get("m_real") or r.M
-            res, aux = r.kw.get("residual"), r.kw.get("aux")
+            res, aux = (None if ln else r.kw.get("residual")), r.kw.get("aux")
             fl += 2.0 * mr * r.N * r.K
             nb += (mr * r.K + r.N * r.K) * r.a.element_size() + mr * r.N * (r.c.element_size() + (res.element_size() if res is not None else 0)
                                                                          + (aux.element_size() if aux is not None else 0))
@@ -303,6 +342,9 @@ class Tower:
             for nm in ("ln_1", "ln_2"):
                 blk[nm + ".w"] = f(p + nm + ".weight").to(device=device, dtype=torch.float32).contiguous()
                 blk[nm + ".b"] = f(p + nm + ".bias").to(device=device, dtype=torch.float32).contiguous()
+            if dt != F32 and self.xdt == F16 and LN_FOLD:
+                blk["qkv_ln"] = LnLinear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), blk["ln_1.w"], blk["ln_1.b"], device)
+                blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device)
             self.blocks.append(blk)
         self._ws = {}
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
@@ -349,7 +391,8 @@ class Tower:
             "ctx": [z(Mp, d, dtype=T) for _ in range(keep)],
             "lse": [z(B, H, L) for _ in range(keep)],
             "u": [z(Mp, 4 * d, dtype=TU) for _ in range(keep)] if train else [None],
-            "stat": [z(4, Mp) for _ in range(keep)],      # ln1 mean, ln1 rstd, ln2 mean, ln2 rstd
+            # per layer, per LayerNorm: mean[Mp] | rstd[Mp] | c1[<= 4d] (the LN operand block of the LN-fold GEMM epilogues, include/lpi_hip.h)
+            "lnblk": [z(2, 2 * Mp + 4 * d) for _ in range(nl)],
             "h": z(Mp, d, dtype=T),
             "g": z(Mp, 4 * d, dtype=T),
             # the LAST block's MLP runs on the B pooled rows only (exact: the heads read nothing else of its output)
@@ -373,6 +416,16 @@ class Tower:
             })
         if train:
             ws["du"], ws["c_du"] = ws["g"].view(TG), ws["c_g"].view(TG)
+        # "stat"[i] = (ln1 mean, ln1 rstd, ln2 mean, ln2 rstd) of layer i: views into the LN blocks
+        ws["stat"] = [(b[0, :Mp], b[0, Mp:2 * Mp], b[1, :Mp], b[1, Mp:2 * Mp]) for b in ws["lnblk"]]
+        ws["ln_ld"] = Mp
+        for i, blk in enumerate(self.blocks):
+            if "qkv_ln" in blk:
+                c1 = blk["qkv_ln"].c1
+                if i == nl - 1 and POOLED_ATTN:      # the last block's in_proj GEMM covers K and V only (rows d.. of the weight)
+                    c1 = c1[d:]
+                ws["lnblk"][i][0, 2 * Mp:2 * Mp + c1.numel()].copy_(c1)
+                ws["lnblk"][i][1, 2 * Mp:2 * Mp + 4 * d].copy_(blk["fc_ln"].c1)
         self._ws[key] = ws
         return bind(ws, Lreal)
 
@@ -397,15 +450,25 @@ class Tower:
             k = i if train else 0
             x_in = ws["x"][i if train else i % 2]
             x_out = ws["x"][i + 1 if train else (i + 1) % 2]
-            xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][k]
+            xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][i]
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
                 call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
-            yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1])
+            # LayerNorm folded into the GEMM behind it (LnLinear): a statistics pass over the stream, then the GEMM reads the stream itself
+            fold = "qkv_ln" in blk and _ln_fold_ok(Mp, d)
+            lnb, ln_ld = ws["lnblk"][i], ws["ln_ld"]
+            if fold:
+                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, None, None, None, 0, st[0], st[1])
+            else:
+                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1])
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
-                yield GemmReq(f"{lt}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
+                if fold:
+                    ql = blk["qkv_ln"]
+                    yield GemmReq(f"{lt}.kv", F16, x_in, ql.w[d:], qkv[:, d:], Mp, 2 * d, d, bias=ql.c2[d:], residual=lnb[0], ldr=ln_ld, epi=EPI_LN, m_real=M)
+                else:
+                    yield GemmReq(f"{lt}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
                 call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, x_in, pidx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
                 yield GemmReq(f"{lt}.cq", dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
                 call("lpi_attn_pooled_fwd_varlen", dt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
@@ -415,7 +478,11 @@ class Tower:
                 yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
+            if fold:
+                ql = blk["qkv_ln"]
+                yield GemmReq(f"{lt}.qkv", F16, x_in, ql.w, qkv, Mp, 3 * d, d, bias=ql.c2, residual=lnb[0], ldr=ln_ld, epi=EPI_LN, m_real=M)
+            else:
+                yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal))
             yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
@@ -425,8 +492,13 @@ class Tower:
                 yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
-            yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
+            if fold:
+                fl = blk["fc_ln"]
+                yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3])
+                yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
+            else:
+                yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
+                yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]

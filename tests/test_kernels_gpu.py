@@ -509,6 +509,72 @@ def test_gemm_splitk_pair_equals_two_launches(dt):
         _lib.gemm_splitk_pair(dt, cdt, E.EPI_DQUICKGELU, 1.0, probs, [o["ks"] for o in ops], [o["scr"] for o in ops], stream())
 
 
+def _ln_fold_operands(M, N, K, seed):
+    """x (fp16 stream, rows with a mean and a few large channels), W, b, gamma, beta -> the operands of the LN-fold GEMM and the f64 reference
+    LN(x) W^T + b (model.py:172-177 with ln_1 -> in_proj / ln_2 -> c_fc)."""
+    x = rnd(M, K, seed=seed) + 0.7 * rnd(M, 1, seed=seed + 1)
+    x[:, 3] *= 20.0
+    x = x.half()
+    w = rnd(N, K, seed=seed + 2, scale=0.05)
+    b, gamma, beta = rnd(N, seed=seed + 3), 1.0 + 0.3 * rnd(K, seed=seed + 4), 0.2 * rnd(K, seed=seed + 5)
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    h = (xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    ref = h @ w.double().t() + b.double()
+    wl = (w.double() * gamma.double()[None, :]).half()
+    c1 = wl.double().sum(1).float()
+    c2 = (w.double() @ beta.double() + b.double()).float()
+    Mp = M + 256          # ldr > M: the block's vectors are strided like the engine's
+    blk = torch.zeros(2 * Mp + N, device=DEV)
+    blk[2 * Mp:] = c1.to(DEV)
+    xg = x.to(DEV)
+    call("lpi_layernorm_fwd", BF16, F16, M, K, xg, K, None, None, None, 0, blk[:Mp], blk[Mp:2 * Mp], stream())
+    assert relerr(blk[:M], mu[:, 0]) < 1e-5 and relerr(blk[Mp:Mp + M], 1.0 / torch.sqrt(var[:, 0] + 1e-5)) < 1e-5
+    return dict(M=M, N=N, K=K, a=xg, b=wl.to(DEV), bias=c2.to(DEV), residual=blk, ldr=Mp), ref
+
+
+@pytest.mark.parametrize("cdt", [BF16, F16])
+def test_gemm_layernorm_fold_epilogues(cdt):
+    """LPI_EPI_LN / LPI_EPI_LN_QUICKGELU: LayerNorm folded into the GEMM (statistics pass + row / column terms in the epilogue) against the f64
+    LN(x) W^T + b, alone and as a grouped launch of two problems; statistics-only LayerNorm; shapes the kernel does not take are refused."""
+    ctd = torch.bfloat16 if cdt == BF16 else torch.float16
+    tol = 6e-3 if cdt == BF16 else 1.5e-3        # the output rounding; the arithmetic itself is fp16 operands, f32 accumulation
+    assert _lib.load().lpi_gemm_ln_supported(F16, 512, 768, 768) == 1 and _lib.load().lpi_gemm_ln_supported(F16, 384, 768, 768) == 0
+    p, ref = _ln_fold_operands(512, 768, 768, seed=1)
+    c = torch.zeros(512, 768, dtype=ctd, device=DEV)
+    call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], p["residual"], p["ldr"], E.EPI_LN, None, 0, 1.0, stream())
+    assert relerr(c, ref) < tol
+    g = torch.zeros(512, 768, dtype=ctd, device=DEV)
+    aux = torch.zeros(512, 768, dtype=torch.bfloat16, device=DEV)      # f16 operands keep the saved derivative in bf16 (gemm_epilogue.h, AuxT)
+    call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, g, 768, p["bias"], p["residual"], p["ldr"], E.EPI_LN_QUICKGELU, aux, 768, 1.0,
+         stream())
+    assert relerr(g, ref * torch.sigmoid(1.702 * ref)) < tol and relerr(aux, gelu_grad_ref(ref)) < 6e-3
+    g2 = torch.zeros_like(g)
+    call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, g2, 768, p["bias"], p["residual"], p["ldr"], E.EPI_LN_QUICKGELU, None, 0, 1.0,
+         stream())
+    assert torch.equal(g, g2)
+    # two problems in one persistent launch (the two towers' in_proj / c_fc): bit for bit the single launches
+    p0, r0 = _ln_fold_operands(8192, 1536, 768, seed=11)
+    p1, r1 = _ln_fold_operands(4096, 1024, 512, seed=21)
+    for epi in (E.EPI_LN, E.EPI_LN_QUICKGELU):
+        outs, singles = [], []
+        for q in (p0, p1):
+            q["c"] = torch.zeros(q["M"], q["N"], dtype=ctd, device=DEV)
+            outs.append(q["c"])
+            one = torch.zeros_like(q["c"])
+            call("lpi_gemm_nt", F16, cdt, q["M"], q["N"], q["K"], q["a"], q["K"], q["b"], q["K"], one, q["N"], q["bias"], q["residual"], q["ldr"], epi,
+                 None, 0, 1.0, stream())
+            singles.append(one)
+        assert _lib.gemm_grouped(F16, cdt, epi, 1.0, [p0, p1], stream())
+        for o, one, r in zip(outs, singles, (r0, r1)):
+            assert torch.equal(o, one)
+            assert relerr(o, r if epi == E.EPI_LN else r * torch.sigmoid(1.702 * r)) < tol
+    with pytest.raises(_lib.LpiError):      # 384 rows: not a shape of the persistent kernel -> refused (the caller runs LayerNorm + GEMM)
+        call("lpi_gemm_nt", F16, cdt, 384, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], p["residual"], p["ldr"], E.EPI_LN, None, 0, 1.0, stream())
+    with pytest.raises(_lib.LpiError):      # the LN operand block is required
+        call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], None, 0, E.EPI_LN, None, 0, 1.0, stream())
+
+
 def test_gemm_256x128_tiles_for_half_empty_launches():
     """Launches with 16..159 256x256 tiles go to the 256x128-tile kernel (twice the workgroups): every epilogue, bit for bit the
     results of the 256x256 kernel (tuning key 5 = 0 disables the rule)."""
