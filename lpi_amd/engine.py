@@ -92,8 +92,10 @@ class LnLinear:
         self.c2 = (w @ be + b.to(device=device, dtype=torch.float64)).float().contiguous()
 
 
-# LPI_LN_FOLD=0: LayerNorm as its own kernel in front of in_proj / c_fc (A/B switch; f32 mode always)
-LN_FOLD = _os.environ.get("LPI_LN_FOLD", "1") != "0"
+# LPI_LN_FOLD: 0 = LayerNorm as its own kernel in front of in_proj / c_fc (f32 mode always); 1 = ln_1 folded into in_proj; 2 = ln_2 folded
+# into c_fc as well.  Measured per layer: the statistics pass saves 18 us against the LayerNorm kernel either way; the fp16-operand in_proj
+# GEMM costs 8 us more than the bf16 one, the c_fc GEMM 18.5 us (profiles/r02_gemm_experiments.md) — so 1 is the default.
+LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "1"))
 
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
@@ -492,7 +494,7 @@ class Tower:
                 yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
-            if fold:
+            if fold and LN_FOLD >= 2:
                 fl = blk["fc_ln"]
                 yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3])
                 yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
