@@ -24,6 +24,8 @@ The JSON line carries, besides the driver's contract keys:
   step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair (all kernels, not just GEMMs);
   parity_mode  : (N = 1) the f32-operand mode that meets the 1e-4 parity bar, same workload, a few steps;
   fwd_only     : (N = 1) BASELINE.json configs[1]: encoder forward + cosine matrix;
+  eval_path    : (N = 1) the reference's evaluation path per batch (task-id pass, L1 task selection, per-sample prompted forward), images/s and
+                 captions/s, and the score matrix + ranks at COCO 5k-test size;
   f16_mode     : (N = 1) the same step with fp16 MFMA operands in the forward (the reference's arithmetic type): 4x lower logit error;
   collectives  : (N > 1) mean microseconds of the feature all-gather and the factor-gradient all-reduce per step;
   cpu_baseline : the oracle (oracle/lpi_oracle.py, "port") timed on this host's cores on a bounded bs=8 sample, thread count swept.
@@ -271,6 +273,75 @@ class Workload:
                             "kernel attribution from lpi_gemm_last_kernel"}
 
 
+def eval_path(a, dev, rank, sync, tasks=3, centres=5, n_img=5000, n_txt=25000):
+    """The evaluation path of the reference (methods/sprompt.py:433-548, _evaluate_retrieval) on the HIP engine, timed next to the train step:
+    per image batch the un-prompted task-id pass (extract_vector), the L1 distance to the tasks' KMeans centres (lpi_l1_task_id) and the
+    prompted forward with PER-SAMPLE prompt stacks (visual_interface); the same for captions; then the N_img x N_txt score matrix (f32
+    GEMM) and the ranks of the ground truth (lpi_retrieval_rank) at COCO 5k-test size.  Synthetic data and keys; forward only, bf16."""
+    import numpy as np
+    import torch
+    from lpi_amd import _lib
+    from lpi_amd.engine import score_matrix
+    from lpi_amd.functional import DecomposedPromptFn
+    wl = Workload(a, dev, rank, "bf16", True, None)
+    enc, B, E = wl.enc, a.batch, wl.cfg.embed_dim
+    names = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")
+    with torch.no_grad():
+        stacks = [DecomposedPromptFn.apply(*[wl.fac[k] * (1.0 + 0.1 * t) for k in names]) for t in range(tasks)]
+        vis_stack = torch.stack([v for v, _ in stacks])          # [tasks, Lyr, P, d_v]
+        txt_stack = torch.stack([t for _, t in stacks])
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        keys_v = torch.nn.functional.normalize(torch.randn(tasks, centres, E, generator=g), dim=-1).to(dev).contiguous()
+        keys_t = torch.nn.functional.normalize(torch.randn(tasks, centres, E, generator=g), dim=-1).to(dev).contiguous()
+    sel = torch.empty(B, dtype=torch.int32, device=dev)
+    s = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+
+    def images_batch():
+        with torch.no_grad():
+            f = enc.encode_image(wl.images, None)                                                   # get_visual_task_id: extract_vector ...
+            _lib.call("lpi_l1_task_id", B, E, tasks, centres, f, E, keys_v, sel, None, s())        # ... nearest task centre (sprompt.py:343-350)
+            return enc.encode_image(wl.images, vis_stack[sel.long()], a.depth)                      # visual_interface (slinet.py:215)
+
+    def captions_batch():
+        with torch.no_grad():
+            f = enc.encode_text(wl.ids, None)
+            _lib.call("lpi_l1_task_id", B, E, tasks, centres, f, E, keys_t, sel, None, s())
+            return enc.encode_text(wl.ids, txt_stack[sel.long()], a.depth)
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / n
+
+    t_img = timed(images_batch, 10, 2)
+    t_txt = timed(captions_batch, 10, 2)
+    fi = torch.nn.functional.normalize(torch.randn(n_img, E, generator=g), dim=-1).to(dev)
+    ft = torch.nn.functional.normalize(torch.randn(n_txt, E, generator=g), dim=-1).to(dev)
+    gt_i = (torch.arange(n_img, dtype=torch.int32).view(-1, 1) * 5 + torch.arange(5, dtype=torch.int32).view(1, -1)).to(dev).contiguous()   # 5 captions per image
+    gt_t = (torch.arange(n_txt, dtype=torch.int32) // 5).view(-1, 1).to(dev).contiguous()
+    r_i = torch.zeros(n_img, dtype=torch.int32, device=dev)
+    r_t = torch.zeros(n_txt, dtype=torch.int32, device=dev)
+
+    def score_and_rank():
+        i2t, t2i = score_matrix(fi, ft)
+        _lib.call("lpi_retrieval_rank", n_img, n_txt, i2t, n_txt, gt_i, 5, r_i, s())
+        _lib.call("lpi_retrieval_rank", n_txt, n_img, t2i, n_img, gt_t, 1, r_t, s())
+
+    t_sc = timed(score_and_rank, 3, 1)
+    del wl
+    torch.cuda.empty_cache()
+    return {"dtype": "bf16", "images_per_s": round(B / t_img, 1), "captions_per_s": round(B / t_txt, 1), "ms_per_image_batch": round(1e3 * t_img, 3),
+            "ms_per_caption_batch": round(1e3 * t_txt, 3), "batch": B, "tasks": tasks,
+            "score_and_rank_ms": round(1e3 * t_sc, 3), "score_shape": [n_img, n_txt],
+            "workload": "methods/sprompt.py:433-548 per batch: un-prompted task-id pass + L1 distance to tasks x 5 KMeans centres + prompted forward with "
+                        "per-sample prompt stacks (depth as the train step); then the f32 score matrix and ground-truth ranks at COCO 5k-test size"}
+
+
 def main():
     a = parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -369,6 +440,7 @@ def main():
                                       "5-9 % slower than the bf16 one on the same GEMM shapes (power-limited clock), hence not the default"}
         del wh
         torch.cuda.empty_cache()
+        extras["eval_path"] = eval_path(a, dev, rank, sync)
 
     if rank == 0:
         gfs = GFLOP_PER_PAIR.get(a.model)
