@@ -392,6 +392,33 @@ def test_f16_operand_mode_is_several_times_closer_to_the_reference_than_bf16(gol
         assert cos(rh[k], g[k]) > 0.995, (k, cos(rh[k], g[k]))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_layernorm_fold_levels_agree_and_do_not_lose_accuracy(monkeypatch, golden, dtype):
+    """LayerNorm folded into in_proj (LPI_LN_FOLD=1, the default) and into c_fc too (=2) against LayerNorm as its own kernel (=0) on the ViT-B/16
+    bs=8 fixture: the three builds agree far inside the mode's error against the reference, the folded ones are not further from the
+    reference than the unfolded one (LN(x) is no longer rounded to the operand type), and the launch counts show the fold really ran."""
+    from lpi_amd import engine as E
+    cfg = synth.VIT_B16
+    g = golden("vitb16_d3_patched")
+    res, launches = {}, {}
+    for level in (0, 1, 2):
+        monkeypatch.setattr(E, "LN_FOLD", level)
+        n0 = _lib.launch_count()
+        res[level], _ = run_hip(cfg, dtype, 8, g["token_ids"], 3)
+        launches[level] = _lib.launch_count() - n0
+    err = {lv: max(maxerr(r["img_f"], g["img_f"]), maxerr(r["txt_f"], g["txt_f"])) for lv, r in res.items()}
+    lerr = {lv: maxerr(r["logits"], g["logits"]) for lv, r in res.items()}
+    print(f"{dtype}: feature err by fold level {err}, logit err {lerr}, launches {launches}")
+    bar = 3e-3 if dtype == "bf16" else 6e-4
+    for lv in (1, 2):
+        assert max(maxerr(res[lv]["img_f"], res[0]["img_f"]), maxerr(res[lv]["txt_f"], res[0]["txt_f"])) <= bar
+        assert err[lv] <= 1.25 * err[0] + 1e-5 and lerr[lv] <= 1.5 * lerr[0] + 1e-4      # maxima over 64 logits: noisy, same order
+        cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+        for k in GRADS:
+            assert cos(res[lv][k], res[0][k]) > 0.995, (lv, k)
+    assert launches[0] == launches[1] == launches[2]      # a statistics pass replaces each folded LayerNorm: the same number of launches
+
+
 def test_tiny_f16_close_to_oracle(golden):
     cfg = synth.TINY
     g = golden("tiny_d2_patched")
