@@ -84,10 +84,17 @@ class LnLinear:
     the fp16 residual stream itself; LN(x) is never written (model.py:172-177: ln_1 -> in_proj, ln_2 -> c_fc; weights are frozen, so nothing
     downstream needs LN(x) either).  Operands are fp16 in bf16 mode too: x is the fp16 stream, and an fp16 gamma o W keeps three more bits."""
 
-    def __init__(self, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, device):
+    def __init__(self, w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, device, bf16_weights: bool = False):
         w = w.to(device=device, dtype=torch.float64)
         g, be = gamma.to(device=device, dtype=torch.float64), beta.to(device=device, dtype=torch.float64)
-        self.w = (w * g[None, :]).to(torch.float16).contiguous()
+        wl = w * g[None, :]
+        if bf16_weights:
+            # bf16 mode: gamma o W keeps bf16's 8 significant bits (the precision of every other weight of the mode) inside the fp16 container.
+            # Not for accuracy — for POWER: the chip is power-limited under the GEMMs and the matrix pipe's energy follows the operands'
+            # mantissa activity; with the three low mantissa bits of B zero the fp16-operand in_proj GEMM loses most of its 4 % penalty
+            # against the bf16 one (24.21 -> 24.08 ms per step, profiles/r02_gemm_experiments.md).  LPI_LN_FOLD_W8=0: full fp16 mantissas.
+            wl = wl.to(torch.bfloat16)
+        self.w = wl.to(torch.float16).contiguous()
         self.c1 = self.w.double().sum(dim=1).float().contiguous()
         self.c2 = (w @ be + b.to(device=device, dtype=torch.float64)).float().contiguous()
 
@@ -345,8 +352,9 @@ class Tower:
                 blk[nm + ".w"] = f(p + nm + ".weight").to(device=device, dtype=torch.float32).contiguous()
                 blk[nm + ".b"] = f(p + nm + ".bias").to(device=device, dtype=torch.float32).contiguous()
             if dt != F32 and self.xdt == F16 and LN_FOLD:
-                blk["qkv_ln"] = LnLinear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), blk["ln_1.w"], blk["ln_1.b"], device)
-                blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device)
+                w8 = dt == BF16 and _os.environ.get("LPI_LN_FOLD_W8", "1") != "0"
+                blk["qkv_ln"] = LnLinear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), blk["ln_1.w"], blk["ln_1.b"], device, w8)
+                blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device, w8)
             self.blocks.append(blk)
         self._ws = {}
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
