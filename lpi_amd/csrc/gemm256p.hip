@@ -41,6 +41,7 @@ struct PProb {
     int N, K, lda, ldb, ldc, ldr, ldaux, tiles_m, tiles_n;
     int vb0;        // first virtual workgroup id (a multiple of 8)
     int bias_off;   // offset (floats) of its bias vector in the LDS copy (SIDE16 epilogues)
+    int group_m;    // order of its tiles inside an XCD's share: group_m row panels at a time, rows fastest (1 = columns fastest)
 };
 struct PGroup {
     PProb p[2];
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int G = gridDim.x;
-    const int group_m = grp.group_m;
+    int group_m = 1;      // of the current problem (bind)
     const float alpha = grp.alpha;
     typedef typename AuxT<T>::type TA;
     typedef float f32x8 __attribute__((ext_vector_type(8)));
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
         const PProb& P = grp.p[pi];
         A = (const T*)P.A; B = (const T*)P.B; C = (TC*)P.C; bias = P.bias; residual = (const float*)P.residual; aux = (TA*)P.aux;
         K = P.K; lda = P.lda; ldb = P.ldb; ldc = P.ldc; ldr = P.ldr; ldaux = P.ldaux; tiles_m = P.tiles_m; tiles_n = P.tiles_n;
-        nwg = tiles_m * tiles_n; vb0 = P.vb0; bias_off = P.bias_off;
+        nwg = tiles_m * tiles_n; vb0 = P.vb0; bias_off = P.bias_off; group_m = P.group_m;
         a_off = (unsigned)(((size_t)srow * lda + schunk * EPC) * sizeof(T));
         b_off = (unsigned)(((size_t)srow * ldb + schunk * EPC) * sizeof(T));
     };
@@ -481,10 +482,6 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
     const int ncu = cu_count_p();
     PGroup g = {};
     g.nprob = np;
-    // tile order inside an XCD's share: group_m row panels at a time, rows fastest.  1 = columns fastest: the N-tiles of a row panel run together,
-    // so its A rows are fetched into the XCD's L2 once and only the (small, shared) weight panels have to stay resident across rounds — measured
-    // on the whole step 24.20 (8) / 24.08 (1 but 8 for the gelu' epilogue) / 24.01 ms (1): 1 is the default.  Tuning key 4 > 0 overrides.
-    g.group_m = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : 1;
     g.alpha = alpha;
     int v = 0, nsum = 0;
     for (int i = 0; i < np; ++i) {
@@ -497,6 +494,11 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
         P.vb0 = v;
         v += P.tiles_m * P.tiles_n;
         P.bias_off = nsum;
+        // Tile order inside an XCD's share.  1 = columns fastest: the N-tiles of a row panel run together, so its A rows are fetched into the
+        // XCD's 4 MB L2 once and only the weight panels have to stay resident from round to round — right while the WHOLE weight matrix fits
+        // (ViT-B/16: 1.2-4.7 MB; whole step 24.16 -> 24.05 ms against 8).  Larger weights (ViT-L/14: 6-8 MB) would be re-read every round:
+        // there 8 row panels at a time, rows fastest, is better (99.7 against 100.7 ms per step).  Tuning key 4 > 0 overrides.
+        P.group_m = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : ((size_t)h.N * h.K * sizeof(T) <= ((size_t)5 << 20) ? 1 : 8);
         nsum += h.N;
     }
     if (SIDE16 && nsum > 8192) return LPI_ENOSYS;       // the bias vectors must fit behind the ring (the caller falls back to the one-tile kernel)
