@@ -107,11 +107,20 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
     };
+    // the A rows' LDS-DMA with its own cache policy (LPI_A_POLICY: "" plain, " nt", " sc1", ...): A/B switch, see profiles/r02_gemm_experiments.md
+#ifndef LPI_A_POLICY
+#define LPI_A_POLICY ""
+#endif
+    auto glds16a = [&](const T* sbase, unsigned voff, unsigned lds_addr) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" LPI_A_POLICY "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    };
     auto stage_A = [&](int m0, int kt, int h, int buf) {
         const T* sb = A + (size_t)(m0 + h * 128) * lda + (size_t)kt * BK;
         const int lo = buf * BUF_BYTES + (h ? OFF_A1 : OFF_A0);
-        glds16(sb, a_off, lds_w + lo);
-        glds16(sb + (size_t)64 * lda, a_off, lds_w + lo + 8192);
+        glds16a(sb, a_off, lds_w + lo);
+        glds16a(sb + (size_t)64 * lda, a_off, lds_w + lo + 8192);
     };
     auto stage_B = [&](int n0, int kt, int h, int buf) {
         const T* sb = B + (size_t)(n0 + h * 128) * ldb + (size_t)kt * BK;
