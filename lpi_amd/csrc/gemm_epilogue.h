@@ -64,7 +64,11 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
         else v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
     }
 #ifndef LPI_ABL_NO_GLOBAL_STORE
+#ifdef LPI_LN_PLAIN_C      /* A/B: the in_proj output (read next by the attention forward) with plain stores */
+    if constexpr (NTC && EPI != LPI_EPI_LN) st4_nt<TC>(C + (size_t)row * ldc + col, v);
+#else
     if constexpr (NTC) st4_nt<TC>(C + (size_t)row * ldc + col, v);
+#endif
     else Elem<TC>::st4(C + (size_t)row * ldc + col, v);
 #else
     if (v[0] == 12345.678f) Elem<TC>::st4(C + (size_t)row * ldc + col, v);      // ablation build: keeps the arithmetic alive, stores nothing
