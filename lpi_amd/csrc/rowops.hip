@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void ln_bwd_h16_pair_kernel(LnBwdP p0, LnBwdP 
 
 // ---------------------------------------------------------------------------------------------------------
 // vision front end
-template <typename T>
+template <typename T, bool VEC4 = false>
 __global__ __launch_bounds__(256) void patchify_kernel(int B, int R, int ps, int G, int Kp, const float* __restrict__ img,
                                                       T* __restrict__ cols, int ldcols) {
     // one thread per 4 consecutive k of one patch row; k = c*ps*ps + dy*ps + dx (conv weight [d,3,ps,ps] flattened)
@@ -331,12 +331,19 @@ __global__ __launch_bounds__(256) void patchify_kernel(int B, int R, int ps, int
     const long patch = t / (Kp >> 2);
     const int b = (int)(patch / (G * G)), gy = (int)(patch % (G * G)) / G, gx = (int)(patch % G);
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC4) {      // ps and R multiples of 4: the four k are four consecutive pixels of one patch row — one 16-byte load, one index split
+        if (k4 < K) {
+            const int c = k4 / (ps * ps), rem = k4 % (ps * ps), dy = rem / ps, dx = rem % ps;
+            v = *reinterpret_cast<const f32x4*>(img + (((size_t)b * 3 + c) * R + gy * ps + dy) * R + gx * ps + dx);
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k4 + j;
-        if (k < K) {
-            const int c = k / (ps * ps), rem = k % (ps * ps), dy = rem / ps, dx = rem % ps;
-            v[j] = img[(((size_t)b * 3 + c) * R + gy * ps + dy) * R + gx * ps + dx];
+        for (int j = 0; j < 4; ++j) {
+            const int k = k4 + j;
+            if (k < K) {
+                const int c = k / (ps * ps), rem = k % (ps * ps), dy = rem / ps, dx = rem % ps;
+                v[j] = img[(((size_t)b * 3 + c) * R + gy * ps + dy) * R + gx * ps + dx];
+            }
         }
     }
     Elem<T>::st4(cols + (size_t)patch * ldcols + k4, v);
@@ -848,10 +855,14 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
     if (ldcols < Kp || (ldcols & 3)) return LPI_EINVAL;
     const long total = (long)B * G * G * (Kp >> 2);
     dim3 g((unsigned)((total + 255) / 256)), b(256);
-    if (dtype == LPI_F32) LPI_LAUNCH(patchify_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (float*)cols, ldcols);
-    else if (dtype == LPI_BF16) LPI_LAUNCH(patchify_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (bf16_t*)cols, ldcols);
-    else if (dtype == LPI_F16) LPI_LAUNCH(patchify_kernel<f16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, (f16_t*)cols, ldcols);
+    const bool vec4 = (ps & 3) == 0 && (R & 3) == 0 && ((uintptr_t)image & 15) == 0;
+#define PATCHIFY(T) do { if (vec4) LPI_LAUNCH((patchify_kernel<T, true>), g, b, 0, S(stream), B, R, ps, G, Kp, image, (T*)cols, ldcols); \
+                         else LPI_LAUNCH((patchify_kernel<T, false>), g, b, 0, S(stream), B, R, ps, G, Kp, image, (T*)cols, ldcols); } while (0)
+    if (dtype == LPI_F32) PATCHIFY(float);
+    else if (dtype == LPI_BF16) PATCHIFY(bf16_t);
+    else if (dtype == LPI_F16) PATCHIFY(f16_t);
     else return LPI_EINVAL;
+#undef PATCHIFY
     LPI_CHECK_LAST();
     return 0;
 }
