@@ -6,7 +6,7 @@ static std::atomic<uint64_t> g_launches{0};
 
 extern "C" void lpi_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
-extern "C" int lpi_version(void) { return 212; }
+extern "C" int lpi_version(void) { return 213; }
 
 static thread_local int t_last_gemm_kernel = -1;
 void lpi_note_gemm_kernel(int which) { t_last_gemm_kernel = which; }
