@@ -48,7 +48,6 @@ struct PGroup {
     int nprob;
     int n_full;        // virtual ids below this run as 256x256 tiles in the persistent loop (a multiple of the grid size, or all)
     int tail_blocks;   // work items of the hybrid short last round (256x128 half tiles), 0 = none
-    int group_m;
     float alpha;
 };
 
