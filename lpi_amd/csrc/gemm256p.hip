@@ -48,6 +48,9 @@ struct PGroup {
     int nprob;
     int n_full;        // virtual ids below this run as 256x256 tiles in the persistent loop (a multiple of the grid size, or all)
     int tail_blocks;   // work items of the hybrid short last round (256x128 half tiles), 0 = none
+    int reserved;      // keeps the kernel-argument layout: without this word the QuickGELU + aux instantiations allocate differently and SPILL
+                       // 56 bytes per lane, with scratch reloads inside the tile loop (checked in the ISA: keep `private_seg_size` of every
+                       // gemm256p_kernel instantiation at 0 when this struct changes)
     float alpha;
 };
 
