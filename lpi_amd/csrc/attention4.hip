@@ -1,0 +1,460 @@
+// Prompted multi-head attention backward, bf16 operands, fourth generation: ONE pass over the scores, 4 fat waves, query slices STREAMED.
+//
+// replaces: the autograd backward of nn.MultiheadAttention as called from ResidualAttentionBlock.attention
+// (retrieval/models/clip/model.py:183-185) for the vision tower (non-causal, L = 1 + P + 196 = 213), like attn_bwd2_kernel of attention2.hip.
+//
+// Why a fourth generation (profiles/r02_pmc.json, DESIGN section 4 "what bounds attention"): the two-phase persistent backward evaluates S, P, dP
+// and dS twice (56 MFMAs and two exponentials per score), keeps a whole head's Q, K, V, dO (and O) in LDS, and its 7 waves (2 / 2 / 2 / 1 per
+// SIMD) overlap neither their loads with their arithmetic (157 us + 177 us -> 228 us) nor one wave's vector work with another's matrix work.
+// Here:
+//   * a workgroup = 4 waves, one per SIMD, each with the whole 512-register file; wave w OWNS 3-4 blocks of 16 keys ("units": 14 for L = 213,
+//     split 4 / 4 / 3 / 3) for a whole head: their K and V rows (MFMA B operands) and their dK^T, dV^T accumulators stay in registers;
+//   * the head's queries stream through LDS in SLICES of 32 rows (Q and dO, 8 KiB per slice) from an 8-slot ring filled by LDS-DMA seven
+//     slices ahead, across head boundaries — every global read of the kernel is an LDS-DMA issued a whole head before its use, so the memory
+//     pipe never waits for the arithmetic nor the arithmetic for it;
+//   * per slice ONE evaluation: S^T = Q K_own^T and dP^T = dO V_own^T (key on the lane), P = exp2(c S - lse), dS = P (dP - delta) / 8;
+//     P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS straight from the accumulators; dS^T crosses LDS once ([key][query]
+//     bf16, 14 KiB per slice) and wave w contracts it over ALL keys with the K^T fragments of its 16 head-dim columns: dQ^T of the slice is
+//     complete (no partial sums across waves, no atomics, no f32 read-modify-write) and is stored at once;
+//   * delta_i = sum_j P_ij dP_ij (== rowsum(dO o O)) comes from the same accumulators: the O rows are never read (-12.5 % bytes), the
+//     per-wave partial sums meet in a 1 KiB LDS table, summed in a fixed order;
+//   * software pipeline over slices, one barrier per slice: iteration t runs stage 1 of slice t + 1 (S, dP, P, partial delta), stage 2 of
+//     slice t (delta, dS, dV, dK) and stage 3 of slice t - 1 (dQ) as independent instruction streams.
+// 40 MFMAs and one exponential per score instead of 56 and two; 586 MB instead of 670 MB per vision layer at B = 256.
+// Results are bitwise reproducible (fixed summation orders), but differ in the last bits from the earlier generations (delta from P dP
+// instead of dO O; dQ summed over keys inside one MFMA chain).
+#include <type_traits>
+#include "common.h"
+
+extern int g_lpi_tuning[16];
+
+namespace {
+
+typedef bf16_t T;
+constexpr int HD = 64;
+constexpr int RB = 128;          // bytes per LDS image row (64 x 2 B, unpadded: what LDS-DMA writes)
+constexpr int KS = 2;            // 32-wide k-steps per 64-element row
+constexpr int NWV = 4;           // waves per workgroup
+constexpr int MAXU = 4;          // 16-key units per wave
+constexpr int MAXKB = 7;         // 32-key blocks per head (Lp <= 224)
+constexpr int NSLOT = 8;         // ring slots
+constexpr int SLOT_BYTES = 2 * 32 * RB;      // Q slice + dO slice
+constexpr int AHEAD = 7;         // slices in flight ahead of stage 2
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SCALE = 0.125f;
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_){a, b}, bf16x2_)); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// one LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB of LDS starting at lds_addr (wave-uniform), lane i at +16 i
+__device__ __forceinline__ void glds16(const void* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+// 64 lanes x 4 B -> 256 B of LDS, lane i at +4 i
+__device__ __forceinline__ void glds4(const void* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+
+typedef __attribute__((address_space(3))) short4v* lds_s4p;
+__device__ __forceinline__ uint2 tr_read(const char* p) {
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)p));
+}
+// two transposing reads 16 rows apart -> one 16x16x32 operand chunk (k elements 4g + 0..3 of the first block, then of the second)
+__device__ __forceinline__ Chunk tr_pair(const char* p, int second) {
+    const uint2 lo = tr_read(p), hi = tr_read(p + second);
+    Chunk c;
+    c.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    return c;
+}
+__device__ __forceinline__ void mma(f32x4& acc, const Chunk& a, const Chunk& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0); }
+
+#define LPI4_BARRIER()                                             \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();                              \
+        asm volatile("" ::: "memory");                             \
+    } while (0)
+
+// dS^T scratch: 64-byte rows (32 queries x bf16); the 8-byte slot index is XOR-ed with ((row >> 2 & 1) << 2 | (row >> 3 & 1) << 1): conflict-free
+// for the transposing reads (tools/lds_swizzle_check.py)
+__device__ __forceinline__ int ds_sw(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1); }
+
+struct Args4 {
+    int L, Lp, H, total;
+    const T* qkv; int ldqkv;
+    const T* dctx; int lddctx;
+    const float* lse;
+    float* delta;
+    T* dqkv; int lddqkv;
+};
+
+// LDS map (byte offsets from the dynamic region; Lp <= 224: 154 368 B):
+//   [0, Lp RB) K image | [Lp RB, 2 Lp RB) V image | ring: NSLOT x (Q slice 4 KiB, dO slice 4 KiB) | dS^T x 2 (Lp x 64 B each) |
+//   red[2][NWV][32] f32 | lse[2][Lp] f32
+template <int NUW, bool SV16>
+__device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
+    const int L = A.L, Lp = A.Lp, H = A.H, NSL = Lp >> 5, total = A.total;
+    const T* const qkv = A.qkv; const int ldqkv = A.ldqkv;
+    const T* const dctx = A.dctx; const int lddctx = A.lddctx;
+    float* const delta = A.delta;
+    T* const dqkv = A.dqkv; const int lddqkv = A.lddqkv;
+    const int dm = H * HD;
+    const float c = SCALE * LOG2E;
+    const int nheads = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this workgroup
+    const int nslices = nheads * NSL;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
+    const int o_ring = 2 * Lp * RB, o_dsb = o_ring + NSLOT * SLOT_BYTES, o_red = o_dsb + 2 * Lp * 64, o_lse = o_red + 2 * NWV * 32 * 4;
+    char* const k_img = smem;
+    char* const v_img = smem + Lp * RB;
+    char* const ring = smem + o_ring;
+    char* const dsb = smem + o_dsb;
+    float* const red = reinterpret_cast<float*>(smem + o_red);
+    float* const lse_l = reinterpret_cast<float*>(smem + o_lse);
+
+    // per-lane byte offsets
+    int rc[KS];                  // row fragment of a 16-row window: row (lane & 15), logical chunk (lane >> 4) + 4 ks, chunk index ^ (row & 6)
+    int tr[4];                   // transposing read of a 16-row window, head-dim block dt
+    int trw;                     // the same for dt = wave (K^T fragments)
+    int dsw[NUW > 0 ? NUW : 1][2];   // dS^T store: [key][query] rows of 64 B inside 32-key blocks of 2 KiB
+    int dsr[2][2];               // dS^T transposing read: [query half][second 16 keys]
+    {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) rc[ks] = r16 * RB + (((g + 4 * ks) ^ (r16 & 6)) << 4);
+        const int rr = 4 * g + (r16 >> 2), p = lane & 3;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) tr[dt] = rr * RB + (((2 * dt + (p >> 1)) ^ (rr & 6)) << 4) + (p & 1) * 8;
+        trw = rr * RB + (((2 * wave + (p >> 1)) ^ (rr & 6)) << 4) + (p & 1) * 8;
+#pragma unroll
+        for (int u = 0; u < NUW; ++u) {
+            const int ug = ub + u;
+            const int rowb = 16 * (ug & 1) + r16;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) dsw[u][t2] = (ug >> 1) * 2048 + rowb * 64 + (((4 * t2 + g) ^ ds_sw(rowb)) << 3);
+        }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int row = 16 * hi + 4 * g + (r16 >> 2);
+                dsr[qs][hi] = row * 64 + (((4 * qs + (lane & 3)) ^ ds_sw(row)) << 3);
+            }
+    }
+
+    // ---- LDS-DMA issue helpers (all wave-uniform control flow; lanes behind L are EXEC-masked or clamped)
+    auto head_of = [&](int it) { return (int)blockIdx.x + it * (int)gridDim.x; };
+    auto issue_kv = [&](int bh) {
+        const int b = bh / H, h = bh % H;
+        const T* kg = qkv + (size_t)b * L * ldqkv + h * HD + dm;
+        const int r8 = lane >> 3, pc = lane & 7;
+        for (int p = wave; p * 8 < L; p += NWV) {
+            const int row = p * 8 + r8;
+            if (row < L) {
+                const T* src = kg + (size_t)row * ldqkv + ((pc ^ (row & 6)) << 3);
+                glds16(src, lds0 + p * 1024);                           // K image
+                glds16(src + dm, lds0 + Lp * RB + p * 1024);            // V image
+            }
+        }
+    };
+    auto issue_lse = [&](int bh, int buf) {
+        const int i = wave * 64 + lane;
+        if (wave * 64 < L) {
+            if (i < L) glds4(A.lse + (size_t)bh * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
+        }
+    };
+    // slice t of head bh -> ring slot: wave w moves rows 8 w .. 8 w + 7 of the slice's Q and dO (rows behind L: the last row again — finite
+    // values; their lse is +inf, so P = 0 there)
+    auto issue_slice = [&](int bh, int t, int slot) {
+        const int b = bh / H, h = bh % H;
+        const int rl = wave * 8 + (lane >> 3), pc = lane & 7;
+        const int row = min(t * 32 + rl, L - 1);
+        const size_t grow = (size_t)b * L + row;
+        const int ch = (pc ^ (rl & 6)) << 3;
+        const unsigned dst = lds0 + o_ring + slot * SLOT_BYTES + wave * 1024;
+        glds16(qkv + grow * ldqkv + h * HD + ch, dst);
+        glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
+    };
+    // prefetch cursor over this workgroup's slice stream
+    int pf_it = 0, pf_t = 0, pf_gs = 0;
+    auto issue_next = [&]() {
+        if (pf_gs < nslices) {
+            issue_slice(head_of(pf_it), pf_t, pf_gs & (NSLOT - 1));
+            ++pf_gs;
+            if (++pf_t == NSL) { pf_t = 0; ++pf_it; }
+        }
+    };
+
+    // ---- per-head register state
+    constexpr int NUA = NUW > 0 ? NUW : 1;
+    Chunk kk[NUA][KS], vv[NUA][KS];      // own K, V rows (B operands of S^T, dP^T)
+    Chunk kT[MAXKB];                     // K^T fragments of head-dim block `wave`, all keys (A operands of dQ^T)
+    f32x4 dk[NUA][4], dv[NUA][4];
+    f32x4 pp[NUA][2], pdp[NUA][2];       // P and dP of the slice between its stage 1 and its stage 2
+    Chunk bp[NUA], bs[NUA];              // P and dS of the slice as B operands (stage 2a -> 2b)
+
+    // stage 1 of slice t: S^T, dP^T -> P, dP (kept in registers for stage 2), this wave's partial delta -> red[par][wave][32]
+    auto stage1 = [&](int t, int slot, int lbuf, int par) {
+        const char* qs_ = ring + slot * SLOT_BYTES;
+        const char* ds_ = qs_ + 32 * RB;
+        Chunk qa[2][KS], da[2][KS];
+        f32x4 nl[2], pd[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qa[t2][ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
+                da[t2][ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
+                if constexpr (SV16) chunk_f16_to_bf16(qa[t2][ks]);
+            }
+            nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g) * (-LOG2E);
+            pd[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < NUW; ++u)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    mma(s, qa[t2][ks], kk[u][ks]);
+                    mma(dp, da[t2][ks], vv[u][ks]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2_fast(fmaf(s[r], c, nl[t2][r]));
+                    pp[u][t2][r] = p;
+                    pd[t2][r] = fmaf(p, dp[r], pd[t2][r]);
+                }
+                pdp[u][t2] = dp;
+            }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pd[t2][r] = row16_sum(pd[t2][r]);
+            if (r16 == 0) *reinterpret_cast<f32x4*>(red + par * (NWV * 32) + wave * 32 + t2 * 16 + 4 * g) = pd[t2];
+        }
+    };
+
+    // stage 2a of slice t: delta (all waves' partial sums, fixed order), dS; dS^T -> dsb[par]; P, dS packed as B operands
+    auto stage2a = [&](int bh, int t, int par) {
+        char* dsp = dsb + par * (Lp * 64);
+        f32x4 dls[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const float* rp = red + par * (NWV * 32) + t2 * 16 + 4 * g;
+            f32x4 dl = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) dl += *reinterpret_cast<const f32x4*>(rp + w * 32);
+            if (wave == 0 && r16 < 4) {      // delta of the slice's 32 queries -> global (scratch of the C ABI: [B, H, L])
+                const int q = t * 32 + t2 * 16 + 4 * g + r16;
+                const float v = r16 == 0 ? dl[0] : r16 == 1 ? dl[1] : r16 == 2 ? dl[2] : dl[3];
+                if (q < L) delta[(size_t)bh * L + q] = v;
+            }
+            dls[t2] = dl * SCALE;
+        }
+#pragma unroll
+        for (int u = 0; u < NUW; ++u) {
+            uint32_t pw[2][2], sw[2][2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x4 s;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[r] = pp[u][t2][r] * fmaf(pdp[u][t2][r], SCALE, -dls[t2][r]);
+                pw[t2][0] = pack2(pp[u][t2][0], pp[u][t2][1]);
+                pw[t2][1] = pack2(pp[u][t2][2], pp[u][t2][3]);
+                sw[t2][0] = pack2(s[0], s[1]);
+                sw[t2][1] = pack2(s[2], s[3]);
+                *reinterpret_cast<uint2*>(dsp + dsw[u][t2]) = make_uint2(sw[t2][0], sw[t2][1]);
+            }
+            bp[u].u = make_uint4(pw[0][0], pw[0][1], pw[1][0], pw[1][1]);
+            bs[u].u = make_uint4(sw[0][0], sw[0][1], sw[1][0], sw[1][1]);
+        }
+    };
+    // stage 2b of slice t: dV^T += dO^T P, dK^T += Q^T dS
+    auto stage2b = [&](int slot) {
+        const char* qs_ = ring + slot * SLOT_BYTES;
+        const char* ds_ = qs_ + 32 * RB;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const Chunk ado = tr_pair(ds_ + tr[dt], 16 * RB);
+            Chunk aq = tr_pair(qs_ + tr[dt], 16 * RB);
+            if constexpr (SV16) chunk_f16_to_bf16(aq);
+#pragma unroll
+            for (int u = 0; u < NUW; ++u) {
+                mma(dv[u][dt], ado, bp[u]);
+                mma(dk[u][dt], aq, bs[u]);
+            }
+        }
+    };
+
+    // stage 3 of slice t: dQ^T[16 wave .., 32 queries] = K^T (all keys) . dS^T -> global
+    auto stage3 = [&](int bh, int t, int par) {
+        const char* dsp = dsb + par * (Lp * 64);
+        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb)
+            if (kb < NSL) {
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    Chunk b;
+                    const uint2 lo = tr_read(dsp + kb * 2048 + dsr[qs][0]), hi = tr_read(dsp + kb * 2048 + dsr[qs][1]);
+                    b.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    mma(dq[qs], kT[kb], b);
+                }
+            }
+        const int b = bh / H, h = bh % H;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int q = t * 32 + qs * 16 + r16;
+            if (q < L)
+                *reinterpret_cast<uint2*>(dqkv + ((size_t)b * L + q) * lddqkv + h * HD + 16 * wave + 4 * g) =
+                    make_uint2(pack2(dq[qs][0], dq[qs][1]), pack2(dq[qs][2], dq[qs][3]));
+        }
+    };
+
+    // ---- launch prologue: first head's K, V, lse and the first AHEAD slices
+    issue_kv(head_of(0));
+    issue_lse(head_of(0), 0);
+    for (int j = 0; j < AHEAD; ++j) issue_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int gs = 0;      // global slice index of stage 2
+    for (int it = 0; it < nheads; ++it) {
+        const int bh = head_of(it);
+        const int lbuf = it & 1;
+        // own K, V rows and the K^T fragments out of the images (landed a head ago)
+#pragma unroll
+        for (int u = 0; u < NUW; ++u)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                kk[u][ks].u = *reinterpret_cast<const uint4*>(k_img + (ub + u) * 16 * RB + rc[ks]);
+                vv[u][ks].u = *reinterpret_cast<const uint4*>(v_img + (ub + u) * 16 * RB + rc[ks]);
+                if constexpr (SV16) { chunk_f16_to_bf16(kk[u][ks]); chunk_f16_to_bf16(vv[u][ks]); }
+            }
+#pragma unroll
+        for (int kb = 0; kb < MAXKB; ++kb) {
+            kT[kb].u = make_uint4(0, 0, 0, 0);
+            if (kb < NSL) {
+                kT[kb] = tr_pair(k_img + kb * 32 * RB + trw, 16 * RB);
+                if constexpr (SV16) chunk_f16_to_bf16(kT[kb]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NUW; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+        stage1(0, gs & (NSLOT - 1), lbuf, 0);
+        LPI4_BARRIER();           // red[0] complete; every wave has its K, V rows: the images are free
+        if (it + 1 < nheads) {
+            issue_kv(head_of(it + 1));
+            issue_lse(head_of(it + 1), lbuf ^ 1);
+        }
+        // end of an iteration: this wave's pieces of slice gs + 2 (stage 1 of the next iteration reads it) have landed — all but the 2 pieces
+        // each of the 5 younger slices (stores issued in between only make the wait stricter); at the end of the stream, or with few slices
+        // per head, everything
+        auto close = [&]() {
+            if (NSL >= 6 && gs + AHEAD < nslices) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LPI4_BARRIER();
+            ++gs;
+        };
+        // Iteration t: stage 3 of slice t - 1 (matrix work) beside stage 2a of slice t (vector work: it frees P / dP), then stage 1 of slice
+        // t + 1 (its exponentials) beside stage 2b of slice t (matrix work)
+        for (int t = 0; t < NSL; ++t) {
+            issue_next();         // slice gs + AHEAD -> the slot stage 2 of slice gs - 1 has just left
+            const int par = t & 1;
+            if (t >= 1) stage3(bh, t - 1, par ^ 1);
+            stage2a(bh, t, par);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < NSL) stage1(t + 1, (gs + 1) & (NSLOT - 1), lbuf, par ^ 1);
+            stage2b(gs & (NSLOT - 1));
+            close();
+        }
+        stage3(bh, NSL - 1, (NSL - 1) & 1);
+        const int b = bh / H, h = bh % H;
+#pragma unroll
+        for (int u = 0; u < NUW; ++u) {
+            const int kr = (ub + u) * 16 + r16;
+            T* dst = dqkv + ((size_t)b * L + kr) * lddqkv + h * HD;
+            store_row_bf16_t(dst + dm, dk[u], g, kr < L);
+            store_row_bf16_t(dst + 2 * dm, dv[u], g, kr < L);
+        }
+    }
+}
+
+template <bool SV16>
+__global__ __launch_bounds__(256) void attn_bwd4_kernel(Args4 A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = A.L, Lp = A.Lp;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NU = Lp >> 4;
+    const int base = NU / NWV, rem = NU % NWV;
+    const int nu = base + (wave < rem ? 1 : 0);
+    const int ub = wave * base + min(wave, rem);
+    // once per launch: rows [L, Lp) of the K and V images are zero (the DMA is EXEC-masked there: padded keys then add nothing to delta, dQ),
+    // entries [L, Lp) of both lse vectors are +inf (P = 0 for padded queries)
+    {
+        const int per = (Lp - L) * (RB / 16);
+        for (int i = threadIdx.x; i < 2 * per; i += blockDim.x) {
+            const int im = i / per, rch = i % per;
+            *reinterpret_cast<uint4*>(smem + (size_t)im * Lp * RB + (size_t)L * RB + rch * 16) = make_uint4(0, 0, 0, 0);
+        }
+        float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * NWV * 32 * 4);
+        for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = INFINITY;
+    }
+    switch (nu) {
+        case 4: bwd4_body<4, SV16>(A, smem, wave, ub); break;
+        case 3: bwd4_body<3, SV16>(A, smem, wave, ub); break;
+        case 2: bwd4_body<2, SV16>(A, smem, wave, ub); break;
+        case 1: bwd4_body<1, SV16>(A, smem, wave, ub); break;
+        default: bwd4_body<0, SV16>(A, smem, wave, ub); break;
+    }
+}
+
+int cu_count4() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+size_t lds_bytes4(int Lp) { return (size_t)2 * Lp * RB + (size_t)NSLOT * SLOT_BYTES + (size_t)2 * Lp * 64 + (size_t)2 * NWV * 32 * 4 + (size_t)2 * Lp * 4; }
+
+}  // namespace
+
+// true if the fourth-generation backward takes this shape (bf16 operands, non-causal, at most 4 x 4 key units)
+bool lpi_attn4_bwd_ok(int L, int causal) {
+    const int Lp = (L + 31) / 32 * 32;
+    return !causal && L >= 1 && Lp <= 32 * MAXKB && Lp / 16 <= NWV * MAXU && lds_bytes4(Lp) <= 160 * 1024;
+}
+
+int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv,
+                  int lddqkv, hipStream_t s, int saved_f16) {
+    const int Lp = (L + 31) / 32 * 32;
+    const size_t lds = lds_bytes4(Lp);
+    const int total = B * H;
+    int grid = std::min(total, cu_count4());
+    if (g_lpi_tuning[11] > 0) grid = std::min(grid, g_lpi_tuning[11]);      // tests: several heads per workgroup at small B H
+    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv};
+    static LdsOnce o0, o1;
+    if (saved_f16) {
+        if (int e = lpi_ensure_lds(o1, (const void*)attn_bwd4_kernel<true>, 160 * 1024)) return e;
+        LPI_LAUNCH((attn_bwd4_kernel<true>), dim3(grid), dim3(64 * NWV), lds, s, A);
+    } else {
+        if (int e = lpi_ensure_lds(o0, (const void*)attn_bwd4_kernel<false>, 160 * 1024)) return e;
+        LPI_LAUNCH((attn_bwd4_kernel<false>), dim3(grid), dim3(64 * NWV), lds, s, A);
+    }
+    LPI_CHECK_LAST();
+    return 0;
+}
