@@ -34,12 +34,12 @@ typedef bf16_t T;
 constexpr int HD = 64;
 constexpr int RB = 128;          // bytes per LDS image row (64 x 2 B, unpadded: what LDS-DMA writes)
 constexpr int KS = 2;            // 32-wide k-steps per 64-element row
-constexpr int NWV = 4;           // waves per workgroup
-constexpr int MAXU = 4;          // 16-key units per wave
+constexpr int NWV = 8;           // waves per workgroup (two per SIMD)
+constexpr int MAXU = 2;          // 16-key units per wave
 constexpr int MAXKB = 7;         // 32-key blocks per head (Lp <= 224)
-constexpr int NSLOT = 8;         // ring slots
-constexpr int SLOT_BYTES = 2 * 32 * RB;      // Q slice + dO slice
-constexpr int AHEAD = 7;         // slices in flight ahead of stage 2
+constexpr int NSLOT = 6;         // ring slots
+constexpr int SLOT_BYTES = 3 * 32 * RB;      // Q slice + dO slice + O slice
+constexpr int AHEAD = 5;         // slices in flight ahead of the slice being computed
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float SCALE = 0.125f;
 
@@ -88,15 +88,16 @@ __device__ __forceinline__ int ds_sw(int row) { return (((row >> 2) & 1) << 2) |
 struct Args4 {
     int L, Lp, H, total;
     const T* qkv; int ldqkv;
+    const T* ctx; int ldctx;
     const T* dctx; int lddctx;
     const float* lse;
     float* delta;
     T* dqkv; int lddqkv;
 };
 
-// LDS map (byte offsets from the dynamic region; Lp <= 224: 154 368 B):
-//   [0, Lp RB) K image | [Lp RB, 2 Lp RB) V image | ring: NSLOT x (Q slice 4 KiB, dO slice 4 KiB) | dS^T x 2 (Lp x 64 B each) |
-//   red[2][NWV][32] f32 | lse[2][Lp] f32
+// LDS map (byte offsets from the dynamic region; Lp <= 224: 161 792 B):
+//   [0, Lp RB) K image | [Lp RB, 2 Lp RB) V image | ring: NSLOT x (Q slice, dO slice, O slice: 4 KiB each) | dS^T x 2 (Lp x 64 B each) |
+//   delta[2][32] f32 | lse[2][Lp] f32
 template <int NUW, bool SV16>
 __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
@@ -110,27 +111,29 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int nheads = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this workgroup
     const int nslices = nheads * NSL;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    const int o_ring = 2 * Lp * RB, o_dsb = o_ring + NSLOT * SLOT_BYTES, o_red = o_dsb + 2 * Lp * 64, o_lse = o_red + 2 * NWV * 32 * 4;
+    const int o_ring = 2 * Lp * RB, o_dsb = o_ring + NSLOT * SLOT_BYTES, o_dl = o_dsb + 2 * Lp * 64, o_lse = o_dl + 2 * 32 * 4;
     char* const k_img = smem;
     char* const v_img = smem + Lp * RB;
     char* const ring = smem + o_ring;
     char* const dsb = smem + o_dsb;
-    float* const red = reinterpret_cast<float*>(smem + o_red);
+    float* const dl_l = reinterpret_cast<float*>(smem + o_dl);
     float* const lse_l = reinterpret_cast<float*>(smem + o_lse);
+    const int dq_dt = wave & 3, dq_qs = wave >> 2;          // this wave's piece of dQ^T: head-dim block, query half
 
     // per-lane byte offsets
     int rc[KS];                  // row fragment of a 16-row window: row (lane & 15), logical chunk (lane >> 4) + 4 ks, chunk index ^ (row & 6)
     int tr[4];                   // transposing read of a 16-row window, head-dim block dt
-    int trw;                     // the same for dt = wave (K^T fragments)
+    int trw;                     // the same for dt = dq_dt (K^T fragments)
     int dsw[NUW > 0 ? NUW : 1][2];   // dS^T store: [key][query] rows of 64 B inside 32-key blocks of 2 KiB
-    int dsr[2][2];               // dS^T transposing read: [query half][second 16 keys]
+    int dsr[2];                  // dS^T transposing read of query half dq_qs: [second 16 keys]
+    int dlo;                     // delta pass: 8 bytes of row 4 wave + g, elements 4 r16 ..
     {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rc[ks] = r16 * RB + (((g + 4 * ks) ^ (r16 & 6)) << 4);
         const int rr = 4 * g + (r16 >> 2), p = lane & 3;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) tr[dt] = rr * RB + (((2 * dt + (p >> 1)) ^ (rr & 6)) << 4) + (p & 1) * 8;
-        trw = rr * RB + (((2 * wave + (p >> 1)) ^ (rr & 6)) << 4) + (p & 1) * 8;
+        trw = rr * RB + (((2 * dq_dt + (p >> 1)) ^ (rr & 6)) << 4) + (p & 1) * 8;
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
             const int ug = ub + u;
@@ -139,12 +142,12 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             for (int t2 = 0; t2 < 2; ++t2) dsw[u][t2] = (ug >> 1) * 2048 + rowb * 64 + (((4 * t2 + g) ^ ds_sw(rowb)) << 3);
         }
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) {
-                const int row = 16 * hi + 4 * g + (r16 >> 2);
-                dsr[qs][hi] = row * 64 + (((4 * qs + (lane & 3)) ^ ds_sw(row)) << 3);
-            }
+        for (int hi = 0; hi < 2; ++hi) {
+            const int row = 16 * hi + 4 * g + (r16 >> 2);
+            dsr[hi] = row * 64 + (((4 * dq_qs + (lane & 3)) ^ ds_sw(row)) << 3);
+        }
+        const int drow = 4 * wave + g;
+        dlo = drow * RB + (((r16 >> 1) ^ (drow & 6)) << 4) + (r16 & 1) * 8;
     }
 
     // ---- LDS-DMA issue helpers (all wave-uniform control flow; lanes behind L are EXEC-masked or clamped)
@@ -168,23 +171,28 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (i < L) glds4(A.lse + (size_t)bh * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
-    // slice t of head bh -> ring slot: wave w moves rows 8 w .. 8 w + 7 of the slice's Q and dO (rows behind L: the last row again — finite
-    // values; their lse is +inf, so P = 0 there)
+    // slice t of head bh -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4); wave w moves piece w and, w < 4, piece w + 8 (rows behind L: the
+    // last row again — finite values; their lse is +inf, so P = 0 there)
     auto issue_slice = [&](int bh, int t, int slot) {
         const int b = bh / H, h = bh % H;
-        const int rl = wave * 8 + (lane >> 3), pc = lane & 7;
+        const int pc = lane & 7;
+        const int rl = (wave & 3) * 8 + (lane >> 3);
         const int row = min(t * 32 + rl, L - 1);
         const size_t grow = (size_t)b * L + row;
         const int ch = (pc ^ (rl & 6)) << 3;
-        const unsigned dst = lds0 + o_ring + slot * SLOT_BYTES + wave * 1024;
-        glds16(qkv + grow * ldqkv + h * HD + ch, dst);
-        glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
+        const unsigned dst = lds0 + o_ring + slot * SLOT_BYTES + (wave & 3) * 1024;
+        if (wave < 4) {
+            glds16(qkv + grow * ldqkv + h * HD + ch, dst);
+            glds16(A.ctx + grow * A.ldctx + h * HD + ch, dst + 2 * 32 * RB);
+        } else {
+            glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
+        }
     };
     // prefetch cursor over this workgroup's slice stream
     int pf_it = 0, pf_t = 0, pf_gs = 0;
     auto issue_next = [&]() {
         if (pf_gs < nslices) {
-            issue_slice(head_of(pf_it), pf_t, pf_gs & (NSLOT - 1));
+            issue_slice(head_of(pf_it), pf_t, pf_gs % NSLOT);
             ++pf_gs;
             if (++pf_t == NSL) { pf_t = 0; ++pf_it; }
         }
@@ -193,93 +201,75 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     // ---- per-head register state
     constexpr int NUA = NUW > 0 ? NUW : 1;
     Chunk kk[NUA][KS], vv[NUA][KS];      // own K, V rows (B operands of S^T, dP^T)
-    Chunk kT[MAXKB];                     // K^T fragments of head-dim block `wave`, all keys (A operands of dQ^T)
+    Chunk kT[MAXKB];                     // K^T fragments of head-dim block dq_dt, all keys (A operands of dQ^T)
     f32x4 dk[NUA][4], dv[NUA][4];
-    f32x4 pp[NUA][2], pdp[NUA][2];       // P and dP of the slice between its stage 1 and its stage 2
-    Chunk bp[NUA], bs[NUA];              // P and dS of the slice as B operands (stage 2a -> 2b)
 
-    // stage 1 of slice t: S^T, dP^T -> P, dP (kept in registers for stage 2), this wave's partial delta -> red[par][wave][32]
-    auto stage1 = [&](int t, int slot, int lbuf, int par) {
+    // delta of slice t's rows 4 wave .. 4 wave + 3 = rowsum(dO o O) -> dl[par] (and the C ABI's delta scratch)
+    auto stage_delta = [&](int bh, int t, int slot, int par) {
+        const char* ds_ = ring + slot * SLOT_BYTES + 32 * RB;
+        const uint2 dd = *reinterpret_cast<const uint2*>(ds_ + dlo);
+        const uint2 oo = *reinterpret_cast<const uint2*>(ds_ + 32 * RB + dlo);
+        const float d0 = __uint_as_float(dd.x << 16), d1 = __uint_as_float(dd.x & 0xFFFF0000u), d2 = __uint_as_float(dd.y << 16), d3 = __uint_as_float(dd.y & 0xFFFF0000u);
+        float o0, o1, o2, o3;
+        if constexpr (SV16) {
+            const f16x4 h = __builtin_bit_cast(f16x4, oo);
+            o0 = (float)h[0]; o1 = (float)h[1]; o2 = (float)h[2]; o3 = (float)h[3];
+        } else {
+            o0 = __uint_as_float(oo.x << 16); o1 = __uint_as_float(oo.x & 0xFFFF0000u); o2 = __uint_as_float(oo.y << 16); o3 = __uint_as_float(oo.y & 0xFFFF0000u);
+        }
+        float v = fmaf(d0, o0, fmaf(d1, o1, fmaf(d2, o2, d3 * o3)));
+        v = row16_sum(v);
+        if (r16 == 0) {
+            const int rl = 4 * wave + g, q = t * 32 + rl;
+            dl_l[par * 32 + rl] = v;
+            if (q < L) delta[(size_t)bh * L + q] = v;
+        }
+    };
+
+    // slice t: S^T, dP^T -> P, dS = P (dP - delta) / 8; dS^T -> dsb[par]; dV^T += dO^T P, dK^T += Q^T dS
+    auto stage_main = [&](int t, int slot, int lbuf, int par) {
         const char* qs_ = ring + slot * SLOT_BYTES;
         const char* ds_ = qs_ + 32 * RB;
-        Chunk qa[2][KS], da[2][KS];
-        f32x4 nl[2], pd[2];
+        char* dsp = dsb + par * (Lp * 64);
+        uint32_t pw[NUA][2][2], sw[NUA][2][2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
+            Chunk qa[KS], da[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                qa[t2][ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
-                da[t2][ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
-                if constexpr (SV16) chunk_f16_to_bf16(qa[t2][ks]);
+                qa[ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
+                da[ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
+                if constexpr (SV16) chunk_f16_to_bf16(qa[ks]);
             }
-            nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g) * (-LOG2E);
-            pd[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            const f32x4 nl = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g) * (-LOG2E);
+            const f32x4 dls = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g) * SCALE;
 #pragma unroll
-        for (int u = 0; u < NUW; ++u)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
+            for (int u = 0; u < NUW; ++u) {
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    mma(s, qa[t2][ks], kk[u][ks]);
-                    mma(dp, da[t2][ks], vv[u][ks]);
+                    mma(s, qa[ks], kk[u][ks]);
+                    mma(dp, da[ks], vv[u][ks]);
                 }
+                f32x4 p, e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2_fast(fmaf(s[r], c, nl[t2][r]));
-                    pp[u][t2][r] = p;
-                    pd[t2][r] = fmaf(p, dp[r], pd[t2][r]);
+                    p[r] = exp2_fast(fmaf(s[r], c, nl[r]));
+                    e[r] = p[r] * fmaf(dp[r], SCALE, -dls[r]);
                 }
-                pdp[u][t2] = dp;
+                pw[u][t2][0] = pack2(p[0], p[1]);
+                pw[u][t2][1] = pack2(p[2], p[3]);
+                sw[u][t2][0] = pack2(e[0], e[1]);
+                sw[u][t2][1] = pack2(e[2], e[3]);
+                *reinterpret_cast<uint2*>(dsp + dsw[u][t2]) = make_uint2(sw[u][t2][0], sw[u][t2][1]);
             }
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pd[t2][r] = row16_sum(pd[t2][r]);
-            if (r16 == 0) *reinterpret_cast<f32x4*>(red + par * (NWV * 32) + wave * 32 + t2 * 16 + 4 * g) = pd[t2];
         }
-    };
-
-    // stage 2a of slice t: delta (all waves' partial sums, fixed order), dS; dS^T -> dsb[par]; P, dS packed as B operands
-    auto stage2a = [&](int bh, int t, int par) {
-        char* dsp = dsb + par * (Lp * 64);
-        f32x4 dls[2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const float* rp = red + par * (NWV * 32) + t2 * 16 + 4 * g;
-            f32x4 dl = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-            for (int w = 1; w < NWV; ++w) dl += *reinterpret_cast<const f32x4*>(rp + w * 32);
-            if (wave == 0 && r16 < 4) {      // delta of the slice's 32 queries -> global (scratch of the C ABI: [B, H, L])
-                const int q = t * 32 + t2 * 16 + 4 * g + r16;
-                const float v = r16 == 0 ? dl[0] : r16 == 1 ? dl[1] : r16 == 2 ? dl[2] : dl[3];
-                if (q < L) delta[(size_t)bh * L + q] = v;
-            }
-            dls[t2] = dl * SCALE;
-        }
+        Chunk bp[NUA], bs[NUA];
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
-            uint32_t pw[2][2], sw[2][2];
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                f32x4 s;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[r] = pp[u][t2][r] * fmaf(pdp[u][t2][r], SCALE, -dls[t2][r]);
-                pw[t2][0] = pack2(pp[u][t2][0], pp[u][t2][1]);
-                pw[t2][1] = pack2(pp[u][t2][2], pp[u][t2][3]);
-                sw[t2][0] = pack2(s[0], s[1]);
-                sw[t2][1] = pack2(s[2], s[3]);
-                *reinterpret_cast<uint2*>(dsp + dsw[u][t2]) = make_uint2(sw[t2][0], sw[t2][1]);
-            }
-            bp[u].u = make_uint4(pw[0][0], pw[0][1], pw[1][0], pw[1][1]);
-            bs[u].u = make_uint4(sw[0][0], sw[0][1], sw[1][0], sw[1][1]);
+            bp[u].u = make_uint4(pw[u][0][0], pw[u][0][1], pw[u][1][0], pw[u][1][1]);
+            bs[u].u = make_uint4(sw[u][0][0], sw[u][0][1], sw[u][1][0], sw[u][1][1]);
         }
-    };
-    // stage 2b of slice t: dV^T += dO^T P, dK^T += Q^T dS
-    auto stage2b = [&](int slot) {
-        const char* qs_ = ring + slot * SLOT_BYTES;
-        const char* ds_ = qs_ + 32 * RB;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const Chunk ado = tr_pair(ds_ + tr[dt], 16 * RB);
@@ -293,29 +283,22 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         }
     };
 
-    // stage 3 of slice t: dQ^T[16 wave .., 32 queries] = K^T (all keys) . dS^T -> global
-    auto stage3 = [&](int bh, int t, int par) {
+    // dQ^T[16 dq_dt .., 16 queries of half dq_qs] of slice t = K^T (all keys) . dS^T -> global
+    auto stage_dq = [&](int bh, int t, int par) {
         const char* dsp = dsb + par * (Lp * 64);
-        f32x4 dq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < MAXKB; ++kb)
             if (kb < NSL) {
-#pragma unroll
-                for (int qs = 0; qs < 2; ++qs) {
-                    Chunk b;
-                    const uint2 lo = tr_read(dsp + kb * 2048 + dsr[qs][0]), hi = tr_read(dsp + kb * 2048 + dsr[qs][1]);
-                    b.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    mma(dq[qs], kT[kb], b);
-                }
+                Chunk b;
+                const uint2 lo = tr_read(dsp + kb * 2048 + dsr[0]), hi = tr_read(dsp + kb * 2048 + dsr[1]);
+                b.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                mma(dq, kT[kb], b);
             }
         const int b = bh / H, h = bh % H;
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            const int q = t * 32 + qs * 16 + r16;
-            if (q < L)
-                *reinterpret_cast<uint2*>(dqkv + ((size_t)b * L + q) * lddqkv + h * HD + 16 * wave + 4 * g) =
-                    make_uint2(pack2(dq[qs][0], dq[qs][1]), pack2(dq[qs][2], dq[qs][3]));
-        }
+        const int q = t * 32 + dq_qs * 16 + r16;
+        if (q < L)
+            *reinterpret_cast<uint2*>(dqkv + ((size_t)b * L + q) * lddqkv + h * HD + 16 * dq_dt + 4 * g) = make_uint2(pack2(dq[0], dq[1]), pack2(dq[2], dq[3]));
     };
 
     // ---- launch prologue: first head's K, V, lse and the first AHEAD slices
@@ -325,7 +308,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int gs = 0;      // global slice index of stage 2
+    int gs = 0;      // global index of the slice being computed
     for (int it = 0; it < nheads; ++it) {
         const int bh = head_of(it);
         const int lbuf = it & 1;
@@ -351,34 +334,29 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-        stage1(0, gs & (NSLOT - 1), lbuf, 0);
-        LPI4_BARRIER();           // red[0] complete; every wave has its K, V rows: the images are free
+        stage_delta(bh, 0, gs % NSLOT, 0);
+        LPI4_BARRIER();           // delta of slice 0 complete; every wave has its K, V rows: the images are free
         if (it + 1 < nheads) {
             issue_kv(head_of(it + 1));
             issue_lse(head_of(it + 1), lbuf ^ 1);
         }
-        // end of an iteration: this wave's pieces of slice gs + 2 (stage 1 of the next iteration reads it) have landed — all but the 2 pieces
-        // each of the 5 younger slices (stores issued in between only make the wait stricter); at the end of the stream, or with few slices
-        // per head, everything
-        auto close = [&]() {
-            if (NSL >= 6 && gs + AHEAD < nslices) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int t = 0; t < NSL; ++t) {
+            issue_next();         // slice gs + AHEAD -> the slot slice gs - 1 has just left
+            const int par = t & 1;
+            if (t + 1 < NSL) stage_delta(bh, t + 1, (gs + 1) % NSLOT, par ^ 1);
+            stage_main(t, gs % NSLOT, lbuf, par);
+            if (t >= 1) stage_dq(bh, t - 1, par ^ 1);
+            // end of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
+            // pieces of the AHEAD - 2 younger slices (2 per slice from waves 0-3, 1 from waves 4-7; stores issued in between only make the
+            // wait stricter); at the end of the stream, or with few slices per head, everything
+            if (NSL >= 6 && gs + AHEAD < nslices) {
+                if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LPI4_BARRIER();
             ++gs;
-        };
-        // Iteration t: stage 3 of slice t - 1 (matrix work) beside stage 2a of slice t (vector work: it frees P / dP), then stage 1 of slice
-        // t + 1 (its exponentials) beside stage 2b of slice t (matrix work)
-        for (int t = 0; t < NSL; ++t) {
-            issue_next();         // slice gs + AHEAD -> the slot stage 2 of slice gs - 1 has just left
-            const int par = t & 1;
-            if (t >= 1) stage3(bh, t - 1, par ^ 1);
-            stage2a(bh, t, par);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < NSL) stage1(t + 1, (gs + 1) & (NSLOT - 1), lbuf, par ^ 1);
-            stage2b(gs & (NSLOT - 1));
-            close();
         }
-        stage3(bh, NSL - 1, (NSL - 1) & 1);
+        stage_dq(bh, NSL - 1, (NSL - 1) & 1);
         const int b = bh / H, h = bh % H;
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
@@ -391,7 +369,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 }
 
 template <bool SV16>
-__global__ __launch_bounds__(256) void attn_bwd4_kernel(Args4 A) {
+__global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = A.L, Lp = A.Lp;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -399,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(Args4 A) {
     const int base = NU / NWV, rem = NU % NWV;
     const int nu = base + (wave < rem ? 1 : 0);
     const int ub = wave * base + min(wave, rem);
-    // once per launch: rows [L, Lp) of the K and V images are zero (the DMA is EXEC-masked there: padded keys then add nothing to delta, dQ),
+    // once per launch: rows [L, Lp) of the K and V images are zero (the DMA is EXEC-masked there: padded keys then add nothing to dQ),
     // entries [L, Lp) of both lse vectors are +inf (P = 0 for padded queries)
     {
         const int per = (Lp - L) * (RB / 16);
@@ -407,12 +385,10 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(Args4 A) {
             const int im = i / per, rch = i % per;
             *reinterpret_cast<uint4*>(smem + (size_t)im * Lp * RB + (size_t)L * RB + rch * 16) = make_uint4(0, 0, 0, 0);
         }
-        float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * NWV * 32 * 4);
+        float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * 32 * 4);
         for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = INFINITY;
     }
     switch (nu) {
-        case 4: bwd4_body<4, SV16>(A, smem, wave, ub); break;
-        case 3: bwd4_body<3, SV16>(A, smem, wave, ub); break;
         case 2: bwd4_body<2, SV16>(A, smem, wave, ub); break;
         case 1: bwd4_body<1, SV16>(A, smem, wave, ub); break;
         default: bwd4_body<0, SV16>(A, smem, wave, ub); break;
@@ -429,24 +405,24 @@ int cu_count4() {
     return n;
 }
 
-size_t lds_bytes4(int Lp) { return (size_t)2 * Lp * RB + (size_t)NSLOT * SLOT_BYTES + (size_t)2 * Lp * 64 + (size_t)2 * NWV * 32 * 4 + (size_t)2 * Lp * 4; }
+size_t lds_bytes4(int Lp) { return (size_t)2 * Lp * RB + (size_t)NSLOT * SLOT_BYTES + (size_t)2 * Lp * 64 + (size_t)2 * 32 * 4 + (size_t)2 * Lp * 4; }
 
 }  // namespace
 
-// true if the fourth-generation backward takes this shape (bf16 operands, non-causal, at most 4 x 4 key units)
+// true if the fourth-generation backward takes this shape (bf16 operands, non-causal, at most 8 x 2 key units)
 bool lpi_attn4_bwd_ok(int L, int causal) {
     const int Lp = (L + 31) / 32 * 32;
     return !causal && L >= 1 && Lp <= 32 * MAXKB && Lp / 16 <= NWV * MAXU && lds_bytes4(Lp) <= 160 * 1024;
 }
 
-int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv,
-                  int lddqkv, hipStream_t s, int saved_f16) {
+int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
+                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = lds_bytes4(Lp);
     const int total = B * H;
     int grid = std::min(total, cu_count4());
     if (g_lpi_tuning[11] > 0) grid = std::min(grid, g_lpi_tuning[11]);      // tests: several heads per workgroup at small B H
-    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv};
+    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv};
     static LdsOnce o0, o1;
     if (saved_f16) {
         if (int e = lpi_ensure_lds(o1, (const void*)attn_bwd4_kernel<true>, 160 * 1024)) return e;
