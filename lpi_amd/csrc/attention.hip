@@ -814,7 +814,7 @@ int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
 // for L > 160 (key 7 = 0), forced at every L it takes by key 7 = 5
 bool lpi_attn4_bwd_ok(int L, int causal);
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
-                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16);
+                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi);
 // third generation: ONE pass per head (dK, dV and dQ from one evaluation of S, P, dP, dS; opt-in, key 7 = 4)
 bool lpi_attn3_bwd_ok(int L, int causal);
 int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
@@ -903,8 +903,8 @@ extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_s
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     if (dtype == LPI_F16) {     // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
                                 // q, k, v are converted on their way into LDS / registers, or in place after the LDS-DMA (persistent kernel)
-        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
+            return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1, rows_hi);
         if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
@@ -918,8 +918,8 @@ extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_s
         // the single-pass kernel is opt-in (key 7 = 4): 29 % fewer MFMAs and half the exponentials buy nothing (244.7 vs 243.1 us at L = 213,
         // B = 256) — at 7 waves per CU the backward is bound by the latency of its dependent chain (LDS read -> MFMA -> exp -> LDS -> MFMA),
         // not by matrix or vector issue
-        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
+        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
+            return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0, rows_hi);
         if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
             return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))

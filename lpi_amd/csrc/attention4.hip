@@ -93,15 +93,17 @@ struct Args4 {
     const float* lse;
     float* delta;
     T* dqkv; int lddqkv;
+    int rows_hi;      // only dQ / dK / dV of token rows < rows_hi are wanted (lpi_attn_bwd_prefix); >= L: all
 };
 
 // LDS map (byte offsets from the dynamic region; Lp <= 224: 161 792 B):
 //   [0, Lp RB) K image | [Lp RB, 2 Lp RB) V image | ring: NSLOT x (Q slice, dO slice, O slice: 4 KiB each) | dS^T x 2 (Lp x 64 B each) |
 //   delta[2][32] f32 | lse[2][Lp] f32
-template <int NUW, bool SV16>
+// NKB: the head's 32-key blocks at compile time (7: L in 193 .. 224, the vision towers' prompted and plain sequences), 0 = read Lp
+template <int NUW, bool SV16, int NKB>
 __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
-    const int L = A.L, Lp = A.Lp, H = A.H, NSL = Lp >> 5, total = A.total;
+    const int L = A.L, Lp = NKB ? 32 * NKB : A.Lp, H = A.H, NSL = NKB ? NKB : (A.Lp >> 5), total = A.total;
     const T* const qkv = A.qkv; const int ldqkv = A.ldqkv;
     const T* const dctx = A.dctx; const int lddctx = A.lddctx;
     float* const delta = A.delta;
@@ -119,6 +121,26 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     float* const dl_l = reinterpret_cast<float*>(smem + o_dl);
     float* const lse_l = reinterpret_cast<float*>(smem + o_lse);
     const int dq_dt = wave & 3, dq_qs = wave >> 2;          // this wave's piece of dQ^T: head-dim block, query half
+    // prefix mode: dQ of the slices that hold rows < rows_hi (every wave works on those: dQ sums over all keys), dK / dV of the units that
+    // hold such rows (their waves work on every slice); delta for every row
+    const int rows_hi = A.rows_hi;
+    const bool own_wanted = NUW > 0 && ub * 16 < rows_hi;
+    // ablation builds (timing only, wrong results): a run-time condition that is never true keeps the code alive
+#ifdef LPI_ABL4_NOCOMPUTE
+    const bool abl_comp = lddqkv == 12345;
+#else
+    constexpr bool abl_comp = true;
+#endif
+#ifdef LPI_ABL4_NODMA
+    const bool abl_dma = lddqkv == 12345;
+#else
+    constexpr bool abl_dma = true;
+#endif
+#ifdef LPI_ABL4_NOSTORE
+    const bool abl_st = lddqkv == 12345;
+#else
+    constexpr bool abl_st = true;
+#endif
 
     // per-lane byte offsets
     int rc[KS];                  // row fragment of a 16-row window: row (lane & 15), logical chunk (lane >> 4) + 4 ks, chunk index ^ (row & 6)
@@ -158,7 +180,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         const int r8 = lane >> 3, pc = lane & 7;
         for (int p = wave; p * 8 < L; p += NWV) {
             const int row = p * 8 + r8;
-            if (row < L) {
+            if (row < L && abl_dma) {
                 const T* src = kg + (size_t)row * ldqkv + ((pc ^ (row & 6)) << 3);
                 glds16(src, lds0 + p * 1024);                           // K image
                 glds16(src + dm, lds0 + Lp * RB + p * 1024);            // V image
@@ -168,7 +190,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     auto issue_lse = [&](int bh, int buf) {
         const int i = wave * 64 + lane;
         if (wave * 64 < L) {
-            if (i < L) glds4(A.lse + (size_t)bh * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
+            if (i < L && abl_dma) glds4(A.lse + (size_t)bh * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
     // slice t of head bh -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4); wave w moves piece w and, w < 4, piece w + 8 (rows behind L: the
@@ -181,11 +203,13 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         const size_t grow = (size_t)b * L + row;
         const int ch = (pc ^ (rl & 6)) << 3;
         const unsigned dst = lds0 + o_ring + slot * SLOT_BYTES + (wave & 3) * 1024;
-        if (wave < 4) {
-            glds16(qkv + grow * ldqkv + h * HD + ch, dst);
-            glds16(A.ctx + grow * A.ldctx + h * HD + ch, dst + 2 * 32 * RB);
-        } else {
-            glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
+        if (abl_dma) {
+            if (wave < 4) {
+                glds16(qkv + grow * ldqkv + h * HD + ch, dst);
+                glds16(A.ctx + grow * A.ldctx + h * HD + ch, dst + 2 * 32 * RB);
+            } else {
+                glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
+            }
         }
     };
     // prefetch cursor over this workgroup's slice stream
@@ -222,7 +246,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         if (r16 == 0) {
             const int rl = 4 * wave + g, q = t * 32 + rl;
             dl_l[par * 32 + rl] = v;
-            if (q < L) delta[(size_t)bh * L + q] = v;
+            if (q < L && abl_st) delta[(size_t)bh * L + q] = v;
         }
     };
 
@@ -287,17 +311,25 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     auto stage_dq = [&](int bh, int t, int par) {
         const char* dsp = dsb + par * (Lp * 64);
         f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the transposing reads of up to four key blocks are in flight together (16 registers), then their MFMAs: one LDS round trip per
+        // group instead of one per key block
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb)
-            if (kb < NSL) {
-                Chunk b;
-                const uint2 lo = tr_read(dsp + kb * 2048 + dsr[0]), hi = tr_read(dsp + kb * 2048 + dsr[1]);
-                b.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                mma(dq, kT[kb], b);
-            }
+        for (int k0 = 0; k0 < (NKB ? NKB : MAXKB); k0 += 4) {
+            Chunk bq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
+                    const uint2 lo = tr_read(dsp + (k0 + j) * 2048 + dsr[0]), hi = tr_read(dsp + (k0 + j) * 2048 + dsr[1]);
+                    bq[j].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) mma(dq, kT[k0 + j], bq[j]);
+            if (NKB) __builtin_amdgcn_sched_barrier(0);
+        }
         const int b = bh / H, h = bh % H;
         const int q = t * 32 + dq_qs * 16 + r16;
-        if (q < L)
+        if (q < L && abl_st)
             *reinterpret_cast<uint2*>(dqkv + ((size_t)b * L + q) * lddqkv + h * HD + 16 * dq_dt + 4 * g) = make_uint2(pack2(dq[0], dq[1]), pack2(dq[2], dq[3]));
     };
 
@@ -309,6 +341,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     __syncthreads();
 
     int gs = 0;      // global index of the slice being computed
+#pragma unroll 1
     for (int it = 0; it < nheads; ++it) {
         const int bh = head_of(it);
         const int lbuf = it & 1;
@@ -322,9 +355,9 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 if constexpr (SV16) { chunk_f16_to_bf16(kk[u][ks]); chunk_f16_to_bf16(vv[u][ks]); }
             }
 #pragma unroll
-        for (int kb = 0; kb < MAXKB; ++kb) {
+        for (int kb = 0; kb < (NKB ? NKB : MAXKB); ++kb) {
             kT[kb].u = make_uint4(0, 0, 0, 0);
-            if (kb < NSL) {
+            if (NKB || kb < NSL) {
                 kT[kb] = tr_pair(k_img + kb * 32 * RB + trw, 16 * RB);
                 if constexpr (SV16) chunk_f16_to_bf16(kT[kb]);
             }
@@ -340,35 +373,48 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             issue_kv(head_of(it + 1));
             issue_lse(head_of(it + 1), lbuf ^ 1);
         }
+#pragma unroll 1
         for (int t = 0; t < NSL; ++t) {
             issue_next();         // slice gs + AHEAD -> the slot slice gs - 1 has just left
             const int par = t & 1;
-            if (t + 1 < NSL) stage_delta(bh, t + 1, (gs + 1) % NSLOT, par ^ 1);
-            stage_main(t, gs % NSLOT, lbuf, par);
-            if (t >= 1) stage_dq(bh, t - 1, par ^ 1);
-            // end of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
+            if (abl_comp) {
+                if (t + 1 < NSL) stage_delta(bh, t + 1, (gs + 1) % NSLOT, par ^ 1);
+                if (own_wanted || t * 32 < rows_hi) stage_main(t, gs % NSLOT, lbuf, par);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(bh, t - 1, par ^ 1);
+            // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
             // pieces of the AHEAD - 2 younger slices (2 per slice from waves 0-3, 1 from waves 4-7; stores issued in between only make the
-            // wait stricter); at the end of the stream, or with few slices per head, everything
+            // wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
+            // stores of the head before (57 KB per CU, all CUs at once).  So the LAST iteration of a head waits for everything but the
+            // youngest slice and the dQ store behind it (slices 0 .. 3 of the next head: issued 4+ iterations ago), and the first two
+            // iterations of a head do not wait at all.  At the end of the stream, or with few slices per head: everything.
             if (NSL >= 6 && gs + AHEAD < nslices) {
-                if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                if (t == NSL - 1) {
+                    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else if (t >= 2) {
+                    if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LPI4_BARRIER();
             ++gs;
         }
-        stage_dq(bh, NSL - 1, (NSL - 1) & 1);
+        if ((NSL - 1) * 32 < rows_hi) stage_dq(bh, NSL - 1, (NSL - 1) & 1);
         const int b = bh / H, h = bh % H;
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
+            if ((ub + u) * 16 >= rows_hi) continue;
             const int kr = (ub + u) * 16 + r16;
             T* dst = dqkv + ((size_t)b * L + kr) * lddqkv + h * HD;
-            store_row_bf16_t(dst + dm, dk[u], g, kr < L);
-            store_row_bf16_t(dst + 2 * dm, dv[u], g, kr < L);
+            store_row_bf16_t(dst + dm, dk[u], g, kr < L && abl_st);
+            store_row_bf16_t(dst + 2 * dm, dv[u], g, kr < L && abl_st);
         }
     }
 }
 
-template <bool SV16>
+template <bool SV16, int NKB>
 __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int L = A.L, Lp = A.Lp;
@@ -388,10 +434,15 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
         float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * 32 * 4);
         for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = INFINITY;
     }
-    switch (nu) {
-        case 2: bwd4_body<2, SV16>(A, smem, wave, ub); break;
-        case 1: bwd4_body<1, SV16>(A, smem, wave, ub); break;
-        default: bwd4_body<0, SV16>(A, smem, wave, ub); break;
+    if constexpr (NKB == 7) {       // Lp == 224: 14 units = 2 x 6 + 1 x 2
+        if (nu == 2) bwd4_body<2, SV16, 7>(A, smem, wave, ub);
+        else bwd4_body<1, SV16, 7>(A, smem, wave, ub);
+    } else {
+        switch (nu) {
+            case 2: bwd4_body<2, SV16, 0>(A, smem, wave, ub); break;
+            case 1: bwd4_body<1, SV16, 0>(A, smem, wave, ub); break;
+            default: bwd4_body<0, SV16, 0>(A, smem, wave, ub); break;
+        }
     }
 }
 
@@ -416,21 +467,25 @@ bool lpi_attn4_bwd_ok(int L, int causal) {
 }
 
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
-                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16) {
+                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = lds_bytes4(Lp);
     const int total = B * H;
     int grid = std::min(total, cu_count4());
     if (g_lpi_tuning[11] > 0) grid = std::min(grid, g_lpi_tuning[11]);      // tests: several heads per workgroup at small B H
-    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv};
-    static LdsOnce o0, o1;
-    if (saved_f16) {
-        if (int e = lpi_ensure_lds(o1, (const void*)attn_bwd4_kernel<true>, 160 * 1024)) return e;
-        LPI_LAUNCH((attn_bwd4_kernel<true>), dim3(grid), dim3(64 * NWV), lds, s, A);
-    } else {
-        if (int e = lpi_ensure_lds(o0, (const void*)attn_bwd4_kernel<false>, 160 * 1024)) return e;
-        LPI_LAUNCH((attn_bwd4_kernel<false>), dim3(grid), dim3(64 * NWV), lds, s, A);
-    }
+    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi};
+    static LdsOnce o0, o1, o2, o3;
+#define BWD4(S, K, O)                                                                               \
+    do {                                                                                            \
+        if (int e = lpi_ensure_lds(O, (const void*)attn_bwd4_kernel<S, K>, 160 * 1024)) return e;   \
+        LPI_LAUNCH((attn_bwd4_kernel<S, K>), dim3(grid), dim3(64 * NWV), lds, s, A);                \
+    } while (0)
+    if (Lp == 224) {
+        if (saved_f16) BWD4(true, 7, o0);
+        else BWD4(false, 7, o1);
+    } else if (saved_f16) BWD4(true, 0, o2);
+    else BWD4(false, 0, o3);
+#undef BWD4
     LPI_CHECK_LAST();
     return 0;
 }

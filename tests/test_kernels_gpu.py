@@ -1453,3 +1453,47 @@ def test_attention_forward_pair_launch_equals_two_launches(dt):
     _lib.attn_fwd_pair(dt, (Bt, Lt, rs_d, Ht, qt, 3 * Ht * 64, ct, Ht * 64, lt_, 1), (Bv, Lv, None, Hv, qv, 3 * Hv * 64, cv, Hv * 64, lv, 0), stream())
     torch.cuda.synchronize()
     assert torch.equal(cv, res["single"][0]) and torch.equal(ct, res["single"][1])
+
+
+@pytest.mark.parametrize("saved", ["bf16", "f16"])
+@pytest.mark.parametrize("B,L,H,cap", [(2, 213, 3, 0), (3, 213, 2, 1), (24, 213, 12, 0), (3, 197, 2, 2), (2, 224, 2, 1), (2, 161, 1, 1), (5, 64, 4, 3), (4, 21, 2, 1), (2, 100, 2, 1)])
+def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
+    """attention4.hip (one pass over the scores; 8 waves own 16-32 keys each; Q / dO / O stream through an LDS ring in 32-query slices,
+    across head boundaries; dS^T crosses LDS once and every wave contracts it over ALL keys for its piece of dQ) against f64 autograd,
+    close to the two-phase kernels (same products; delta is summed in another order), bitwise equal to itself across runs, and — with the
+    grid capped (tuning key 11) — with several heads per workgroup, i.e. the ring running across head seams and padded rows landing in
+    slots earlier slices used.  replaces: the backward of nn.MultiheadAttention (retrieval/models/clip/model.py:183-185)."""
+    d = H * 64
+    tq = torch.float16 if saved == "f16" else torch.bfloat16
+    dt = F16 if saved == "f16" else BF16
+    qkv = rnd(B * L, 3 * d, seed=61).to(tq)
+    dctx = rnd(B * L, d, seed=62).bfloat16().to(DEV)
+    qd = qkv.to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=tq)
+    lse = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, 0, stream())
+    qr = qkv.double().requires_grad_(True)
+    oref, _ = attn_ref(qr, B, L, H, 0)
+    oref.backward(dctx.double().cpu())
+    out = {}
+    try:
+        call("lpi_set_tuning", 11, cap)
+        for gen in (3, 5, 5):
+            call("lpi_set_tuning", 7, gen)
+            dqkv = torch.full((B * L, 3 * d), float("nan"), device=DEV, dtype=torch.bfloat16)
+            delta = torch.zeros(B, H, L, device=DEV)
+            call("lpi_attn_bwd", dt, B, L, H, qd, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, stream())
+            torch.cuda.synchronize()
+            out.setdefault(gen, []).append((dqkv, delta))
+    finally:
+        call("lpi_set_tuning", 7, 0)
+        call("lpi_set_tuning", 11, 0)
+    new, new2, old = out[5][0], out[5][1], out[3][0]
+    assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
+    assert bool(torch.isfinite(new[0].float()).all())
+    dref = (dctx.double().cpu() * ctx.double().cpu()).reshape(B, L, H, 64).sum(-1).permute(0, 2, 1)
+    assert relerr(new[1], dref) < 1e-5                                             # delta = rowsum(dO o O) of the stored O, f32 sums
+    assert relerr(new[0], old[0].double().cpu()) < 2e-2
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        e = relerr(new[0][:, sl], qr.grad[:, sl])
+        assert e < 4e-2, (name, e)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time the vision attention backward (B 256, L 213, H 12, bf16) of the library named by LPI_LIB: tuning key 7 values from argv (default 3 5)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lpi_amd._lib import BF16, call  # noqa: E402
+
+dev = "cuda:0"
+s = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+B, L, H = 256, 213, 12
+d = H * 64
+qkv = torch.randn(B * L, 3 * d, device=dev).to(torch.bfloat16)
+dctx = torch.randn(B * L, d, device=dev).to(torch.bfloat16)
+ctx = torch.zeros(B * L, d, device=dev, dtype=torch.bfloat16)
+dqkv = torch.zeros(B * L, 3 * d, device=dev, dtype=torch.bfloat16)
+lse = torch.zeros(B, H, L, device=dev)
+delta = torch.zeros(B, H, L, device=dev)
+call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, 0, s())
+keys = [int(a) for a in sys.argv[1:]] or [3, 5]
+for key in keys * 2:
+    call("lpi_set_tuning", 7, key)
+    fn = lambda: call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, s())  # noqa: E731
+    best = 1e9
+    for _ in range(3):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 50)
+    print(f"{os.environ.get('LPI_LIB', 'base'):40s} key7={key}: bwd {best:7.1f} us", flush=True)
+call("lpi_set_tuning", 7, 0)
