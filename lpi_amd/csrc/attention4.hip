@@ -94,14 +94,19 @@ struct Args4 {
     float* delta;
     T* dqkv; int lddqkv;
     int rows_hi;      // only dQ / dK / dV of token rows < rows_hi are wanted (lpi_attn_bwd_prefix); >= L: all
+    int flags;        // A/B switches (tuning key 12): 1 = K / V of the next head as one burst after the prologue
 };
 
 // LDS map (byte offsets from the dynamic region; Lp <= 224: 161 792 B):
 //   [0, Lp RB) K image | [Lp RB, 2 Lp RB) V image | ring: NSLOT x (Q slice, dO slice, O slice: 4 KiB each) | dS^T x 2 (Lp x 64 B each) |
 //   delta[2][32] f32 | lse[2][Lp] f32
-// NKB: the head's 32-key blocks at compile time (7: L in 193 .. 224, the vision towers' prompted and plain sequences), 0 = read Lp
-template <int NUW, bool SV16, int NKB>
-__device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub) {
+// NKB: the head's 32-key blocks at compile time (7: L in 193 .. 224, the vision towers' prompted and plain sequences), 0 = read Lp.
+// DQN: pieces of dQ^T (16 head-dim columns x 16 queries of a slice, 7 MFMAs at Lp = 224) this wave computes per slice: 1 = piece
+// (dq_dt, dq_qs), 2 = both query halves of head-dim block dq_dt, 0 = none.  At Lp = 224 the key units split 2,2,2,2,2,2,1,1 over the
+// waves, i.e. 4,4,3,3 over the SIMDs (waves w and w + 4 share one): the eight dQ pieces go 1,1,3,3 so that every SIMD issues 69-71 MFMAs
+// per slice — waves 0-3 one piece each, waves 4, 5 none, waves 6, 7 (one unit) two.
+template <int NUW, bool SV16, int NKB, int DQN>
+__device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub, int dq_dt, int dq_qs) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
     const int L = A.L, Lp = NKB ? 32 * NKB : A.Lp, H = A.H, NSL = NKB ? NKB : (A.Lp >> 5), total = A.total;
     const T* const qkv = A.qkv; const int ldqkv = A.ldqkv;
@@ -120,7 +125,6 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     char* const dsb = smem + o_dsb;
     float* const dl_l = reinterpret_cast<float*>(smem + o_dl);
     float* const lse_l = reinterpret_cast<float*>(smem + o_lse);
-    const int dq_dt = wave & 3, dq_qs = wave >> 2;          // this wave's piece of dQ^T: head-dim block, query half
     // prefix mode: dQ of the slices that hold rows < rows_hi (every wave works on those: dQ sums over all keys), dK / dV of the units that
     // hold such rows (their waves work on every slice); delta for every row
     const int rows_hi = A.rows_hi;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     int tr[4];                   // transposing read of a 16-row window, head-dim block dt
     int trw;                     // the same for dt = dq_dt (K^T fragments)
     int dsw[NUW > 0 ? NUW : 1][2];   // dS^T store: [key][query] rows of 64 B inside 32-key blocks of 2 KiB
-    int dsr[2];                  // dS^T transposing read of query half dq_qs: [second 16 keys]
+    int dsr[DQN > 0 ? DQN : 1][2];   // dS^T transposing read of query half dq_qs (+ piece): [second 16 keys]
     int dlo;                     // delta pass: 8 bytes of row 4 wave + g, elements 4 r16 ..
     {
 #pragma unroll
@@ -164,61 +168,75 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             for (int t2 = 0; t2 < 2; ++t2) dsw[u][t2] = (ug >> 1) * 2048 + rowb * 64 + (((4 * t2 + g) ^ ds_sw(rowb)) << 3);
         }
 #pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-            const int row = 16 * hi + 4 * g + (r16 >> 2);
-            dsr[hi] = row * 64 + (((4 * dq_qs + (lane & 3)) ^ ds_sw(row)) << 3);
-        }
+        for (int pi = 0; pi < DQN; ++pi)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int row = 16 * hi + 4 * g + (r16 >> 2);
+                dsr[pi][hi] = row * 64 + (((4 * (dq_qs + pi) + (lane & 3)) ^ ds_sw(row)) << 3);
+            }
         const int drow = 4 * wave + g;
         dlo = drow * RB + (((r16 >> 1) ^ (drow & 6)) << 4) + (r16 & 1) * 8;
     }
 
     // ---- LDS-DMA issue helpers (all wave-uniform control flow; lanes behind L are EXEC-masked or clamped)
-    auto head_of = [&](int it) { return (int)blockIdx.x + it * (int)gridDim.x; };
-    auto issue_kv = [&](int bh) {
-        const int b = bh / H, h = bh % H;
-        const T* kg = qkv + (size_t)b * L * ldqkv + h * HD + dm;
+    // A head cursor: (sample, head) of the workgroup's it-th head = blockIdx.x + it gridDim.x, advanced without divisions
+    struct Head { int b, h; };
+    const int G = (int)gridDim.x, Gb = G / H, Gh = G % H;
+    auto next_head = [&](Head& x) {
+        x.b += Gb; x.h += Gh;
+        if (x.h >= H) { x.h -= H; ++x.b; }
+    };
+    // K and V rows of a head -> their images, in PARTS of 16 pieces of 8 rows (2 per wave): the images are free from a head's prologue
+    // on and needed at the next one, so the parts go out over the first iterations of a head instead of as one 57 KB burst per CU beside
+    // the dK / dV stores of the head before
+    const int nblk = (L + 7) >> 3;
+    const int kv_parts = (2 * nblk + 15) >> 4;
+    auto issue_kv_part = [&](const Head& x, int part) {
+        const T* kg = qkv + (size_t)x.b * L * ldqkv + x.h * HD + dm;
         const int r8 = lane >> 3, pc = lane & 7;
-        for (int p = wave; p * 8 < L; p += NWV) {
-            const int row = p * 8 + r8;
-            if (row < L && abl_dma) {
-                const T* src = kg + (size_t)row * ldqkv + ((pc ^ (row & 6)) << 3);
-                glds16(src, lds0 + p * 1024);                           // K image
-                glds16(src + dm, lds0 + Lp * RB + p * 1024);            // V image
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pi = part * 16 + j * 8 + wave;
+            if (pi < 2 * nblk) {
+                const int isv = pi >= nblk ? 1 : 0, blk = pi - isv * nblk;
+                const int row = blk * 8 + r8;
+                if (row < L && abl_dma) glds16(kg + (unsigned)(row * ldqkv + isv * dm + ((pc ^ (row & 6)) << 3)), lds0 + isv * Lp * RB + blk * 1024);
             }
         }
     };
-    auto issue_lse = [&](int bh, int buf) {
+    auto issue_lse = [&](const Head& x, int buf) {
         const int i = wave * 64 + lane;
         if (wave * 64 < L) {
-            if (i < L && abl_dma) glds4(A.lse + (size_t)bh * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
+            if (i < L && abl_dma) glds4(A.lse + (size_t)(x.b * H + x.h) * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
-    // slice t of head bh -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4); wave w moves piece w and, w < 4, piece w + 8 (rows behind L: the
-    // last row again — finite values; their lse is +inf, so P = 0 there)
-    auto issue_slice = [&](int bh, int t, int slot) {
-        const int b = bh / H, h = bh % H;
-        const int pc = lane & 7;
-        const int rl = (wave & 3) * 8 + (lane >> 3);
-        const int row = min(t * 32 + rl, L - 1);
-        const size_t grow = (size_t)b * L + row;
-        const int ch = (pc ^ (rl & 6)) << 3;
-        const unsigned dst = lds0 + o_ring + slot * SLOT_BYTES + (wave & 3) * 1024;
+    // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): waves 0-3 (which also compute a dQ piece) move one Q piece each,
+    // waves 4, 5 the dO pieces, waves 6, 7 the O pieces, two each (rows behind L: the last row again — finite values; their lse is +inf,
+    // so P = 0 there)
+    const T* const sl_base = wave < 4 ? qkv : (wave < 6 ? dctx : A.ctx);      // this wave's source matrix, its row stride, its part of a slot
+    const int sl_ld = wave < 4 ? ldqkv : (wave < 6 ? lddctx : A.ldctx);
+    const int sl_np = wave < 4 ? 1 : 2;
+    const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
+    const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : (wave < 6 ? 1 : 2)) * 32 * RB + sl_blk0 * 1024;
+    const int sl_rl = sl_blk0 * 8 + (lane >> 3);
+    const int sl_ch = ((lane & 7) ^ (sl_rl & 6)) << 3;         // (row & 6) is the same for rows 8 apart
+    auto issue_slice = [&](const Head& x, int t, int slot) {
         if (abl_dma) {
-            if (wave < 4) {
-                glds16(qkv + grow * ldqkv + h * HD + ch, dst);
-                glds16(A.ctx + grow * A.ldctx + h * HD + ch, dst + 2 * 32 * RB);
-            } else {
-                glds16(dctx + grow * lddctx + h * HD + ch, dst + 32 * RB);
-            }
+            const T* hb = sl_base + (size_t)x.b * L * sl_ld + x.h * HD;
+            const unsigned dst = sl_dst + slot * SLOT_BYTES;
+            glds16(hb + (unsigned)(min(t * 32 + sl_rl, L - 1) * sl_ld + sl_ch), dst);
+            if (sl_np == 2) glds16(hb + (unsigned)(min(t * 32 + sl_rl + 8, L - 1) * sl_ld + sl_ch), dst + 1024);
         }
     };
     // prefetch cursor over this workgroup's slice stream
-    int pf_it = 0, pf_t = 0, pf_gs = 0;
+    Head pf{(int)blockIdx.x / H, (int)blockIdx.x % H};
+    int pf_t = 0, pf_gs = 0, pf_slot = 0;
     auto issue_next = [&]() {
         if (pf_gs < nslices) {
-            issue_slice(head_of(pf_it), pf_t, pf_gs % NSLOT);
+            issue_slice(pf, pf_t, pf_slot);
             ++pf_gs;
-            if (++pf_t == NSL) { pf_t = 0; ++pf_it; }
+            if (++pf_slot == NSLOT) pf_slot = 0;
+            if (++pf_t == NSL) { pf_t = 0; next_head(pf); }
         }
     };
 
@@ -229,7 +247,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     f32x4 dk[NUA][4], dv[NUA][4];
 
     // delta of slice t's rows 4 wave .. 4 wave + 3 = rowsum(dO o O) -> dl[par] (and the C ABI's delta scratch)
-    auto stage_delta = [&](int bh, int t, int slot, int par) {
+    auto stage_delta = [&](float* drow, int t, int slot, int par) {
         const char* ds_ = ring + slot * SLOT_BYTES + 32 * RB;
         const uint2 dd = *reinterpret_cast<const uint2*>(ds_ + dlo);
         const uint2 oo = *reinterpret_cast<const uint2*>(ds_ + 32 * RB + dlo);
@@ -246,7 +264,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         if (r16 == 0) {
             const int rl = 4 * wave + g, q = t * 32 + rl;
             dl_l[par * 32 + rl] = v;
-            if (q < L && abl_st) delta[(size_t)bh * L + q] = v;
+            if (q < L && abl_st) drow[q] = v;
         }
     };
 
@@ -307,44 +325,62 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         }
     };
 
-    // dQ^T[16 dq_dt .., 16 queries of half dq_qs] of slice t = K^T (all keys) . dS^T -> global
-    auto stage_dq = [&](int bh, int t, int par) {
-        const char* dsp = dsb + par * (Lp * 64);
-        f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
-        // the transposing reads of up to four key blocks are in flight together (16 registers), then their MFMAs: one LDS round trip per
-        // group instead of one per key block
+    // dQ^T[16 dq_dt .., 16 queries of half dq_qs (+ piece)] of slice t = K^T (all keys) . dS^T -> global
+    auto stage_dq = [&](T* dqh, int t, int par) {
+        if constexpr (DQN > 0) {
+            const char* dsp = dsb + par * (Lp * 64);
+            f32x4 dq[DQN];
 #pragma unroll
-        for (int k0 = 0; k0 < (NKB ? NKB : MAXKB); k0 += 4) {
-            Chunk bq[4];
+            for (int pi = 0; pi < DQN; ++pi) dq[pi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the transposing reads of a group of key blocks are in flight together (16 registers), then their MFMAs: one LDS round trip
+            // per group instead of one per key block
+            constexpr int GRP = DQN == 2 ? 2 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
-                    const uint2 lo = tr_read(dsp + (k0 + j) * 2048 + dsr[0]), hi = tr_read(dsp + (k0 + j) * 2048 + dsr[1]);
-                    bq[j].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
+            for (int k0 = 0; k0 < (NKB ? NKB : MAXKB); k0 += GRP) {
+                Chunk bq[GRP][DQN];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) mma(dq, kT[k0 + j], bq[j]);
-            if (NKB) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < GRP; ++j)
+                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
+#pragma unroll
+                        for (int pi = 0; pi < DQN; ++pi) {
+                            const uint2 lo = tr_read(dsp + (k0 + j) * 2048 + dsr[pi][0]), hi = tr_read(dsp + (k0 + j) * 2048 + dsr[pi][1]);
+                            bq[j][pi].u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                        }
+                    }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j)
+                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
+#pragma unroll
+                        for (int pi = 0; pi < DQN; ++pi) mma(dq[pi], kT[k0 + j], bq[j][pi]);
+                    }
+                if (NKB) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int pi = 0; pi < DQN; ++pi) {
+                const int q = t * 32 + (dq_qs + pi) * 16 + r16;
+                if (q < L && abl_st)
+                    *reinterpret_cast<uint2*>(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g)) = make_uint2(pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
+            }
         }
-        const int b = bh / H, h = bh % H;
-        const int q = t * 32 + dq_qs * 16 + r16;
-        if (q < L && abl_st)
-            *reinterpret_cast<uint2*>(dqkv + ((size_t)b * L + q) * lddqkv + h * HD + 16 * dq_dt + 4 * g) = make_uint2(pack2(dq[0], dq[1]), pack2(dq[2], dq[3]));
     };
 
     // ---- launch prologue: first head's K, V, lse and the first AHEAD slices
-    issue_kv(head_of(0));
-    issue_lse(head_of(0), 0);
+    Head cur{(int)blockIdx.x / H, (int)blockIdx.x % H};
+    for (int part = 0; part < kv_parts; ++part) issue_kv_part(cur, part);
+    issue_lse(cur, 0);
     for (int j = 0; j < AHEAD; ++j) issue_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int gs = 0;      // global index of the slice being computed
+    int slot = 0;    // its ring slot
 #pragma unroll 1
     for (int it = 0; it < nheads; ++it) {
-        const int bh = head_of(it);
         const int lbuf = it & 1;
+        Head nxt = cur;
+        next_head(nxt);
+        float* const drow = delta + (size_t)(cur.b * H + cur.h) * L;                   // this head's rows of the outputs
+        T* const dqh = dqkv + (size_t)cur.b * L * lddqkv + cur.h * HD;
         // own K, V rows and the K^T fragments out of the images (landed a head ago)
 #pragma unroll
         for (int u = 0; u < NUW; ++u)
@@ -355,7 +391,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 if constexpr (SV16) { chunk_f16_to_bf16(kk[u][ks]); chunk_f16_to_bf16(vv[u][ks]); }
             }
 #pragma unroll
-        for (int kb = 0; kb < (NKB ? NKB : MAXKB); ++kb) {
+        for (int kb = 0; kb < (DQN ? (NKB ? NKB : MAXKB) : 0); ++kb) {
             kT[kb].u = make_uint4(0, 0, 0, 0);
             if (NKB || kb < NSL) {
                 kT[kb] = tr_pair(k_img + kb * 32 * RB + trw, 16 * RB);
@@ -367,50 +403,63 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-        stage_delta(bh, 0, gs % NSLOT, 0);
+        stage_delta(drow, 0, slot, 0);
         LPI4_BARRIER();           // delta of slice 0 complete; every wave has its K, V rows: the images are free
+        const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
-            issue_kv(head_of(it + 1));
-            issue_lse(head_of(it + 1), lbuf ^ 1);
+            issue_lse(nxt, lbuf ^ 1);
+            if (!spread_kv)
+                for (int part = 0; part < kv_parts; ++part) issue_kv_part(nxt, part);
         }
+        // the last dQ store of a head (slice NSL - 2, in iteration NSL - 1) is what the wait of that iteration may leave in flight
+        const bool dq_last = DQN > 0 && (NSL - 2) * 32 < rows_hi;
 #pragma unroll 1
         for (int t = 0; t < NSL; ++t) {
             issue_next();         // slice gs + AHEAD -> the slot slice gs - 1 has just left
+            if (spread_kv && t < kv_parts && it + 1 < nheads) issue_kv_part(nxt, t);
             const int par = t & 1;
+            const int slot1 = slot + 1 == NSLOT ? 0 : slot + 1;
             if (abl_comp) {
-                if (t + 1 < NSL) stage_delta(bh, t + 1, (gs + 1) % NSLOT, par ^ 1);
-                if (own_wanted || t * 32 < rows_hi) stage_main(t, gs % NSLOT, lbuf, par);
+                if (t + 1 < NSL) stage_delta(drow, t + 1, slot1, par ^ 1);
+                if (own_wanted || t * 32 < rows_hi) stage_main(t, slot, lbuf, par);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(bh, t - 1, par ^ 1);
+            if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1);
             // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
-            // pieces of the AHEAD - 2 younger slices (2 per slice from waves 0-3, 1 from waves 4-7; stores issued in between only make the
-            // wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
+            // pieces of the AHEAD - 2 younger slices (1 per slice from waves 0-3, 2 from waves 4-7; stores and K / V pieces issued in between
+            // only make the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
             // stores of the head before (57 KB per CU, all CUs at once).  So the LAST iteration of a head waits for everything but the
             // youngest slice and the dQ store behind it (slices 0 .. 3 of the next head: issued 4+ iterations ago), and the first two
             // iterations of a head do not wait at all.  At the end of the stream, or with few slices per head: everything.
             if (NSL >= 6 && gs + AHEAD < nslices) {
-                if (t == NSL - 1) {
-                    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if (t == NSL - 1) {       // may stay in flight: this wave's pieces of the youngest slice (1 | 2) and its DQN dQ stores behind them
+                    if (wave < 4) {
+                        if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                    } else {
+                        if (DQN >= 2 && dq_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if (DQN == 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    }
                 } else if (t >= 2) {
-                    if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LPI4_BARRIER();
             ++gs;
+            slot = slot1;
         }
-        if ((NSL - 1) * 32 < rows_hi) stage_dq(bh, NSL - 1, (NSL - 1) & 1);
-        const int b = bh / H, h = bh % H;
+        if ((NSL - 1) * 32 < rows_hi) stage_dq(dqh, NSL - 1, (NSL - 1) & 1);
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
             if ((ub + u) * 16 >= rows_hi) continue;
             const int kr = (ub + u) * 16 + r16;
-            T* dst = dqkv + ((size_t)b * L + kr) * lddqkv + h * HD;
+            T* dst = dqh + (unsigned)(kr * lddqkv);
             store_row_bf16_t(dst + dm, dk[u], g, kr < L && abl_st);
             store_row_bf16_t(dst + 2 * dm, dv[u], g, kr < L && abl_st);
         }
+        cur = nxt;
     }
 }
 
@@ -435,13 +484,14 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
         for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = INFINITY;
     }
     if constexpr (NKB == 7) {       // Lp == 224: 14 units = 2 x 6 + 1 x 2
-        if (nu == 2) bwd4_body<2, SV16, 7>(A, smem, wave, ub);
-        else bwd4_body<1, SV16, 7>(A, smem, wave, ub);
+        if (wave < 4) bwd4_body<2, SV16, 7, 1>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);        // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
+        else if (wave < 6) bwd4_body<2, SV16, 7, 0>(A, smem, wave, ub, 0, 0);
+        else bwd4_body<1, SV16, 7, 2>(A, smem, wave, ub, wave - 4, 0);                               // head-dim blocks 2, 3: both query halves
     } else {
         switch (nu) {
-            case 2: bwd4_body<2, SV16, 0>(A, smem, wave, ub); break;
-            case 1: bwd4_body<1, SV16, 0>(A, smem, wave, ub); break;
-            default: bwd4_body<0, SV16, 0>(A, smem, wave, ub); break;
+            case 2: bwd4_body<2, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            case 1: bwd4_body<1, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            default: bwd4_body<0, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
         }
     }
 }
@@ -473,7 +523,7 @@ int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
     const int total = B * H;
     int grid = std::min(total, cu_count4());
     if (g_lpi_tuning[11] > 0) grid = std::min(grid, g_lpi_tuning[11]);      // tests: several heads per workgroup at small B H
-    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi};
+    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12]};
     static LdsOnce o0, o1, o2, o3;
 #define BWD4(S, K, O)                                                                               \
     do {                                                                                            \

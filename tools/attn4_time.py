@@ -19,9 +19,11 @@ dqkv = torch.zeros(B * L, 3 * d, device=dev, dtype=torch.bfloat16)
 lse = torch.zeros(B, H, L, device=dev)
 delta = torch.zeros(B, H, L, device=dev)
 call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, 0, s())
-keys = [int(a) for a in sys.argv[1:]] or [3, 5]
+keys = [a for a in sys.argv[1:]] or ["3", "5"]
 for key in keys * 2:
-    call("lpi_set_tuning", 7, key)
+    k7, _, k12 = key.partition(":")       # "5:1" = generation 5 with A/B flags (tuning key 12) = 1
+    call("lpi_set_tuning", 7, int(k7))
+    call("lpi_set_tuning", 12, int(k12 or 0))
     fn = lambda: call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, s())  # noqa: E731
     best = 1e9
     for _ in range(3):
@@ -35,3 +37,4 @@ for key in keys * 2:
         best = min(best, e0.elapsed_time(e1) * 50)
     print(f"{os.environ.get('LPI_LIB', 'base'):40s} key7={key}: bwd {best:7.1f} us", flush=True)
 call("lpi_set_tuning", 7, 0)
+call("lpi_set_tuning", 12, 0)

@@ -58,7 +58,7 @@ def main():
                 counters[k][c] = (n, v)
                 if c == "GRBM_GUI_ACTIVE" and k in dur:
                     durs[k] = dur[k]
-    out = {"command": cmd, "dtype": dtype, "tuning": [int(x) for x in tuning.split(",")], "lib_version": int(libv),
+    out = {"command": cmd, "dtype": dtype, "tuning": [int(x) for x in tuning.split(",") if x], "lib_version": int(libv),
            "formulas": {"hbm_mb_per_launch": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes (gfx950 FETCH_SIZE half-count corrected; separate passes)",
                         "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)",
                         "clock_ghz": "GRBM_GUI_ACTIVE / 8 / kernel duration of the same pass"},
@@ -85,8 +85,7 @@ def main():
             avg_ns = durs[k][1] / durs[k][0]
             e["avg_us_in_counter_pass"] = round(avg_ns / 1e3, 1)
             e["clock_ghz"] = round(g / 8 / avg_ns, 3)
-        for c in ("SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT",
-                  "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_VALU"):
+        for c in sorted(c for c in cs if c.startswith("SQ_")):
             v = per(c)
             if v is not None:
                 e[c.lower() + "_per_launch"] = round(v, 1)
