@@ -263,7 +263,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         v = row16_sum(v);
         if (r16 == 0) {
             const int rl = 4 * wave + g, q = t * 32 + rl;
-            dl_l[par * 32 + rl] = v;
+            dl_l[par * 32 + rl] = v * SCALE;
             if (q < L && abl_st) drow[q] = v;
         }
     };
@@ -274,30 +274,39 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         const char* ds_ = qs_ + 32 * RB;
         char* dsp = dsb + par * (Lp * 64);
         uint32_t pw[NUA][2][2], sw[NUA][2][2];
+        // every row-fragment read of the slice first (both 16-query halves: 8 x 16 B per lane in flight), so that the second half's
+        // LDS round trip hides under the first half's arithmetic
+        Chunk qa[2][KS], da[2][KS];
+        f32x4 nl[2], dls[2];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-            Chunk qa[KS], da[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                qa[ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
-                da[ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
-                if constexpr (SV16) chunk_f16_to_bf16(qa[ks]);
+                qa[t2][ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
+                da[t2][ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
             }
-            const f32x4 nl = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g) * (-LOG2E);
-            const f32x4 dls = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g) * SCALE;
+            nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g);      // -lse log2(e): scaled in place per head
+            dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // delta / 8
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            if constexpr (SV16) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) chunk_f16_to_bf16(qa[t2][ks]);
+            }
 #pragma unroll
             for (int u = 0; u < NUW; ++u) {
                 f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    mma(s, qa[ks], kk[u][ks]);
-                    mma(dp, da[ks], vv[u][ks]);
+                    mma(s, qa[t2][ks], kk[u][ks]);
+                    mma(dp, da[t2][ks], vv[u][ks]);
                 }
                 f32x4 p, e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    p[r] = exp2_fast(fmaf(s[r], c, nl[r]));
-                    e[r] = p[r] * fmaf(dp[r], SCALE, -dls[r]);
+                    p[r] = exp2_fast(fmaf(s[r], c, nl[t2][r]));
+                    e[r] = p[r] * fmaf(dp[r], SCALE, -dls[t2][r]);
                 }
                 pw[u][t2][0] = pack2(p[0], p[1]);
                 pw[u][t2][1] = pack2(p[2], p[3]);
@@ -312,15 +321,23 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             bp[u].u = make_uint4(pw[u][0][0], pw[u][0][1], pw[u][1][0], pw[u][1][1]);
             bs[u].u = make_uint4(sw[u][0][0], sw[u][0][1], sw[u][1][0], sw[u][1][1]);
         }
+        // the transposing reads of two head-dim blocks are in flight together
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const Chunk ado = tr_pair(ds_ + tr[dt], 16 * RB);
-            Chunk aq = tr_pair(qs_ + tr[dt], 16 * RB);
-            if constexpr (SV16) chunk_f16_to_bf16(aq);
+        for (int d0 = 0; d0 < 4; d0 += 2) {
+            Chunk ado[2], aq[2];
 #pragma unroll
-            for (int u = 0; u < NUW; ++u) {
-                mma(dv[u][dt], ado, bp[u]);
-                mma(dk[u][dt], aq, bs[u]);
+            for (int j = 0; j < 2; ++j) {
+                ado[j] = tr_pair(ds_ + tr[d0 + j], 16 * RB);
+                aq[j] = tr_pair(qs_ + tr[d0 + j], 16 * RB);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (SV16) chunk_f16_to_bf16(aq[j]);
+#pragma unroll
+                for (int u = 0; u < NUW; ++u) {
+                    mma(dv[u][d0 + j], ado[j], bp[u]);
+                    mma(dk[u][d0 + j], aq[j], bs[u]);
+                }
             }
         }
     };
@@ -403,8 +420,10 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+        // this head's lse vector (landed a head ago): -lse log2(e) in place, one entry per thread (the entries behind L stay -inf)
+        if ((int)threadIdx.x < L) lse_l[lbuf * Lp + threadIdx.x] *= -LOG2E;
         stage_delta(drow, 0, slot, 0);
-        LPI4_BARRIER();           // delta of slice 0 complete; every wave has its K, V rows: the images are free
+        LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
             issue_lse(nxt, lbuf ^ 1);
@@ -473,7 +492,7 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
     const int nu = base + (wave < rem ? 1 : 0);
     const int ub = wave * base + min(wave, rem);
     // once per launch: rows [L, Lp) of the K and V images are zero (the DMA is EXEC-masked there: padded keys then add nothing to dQ),
-    // entries [L, Lp) of both lse vectors are +inf (P = 0 for padded queries)
+    // entries [L, Lp) of both lse vectors are -inf (they hold -lse log2(e): P = 0 for padded queries)
     {
         const int per = (Lp - L) * (RB / 16);
         for (int i = threadIdx.x; i < 2 * per; i += blockDim.x) {
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
             *reinterpret_cast<uint4*>(smem + (size_t)im * Lp * RB + (size_t)L * RB + rch * 16) = make_uint4(0, 0, 0, 0);
         }
         float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * 32 * 4);
-        for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = INFINITY;
+        for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = -INFINITY;
     }
     if constexpr (NKB == 7) {       // Lp == 224: 14 units = 2 x 6 + 1 x 2
         if (wave < 4) bwd4_body<2, SV16, 7, 1>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);        // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
