@@ -39,7 +39,7 @@ constexpr int MAXU = 2;          // 16-key units per wave
 constexpr int MAXKB = 7;         // 32-key blocks per head (Lp <= 224)
 constexpr int NSLOT = 6;         // ring slots
 constexpr int SLOT_BYTES = 3 * 32 * RB;      // Q slice + dO slice + O slice
-constexpr int AHEAD = 5;         // slices in flight ahead of the slice being computed
+constexpr int AHEAD = 4;         // slices in flight ahead of the slice being computed (a slot stays in use one iteration longer: STAG)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float SCALE = 0.125f;
 
@@ -105,7 +105,10 @@ struct Args4 {
 // (dq_dt, dq_qs), 2 = both query halves of head-dim block dq_dt, 0 = none.  At Lp = 224 the key units split 2,2,2,2,2,2,1,1 over the
 // waves, i.e. 4,4,3,3 over the SIMDs (waves w and w + 4 share one): the eight dQ pieces go 1,1,3,3 so that every SIMD issues 69-71 MFMAs
 // per slice — waves 0-3 one piece each, waves 4, 5 none, waves 6, 7 (one unit) two.
-template <int NUW, bool SV16, int NKB, int DQN>
+// STAG: this wave runs the matrix half of a slice (dV, dK) one iteration late, IN FRONT of the next slice's score half: the two waves of a
+// SIMD (w and w + 4) run the same program between the same barriers, so unstaggered they want the matrix pipe together and the vector
+// pipe together; with waves 4-7 half an iteration behind, one wave's MFMAs run beside the other's exponentials.
+template <int NUW, bool SV16, int NKB, int DQN, bool STAG>
 __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub, int dq_dt, int dq_qs) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
     const int L = A.L, Lp = NKB ? 32 * NKB : A.Lp, H = A.H, NSL = NKB ? NKB : (A.Lp >> 5), total = A.total;
@@ -142,8 +145,26 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #endif
 #ifdef LPI_ABL4_NOSTORE
     const bool abl_st = lddqkv == 12345;
+#elif defined(LPI_ABL4_STAMPS)
+    const bool abl_st = true;
 #else
     constexpr bool abl_st = true;
+#endif
+    // diagnostic build (tools/attn4_stamps.py): workgroup 0 writes s_memtime stamps of its phases into the delta scratch ([wave][n] u64,
+    // 2048 per wave) instead of delta; never in the product build
+#ifdef LPI_ABL4_STAMPS
+    unsigned long long* const stamp_buf = reinterpret_cast<unsigned long long*>(A.delta) + wave * 2048;
+    int stamp_n = 0;
+    auto STAMP = [&]() {
+        if (blockIdx.x == 0 && stamp_n < 2048) {
+            const unsigned long long tk = __builtin_amdgcn_s_memtime();
+            if (lane == 0) stamp_buf[stamp_n] = tk;
+            ++stamp_n;
+        }
+    };
+#define LPI4_STAMP() STAMP()
+#else
+#define LPI4_STAMP() do {} while (0)
 #endif
 
     // per-lane byte offsets
@@ -264,12 +285,15 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         if (r16 == 0) {
             const int rl = 4 * wave + g, q = t * 32 + rl;
             dl_l[par * 32 + rl] = v * SCALE;
+#ifndef LPI_ABL4_STAMPS
             if (q < L && abl_st) drow[q] = v;
+#endif
         }
     };
 
-    // slice t: S^T, dP^T -> P, dS = P (dP - delta) / 8; dS^T -> dsb[par]; dV^T += dO^T P, dK^T += Q^T dS
-    auto stage_main = [&](int t, int slot, int lbuf, int par) {
+    Chunk bp[NUA], bs[NUA];              // P and dS of a slice as MFMA B operands: score half -> matrix half
+    // score half of slice t: S^T, dP^T -> P, dS = P (dP - delta) / 8; dS^T -> dsb[par]
+    auto stage_s = [&](int t, int slot, int lbuf, int par) {
         const char* qs_ = ring + slot * SLOT_BYTES;
         const char* ds_ = qs_ + 32 * RB;
         char* dsp = dsb + par * (Lp * 64);
@@ -315,12 +339,16 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 *reinterpret_cast<uint2*>(dsp + dsw[u][t2]) = make_uint2(sw[u][t2][0], sw[u][t2][1]);
             }
         }
-        Chunk bp[NUA], bs[NUA];
 #pragma unroll
         for (int u = 0; u < NUW; ++u) {
             bp[u].u = make_uint4(pw[u][0][0], pw[u][0][1], pw[u][1][0], pw[u][1][1]);
             bs[u].u = make_uint4(sw[u][0][0], sw[u][0][1], sw[u][1][0], sw[u][1][1]);
         }
+    };
+    // matrix half of the slice in ring slot `slot`: dV^T += dO^T P, dK^T += Q^T dS
+    auto stage_m = [&](int slot) {
+        const char* qs_ = ring + slot * SLOT_BYTES;
+        const char* ds_ = qs_ + 32 * RB;
         // the transposing reads of two head-dim blocks are in flight together
 #pragma unroll
         for (int d0 = 0; d0 < 4; d0 += 2) {
@@ -394,6 +422,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll 1
     for (int it = 0; it < nheads; ++it) {
         const int lbuf = it & 1;
+        LPI4_STAMP();
         Head nxt = cur;
         next_head(nxt);
         float* const drow = delta + (size_t)(cur.b * H + cur.h) * L;                   // this head's rows of the outputs
@@ -430,26 +459,40 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (!spread_kv)
                 for (int part = 0; part < kv_parts; ++part) issue_kv_part(nxt, part);
         }
+        LPI4_STAMP();
         // the last dQ store of a head (slice NSL - 2, in iteration NSL - 1) is what the wait of that iteration may leave in flight
         const bool dq_last = DQN > 0 && (NSL - 2) * 32 < rows_hi;
 #pragma unroll 1
         for (int t = 0; t < NSL; ++t) {
-            issue_next();         // slice gs + AHEAD -> the slot slice gs - 1 has just left
+            LPI4_STAMP();
+            issue_next();         // slice gs + AHEAD -> the slot slice gs - 2 has left (its staggered matrix half ran in the last iteration)
             if (spread_kv && t < kv_parts && it + 1 < nheads) issue_kv_part(nxt, t);
+            LPI4_STAMP();
             const int par = t & 1;
             const int slot1 = slot + 1 == NSLOT ? 0 : slot + 1;
             if (abl_comp) {
                 if (t + 1 < NSL) stage_delta(drow, t + 1, slot1, par ^ 1);
-                if (own_wanted || t * 32 < rows_hi) stage_main(t, slot, lbuf, par);
+                LPI4_STAMP();
+                if constexpr (STAG) {
+                    if (t >= 1 && (own_wanted || (t - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);
+                    LPI4_STAMP();
+                    if (own_wanted || t * 32 < rows_hi) stage_s(t, slot, lbuf, par);
+                } else if (own_wanted || t * 32 < rows_hi) {
+                    stage_s(t, slot, lbuf, par);
+                    LPI4_STAMP();
+                    stage_m(slot);
+                }
+                LPI4_STAMP();
             }
             __builtin_amdgcn_sched_barrier(0);
             if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1);
+            LPI4_STAMP();
             // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
             // pieces of the AHEAD - 2 younger slices (1 per slice from waves 0-3, 2 from waves 4-7; stores and K / V pieces issued in between
             // only make the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
             // stores of the head before (57 KB per CU, all CUs at once).  So the LAST iteration of a head waits for everything but the
-            // youngest slice and the dQ store behind it (slices 0 .. 3 of the next head: issued 4+ iterations ago), and the first two
-            // iterations of a head do not wait at all.  At the end of the stream, or with few slices per head: everything.
+            // youngest slice and the dQ store behind it (slices 0 .. 2 of the next head: issued 3+ iterations ago), and the first
+            // iteration of a head does not wait at all.  At the end of the stream, or with few slices per head: everything.
             if (NSL >= 6 && gs + AHEAD < nslices) {
                 if (t == NSL - 1) {       // may stay in flight: this wave's pieces of the youngest slice (1 | 2) and its DQN dQ stores behind them
                     if (wave < 4) {
@@ -460,14 +503,19 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                         else if (DQN == 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     }
-                } else if (t >= 2) {
-                    if (wave < 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else if (t >= 1) {
+                    if (wave < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LPI4_STAMP();
             LPI4_BARRIER();
+            LPI4_STAMP();
             ++gs;
             slot = slot1;
+        }
+        if constexpr (STAG) {
+            if (abl_comp && (own_wanted || (NSL - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);      // the last slice's matrix half
         }
         if ((NSL - 1) * 32 < rows_hi) stage_dq(dqh, NSL - 1, (NSL - 1) & 1);
 #pragma unroll
@@ -503,14 +551,14 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
         for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = -INFINITY;
     }
     if constexpr (NKB == 7) {       // Lp == 224: 14 units = 2 x 6 + 1 x 2
-        if (wave < 4) bwd4_body<2, SV16, 7, 1>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);        // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
-        else if (wave < 6) bwd4_body<2, SV16, 7, 0>(A, smem, wave, ub, 0, 0);
-        else bwd4_body<1, SV16, 7, 2>(A, smem, wave, ub, wave - 4, 0);                               // head-dim blocks 2, 3: both query halves
+        if (wave < 4) bwd4_body<2, SV16, 7, 1, false>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);     // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
+        else if (wave < 6) bwd4_body<2, SV16, 7, 0, true>(A, smem, wave, ub, 0, 0);
+        else bwd4_body<1, SV16, 7, 2, true>(A, smem, wave, ub, wave - 4, 0);                             // head-dim blocks 2, 3: both query halves
     } else {
         switch (nu) {
-            case 2: bwd4_body<2, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
-            case 1: bwd4_body<1, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
-            default: bwd4_body<0, SV16, 0, 1>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            case 2: bwd4_body<2, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            case 1: bwd4_body<1, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            default: bwd4_body<0, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
         }
     }
 }

@@ -20,21 +20,24 @@ lse = torch.zeros(B, H, L, device=dev)
 delta = torch.zeros(B, H, L, device=dev)
 call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, 0, s())
 keys = [a for a in sys.argv[1:]] or ["3", "5"]
-for key in keys * 2:
-    k7, _, k12 = key.partition(":")       # "5:1" = generation 5 with A/B flags (tuning key 12) = 1
-    call("lpi_set_tuning", 7, int(k7))
-    call("lpi_set_tuning", 12, int(k12 or 0))
-    fn = lambda: call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, s())  # noqa: E731
-    best = 1e9
-    for _ in range(3):
+fn = lambda: call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, s())  # noqa: E731
+times = {k: [] for k in keys}
+for rnd in range(9):          # configurations interleaved, so that clock / box drift hits them alike
+    for key in keys:
+        k7, _, k12 = key.partition(":")       # "5:1" = generation 5 with A/B flags (tuning key 12) = 1
+        call("lpi_set_tuning", 7, int(k7))
+        call("lpi_set_tuning", 12, int(k12 or 0))
         fn(); fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(30):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 50)
-    print(f"{os.environ.get('LPI_LIB', 'base'):40s} key7={key}: bwd {best:7.1f} us", flush=True)
+        if rnd:
+            times[key].append(e0.elapsed_time(e1) * 1000 / 30)
+for key in keys:
+    t = sorted(times[key])
+    print(f"{os.environ.get('LPI_LIB', 'base'):40s} key7={key}: bwd median {t[len(t) // 2]:7.1f} us  min {t[0]:7.1f}  max {t[-1]:7.1f}", flush=True)
 call("lpi_set_tuning", 7, 0)
 call("lpi_set_tuning", 12, 0)
