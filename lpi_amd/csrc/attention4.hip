@@ -173,7 +173,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     int trw;                     // the same for dt = dq_dt (K^T fragments)
     int dsw[NUW > 0 ? NUW : 1][2];   // dS^T store: [key][query] rows of 64 B inside 32-key blocks of 2 KiB
     int dsr[DQN > 0 ? DQN : 1][2];   // dS^T transposing read of query half dq_qs (+ piece): [second 16 keys]
-    int dlo;                     // delta pass: 8 bytes of row 4 wave + g, elements 4 r16 ..
+    int dlo;                     // delta pass (waves 0-3): 16 bytes of row 8 wave + (lane >> 3), chunk lane & 7
     {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) rc[ks] = r16 * RB + (((g + 4 * ks) ^ (r16 & 6)) << 4);
@@ -195,8 +195,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 const int row = 16 * hi + 4 * g + (r16 >> 2);
                 dsr[pi][hi] = row * 64 + (((4 * (dq_qs + pi) + (lane & 3)) ^ ds_sw(row)) << 3);
             }
-        const int drow = 4 * wave + g;
-        dlo = drow * RB + (((r16 >> 1) ^ (drow & 6)) << 4) + (r16 & 1) * 8;
+        const int drow = 8 * (wave & 3) + (lane >> 3);
+        dlo = drow * RB + (((lane & 7) ^ (drow & 6)) << 4);
     }
 
     // ---- LDS-DMA issue helpers (all wave-uniform control flow; lanes behind L are EXEC-masked or clamped)
@@ -213,11 +213,12 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int nblk = (L + 7) >> 3;
     const int kv_parts = (2 * nblk + 15) >> 4;
     auto issue_kv_part = [&](const Head& x, int part) {
+        if (wave >= 6) return;                // waves 6, 7 (two dQ pieces each) issue no DMA: they are the longest per iteration
         const T* kg = qkv + (size_t)x.b * L * ldqkv + x.h * HD + dm;
         const int r8 = lane >> 3, pc = lane & 7;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int pi = part * 16 + j * 8 + wave;
+        const int np = wave < 4 ? 3 : 2, p0 = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);      // 16 pieces of a part: 3,3,3,3,2,2
+        for (int j = 0; j < np; ++j) {
+            const int pi = part * 16 + p0 + j;
             if (pi < 2 * nblk) {
                 const int isv = pi >= nblk ? 1 : 0, blk = pi - isv * nblk;
                 const int row = blk * 8 + r8;
@@ -231,22 +232,21 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (i < L && abl_dma) glds4(A.lse + (size_t)(x.b * H + x.h) * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
-    // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): waves 0-3 (which also compute a dQ piece) move one Q piece each,
-    // waves 4, 5 the dO pieces, waves 6, 7 the O pieces, two each (rows behind L: the last row again — finite values; their lse is +inf,
-    // so P = 0 there)
-    const T* const sl_base = wave < 4 ? qkv : (wave < 6 ? dctx : A.ctx);      // this wave's source matrix, its row stride, its part of a slot
-    const int sl_ld = wave < 4 ? ldqkv : (wave < 6 ? lddctx : A.ldctx);
-    const int sl_np = wave < 4 ? 1 : 2;
+    // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): wave w < 4 moves piece w of Q and of dO, waves 4, 5 two pieces of
+    // O each, waves 6, 7 nothing (rows behind L: the last row again — finite values; their lse is -inf, so P = 0 there)
+    const T* const sl_base = wave < 4 ? qkv : A.ctx;           // this wave's first source matrix and row stride
+    const int sl_ld = wave < 4 ? ldqkv : A.ldctx;
     const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
-    const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : (wave < 6 ? 1 : 2)) * 32 * RB + sl_blk0 * 1024;
+    const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : 2) * 32 * RB + sl_blk0 * 1024;
     const int sl_rl = sl_blk0 * 8 + (lane >> 3);
     const int sl_ch = ((lane & 7) ^ (sl_rl & 6)) << 3;         // (row & 6) is the same for rows 8 apart
     auto issue_slice = [&](const Head& x, int t, int slot) {
-        if (abl_dma) {
+        if (abl_dma && wave < 6) {
             const T* hb = sl_base + (size_t)x.b * L * sl_ld + x.h * HD;
             const unsigned dst = sl_dst + slot * SLOT_BYTES;
             glds16(hb + (unsigned)(min(t * 32 + sl_rl, L - 1) * sl_ld + sl_ch), dst);
-            if (sl_np == 2) glds16(hb + (unsigned)(min(t * 32 + sl_rl + 8, L - 1) * sl_ld + sl_ch), dst + 1024);
+            if (wave < 4) glds16(dctx + (size_t)x.b * L * lddctx + x.h * HD + (unsigned)(min(t * 32 + sl_rl, L - 1) * lddctx + sl_ch), dst + 32 * RB);
+            else glds16(hb + (unsigned)(min(t * 32 + sl_rl + 8, L - 1) * sl_ld + sl_ch), dst + 1024);
         }
     };
     // prefetch cursor over this workgroup's slice stream
@@ -267,23 +267,22 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     Chunk kT[MAXKB];                     // K^T fragments of head-dim block dq_dt, all keys (A operands of dQ^T)
     f32x4 dk[NUA][4], dv[NUA][4];
 
-    // delta of slice t's rows 4 wave .. 4 wave + 3 = rowsum(dO o O) -> dl[par] (and the C ABI's delta scratch)
+    // delta of slice t's rows 8 wave .. 8 wave + 7 = rowsum(dO o O) -> dl[par] (/ 8) and the C ABI's delta scratch; waves 0-3 (they have the
+    // slack: waves 4-7 run the longer iteration), 8 lanes of 8 elements per row
     auto stage_delta = [&](float* drow, int t, int slot, int par) {
+        if (wave >= 4) return;
         const char* ds_ = ring + slot * SLOT_BYTES + 32 * RB;
-        const uint2 dd = *reinterpret_cast<const uint2*>(ds_ + dlo);
-        const uint2 oo = *reinterpret_cast<const uint2*>(ds_ + 32 * RB + dlo);
-        const float d0 = __uint_as_float(dd.x << 16), d1 = __uint_as_float(dd.x & 0xFFFF0000u), d2 = __uint_as_float(dd.y << 16), d3 = __uint_as_float(dd.y & 0xFFFF0000u);
-        float o0, o1, o2, o3;
-        if constexpr (SV16) {
-            const f16x4 h = __builtin_bit_cast(f16x4, oo);
-            o0 = (float)h[0]; o1 = (float)h[1]; o2 = (float)h[2]; o3 = (float)h[3];
-        } else {
-            o0 = __uint_as_float(oo.x << 16); o1 = __uint_as_float(oo.x & 0xFFFF0000u); o2 = __uint_as_float(oo.y << 16); o3 = __uint_as_float(oo.y & 0xFFFF0000u);
-        }
-        float v = fmaf(d0, o0, fmaf(d1, o1, fmaf(d2, o2, d3 * o3)));
-        v = row16_sum(v);
-        if (r16 == 0) {
-            const int rl = 4 * wave + g, q = t * 32 + rl;
+        Chunk dd, oo;
+        dd.u = *reinterpret_cast<const uint4*>(ds_ + dlo);
+        oo.u = *reinterpret_cast<const uint4*>(ds_ + 32 * RB + dlo);
+        float v = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v = fmaf((float)dd.h[e], SV16 ? (float)oo.hh[e] : (float)oo.h[e], v);
+        v += dpp_move<0xB1>(v);     // lane ^ 1
+        v += dpp_move<0x4E>(v);     // lane ^ 2
+        v += dpp_move<0x141>(v);    // the other quad of each 8 lanes
+        if ((lane & 7) == 0) {
+            const int rl = 8 * wave + (lane >> 3), q = t * 32 + rl;
             dl_l[par * 32 + rl] = v * SCALE;
 #ifndef LPI_ABL4_STAMPS
             if (q < L && abl_st) drow[q] = v;
@@ -488,24 +487,17 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1);
             LPI4_STAMP();
             // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
-            // pieces of the AHEAD - 2 younger slices (1 per slice from waves 0-3, 2 from waves 4-7; stores and K / V pieces issued in between
-            // only make the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
+            // pieces of the AHEAD - 2 younger slices (2 per slice from each of waves 0-5; stores and K / V pieces issued in between only make
+            // the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
             // stores of the head before (57 KB per CU, all CUs at once).  So the LAST iteration of a head waits for everything but the
             // youngest slice and the dQ store behind it (slices 0 .. 2 of the next head: issued 3+ iterations ago), and the first
             // iteration of a head does not wait at all.  At the end of the stream, or with few slices per head: everything.
             if (NSL >= 6 && gs + AHEAD < nslices) {
-                if (t == NSL - 1) {       // may stay in flight: this wave's pieces of the youngest slice (1 | 2) and its DQN dQ stores behind them
-                    if (wave < 4) {
-                        if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-                    } else {
-                        if (DQN >= 2 && dq_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else if (DQN == 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                if (wave < 6) {           // waves 6, 7 issue no DMA
+                    if (t == NSL - 1) {   // may stay in flight: this wave's 2 pieces of the youngest slice and its DQN dQ stores behind them
+                        if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    }
-                } else if (t >= 1) {
-                    if (wave < 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else if (t >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LPI4_STAMP();
