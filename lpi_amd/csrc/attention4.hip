@@ -213,7 +213,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int nblk = (L + 7) >> 3;
     const int kv_parts = (2 * nblk + 15) >> 4;
     auto issue_kv_part = [&](const Head& x, int part) {
-        if (wave >= 6) return;                // waves 6, 7 (two dQ pieces each) issue no DMA: they are the longest per iteration
+        if (wave >= 6) return;                // waves 6, 7 move the O pieces of every slice instead
         const T* kg = qkv + (size_t)x.b * L * ldqkv + x.h * HD + dm;
         const int r8 = lane >> 3, pc = lane & 7;
         const int np = wave < 4 ? 3 : 2, p0 = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);      // 16 pieces of a part: 3,3,3,3,2,2
@@ -232,16 +232,18 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (i < L && abl_dma) glds4(A.lse + (size_t)(x.b * H + x.h) * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
-    // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): wave w < 4 moves piece w of Q and of dO, waves 4, 5 two pieces of
-    // O each, waves 6, 7 nothing (rows behind L: the last row again — finite values; their lse is -inf, so P = 0 there)
+    // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): wave w < 4 moves piece w of Q and of dO, waves 6, 7 two pieces of
+    // O each, waves 4, 5 (the longest iteration: staggered, two key units) none (rows behind L: the last row again — finite values; their
+    // lse is -inf, so P = 0 there)
     const T* const sl_base = wave < 4 ? qkv : A.ctx;           // this wave's first source matrix and row stride
     const int sl_ld = wave < 4 ? ldqkv : A.ldctx;
     const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
     const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : 2) * 32 * RB + sl_blk0 * 1024;
     const int sl_rl = sl_blk0 * 8 + (lane >> 3);
     const int sl_ch = ((lane & 7) ^ (sl_rl & 6)) << 3;         // (row & 6) is the same for rows 8 apart
+    const bool sl_mine = wave < 4 || wave >= 6;
     auto issue_slice = [&](const Head& x, int t, int slot) {
-        if (abl_dma && wave < 6) {
+        if (abl_dma && sl_mine) {
             const T* hb = sl_base + (size_t)x.b * L * sl_ld + x.h * HD;
             const unsigned dst = sl_dst + slot * SLOT_BYTES;
             glds16(hb + (unsigned)(min(t * 32 + sl_rl, L - 1) * sl_ld + sl_ch), dst);
@@ -269,15 +271,18 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 
     // delta of slice t's rows 8 wave .. 8 wave + 7 = rowsum(dO o O) -> dl[par] (/ 8) and the C ABI's delta scratch; waves 0-3 (they have the
     // slack: waves 4-7 run the longer iteration), 8 lanes of 8 elements per row
-    auto stage_delta = [&](float* drow, int t, int slot, int par) {
+    Chunk dl_d, dl_o;
+    auto stage_delta_load = [&](int slot) {         // issued in front of the iteration's DMA: the LDS round trip runs under it
         if (wave >= 4) return;
         const char* ds_ = ring + slot * SLOT_BYTES + 32 * RB;
-        Chunk dd, oo;
-        dd.u = *reinterpret_cast<const uint4*>(ds_ + dlo);
-        oo.u = *reinterpret_cast<const uint4*>(ds_ + 32 * RB + dlo);
+        dl_d.u = *reinterpret_cast<const uint4*>(ds_ + dlo);
+        dl_o.u = *reinterpret_cast<const uint4*>(ds_ + 32 * RB + dlo);
+    };
+    auto stage_delta = [&](float* drow, int t, int par) {
+        if (wave >= 4) return;
         float v = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v = fmaf((float)dd.h[e], SV16 ? (float)oo.hh[e] : (float)oo.h[e], v);
+        for (int e = 0; e < 8; ++e) v = fmaf((float)dl_d.h[e], SV16 ? (float)dl_o.hh[e] : (float)dl_o.h[e], v);
         v += dpp_move<0xB1>(v);     // lane ^ 1
         v += dpp_move<0x4E>(v);     // lane ^ 2
         v += dpp_move<0x141>(v);    // the other quad of each 8 lanes
@@ -450,7 +455,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 
         // this head's lse vector (landed a head ago): -lse log2(e) in place, one entry per thread (the entries behind L stay -inf)
         if ((int)threadIdx.x < L) lse_l[lbuf * Lp + threadIdx.x] *= -LOG2E;
-        stage_delta(drow, 0, slot, 0);
+        stage_delta_load(slot);
+        stage_delta(drow, 0, 0);
         LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
@@ -464,13 +470,14 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll 1
         for (int t = 0; t < NSL; ++t) {
             LPI4_STAMP();
+            const int slot1 = slot + 1 == NSLOT ? 0 : slot + 1;
+            if (abl_comp && t + 1 < NSL) stage_delta_load(slot1);
             issue_next();         // slice gs + AHEAD -> the slot slice gs - 2 has left (its staggered matrix half ran in the last iteration)
             if (spread_kv && t < kv_parts && it + 1 < nheads) issue_kv_part(nxt, t);
             LPI4_STAMP();
             const int par = t & 1;
-            const int slot1 = slot + 1 == NSLOT ? 0 : slot + 1;
             if (abl_comp) {
-                if (t + 1 < NSL) stage_delta(drow, t + 1, slot1, par ^ 1);
+                if (t + 1 < NSL) stage_delta(drow, t + 1, par ^ 1);
                 LPI4_STAMP();
                 if constexpr (STAG) {
                     if (t >= 1 && (own_wanted || (t - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);
@@ -487,18 +494,19 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1);
             LPI4_STAMP();
             // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
-            // pieces of the AHEAD - 2 younger slices (2 per slice from each of waves 0-5; stores and K / V pieces issued in between only make
-            // the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
+            // pieces of the AHEAD - 2 younger slices (2 per slice from each of waves 0-3, 6, 7; stores and K / V pieces issued in between only
+            // make the wait stricter).  vmcnt counts stores too, in order: a wait in the first iterations of a head would also wait for the dK / dV
             // stores of the head before (57 KB per CU, all CUs at once).  So the LAST iteration of a head waits for everything but the
             // youngest slice and the dQ store behind it (slices 0 .. 2 of the next head: issued 3+ iterations ago), and the first
             // iteration of a head does not wait at all.  At the end of the stream, or with few slices per head: everything.
             if (NSL >= 6 && gs + AHEAD < nslices) {
-                if (wave < 6) {           // waves 6, 7 issue no DMA
+                if (sl_mine) {            // waves 4, 5 move no slice pieces (their K / V pieces are older than any wait that matters)
                     if (t == NSL - 1) {   // may stay in flight: this wave's 2 pieces of the youngest slice and its DQN dQ stores behind them
-                        if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        if (DQN >= 2 && dq_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     } else if (t >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                }
+                } else if (t == NSL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next head's K / V pieces (issued 3+ iterations ago)
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             LPI4_STAMP();
             LPI4_BARRIER();
