@@ -179,7 +179,11 @@ class Workload:
             self.text_rows = self.ids.rows / B
         self.fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not fwd_only)
                     for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
-        self.opt = torch.optim.SGD(list(self.fac.values()), momentum=0.9, lr=0.05, weight_decay=2e-4)    # sprompt.py:253
+        # sprompt.py:253: SGD(momentum 0.9, lr 0.05, weight decay 2e-4) — the factors live in one flat vector, their gradients in another:
+        # the optimiser step is ONE lpi_sgd_step launch and the data-parallel all-reduce takes the flat gradient as it is
+        from lpi_amd.optim import FlatSGD, flatten
+        self.flat, self.flat_grad, self.grad_views = flatten(self.fac)
+        self.opt = FlatSGD(self.fac, lr=0.05, momentum=0.9, weight_decay=2e-4, flat=self.flat, flat_grad=self.flat_grad, grad_views=self.grad_views)
         self.cu_lanes = None
         if a.cu_lanes >= 1:
             from lpi_amd import lanes as _lanes
@@ -199,7 +203,8 @@ class Workload:
                              lockstep=not a.no_lockstep)
         else:
             train_step(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange, overlap_towers=self.overlap,
-                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes, lockstep=not a.no_lockstep)
+                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes, lockstep=not a.no_lockstep,
+                       flat_grad=self.flat_grad, grad_views=self.grad_views)
             self.opt.step()
 
     def run(self, steps, warmup, sync):

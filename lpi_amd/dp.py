@@ -91,8 +91,17 @@ class Exchange:
             out = h[self.rank * B:(self.rank + 1) * B].to(buf.device)
         return out[:, :E].contiguous(), out[:, E:].contiguous()
 
-    def allreduce_grads(self, params):
-        """SUM all-reduce of the (small) prompt-factor gradients as one flat message."""
+    def allreduce_grads(self, params, flat=None):
+        """SUM all-reduce of the (small) prompt-factor gradients as one flat message.  flat: the flat gradient vector the parameters' .grad
+        tensors are slices of (optim.flatten): reduced in place, nothing packed or copied back."""
+        if flat is not None and all(p.grad is not None and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params):
+            if self.device_collectives or not flat.is_cuda:
+                self._timed("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group), flat.is_cuda)
+            else:
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(h)
+            return flat.numel()
         params = [p for p in params if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in params])
         if self.device_collectives or not flat.is_cuda:

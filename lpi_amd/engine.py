@@ -729,6 +729,19 @@ class DualEncoder:
         self._vis_ctx = ctx
         return out, ctx
 
+    def _dprompts(self, ws, Lyr, P, d, depth):
+        """The tower's prompt-gradient buffer [Lyr, P, d] f32, kept in the workspace: rows of layers < depth are OVERWRITTEN by every backward
+        (vis_assemble_bwd / rows_sum_over_batch write, they do not accumulate), the rows behind them are zero from the allocation on — no fill
+        kernel in the step.  Re-zeroed if the depth shrinks."""
+        key = (Lyr, P, d)
+        ent = ws.get("dprompts")
+        if ent is None or ent[0] != key:
+            ent = ws["dprompts"] = [key, torch.zeros(Lyr, P, d, device=self.device), depth]
+        elif depth < ent[2]:
+            ent[1].zero_()
+        ent[2] = depth
+        return ent[1]
+
     def encode_image_backward(self, dout, ctx=None):
         """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch.
         ctx: the context encode_image(return_ctx=True) returned (default: the engine's last forward)."""
@@ -752,7 +765,7 @@ class DualEncoder:
         if pr is None:
             return None
         Lyr = pr.shape[-3]
-        dpr = torch.zeros(Lyr, P, d, device=self.device)
+        dpr = self._dprompts(ws, Lyr, P, d, depth)
         yield from self.vis.backward_gen(ws, pr, depth, dpr, None)
         call("lpi_vis_assemble_bwd", dt, B, cfg.n_patches, P, d, ws["dx"] if dt == F32 else ws["dxT"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
              ws["front"]["stat"][1], dpr[0], s)
@@ -823,7 +836,7 @@ class DualEncoder:
         if pr is None:
             return None
         Lyr = pr.shape[-3]
-        dpr = torch.zeros(Lyr, P, d, device=self.device)
+        dpr = self._dprompts(ws, Lyr, P, d, depth)
         yield from self.txt.backward_gen(ws, pr, depth, dpr, eot_idx)
         call("lpi_rows_sum_over_batch_varlen", dt, B, L, ws["rs"], 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
         return dpr
@@ -1073,11 +1086,11 @@ def prompt_cp_fwd(d1, d2, d3, scale=1.0):
     return out
 
 
-def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0):
+def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0, out=None):
+    """out: (g2, g3) to write into (contiguous f32, e.g. slices of a flat gradient buffer: optim.flatten); default: new tensors."""
     Lyr, r = d1.shape
     P, D = d2.shape[0], d3.shape[0]
-    g2 = torch.empty_like(d2)
-    g3 = torch.empty_like(d3)
+    g2, g3 = out if out is not None else (torch.empty_like(d2), torch.empty_like(d3))
     scratch = torch.empty(Lyr * P * r, device=d1.device)
     call("lpi_prompt_cp_bwd", Lyr, P, D, r, d1, d2, d3, float(scale), dout.contiguous(), g1, g2, g3, int(accumulate_g1), scratch, _stream())
     return g2, g3
@@ -1086,7 +1099,7 @@ def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0):
 def align_loss_fwd_bwd(vis, txt, temp=0.01, weight=0.1, need_grad=True):
     Lyr, P, Dv = vis.shape
     Dt = txt.shape[-1]
-    loss = torch.zeros(1, device=vis.device)
+    loss = torch.empty(1, device=vis.device)          # written, not accumulated
     dv = torch.empty_like(vis) if need_grad else None
     dtx = torch.empty_like(txt) if need_grad else None
     call("lpi_align_loss_fwd_bwd", Lyr, P, Dv, Dt, vis.contiguous(), txt.contiguous(), float(temp), float(weight), loss, dv, dtx, _stream())

@@ -13,19 +13,24 @@ class DecomposedPromptFn(torch.autograd.Function):
     """DecomposedPrompt.forward (models/prompts/prompts.py:38-57): (vis [Lyr,P,Dv], txt [Lyr,P,Dt])."""
 
     @staticmethod
-    def forward(ctx, d1, d2v, d2t, d3v, d3t, scale=1.0):
+    def forward(ctx, d1, d2v, d2t, d3v, d3t, scale=1.0, grad_out=None):
+        """grad_out: five contiguous f32 tensors (in argument order) that receive the gradients — slices of a flat gradient buffer
+        (optim.flatten), so that the parameters' .grad are views of it and the optimiser / the all-reduce run on one flat vector."""
         args = [t.detach().contiguous().float() for t in (d1, d2v, d2t, d3v, d3t)]
         ctx.save_for_backward(*args)
-        ctx.scale = scale
+        ctx.scale, ctx.grad_out = scale, grad_out
         return E.prompt_cp_fwd(args[0], args[1], args[3], scale), E.prompt_cp_fwd(args[0], args[2], args[4], scale)
 
     @staticmethod
     def backward(ctx, gvis, gtxt):
         d1, d2v, d2t, d3v, d3t = ctx.saved_tensors
-        g1 = torch.zeros_like(d1)
-        g2v, g3v = E.prompt_cp_bwd(d1, d2v, d3v, gvis.contiguous().float(), g1, False, ctx.scale)
-        g2t, g3t = E.prompt_cp_bwd(d1, d2t, d3t, gtxt.contiguous().float(), g1, True, ctx.scale)   # shared dim_1_share
-        return g1, g2v, g2t, g3v, g3t, None
+        go = ctx.grad_out
+        g1 = go[0] if go is not None else torch.empty_like(d1)      # the first call overwrites it, the second accumulates (shared dim_1_share)
+        g2v, g3v = E.prompt_cp_bwd(d1, d2v, d3v, gvis.contiguous().float(), g1, False, ctx.scale, out=None if go is None else (go[1], go[3]))
+        g2t, g3t = E.prompt_cp_bwd(d1, d2t, d3t, gtxt.contiguous().float(), g1, True, ctx.scale, out=None if go is None else (go[2], go[4]))
+        if go is not None:      # fresh view objects: autograd's AccumulateGrad adopts a gradient it holds the only reference to, and clones one it does not
+            g1, g2v, g2t, g3v, g3t = (t.view(t.shape) for t in (g1, g2v, g2t, g3v, g3t))
+        return g1, g2v, g2t, g3v, g3t, None, None
 
 
 class EncodeImageFn(torch.autograd.Function):
@@ -100,6 +105,31 @@ class EncodeBothFn(torch.autograd.Function):
         return None, None, None, outs[0], outs[1], None
 
 
+def contrastive_loss_and_grads(img_f, txt_f, scale, gather=None, exchange=None, need=True):
+    """The contrastive loss of this rank and its gradients w.r.t. the rank's own feature rows, in the mode the exchange selects (see
+    ClipLossFn) -> (loss [1], dI [B,E] | None, dT | None, logits | None).  Shared by ClipLossFn and step.train_step (which seeds the
+    towers' backward with dI / dT directly)."""
+    if gather is not None:
+        img_all, txt_all, r0 = gather(img_f.detach(), txt_f.detach())
+    else:
+        img_all, txt_all, r0 = img_f.detach().contiguous(), txt_f.detach().contiguous(), 0
+    B = img_f.shape[0]
+    ll = bool(getattr(exchange, "local_loss", False))
+    gwg = bool(getattr(exchange, "gather_with_grad", False))
+    logits = None
+    if ll:
+        loss, dI, dT, dIk, dTk = E.clip_loss_local_fwd_bwd(img_all, txt_all, scale, r0, B, need, key_grads=gwg and need)
+        if need and gwg:
+            kI, kT = exchange.reduce_scatter_rows(dIk, dTk, B)        # this rank's rows of the SUM over ranks
+            dI, dT = dI + kI, dT + kT
+    elif gwg:
+        loss, dIa, dTa = E.clip_loss_full_grad(img_all, txt_all, scale)
+        dI, dT = exchange.reduce_scatter_rows(dIa, dTa, B) if need else (None, None)
+    else:
+        loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need, r0, B)     # gradients of the local rows only
+    return loss, dI, dT, logits
+
+
 class ClipLossFn(torch.autograd.Function):
     """logit_scale * I @ T^T then ClipLoss (slinet.py:138-141, loss/loss.py:75-87).  With a process group the features are
     all-gathered first (dp.py) in one of the four modes of the reference's dead ``gather_features`` / ``get_logits`` /
@@ -116,26 +146,8 @@ class ClipLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img_f, txt_f, scale, gather=None, exchange=None):
-        if gather is not None:
-            img_all, txt_all, r0 = gather(img_f.detach(), txt_f.detach())
-        else:
-            img_all, txt_all, r0 = img_f.detach().contiguous(), txt_f.detach().contiguous(), 0
         need = img_f.requires_grad or txt_f.requires_grad
-        B = img_f.shape[0]
-        ll = bool(getattr(exchange, "local_loss", False))
-        gwg = bool(getattr(exchange, "gather_with_grad", False))
-        ctx.logits = None
-        if ll:
-            loss, dI, dT, dIk, dTk = E.clip_loss_local_fwd_bwd(img_all, txt_all, scale, r0, B, need, key_grads=gwg and need)
-            if need and gwg:
-                kI, kT = exchange.reduce_scatter_rows(dIk, dTk, B)        # this rank's rows of the SUM over ranks
-                dI, dT = dI + kI, dT + kT
-        elif gwg:
-            loss, dIa, dTa = E.clip_loss_full_grad(img_all, txt_all, scale)
-            dI, dT = exchange.reduce_scatter_rows(dIa, dTa, B) if need else (None, None)
-        else:
-            loss, logits, dI, dT = E.clip_loss_fwd_bwd(img_all, txt_all, scale, need, r0, B)     # gradients of the local rows only
-            ctx.logits = logits
+        loss, dI, dT, ctx.logits = contrastive_loss_and_grads(img_f, txt_f, scale, gather, exchange, need)
         if need:
             ctx.save_for_backward(dI, dT)
         return loss[0]

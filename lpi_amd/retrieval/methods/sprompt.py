@@ -138,8 +138,14 @@ class SPrompts(BaseLearner):
                 param.requires_grad_(True)
         enabled = {n for n, p in network.named_parameters() if p.requires_grad}
         print(f"Parameters to be updated: {enabled}")
-        optimizer = optim.SGD(network.parameters(), momentum=0.9, lr=self.lrate, weight_decay=self.weight_decay)
-        scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer=optimizer, T_max=self.epochs)
+        if self.args.get("fused_sgd", True) and str(self._device).startswith("cuda"):
+            # the same SGD / cosine arithmetic (sprompt.py:253-255) as one HIP kernel over the task's five factors (lpi_sgd_step)
+            from lpi_amd.optim import CosineLR, FlatSGD
+            optimizer = FlatSGD([p for p in network.parameters() if p.requires_grad], lr=self.lrate, momentum=0.9, weight_decay=self.weight_decay)
+            scheduler = CosineLR(optimizer, T_max=self.epochs)
+        else:
+            optimizer = optim.SGD(network.parameters(), momentum=0.9, lr=self.lrate, weight_decay=self.weight_decay)
+            scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer=optimizer, T_max=self.epochs)
         self.run_epoch = self.epochs
         return self.train_function(train_loader, test_loader, optimizer, scheduler)
 

@@ -8,18 +8,21 @@ from __future__ import annotations
 
 import torch
 
-from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeBothFn, EncodeImageFn, EncodeTextFn
+from . import engine as E
+from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeBothFn, EncodeImageFn, EncodeTextFn, contrastive_loss_and_grads
 from .synth import PROMPT_NAMES
+
+_CP_ORDER = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")
 
 
 def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = False,
-                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, exchange=None):
+                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, exchange=None, grad_out=None, losses=True):
     """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
     Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits).
 
     cu_lanes: a list of n CU-masked torch streams (lanes.make_lane_streams): the batch is cut into n contiguous parts and part k
     runs both towers on lane k's share of the chip (even lanes vision first, odd lanes text first, so that the lanes are out of phase)."""
-    vis, txt = DecomposedPromptFn.apply(*[factors[k] for k in ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")])
+    vis, txt = DecomposedPromptFn.apply(*[factors[k] for k in _CP_ORDER], 1.0, grad_out)
     if cu_lanes:
         main = torch.cuda.current_stream()
         B, n = images.shape[0], len(cu_lanes)
@@ -74,27 +77,45 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
     else:
         img_f = EncodeImageFn.apply(enc, images, vis, depth)
         txt_f = EncodeTextFn.apply(enc, ids, txt, depth)
-    fn = ClipLossFn
-    base = fn.apply(img_f, txt_f, enc.logit_scale_exp, gather, exchange)
+    if not losses:
+        return None, img_f, txt_f, vis, txt
+    base = ClipLossFn.apply(img_f, txt_f, enc.logit_scale_exp, gather, exchange)
     losses = {"base_loss": base, "alignment_loss": AlignLossFn.apply(vis, txt, 0.01, align_weight)}
     return losses, img_f, txt_f, vis, txt
 
 
 def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = False,
-               vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True):
+               vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, flat_grad=None, grad_views=None):
     """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
 
     exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
-    gradients SUM all-reduced; the data-independent alignment term is scaled by 1/W so that it counts once)."""
+    gradients SUM all-reduced; the data-independent alignment term is scaled by 1/W so that it counts once).
+    flat_grad / grad_views (optim.flatten): the factor gradients are written into that flat vector (the .grad tensors are its slices), the
+    all-reduce runs on it as it is and optim.FlatSGD steps in one launch.
+
+    The loss kernels produce the loss values AND their gradients w.r.t. features / prompts in one pass, so the towers' backward is seeded with
+    those gradients directly (torch.autograd.backward on the features and the prompt stacks): no scalar loss graph, no `grad * g` kernels.  The
+    weights of the sum (sprompt.py:308: the plain sum of the dict; data parallel: see above) are host numbers folded into the seeds."""
     for k in PROMPT_NAMES:
         factors[k].grad = None
     gather = exchange.gather if exchange is not None else None
-    losses, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
-                                                  cu_lanes, lockstep, exchange)
+    gv = None if grad_views is None else [grad_views[list(factors).index(k)] for k in _CP_ORDER]
+    _, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
+                                             cu_lanes, lockstep, exchange, grad_out=gv, losses=False)
     world = exchange.world if exchange is not None else 1
-    total = losses["base_loss"] * float(getattr(exchange, "loss_weight", 1.0)) + losses["alignment_loss"] / world
-    total.backward()
+    w_base = float(getattr(exchange, "loss_weight", 1.0))
+    with torch.no_grad():
+        base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
+        # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again on the host
+        align, dv, dt = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True)
+        if w_base != 1.0:
+            dI, dT = dI * w_base, dT * w_base
+    torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])
     if exchange is not None:
-        exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES])
+        if gv is not None:
+            exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES], flat=flat_grad)
+        else:
+            exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES])
+    align_out = align[0] if world == 1 else align[0] * float(world)
     return {"img_f": img_f.detach(), "txt_f": txt_f.detach(), "vis_prompt": vis.detach(), "txt_prompt": txt.detach(),
-            "base_loss": losses["base_loss"].detach(), "alignment_loss": losses["alignment_loss"].detach()}
+            "base_loss": base[0], "alignment_loss": align_out}

@@ -42,8 +42,19 @@ def _worker(rank, port, q):
     ta = torch.cat([ta[:r0], txt_f, ta[r0 + B:]])
     losses, _ = orc.cal_loss(ia, ta, vp, tp)
     (losses["base_loss"] + losses["alignment_loss"] / ex.world).backward()
+    g0 = [v.grad.clone() for v in fac.values()]
     n = ex.allreduce_grads(list(fac.values()))
     assert n == sum(v.numel() for v in fac.values())
+    # the same reduction with the gradients laid out as slices of ONE flat vector (optim.flatten): reduced in place, nothing packed or copied
+    flat = torch.cat([g.reshape(-1) for g in g0])
+    o = 0
+    twins = [torch.zeros_like(v) for v in fac.values()]
+    for t, g in zip(twins, g0):
+        t.grad = flat[o:o + g.numel()].view_as(g)
+        o += g.numel()
+    assert ex.allreduce_grads(twins, flat=flat) == n
+    for t, v in zip(twins, fac.values()):
+        assert t.grad.data_ptr() >= flat.data_ptr() and torch.equal(t.grad, v.grad)
     q.put((rank, float(losses["base_loss"]), {k: v.grad.numpy().copy() for k, v in fac.items()}))
     dist.barrier()
     dist.destroy_process_group()

@@ -163,3 +163,40 @@ def test_nt_bxent_loss_has_no_cpu_fallback():
     from lpi_amd.retrieval.loss.loss import nt_bxent_loss
     with pytest.raises(_lib.LpiError):
         nt_bxent_loss(torch.randn(3, 8), torch.eye(3), 0.001)
+
+
+def test_flat_sgd_equals_torch_sgd_and_flat_gradients_are_the_autograd_gradients():
+    """optim.FlatSGD (one lpi_sgd_step launch over the five factors laid out in one flat vector) against torch.optim.SGD with the reference's
+    hyper-parameters and cosine schedule (sprompt.py:253-255) over four steps of the tiny model; the gradients that train_step writes into the
+    flat vector (functional.DecomposedPromptFn grad_out) are the .grad tensors themselves and equal the gradients of the loss-graph path
+    (forward_loss + backward), bit for bit."""
+    from lpi_amd.engine import DualEncoder
+    from lpi_amd.optim import CosineLR, FlatSGD, flatten
+    from lpi_amd.step import forward_loss, train_step
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device=DEV)
+    img = torch.from_numpy(synth.images(4, cfg.image_resolution)).to(DEV)
+    ids = torch.from_numpy(synth.token_ids(4)).to(DEV)
+    fac_np = synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width)
+    fa = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in fac_np.items()}
+    fb = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in fac_np.items()}
+    flat, flat_grad, views = flatten(fa)
+    oa = FlatSGD(fa, lr=0.05, momentum=0.9, weight_decay=2e-4, flat=flat, flat_grad=flat_grad, grad_views=views)
+    sa = CosineLR(oa, T_max=4)
+    ob = torch.optim.SGD(list(fb.values()), lr=0.05, momentum=0.9, weight_decay=2e-4)
+    sb = torch.optim.lr_scheduler.CosineAnnealingLR(ob, T_max=4)
+    for step in range(4):
+        out = train_step(enc, img, ids, fa, 2, flat_grad=flat_grad, grad_views=views)
+        for k, v in zip(fa, views):
+            assert fa[k].grad.data_ptr() == v.data_ptr()              # the .grad tensors ARE the slices of the flat gradient
+        ob.zero_grad()
+        losses, *_ = forward_loss(enc, img, ids, fb, 2)
+        (losses["base_loss"] + losses["alignment_loss"]).backward()
+        assert abs(float(out["base_loss"]) - float(losses["base_loss"])) < 1e-6 and abs(float(out["alignment_loss"]) - float(losses["alignment_loss"])) < 1e-6
+        for k in fa:
+            assert torch.equal(fa[k].grad, fb[k].grad), (step, k)
+        oa.step(); sa.step()
+        ob.step(); sb.step()
+        assert abs(oa.param_groups[0]["lr"] - ob.param_groups[0]["lr"]) < 1e-9
+        for k in fa:
+            assert float((fa[k] - fb[k]).abs().max()) <= 1e-6 * float(fb[k].abs().max()), (step, k)
