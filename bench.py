@@ -71,9 +71,6 @@ def parse_args():
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
-    ap.add_argument("--cu-lanes", type=int, default=0,
-                    help="split the batch over this many CU-masked streams (lpi_amd/lanes.py); measured -4 %% with two lanes: A/B switch")
-    ap.add_argument("--cu-mode", default="half", choices=["xcd", "half", "block"], help="how the CUs are divided between the lanes")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU with a gloo group (messages staged through the host): exercises the multi-rank path on a 1-GPU box")
     return ap.parse_args()
@@ -184,12 +181,6 @@ class Workload:
         from lpi_amd.optim import FlatSGD, flatten
         self.flat, self.flat_grad, self.grad_views = flatten(self.fac)
         self.opt = FlatSGD(self.fac, lr=0.05, momentum=0.9, weight_decay=2e-4, flat=self.flat, flat_grad=self.flat_grad, grad_views=self.grad_views)
-        self.cu_lanes = None
-        if a.cu_lanes >= 1:
-            from lpi_amd import lanes as _lanes
-            # --cu-lanes 1 (diagnostic): the whole batch on ONE lane that owns half of the chip
-            self._lane_objs = _lanes.make_lane_streams(max(2, a.cu_lanes), a.cu_mode, dev)[:a.cu_lanes]
-            self.cu_lanes = [m.stream for m in self._lane_objs]
         self.overlap = a.overlap
 
     def step(self):
@@ -199,11 +190,10 @@ class Workload:
         if self.fwd_only:
             with torch.no_grad():
                 forward_loss(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange.gather if self.exchange else None,
-                             overlap_towers=self.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes,
-                             lockstep=not a.no_lockstep)
+                             overlap_towers=self.overlap, vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, lockstep=not a.no_lockstep)
         else:
             train_step(self.enc, self.images, self.ids, self.fac, a.depth, self.exchange, overlap_towers=self.overlap,
-                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, cu_lanes=self.cu_lanes, lockstep=not a.no_lockstep,
+                       vision_lanes=a.vision_lanes, text_lanes=a.text_lanes, lockstep=not a.no_lockstep,
                        flat_grad=self.flat_grad, grad_views=self.grad_views)
             self.opt.step()
 
@@ -232,14 +222,13 @@ class Workload:
         from lpi_amd import _lib, engine
         a = self.a
         overlap_saved, self.overlap = self.overlap, False     # time each kernel alone: no second stream sharing the GPU
-        lanes_saved, self.cu_lanes = self.cu_lanes, None
         engine.GEMM_PROFILE = []
         self.step()                                           # instrumented warm-up, discarded
         torch.cuda.synchronize()
         engine.GEMM_PROFILE = []
         for _ in range(nprof):
             self.step()
-        self.overlap, self.cu_lanes = overlap_saved, lanes_saved
+        self.overlap = overlap_saved
         torch.cuda.synchronize()
         ev_raw = engine.GEMM_PROFILE
         engine.GEMM_PROFILE = None
@@ -392,8 +381,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         from lpi_amd.dp import Exchange
         exchange = Exchange(timing=True)
-    if os.environ.get("LPI_MAIN_STREAM") == "side" or a.cu_lanes:
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # CU-masked lanes must not sit beside the (blocking) null stream
+    if os.environ.get("LPI_MAIN_STREAM") == "side":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # A/B: the step on a side stream instead of the (blocking) null stream
 
     def sync():
         if exchange is not None:
@@ -482,7 +471,7 @@ def main():
                        # (packed: every caption cut at its OWN EOT; --no-text-pack: at the longest one; --no-text-trim: all 77)
                        "text_rows_computed": round(wl.text_rows, 2),
                        "text_layout": "77 columns" if a.no_text_trim else ("cut at the longest caption" if a.no_text_pack else "packed (engine.PackedIds)"),
-                       "towers": "one after the other" if (a.no_lockstep or a.overlap or a.cu_lanes) else "lock step, GEMMs of one layer op grouped in one launch",
+                       "towers": "one after the other" if (a.no_lockstep or a.overlap) else "lock step, GEMMs of one layer op grouped in one launch",
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
                        "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
                        "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "

@@ -49,7 +49,7 @@ extern "C" {
 #define LPI_EPI_LN_QUICKGELU 4 /* ... followed by the QuickGELU epilogue (aux as for LPI_EPI_QUICKGELU).  Both: bf16 / f16 operands, shapes the
                                * persistent 256x256 kernel takes (LPI_ENOSYS otherwise: the caller runs LayerNorm + GEMM). */
 
-int lpi_version(void);
+int lpi_version(void);   /* the C-ABI version: changes with every change of a signature or of an argument's meaning (bindings check it) */
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
 uint64_t lpi_launch_count(void);
 
@@ -67,15 +67,14 @@ uint64_t lpi_launch_count(void);
  *              workgroups for launches that would leave the chip half empty; default 160, 0 disables it; same results bit for bit);
  *   key 6      != 0 (default): a 256x256 launch of 256k + rem tiles with rem <= 128 runs those rem tiles as 2*rem tiles of 256x128
  *              inside the same launch — one round of half tiles instead of a half-empty round (bf16; same results bit for bit);
- *   key 7      attention kernel generation for bf16 operands: 0 (default) the persistent LDS-DMA backward of attention2.hip where it is
- *              faster (L > 160), 1 the one-head-per-workgroup kernels of attention.hip everywhere, 2 / 3 force the persistent forward /
- *              backward at every L they take (same results bit for bit), 4 the single-pass backward (non-causal; dQ summed in a
- *              different, still fixed, order).
+ *   key 7      attention backward generation for 2-byte operands: 0 (default) the streamed single-pass kernel of attention4.hip where it
+ *              applies and is faster (non-causal, 160 < L <= 224: the vision tower), the one-head-per-workgroup kernels of attention.hip
+ *              elsewhere; 1 the kernels of attention.hip everywhere; 5 forces attention4.hip at every L it takes (same products, delta
+ *              summed in another order: equal to rounding, not bit for bit).
  *   key 8      != 0: lpi_gemm_nt_grouped never groups (issues its problems one after the other; A/B switch, same bits).
- *   key 9      two-workgroups-per-CU GEMM (gemm_duo.hip: 256x128 tiles, 4 waves of 128x64, 80 KiB of LDS, so that one workgroup's
- *              epilogue runs under the other's main loop): bit mask over the epilogue kinds it is used for where the shape allows —
- *              1 store-only (bias), 2 residual, 4 QuickGELU (+ saved u), 8 gelu'(u); 0 = never.  Same bits as the other GEMM kernels.
- *   keys 10..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
+ *   key 11     > 0: the streamed attention backward launches at most this many workgroups (tests: several heads per workgroup at small B H).
+ *   key 12     A/B switches of the streamed attention backward (bit 0: K / V of the next head as one burst instead of spread over the head).
+ *   keys 9, 10, 13..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */
 
@@ -374,18 +373,8 @@ int lpi_bpe_tokenize(void* handle, const char* const* texts, int n, int context_
 #define LPI_GEMM_K_256_TAIL 2   /* gemm256_tail_kernel: 256x256 tiles, short last round as halves */
 #define LPI_GEMM_K_256X128 3    /* gemm256x128_kernel                                             */
 #define LPI_GEMM_K_SPLITK 4     /* split-K gemm_nt_kernel + splitk_reduce_kernel                  */
-#define LPI_GEMM_K_DUO 5        /* gemm_duo_kernel: 256x128 tiles, two 4-wave workgroups per CU   */
 int lpi_gemm_last_kernel(void);
 
-/* ---- CU-partitioned lanes (speed only) --------------------------------------------------------------------
- * A HIP stream whose kernels run on the CUs whose bits are set in mask[0..words) (hipExtStreamCreateWithCUMask): lpi_amd/step.py
- * runs two half-batch lanes of the train step (sprompt.py:297-311 is a single stream in the reference) on two disjoint halves of
- * the chip so that one lane's HBM-bound kernels overlap the other's matrix-core kernels.  lpi_probe_placement reports, per
- * workgroup b of a `blocks` x `threads` launch holding `lds_bytes` of LDS: out[2b] = HW_REG_XCC_ID, out[2b+1] = HW_REG_HW_ID. */
-int lpi_stream_create_cu_mask(const uint32_t* mask, int words, void** stream_out);
-int lpi_stream_destroy(void* stream);
-int lpi_device_cu_count(void);
-int lpi_probe_placement(int blocks, int threads, int lds_bytes, int spin, uint32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,13 +99,12 @@ SIGNATURES = {
     "lpi_bpe_destroy": [_P],
     "lpi_bpe_encode": [_P, _P, _P, _I],
     "lpi_bpe_tokenize": [_P, _P, _I, _I, _I, _P],
-    # CU-partitioned lanes
-    "lpi_stream_create_cu_mask": [_P, _I, _P],
-    "lpi_stream_destroy": [_P],
-    "lpi_device_cu_count": [],
-    "lpi_probe_placement": [_I, _I, _I, _I, _P, _P],
 }
 _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_destroy": None}
+
+# The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
+# liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
+EXPECTED_ABI = 300
 
 _lib = None
 
@@ -131,6 +130,9 @@ def load() -> ctypes.CDLL:
             raise LpiError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
+    got = int(lib.lpi_version())
+    if got != EXPECTED_ABI:
+        raise LpiError(f"{LIB_PATH} has C-ABI version {got}, this binding expects {EXPECTED_ABI}: rebuild it (lpi_amd/csrc/build.sh)")
     _lib = lib
     # LPI_TUNING="key=value,key=value": speed-only knobs of lpi_set_tuning applied at load (A/B runs of bench.py; never results)
     for kv in filter(None, os.environ.get("LPI_TUNING", "").split(",")):

@@ -802,24 +802,11 @@ inline bool bad_attn(int dtype, int B, int L, int H, int ld) {
 
 }  // namespace
 
-// second generation (attention2.hip): persistent workgroups, LDS-DMA double buffering; bf16 only.  Tuning key 7: 0 = use it where it
-// is faster (default: the backward at L > 160), 1 = first-generation kernels everywhere (A/B and bit-for-bit cross-check),
-// 2 = force the second-generation forward, 3 = force the second-generation backward at every L it takes.
-bool lpi_attn2_fwd_ok(int L);
-bool lpi_attn2_bwd_ok(int L);
-int lpi_attn2_fwd(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, int causal, hipStream_t s);
-int lpi_attn2_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                  const float* lse, float* delta, void* dqkv, int lddqkv, int causal, hipStream_t s, int saved_f16, int rows_hi);
-// fourth generation (attention4.hip): ONE pass, 4 fat waves, query slices streamed through an LDS ring; non-causal, L <= 224; the default
-// for L > 160 (key 7 = 0), forced at every L it takes by key 7 = 5
+// attention4.hip: the backward as ONE pass, 8 waves owning 16-32 keys each, query slices streamed through an LDS ring; non-causal, L <= 224;
+// the default for L > 160 (tuning key 7 = 0), forced at every L it takes by key 7 = 5, never with key 7 = 1
 bool lpi_attn4_bwd_ok(int L, int causal);
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
                   float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi);
-// third generation: ONE pass per head (dK, dV and dQ from one evaluation of S, P, dP, dS; opt-in, key 7 = 4)
-bool lpi_attn3_bwd_ok(int L, int causal);
-int lpi_attn3_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                  const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16);
-
 extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                                    float* lse, int causal, void* stream) {
     const int* rs = row_start;      // ragged batch: the one-head-per-workgroup kernels take a per-sample length
@@ -831,10 +818,8 @@ extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_s
     if (dtype == LPI_F16)       // f16 operand mode: q, k, v and ctx are fp16 (the reference's own arithmetic type)
         return causal ? fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<f16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     if (dtype == LPI_BF16) {
-        // measured (MI355X, B = 256): the persistent forward is SLOWER than two one-head workgroups per CU (112.7 vs 102.5 us at L = 213:
-        // the forward is bound by dependent-chain latency at low occupancy, and 14 waves per CU hide more of it than 7 with DMA
-        // double buffering), so it is opt-in (key 7 = 2)
-        if (!rs && g_lpi_tuning[7] == 2 && lpi_attn2_fwd_ok(L)) return lpi_attn2_fwd(B, L, H, qkv, ldqkv, ctx, ldctx, lse, causal, s);
+        // (a persistent forward with K / V double-buffered by LDS-DMA measured SLOWER than two one-head workgroups per CU — 112.7 vs
+        // 102.5 us at L = 213 —: tools/probe/attention2.hip, profiles/r02_gemm_experiments.md)
         return causal ? fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     }
     return LPI_EINVAL;
@@ -879,7 +864,7 @@ extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* st
         if (!d[i].qkv || !d[i].ctx || !d[i].lse || bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv) || d[i].ldctx < d[i].H * HD || (d[i].ldctx & 7)) return LPI_EINVAL;
         if (((uintptr_t)d[i].qkv | (uintptr_t)d[i].ctx) & 15) return LPI_EINVAL;
     }
-    if (dtype == LPI_BF16 && g_lpi_tuning[7] != 2) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
+    if (dtype == LPI_BF16) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
     if (dtype == LPI_F16) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
     for (int i = 0; i < 2; ++i)
         if (int e = lpi_attn_fwd_varlen(dtype, d[i].B, d[i].L, d[i].row_start, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, d[i].causal, stream))
@@ -902,28 +887,18 @@ extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_s
         return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     if (dtype == LPI_F16) {     // saved qkv / ctx are fp16 (f16-mode forward); dctx and dqkv are bf16, and so are the MFMA operands:
-                                // q, k, v are converted on their way into LDS / registers, or in place after the LDS-DMA (persistent kernel)
+                                // q, k, v are converted on their way into LDS / registers (attention4.hip: in registers after the LDS read)
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1, rows_hi);
-        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
-            return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 1);
-        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 1, rows_hi);
         return causal ? bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
                       : bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     }
     if (dtype == LPI_BF16) {
-        // the persistent backward wins where a head's four images fill a CU's LDS (one workgroup per CU either way: 255.7 vs 281.9 us
-        // at L = 213); at short L several one-head workgroups per CU are faster (34.5 vs 37.2 us at L = 59): key 7 = 3 forces it
-        // the single-pass kernel is opt-in (key 7 = 4): 29 % fewer MFMAs and half the exponentials buy nothing (244.7 vs 243.1 us at L = 213,
-        // B = 256) — at 7 waves per CU the backward is bound by the latency of its dependent chain (LDS read -> MFMA -> exp -> LDS -> MFMA),
-        // not by matrix or vector issue
+        // the streamed single-pass backward where a head's matrices would fill a CU's LDS (L = 213: 165-175 us against 271 us for the fused
+        // kernel below and 228 us for the two-phase persistent one, tools/probe/attention2.hip); at short L several one-head workgroups
+        // per CU are faster
         if (!rs && g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, causal) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
             return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0, rows_hi);
-        if (!rs && rows_hi >= L && g_lpi_tuning[3] == 0 && lpi_attn3_bwd_ok(L, causal) && g_lpi_tuning[7] == 4)
-            return lpi_attn3_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, 0);
-        if (!rs && g_lpi_tuning[3] == 0 && lpi_attn2_bwd_ok(L) && (g_lpi_tuning[7] == 3 || (g_lpi_tuning[7] == 0 && L > 160)))
-            return lpi_attn2_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, s, 0, rows_hi);
         return causal ? bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
                       : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);
     }

@@ -395,9 +395,6 @@ extern "C" int lpi_gemm_nt_splitk_pair(int dtype, int c_dtype, int epilogue, flo
 bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
 int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                         const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
-bool lpi_gemm_duo_eligible(int dtype, int M, int N, int K);
-int lpi_gemm_duo_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
 int lpi_gemm256_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                        const float* bias, const float* residual, int ldr, int epilogue, void* aux, int ldaux, float alpha, hipStream_t s);
 bool lpi_gemm256x128_eligible(int dtype, int M, int N, int K);
@@ -444,14 +441,6 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) {      // only the persistent 256x256 kernel has the LN-fold epilogues
         if (!lpi_gemm256_eligible(dtype, M, N, K)) return LPI_ENOSYS;
         return lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
-    }
-    // two workgroups per CU (gemm_duo.hip) for the epilogue kinds selected by tuning key 9
-    if (g_lpi_tuning[9] != 0 && lpi_gemm_duo_eligible(dtype, M, N, K) && (M / 256) * (N / 128) >= 512) {
-        const int kind = epilogue == LPI_EPI_QUICKGELU ? 4 : epilogue == LPI_EPI_DQUICKGELU ? 8 : residual ? 2 : 1;
-        if (g_lpi_tuning[9] & kind) {
-            const int rc = lpi_gemm_duo_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
-            if (rc != LPI_ENOSYS) return rc;
-        }
     }
     // Half-empty launches: fewer than tuning key 5 (default 160) 256x256 tiles -> 256x128 tiles, twice the workgroups (bf16 only:
     // the f32 path is MFMA-bound at any tile size).  Key 5 = 0 disables it.

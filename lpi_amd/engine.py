@@ -639,7 +639,7 @@ class DualEncoder:
     def lane(self, i: int, stream=None):
         """Lane i > 0: an engine that SHARES the frozen weights but owns its workspace arena and HIP stream, so that
         micro-batches can be in flight concurrently (step.py); lane 0 is this engine on the caller's stream.
-        stream: use this torch stream (e.g. a CU-masked one, lanes.py) instead of creating a plain one."""
+        stream: use this torch stream instead of creating a plain one."""
         if i == 0:
             return self
         lanes = self.__dict__.setdefault("_lanes", {})

@@ -16,35 +16,12 @@ _CP_ORDER = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "di
 
 
 def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, align_weight: float = 0.1, overlap_towers: bool = False,
-                 vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, exchange=None, grad_out=None, losses=True):
+                 vision_lanes: int = 1, text_lanes: int = 1, lockstep: bool = True, exchange=None, grad_out=None, losses=True):
     """factors: the five DecomposedPrompt parameters (device tensors, requires_grad as wanted).
     Returns (losses dict of 0-d tensors, img_f, txt_f, vis, txt, logits).
-
-    cu_lanes: a list of n CU-masked torch streams (lanes.make_lane_streams): the batch is cut into n contiguous parts and part k
-    runs both towers on lane k's share of the chip (even lanes vision first, odd lanes text first, so that the lanes are out of phase)."""
+"""
     vis, txt = DecomposedPromptFn.apply(*[factors[k] for k in _CP_ORDER], 1.0, grad_out)
-    if cu_lanes:
-        main = torch.cuda.current_stream()
-        B, n = images.shape[0], len(cu_lanes)
-        if B % n:
-            raise ValueError("batch must divide by the number of lanes")
-        fi, ft = [None] * n, [None] * n
-        for k, st in enumerate(cu_lanes):
-            eng = enc.lane(k + 1, stream=st)
-            sl = slice(k * (B // n), (k + 1) * (B // n))
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                for kind in (("v", "t") if k % 2 == 0 else ("t", "v")):
-                    if kind == "v":
-                        fi[k] = EncodeImageFn.apply(eng, images[sl], vis, depth)
-                    else:
-                        ft[k] = EncodeTextFn.apply(eng, ids[sl], txt, depth)
-            fi[k].record_stream(main)
-            ft[k].record_stream(main)
-        for st in cu_lanes:
-            main.wait_stream(st)
-        img_f, txt_f = torch.cat(fi), torch.cat(ft)
-    elif overlap_towers:
+    if overlap_towers:
         # The towers are independent until the similarity matrix, and so are micro-batches of one tower: each (tower, micro-batch)
         # "lane" runs on its own HIP stream with its own workspace.  One lane's HBM-bound kernels (LayerNorm, attention, GEMM
         # epilogues) then overlap another lane's MFMA-bound GEMM main loops, and lanes fill each other's partial last round of
@@ -85,7 +62,7 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
 
 
 def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = False,
-               vision_lanes: int = 1, text_lanes: int = 1, cu_lanes=None, lockstep: bool = True, flat_grad=None, grad_views=None):
+               vision_lanes: int = 1, text_lanes: int = 1, lockstep: bool = True, flat_grad=None, grad_views=None):
     """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
 
     exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
@@ -101,7 +78,7 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     gather = exchange.gather if exchange is not None else None
     gv = None if grad_views is None else [grad_views[list(factors).index(k)] for k in _CP_ORDER]
     _, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
-                                             cu_lanes, lockstep, exchange, grad_out=gv, losses=False)
+                                             lockstep, exchange, grad_out=gv, losses=False)
     world = exchange.world if exchange is not None else 1
     w_base = float(getattr(exchange, "loss_weight", 1.0))
     with torch.no_grad():

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()
     for s in header_symbols():
         assert hasattr(lib, s), s
-    assert lib.lpi_version() >= 100
+    assert lib.lpi_version() == _lib.EXPECTED_ABI          # a stale build must not load (load() raises on a mismatch)
     assert _lib.launch_count() >= 0
 
 

@@ -1066,33 +1066,6 @@ def test_copy_rows_and_score_matrix():
     assert torch.equal(s_t2i, s_i2t.t().contiguous())
 
 
-@pytest.mark.parametrize("B,L,H,causal", [(24, 213, 12, 0), (40, 59, 8, 1), (3, 77, 8, 1), (2, 21, 2, 0), (5, 33, 3, 1), (2, 224, 2, 0), (300, 64, 4, 0)])
-def test_attention_second_generation_equals_first_bit_for_bit(B, L, H, causal):
-    """attention2.hip (persistent workgroups, LDS-DMA double buffering, swizzled 128-byte LDS rows) keeps attention.hip's tile
-    arithmetic and summation order: same bits, forward and backward, incl. workgroups that walk several heads (B*H > workgroups)
-    and heads whose padded rows [L, Lp) sit in images that earlier heads used."""
-    d = H * 64
-    qkv = rnd(B * L, 3 * d, seed=41).to(torch.bfloat16).to(DEV)
-    dctx = rnd(B * L, d, seed=42).to(torch.bfloat16).to(DEV)
-    out = {}
-    try:
-        for gen in (1, 0):
-            ctx = torch.full((B * L, d), 3.0, device=DEV, dtype=torch.bfloat16)
-            lse = torch.zeros(B, H, L, device=DEV)
-            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
-            delta = torch.zeros(B, H, L, device=DEV)
-            call("lpi_set_tuning", 7, 1 if gen else 2)          # 2: the persistent forward
-            call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, causal, stream())
-            call("lpi_set_tuning", 7, 1 if gen else 3)          # 3: the persistent backward at every L
-            call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, stream())
-            torch.cuda.synchronize()
-            out[gen] = (ctx, lse, dqkv, delta)
-    finally:
-        call("lpi_set_tuning", 7, 0)
-    for a, b, name in zip(out[1], out[0], ("ctx", "lse", "dqkv", "delta")):
-        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
-
-
 @pytest.mark.parametrize("tm,N,K", [(3, 512, 128), (40, 2048, 512), (43, 1536, 512), (213, 768, 768), (100, 768, 256), (30, 3072, 768)])
 def test_gemm_persistent_equals_one_tile_per_workgroup(tm, N, K):
     """gemm256p.hip (a workgroup per CU walks its tiles; the next tile's K-tile 0 lands under a 4-pass epilogue) vs gemm256.hip
@@ -1233,70 +1206,6 @@ def test_layernorm_f16_output_and_pooled_attention_f16():
     call("lpi_attn_pooled_bwd", F16, B, L, H, q_rows, dd, qkv.to(DEV), 3 * dd, idx.to(DEV), dctx_rows.to(DEV), dd, lse, dq, dd, dqkv, 3 * dd, 1, stream())
     assert relerr(dq, qr.grad[rws, :dd]) < 4e-2
     assert relerr(dqkv[:, dd:2 * dd], qr.grad[:, dd:2 * dd]) < 4e-2 and relerr(dqkv[:, 2 * dd:], qr.grad[:, 2 * dd:]) < 4e-2
-
-
-@pytest.mark.parametrize("B,L,H,causal", [(24, 213, 12, 0), (5, 59, 8, 1)])
-def test_attention_backward_generations_agree_for_f16_saved_tensors(B, L, H, causal):
-    """f16 mode's backward: the persistent kernel (LDS-DMA, images converted fp16 -> bf16 in place) == the first-generation kernel
-    (converted on the way into LDS), bit for bit."""
-    d = H * 64
-    qkv = rnd(B * L, 3 * d, seed=41).half().to(DEV)
-    dctx = rnd(B * L, d, seed=42).bfloat16().to(DEV)
-    ctx = torch.zeros(B * L, d, device=DEV, dtype=torch.float16)
-    lse = torch.zeros(B, H, L, device=DEV)
-    call("lpi_attn_fwd", F16, B, L, H, qkv, 3 * d, ctx, d, lse, causal, stream())
-    out = {}
-    try:
-        for gen in (1, 3):
-            call("lpi_set_tuning", 7, gen)
-            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
-            delta = torch.zeros(B, H, L, device=DEV)
-            call("lpi_attn_bwd", F16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, stream())
-            torch.cuda.synchronize()
-            out[gen] = (dqkv, delta)
-    finally:
-        call("lpi_set_tuning", 7, 0)
-    for a, b, name in zip(out[1], out[3], ("dqkv", "delta")):
-        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
-
-
-@pytest.mark.parametrize("saved", ["bf16", "f16"])
-@pytest.mark.parametrize("B,L,H", [(2, 213, 3), (24, 213, 12), (3, 197, 2), (2, 224, 2), (5, 64, 4), (40, 33, 3)])
-def test_attention_single_pass_backward(saved, B, L, H):
-    """attention2.hip's third-generation backward (one pass: dK, dV and — through a per-wave LDS transpose of dS — dQ, contributions
-    added in a fixed order) against f64 autograd, against the two-phase kernels (same operands; dQ's summation order differs, so close
-    rather than equal), and bitwise equal to itself across runs."""
-    d = H * 64
-    tq = torch.float16 if saved == "f16" else torch.bfloat16
-    dt = F16 if saved == "f16" else BF16
-    qkv = rnd(B * L, 3 * d, seed=51).to(tq)
-    dctx = rnd(B * L, d, seed=52).bfloat16().to(DEV)
-    qd = qkv.to(DEV)
-    ctx = torch.zeros(B * L, d, device=DEV, dtype=tq)
-    lse = torch.zeros(B, H, L, device=DEV)
-    call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, 0, stream())
-    qr = qkv.double().requires_grad_(True)
-    oref, _ = attn_ref(qr, B, L, H, 0)
-    oref.backward(dctx.double().cpu())
-    out = {}
-    try:
-        for gen in (1, 4, 4):
-            call("lpi_set_tuning", 7, gen)
-            dqkv = torch.full((B * L, 3 * d), 5.0, device=DEV, dtype=torch.bfloat16)
-            delta = torch.zeros(B, H, L, device=DEV)
-            call("lpi_attn_bwd", dt, B, L, H, qd, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, stream())
-            torch.cuda.synchronize()
-            out.setdefault(gen, []).append((dqkv, delta))
-    finally:
-        call("lpi_set_tuning", 7, 0)
-    new, new2, old = out[4][0], out[4][1], out[1][0]
-    assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
-    assert torch.equal(new[1], old[1])                                             # delta: same arithmetic
-    assert relerr(new[0][:, d:], old[0][:, d:].double().cpu()) < 2e-2              # dK, dV: same products, query tiles summed in a rotated order
-    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
-        e = relerr(new[0][:, sl], qr.grad[:, sl])
-        assert e < 4e-2, (name, e)
-    assert relerr(new[0][:, :d], old[0][:, :d].double().cpu()) < 2e-2
 
 
 @pytest.mark.parametrize("W,B,E_", [(4, 64, 128), (2, 3, 128), (8, 128, 512)])
@@ -1460,7 +1369,7 @@ def test_attention_forward_pair_launch_equals_two_launches(dt):
 def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     """attention4.hip (one pass over the scores; 8 waves own 16-32 keys each; Q / dO / O stream through an LDS ring in 32-query slices,
     across head boundaries; dS^T crosses LDS once and every wave contracts it over ALL keys for its piece of dQ) against f64 autograd,
-    close to the two-phase kernels (same products; delta is summed in another order), bitwise equal to itself across runs, and — with the
+    close to the kernels of attention.hip (same products; delta is summed in another order), bitwise equal to itself across runs, and — with the
     grid capped (tuning key 11) — with several heads per workgroup, i.e. the ring running across head seams and padded rows landing in
     slots earlier slices used.  replaces: the backward of nn.MultiheadAttention (retrieval/models/clip/model.py:183-185)."""
     d = H * 64
@@ -1478,7 +1387,7 @@ def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     out = {}
     try:
         call("lpi_set_tuning", 11, cap)
-        for gen in (3, 5, 5):
+        for gen in (1, 5, 5):       # 1: the one-head-per-workgroup kernels of attention.hip
             call("lpi_set_tuning", 7, gen)
             dqkv = torch.full((B * L, 3 * d), float("nan"), device=DEV, dtype=torch.bfloat16)
             delta = torch.zeros(B, H, L, device=DEV)
@@ -1488,7 +1397,7 @@ def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     finally:
         call("lpi_set_tuning", 7, 0)
         call("lpi_set_tuning", 11, 0)
-    new, new2, old = out[5][0], out[5][1], out[3][0]
+    new, new2, old = out[5][0], out[5][1], out[1][0]
     assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
     assert bool(torch.isfinite(new[0].float()).all())
     dref = (dctx.double().cpu() * ctx.double().cpu()).reshape(B, L, H, 64).sum(-1).permute(0, 2, 1)

@@ -1,7 +1,7 @@
 """Register-spill guard for the kernels whose LDS-DMA pipelines a spill breaks (CPU test on the built objects, no GPU).
 
 A scratch reload is a vector-memory operation followed by a compiler-inserted `s_waitcnt vmcnt(0)`: in the persistent GEMM and in the
-persistent attention backward that wait drains the in-flight LDS-DMA of the next tile / head.  The allocation is
+streamed attention backward that wait drains the in-flight LDS-DMA of the next tile / of the slice ring.  The allocation is
 fragile — removing one unused word from the kernel-argument struct once made the QuickGELU instantiations of the GEMM spill 56 bytes per
 lane — so the build's own metadata is checked: `.private_segment_fixed_size` of every such kernel must be 0."""
 import os
@@ -42,9 +42,10 @@ def test_persistent_gemm_instantiations_do_not_spill(tmp_path):
     assert {k: v for k, v in ks.items() if v} == {}
 
 
-def test_persistent_attention_backward_of_the_vision_tower_does_not_spill(tmp_path):
-    ks = _kernel_scratch("attention2.o", tmp_path)
-    # attn_bwd2_kernel<CAUSAL = false, SV16, OIMG = true>: the vision tower's backward in bf16 and f16 mode
-    vision = {k: v for k, v in ks.items() if re.search(r"attn_bwd2_kernelILb0ELb[01]ELb1E", k)}
+def test_streamed_attention_backward_of_the_vision_tower_does_not_spill(tmp_path):
+    ks = _kernel_scratch("attention4.o", tmp_path)
+    # attn_bwd4_kernel<SV16, NKB = 7>: the vision tower's backward (Lp = 224) in bf16 and f16 mode — a scratch reload's vmcnt(0) would drain
+    # the ring's LDS-DMA every iteration
+    vision = {k: v for k, v in ks.items() if re.search(r"attn_bwd4_kernelILb[01]ELi7E", k)}
     assert len(vision) == 2, sorted(ks)
     assert all(v == 0 for v in vision.values()), vision

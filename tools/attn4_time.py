@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the vision attention backward (B 256, L 213, H 12, bf16) of the library named by LPI_LIB: tuning key 7 values from argv (default 3 5)."""
+"""Time the vision attention backward (B 256, L 213, H 12, bf16) of the library named by LPI_LIB: tuning key 7 values from argv (default 1 5)."""
 import os
 import sys
 
@@ -19,7 +19,7 @@ dqkv = torch.zeros(B * L, 3 * d, device=dev, dtype=torch.bfloat16)
 lse = torch.zeros(B, H, L, device=dev)
 delta = torch.zeros(B, H, L, device=dev)
 call("lpi_attn_fwd", BF16, B, L, H, qkv, 3 * d, ctx, d, lse, 0, s())
-keys = [a for a in sys.argv[1:]] or ["3", "5"]
+keys = [a for a in sys.argv[1:]] or ["1", "5"]
 fn = lambda: call("lpi_attn_bwd", BF16, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, 0, s())  # noqa: E731
 times = {k: [] for k in keys}
 for rnd in range(9):          # configurations interleaved, so that clock / box drift hits them alike

@@ -24,7 +24,7 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
     bwd = lambda: call("lpi_attn_bwd", dt, B, L, H, qkv, 3 * d, ctx, d, dctx, d, lse, delta, dqkv, 3 * d, causal, s())  # noqa: E731
     out = []
     for fn, fl, key3, key7 in ((fwd, 4.0 * L * L * 64 * H * B, 0, 1), (bwd, 8.0 * L * L * 64 * H * B, 0, 1), (bwd, 8.0 * L * L * 64 * H * B, 1, 1),
-                               (fwd, 4.0 * L * L * 64 * H * B, 0, 2), (bwd, 8.0 * L * L * 64 * H * B, 0, 3), (bwd, 8.0 * L * L * 64 * H * B, 0, 4)):
+                               (bwd, 8.0 * L * L * 64 * H * B, 0, 0)):
         call("lpi_set_tuning", 3, key3)
         call("lpi_set_tuning", 7, key7)
         best = 1e9
@@ -40,5 +40,5 @@ for name, B, L, H, causal in (("vision", 256, 213, 12, 0), ("text", 256, 77, 8, 
         out.append(f"{best:7.1f} us {fl / best / 1e6:6.1f} TF")
     call("lpi_set_tuning", 3, 0)
     call("lpi_set_tuning", 7, 0)
-    print(f"{name:7s} L={L:3d} gen1: fwd {out[0]} | bwd fused {out[1]} | bwd two-pass {out[2]}  (dense algorithmic FLOPs)")
-    print(f"{name:7s} L={L:3d} gen2: fwd {out[3]} | bwd {out[4]} | gen3 (single pass, non-causal only) bwd {out[5]}")
+    print(f"{name:7s} L={L:3d} attention.hip: fwd {out[0]} | bwd fused {out[1]} | bwd two-pass {out[2]}  (dense algorithmic FLOPs)")
+    print(f"{name:7s} L={L:3d} default dispatch (the streamed single-pass backward of attention4.hip where it applies): bwd {out[3]}")

@@ -6,10 +6,10 @@ cd "$(dirname "$0")/../lpi_amd/csrc"
 suffix=$1; srcs=",$2,"; shift 2
 mkdir -p build_var
 objs=""
-for f in api gemm gemm256 gemm256p gemm256x128 gemm_duo attention attention2 attention4 attn_pooled rowops loss bpe; do
+for f in api gemm gemm256 gemm256p gemm256x128 attention attention4 attn_pooled rowops loss bpe; do
   if [[ "$srcs" == *",$f,"* ]]; then
     extra=""
-    case $f in attention|attention2|attention4) extra="-fno-honor-nans";; esac
+    case $f in attention|attention4) extra="-fno-honor-nans";; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-unused-variable $extra "$@" -c $f.hip -o build_var/${f}_$suffix.o &
     objs="$objs build_var/${f}_$suffix.o"
   else
