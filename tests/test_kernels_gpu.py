@@ -746,52 +746,6 @@ def test_gemm_grouped_f16_operands_and_fallback():
     assert relerr(small[1]["c"], small[1]["a"].double().cpu() @ small[1]["b"].double().cpu().t()) < TOL[BF16]
 
 
-@pytest.mark.parametrize("tm,N,K", [(70, 1024, 512), (40, 2304, 768), (130, 512, 128), (100, 768, 1024)])
-def test_gemm_two_workgroups_per_cu_kernel_equals_the_default_kernels(tm, N, K):
-    """gemm_duo.hip (tuning key 9: 256x128 tiles, two 4-wave workgroups per CU) gives the bits of the default kernels for every epilogue
-    kind, bf16 and f16 operands; and is correct against f64."""
-    M = tm * 256
-    outs = {}
-    for tag, dt, tdt in (("bf16", BF16, torch.bfloat16), ("f16", F16, torch.float16)):
-        a = rnd(M, K, seed=1).to(tdt).to(DEV)
-        b = rnd(N, K, seed=2, scale=0.05).to(tdt).to(DEV)
-        bias = rnd(N, seed=3).to(DEV)
-        res16 = (rnd(M, N, seed=4) * 4).half().to(DEV)
-        u0 = rnd(M, N, seed=5).bfloat16().to(DEV)
-
-        def run_all():
-            out = {}
-            c = torch.zeros(M, N, device=DEV, dtype=tdt)
-            E.gemm(dt, a, b, c, M, N, K, bias=bias, alpha=0.5)
-            out["plain"] = c
-            c = torch.zeros(M, N, device=DEV, dtype=torch.float32)
-            E.gemm(dt, a, b, c, M, N, K, bias=bias)
-            out["f32out"] = c
-            c = torch.zeros(M, N, device=DEV, dtype=torch.float16)
-            E.gemm(dt, a, b, c, M, N, K, bias=bias, residual=res16)
-            out["f16res"] = c
-            g, u = torch.zeros(M, N, device=DEV, dtype=tdt), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16 if dt == F16 else tdt)
-            E.gemm(dt, a, b, g, M, N, K, bias=bias, epi=E.EPI_QUICKGELU, aux=u)
-            out["gelu"], out["u"] = g, u
-            if dt == BF16:
-                du = torch.zeros(M, N, device=DEV, dtype=tdt)
-                E.gemm(dt, a, b, du, M, N, K, epi=E.EPI_DQUICKGELU, aux=u0)
-                out["dgelu"] = du
-            torch.cuda.synchronize()
-            return out
-        old = run_all()
-        call("lpi_set_tuning", 9, 15)
-        try:
-            new = run_all()
-            assert _lib.load().lpi_gemm_last_kernel() == 5          # LPI_GEMM_K_DUO
-        finally:
-            call("lpi_set_tuning", 9, 0)
-        for k in new:
-            assert torch.equal(new[k], old[k]), (tag, k)
-        ab = a.double().cpu() @ b.double().cpu().t()
-        assert relerr(new["plain"], 0.5 * ab + bias.double().cpu()) < (TOL[BF16] if dt == BF16 else 2e-3)
-
-
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
 @pytest.mark.parametrize("B,L,H,causal,ragged", [(2, 213, 3, 0, False), (4, 59, 2, 1, True), (3, 77, 2, 1, False), (2, 197, 1, 0, False)])
 def test_attention_backward_of_a_row_prefix(dt, B, L, H, causal, ragged):
