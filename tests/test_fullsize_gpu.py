@@ -184,7 +184,9 @@ def test_vit_l14_bf16_mode_close_to_oracle():
     cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
     for k in synth.PROMPT_NAMES:
         c = cos(fac[k].grad.double().cpu().numpy(), ref["grad." + k].astype(np.float64))
-        assert c >= 0.98, (k, c)
+        rel = float(np.abs(fac[k].grad.double().cpu().numpy() - ref["grad." + k]).max() / np.abs(ref["grad." + k]).max())
+        print("ViT-L/14 bf16 vs the f32 oracle", k, "cosine", round(c, 5), "max relative error", round(rel, 4))
+        assert c >= 0.998 and rel <= 8e-2, (k, c, rel)       # measured >= 0.99900 / <= 4.7e-2
     del enc
     torch.cuda.empty_cache()
 
@@ -239,8 +241,8 @@ def test_throughput_modes_train_step_at_the_benchmarked_configuration(enc32, dat
     for k in synth.PROMPT_NAMES:
         a, b = fb[k].grad.double().cpu(), f32[k].grad.double().cpu()
         report[k] = (cos(a, b), float((a - b).abs().max() / b.abs().max()))
-        assert report[k][0] >= 0.99, (k, report[k])
-        assert report[k][1] <= 0.15, (k, report[k])
+        assert report[k][0] >= 0.9995, (k, report[k])        # measured >= 0.99994
+        assert report[k][1] <= 0.03, (k, report[k])          # measured <= 1.5e-2 (bf16), <= 1.1e-2 (f16) at B = 256, depth 3
     print(f"{mode} vs f32 factor gradients (cosine, max rel err):", {k: (round(c, 5), round(r, 4)) for k, (c, r) in report.items()})
     for k, tol in (("base_loss", ltol_rel), ("alignment_loss", 1e-5)):
         assert abs(float(ob[k]) - float(o32[k])) <= tol * max(1.0, abs(float(o32[k]))), (k, float(ob[k]), float(o32[k]))

@@ -40,7 +40,13 @@ def maxerr(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
 
 
-def check(res, ref, tol, gtol, gabs=0.0):
+def relmax(a, b):
+    """max |a - b| / max |b|: the bar for gradients — the factor gradients of the synthetic-weight fixtures are 6e-4 .. 1.5e-2 in magnitude, so an
+    absolute 1e-4 (north_star's figure) would let a 17 % error pass."""
+    return maxerr(a, b) / (float(np.abs(np.asarray(b, dtype=np.float64)).max()) + 1e-30)
+
+
+def check(res, ref, tol, gtol, gabs=1e-7):
     for k in ("img_f", "txt_f", "logits", "base_loss", "alignment_loss"):
         assert maxerr(res[k], ref[k]) <= tol, (k, maxerr(res[k], ref[k]))
     for k in ("vis_prompt", "txt_prompt"):
@@ -49,7 +55,7 @@ def check(res, ref, tol, gtol, gabs=0.0):
     for k in GRADS:
         e = maxerr(res[k], ref[k])
         scale = np.abs(ref[k]).max()
-        assert e <= max(gtol * scale, gabs), (k, e, scale)
+        assert e <= gtol * scale + gabs, (k, e, scale)      # RELATIVE (+ a floor of 1e-7 for exact zeros)
 
 
 @pytest.mark.parametrize("name,depth", [("tiny_d1", 1), ("tiny_d2_patched", 2)])
@@ -57,10 +63,10 @@ def test_tiny_f32_vs_golden_and_oracle(golden, name, depth):
     cfg = synth.TINY
     g = golden(name)
     res, fac_np = run_hip(cfg, "f32", 4, g["token_ids"], depth)
-    check(res, g, tol=1e-4, gtol=1e-3, gabs=1e-4)          # vs the reference's own outputs
+    check(res, g, tol=1e-4, gtol=1e-3)                     # vs the reference's own outputs (measured <= 2e-5 relative)
     orc = O.Oracle(cfg, synth.clip_state_dict(cfg), torch.float64)
     ref = O.train_step(orc, synth.images(4, 32), g["token_ids"], fac_np, depth=depth)
-    check(res, ref, tol=2e-5, gtol=2e-4, gabs=1e-6)        # vs the fp64 oracle: f32 round-off only
+    check(res, ref, tol=2e-5, gtol=2e-4)                   # vs the fp64 oracle: f32 round-off only
 
 
 @pytest.mark.parametrize("name,depth", [("vitb16_d1", 1), ("vitb16_d3_patched", 3)])
@@ -69,7 +75,7 @@ def test_vitb16_f32_vs_golden(golden, name, depth):
     cfg = synth.VIT_B16
     g = golden(name)
     res, _ = run_hip(cfg, "f32", 8, g["token_ids"], depth)
-    check(res, g, tol=1e-4, gtol=5e-3, gabs=1e-4)
+    check(res, g, tol=1e-4, gtol=1e-3)                     # measured 1.4e-5 relative
     # top-k index parity wherever the reference's recorded margin dominates the measured logit error
     err = maxerr(res["logits"], g["logits"])
     for tag, S in (("i2t", res["logits"]), ("t2i", res["logits"].T)):
@@ -98,8 +104,10 @@ def test_vitb16_bf16_close_to_golden(golden):
         assert maxerr(res[k], g[k]) < 2e-2, (k, maxerr(res[k], g[k]))
     assert maxerr(res["logits"], g["logits"]) < 0.3
     cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+    print("bf16 vs the reference fixture, factor gradients (cosine, max relative error):", {k: (round(cos(res[k], g[k]), 5), round(relmax(res[k], g[k]), 4)) for k in GRADS})
     for k in GRADS:
-        assert cos(res[k], g[k]) > 0.99, (k, cos(res[k], g[k]))
+        assert cos(res[k], g[k]) > 0.998, (k, cos(res[k], g[k]))                # measured >= 0.99929
+        assert relmax(res[k], g[k]) <= 8e-2, (k, relmax(res[k], g[k]))          # measured <= 5.2e-2 (dim_1_share; the others <= 3.7e-2) at bs = 8
 
 
 def test_eval_interfaces_f32(golden):
@@ -261,6 +269,8 @@ def test_bf16_mode_fp16_residual_stream_vs_f32_stream(monkeypatch):
         a, b, r = (np.asarray(v, dtype=np.float64).ravel() for v in (res[True][k], res[False][k], ref[k]))
         assert a @ r / (np.linalg.norm(a) * np.linalg.norm(r)) >= 0.99, k
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) >= 0.995, k
+        print("fp16 vs f32 residual stream", k, "max relative error vs f64:", round(relmax(a, r), 4), round(relmax(b, r), 4))
+        assert relmax(a, r) <= 5e-2 and relmax(b, r) <= 5e-2, (k, relmax(a, r), relmax(b, r))
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 1e-3)])
@@ -302,7 +312,7 @@ def test_packed_text_batch_vs_reference_fixture(golden, name, depth):
     """The reference's own outputs (fixtures) reached through the packed text path, f32 parity bars."""
     g = golden(name)
     res, _ = run_hip(synth.TINY, "f32", 4, g["token_ids"], depth, pack=True)
-    check(res, g, tol=1e-4, gtol=1e-3, gabs=1e-4)
+    check(res, g, tol=1e-4, gtol=1e-3)
 
 
 def test_vitb16_fixture_through_the_f32_256x256_kernel(golden):
@@ -317,7 +327,7 @@ def test_vitb16_fixture_through_the_f32_256x256_kernel(golden):
         assert _lib.load().lpi_gemm_last_kernel() >= 0
     finally:
         _lib.call("lpi_set_tuning", 1, 1500)
-    check(res, g, tol=1e-4, gtol=5e-3, gabs=1e-4)
+    check(res, g, tol=1e-4, gtol=1e-3)
     res_default, _ = run_hip(cfg, "f32", 8, g["token_ids"], 3)
     assert maxerr(res["logits"], res_default["logits"]) < 2e-5          # the two kernels differ by f32 summation order only
 
@@ -388,8 +398,10 @@ def test_f16_operand_mode_is_several_times_closer_to_the_reference_than_bf16(gol
     assert eh < eb / 2.5 and lh < lb / 2.5
     assert abs(float(rh["base_loss"]) - float(g["base_loss"])) < 2e-3
     cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+    print("f16 mode vs the reference fixture, factor gradients (cosine, max relative error):", {k: (round(cos(rh[k], g[k]), 5), round(relmax(rh[k], g[k]), 4)) for k in GRADS})
     for k in GRADS:
-        assert cos(rh[k], g[k]) > 0.995, (k, cos(rh[k], g[k]))
+        assert cos(rh[k], g[k]) > 0.999, (k, cos(rh[k], g[k]))                  # measured >= 0.99976
+        assert relmax(rh[k], g[k]) <= 5e-2, (k, relmax(rh[k], g[k]))            # measured <= 3.0e-2
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
