@@ -356,9 +356,10 @@ def test_prompt_cp_fwd_bwd():
     assert relerr(g1, 2 * a.grad) < 1e-5
 
 
-@pytest.mark.parametrize("n", [1, 4, 8, 256, 300, 2048])
-def test_clip_loss(n):
-    Ed = 512
+@pytest.mark.parametrize("n,Ed", [(1, 512), (4, 512), (8, 512), (256, 512), (300, 512), (2048, 512), (4096, 768)])
+def test_clip_loss(n, Ed):
+    """(2048, 512): the global matrix of BASELINE configs[3] (8 ranks x 256 pairs); (4096, 768): that of configs[4] (ViT-L/14, global batch
+    4096, embed 768)."""
     i = torch.nn.functional.normalize(rnd(n, Ed, seed=1), dim=-1)
     t = torch.nn.functional.normalize(rnd(n, Ed, seed=2), dim=-1)
     scale = 1 / 0.07
@@ -916,12 +917,13 @@ def test_row_kernels_varlen():
 
 
 # ---------------------------------------------------------------------------------------------------------------- round 2 kernels
-@pytest.mark.parametrize("n,r0,nloc", [(6, 2, 3), (256, 128, 128), (300, 44, 256)])
-def test_clip_loss_local_rows(n, r0, nloc):
+@pytest.mark.parametrize("n,r0,nloc,E_", [(6, 2, 3, 128), (256, 128, 128, 128), (300, 44, 256, 128), (4096, 1536, 512, 768)])
+def test_clip_loss_local_rows(n, r0, nloc, E_):
     """engine.clip_loss_fwd_bwd with a local row window (the data-parallel backward, sprompt.py:75-80) vs f64 autograd: the loss is the
-    global one; the gradients are those of the window's rows of BOTH feature matrices; strided (gathered-buffer) views are accepted."""
+    global one; the gradients are those of the window's rows of BOTH feature matrices; strided (gathered-buffer) views are accepted.
+    (4096, 1536, 512, 768): rank 3 of 8 at BASELINE configs[4]'s size — 512 pairs per GPU, embed 768, the 4096 x 4096 global matrix."""
     torch.manual_seed(n)
-    E_, scale = 128, 14.3
+    scale = 14.3
     buf = torch.nn.functional.normalize(torch.randn(n, 2 * E_, dtype=torch.float64), dim=1)
     i64, t64 = buf[:, :E_].clone().requires_grad_(True), buf[:, E_:].clone().requires_grad_(True)
     lg = scale * i64 @ t64.t()
