@@ -19,10 +19,14 @@ The JSON line carries, besides the driver's contract keys:
   median_ms_per_step  : median of the K per-step durations (HIP events recorded after every step inside that same region);
   roofline     : the dominant kernel (the 256x256 GEMM, MFMA bound): executed FLOPs of its launches / their duration, bracketed by
                  HIP events on the launch stream in an instrumented pass after the timed region; which kernel a launch went to is
-                 reported by the library (lpi_gemm_last_kernel), not re-derived here; `traffic` / `mfma_util` come from the
-                 committed rocprofv3 --pmc summary (profiles/r02_pmc.json) when its tuning stamp matches the running build;
-  step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair (all kernels, not just GEMMs);
-  parity_mode  : (N = 1) the f32-operand mode that meets the 1e-4 parity bar, same workload, a few steps;
+                 reported by the library (lpi_gemm_last_kernel), not re-derived here; each launch counts with the
+                 median of five instrumented steps; `traffic` / `mfma_util` come from the committed rocprofv3 --pmc summary
+                 (profiles/r03_pmc.json) when its tuning stamp matches the running build;
+  step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair — model-FLOP utilisation (all kernels, not just GEMMs);
+  hw_flop_frac : the same with the FLOPs the kernels actually execute (dead text rows, the pooled last block, the prompt-row backward of the
+                 first block are skipped exactly, so this is lower);
+  parity_mode  : (N = 1) the f32-operand mode that meets the 1e-4 parity bar, same workload, 20 steps, its own roofline block (157.3 TF peak);
+  vit_l14      : (N = 1) BASELINE.json configs[4]'s per-GPU workload (ViT-L/14, 512 pairs, depth 12, r 8, bf16);
   fwd_only     : (N = 1) BASELINE.json configs[1]: encoder forward + cosine matrix;
   eval_path    : (N = 1) the reference's evaluation path per batch (task-id pass, L1 task selection, per-sample prompted forward), images/s and
                  captions/s, and the score matrix + ranks at COCO 5k-test size;
@@ -214,10 +218,12 @@ class Workload:
         per = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
         return el, per
 
-    def gemm_roofline(self, nprof=3):
+    def gemm_roofline(self, nprof=5):
         """Instrumented pass: HIP events around every GEMM launch; the library says which kernel each launch used.  An event pair also spans any time
-        the GPU waits for a late host (the host creates two events per launch here): one instrumented warm-up step runs first, and of the nprof
-        recorded steps every launch counts with its MINIMUM time (a cold host on a fresh box once inflated the average launch 2.5x)."""
+        the GPU waits for a late host (the host creates two events per launch here: a cold host on a fresh box once inflated the mean launch
+        2.5x), so one instrumented warm-up step runs first and every launch of the step counts with the MEDIAN of its nprof measurements —
+        robust against a late host without being a best case (the fastest-of-n figure is reported beside it)."""
+        import numpy as np
         import torch
         from lpi_amd import _lib, engine
         a = self.a
@@ -232,29 +238,32 @@ class Workload:
         torch.cuda.synchronize()
         ev_raw = engine.GEMM_PROFILE
         engine.GEMM_PROFILE = None
-        # every step issues the same launches in the same order: launch i of the step = the fastest of its nprof measurements
+        # every step issues the same launches in the same order: launch i of the step = the median of its nprof measurements
         nrec, per = nprof, len(ev_raw) // nprof
-        if per * nprof == len(ev_raw) and all(ev_raw[i][2:] == ev_raw[i + k * per][2:] for i in range(per) for k in range(1, nprof)):
-            best = []
+        same = per * nprof == len(ev_raw) and all(ev_raw[i][2:] == ev_raw[i + k * per][2:] for i in range(per) for k in range(1, nprof))
+        if same:
+            ev_all = []
             for i in range(per):
-                cands = [ev_raw[i + k * per] for k in range(nprof)]
-                best.append(min(cands, key=lambda e: e[0].elapsed_time(e[1])))
-            ev_all, nprof = best, 1
+                ts = sorted(ev_raw[i + k * per][0].elapsed_time(ev_raw[i + k * per][1]) for k in range(nprof))
+                ev_all.append((float(np.median(ts)), ts[0]) + tuple(ev_raw[i][2:]))
+            nprof = 1
         else:
-            ev_all = ev_raw
+            ev_all = [(e[0].elapsed_time(e[1]),) * 2 + tuple(e[2:]) for e in ev_raw]
         bucket = lambda e: GEMM_KERNEL_NAMES.get(e[4], "other")  # noqa: E731
         # the dominant kernel = the 256x256 GEMM (its two entry kernels); the few-row GEMMs (split-K 128x128 + reduce) and the
         # half-empty launches that go to the 256x128-tile kernel are reported beside it, not averaged into its launch time
         ev = [e for e in ev_all if bucket(e) == "k256"] or ev_all
         small = [e for e in ev_all if bucket(e) in ("few_rows", "k128")]
         half = [e for e in ev_all if bucket(e) == "k256x128"]
-        t_ms = lambda es: sum(e[0].elapsed_time(e[1]) for e in es)  # noqa: E731
+        t_ms = lambda es: sum(e[0] for e in es)  # noqa: E731
         ms, small_ms, half_ms = t_ms(ev), t_ms(small), t_ms(half)
+        ms_best = sum(e[1] for e in ev)
+        self.gemm_gflop_all = sum(e[2] for e in ev_all) / nprof / 1e9          # every GEMM launch of a step (executed FLOPs)
         fl, by, half_fl = sum(e[2] for e in ev), sum(e[3] for e in ev), sum(e[2] for e in half)
         ach = fl / (ms * 1e-3) / 1e12
         tuning = [int(_lib.load().lpi_get_tuning(k)) for k in range(8)]
         traffic = mfma_util = tsrc = None
-        pmc = os.path.join(REPO, "profiles", "r02_pmc.json")
+        pmc = os.path.join(REPO, "profiles", "r03_pmc.json")
         if os.path.exists(pmc):      # separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_summary.py
             pj = json.load(open(pmc))
             if pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(_lib.load().lpi_version()):
@@ -264,21 +273,22 @@ class Workload:
                     traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / w * 1e6)
                     if all("mfma_busy_frac" in v for v in ks):
                         mfma_util = round(sum(v["mfma_busy_frac"] * v["launches"] for v in ks) / w, 4)
-                    tsrc = "profiles/r02_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
+                    tsrc = "profiles/r03_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
         return {"bound": "mfma", "kernel": "gemm256p_kernel (the persistent 256x256 GEMM; the vision and the text tower's GEMM of the same layer op go out as ONE "
                                             "grouped launch, a short last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
                 "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
+                "achieved_fastest_of_n": round(fl / (ms_best * 1e-3) / 1e12, 2),
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
                 "algorithmic_bytes_per_launch": round(by / len(ev)),
                 "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
                 "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
                 "few_row_gemms": {"launches_per_step": len(small) // nprof, "ms_per_step": round(small_ms / nprof, 3),
-                                  "kernel": "gemm_nt_kernel (split-K + splitk_reduce_kernel for M <= 256)"},
+                                  "kernel": "gemm_nt_kernel: 128x128 tiles (f32 mode: every launch below the 256x256 kernel's tile-count threshold); M <= 256: split-K + splitk_reduce_kernel"},
                 "half_empty_gemms": {"launches_per_step": len(half) // nprof, "ms_per_step": round(half_ms / nprof, 3),
                                      "achieved_tflops": round(half_fl / (half_ms * 1e-3) / 1e12, 2) if half_ms else None,
                                      "kernel": "gemm256x128_kernel (launches with 16..159 256x256 tiles)"},
                 "tuning": tuning,
-                "measured": f"HIP events around every GEMM launch of {nrec} extra steps (each launch: the fastest of its {nrec} measurements), towers on one stream "
+                "measured": f"HIP events around every GEMM launch of {nrec} extra steps (each launch: the MEDIAN of its {nrec} measurements), towers on one stream "
                             "(kernel alone on the GPU); "
                             "kernel attribution from lpi_gemm_last_kernel"}
 
@@ -352,6 +362,65 @@ def eval_path(a, dev, rank, sync, tasks=3, centres=5, n_img=5000, n_txt=25000):
                         "per-sample prompt stacks (depth as the train step); then the f32 score matrix and ground-truth ranks at COCO 5k-test size"}
 
 
+def attention_gflop(cfg, B, P, text_rows, fwd_only):
+    """Matrix FLOPs the attention kernels execute per step (2 x MACs, dense L x L per head over the rows actually computed; the causal text
+    tower's masked tiles count half): forward 4 L^2 d per sample and layer, backward 8 L^2 d (the recomputed scores are not counted: the
+    model-FLOP convention of SURVEY 8(d)); the last block attends from the pooled row only (attn_pooled.hip), the first block's backward covers
+    the prompt rows only."""
+    Lv, dv, nv = 1 + P + cfg.n_patches, cfg.vision_width, cfg.vision_layers
+    Lt, dt, nt = text_rows, cfg.transformer_width, cfg.transformer_layers
+    fv = 4.0 * Lv * Lv * dv * B * (nv - 1)
+    ft = 0.5 * 4.0 * Lt * Lt * dt * B * (nt - 1)
+    if fwd_only:
+        return (fv + ft) / 1e9
+    return (fv + ft + 2.0 * (fv + ft) * (max(nv - 2, 0) / max(nv - 1, 1))) / 1e9
+
+
+def run_record(a, dev, proc_rank, sync, dtype, fwd_only, steps, warm, roofline=True, **over):
+    """One more workload of the same bench (a precision mode, the forward-only configuration, another model) as a first-class record: the same
+    timing contract (wall clock around exactly `steps` steps, median of per-step HIP events) and, for training steps, its own roofline block from
+    its own instrumented pass against the matching peak."""
+    import copy
+    import numpy as np
+    import torch
+    a2 = copy.copy(a)
+    for k, v in over.items():
+        setattr(a2, k, v)
+    wl = Workload(a2, dev, proc_rank, dtype, fwd_only, None)
+    el, per = wl.run(steps, warm, sync)
+    B = a2.batch
+    v = B * steps / el
+    gfs = GFLOP_PER_PAIR.get(a2.model)
+    rec = {"dtype": dtype, "value": round(v, 2), "unit": "pairs/s", "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * el / steps, 3),
+           "median_ms_per_step": round(float(np.median(per)), 3),
+           "step_mfma_frac": None if gfs is None else round(v * gfs[1 if fwd_only else 0] * 1e9 / (PEAK_TF[dtype] * 1e12), 4),
+           "peak_tflops": PEAK_TF[dtype]}
+    if roofline and not fwd_only:
+        rec["roofline"] = wl.gemm_roofline()
+        hw = wl.gemm_gflop_all + attention_gflop(wl.cfg, B, 16, wl.text_rows, fwd_only)
+        rec["hw_flop_frac"] = round(hw * 1e9 / (1e-3 * float(np.median(per))) / (PEAK_TF[dtype] * 1e12), 4)
+        rec["executed_gflop_per_step"] = round(hw, 1)
+    del wl
+    torch.cuda.empty_cache()
+    return rec
+
+
+def packed_ids_host_cost(B, dev, n=20):
+    """Per-batch host cost of the packed text layout (engine.PackedIds: argmax / cumsum over the tokenizer's [B, 77] ids and the upload of the index
+    arrays) — host work next to tokenisation, outside the timed step like it, reported so that it is not hidden."""
+    import torch
+    from lpi_amd import synth
+    from lpi_amd.engine import PackedIds
+    ids_host = synth.token_ids(B, seed=synth.TOKEN_SEED)
+    PackedIds(ids_host).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        PackedIds(ids_host).to(dev)
+    torch.cuda.synchronize()
+    return round(1e6 * (time.perf_counter() - t0) / n, 1)
+
+
 def main():
     a = parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -414,43 +483,29 @@ def main():
 
     roofline = None if a.no_roofline else wl.gemm_roofline()
 
+    hw_gflop = None
+    if roofline is not None and not a.fwd_only:
+        hw_gflop = wl.gemm_gflop_all + attention_gflop(cfg, B, 16, wl.text_rows, False)
     extras = {}
     if world == 1 and not a.no_extras and not a.fwd_only and a.dtype == "bf16":
-        # the same workload in the parity mode (f32 operands: meets the 1e-4 bar, roofline vs the 157.3 TF f32 MFMA peak) ...
         del wl.opt
-        gfs = GFLOP_PER_PAIR.get(a.model)
-        w32 = Workload(a, dev, rank, "f32", False, None)
-        e32, p32 = w32.run(6, 2, sync)
-        v32 = B * 6 / e32
-        extras["parity_mode"] = {"dtype": "f32", "value": round(v32, 2), "unit": "pairs/s", "steps": 6, "ms_per_step": round(1e3 * e32 / 6, 3),
-                                 "median_ms_per_step": round(float(np.median(p32)), 3),
-                                 "step_mfma_frac": None if gfs is None else round(v32 * gfs[0] * 1e9 / (PEAK_TF["f32"] * 1e12), 4),
-                                 "peak_tflops": PEAK_TF["f32"], "note": "f32-in / f32-accumulate MFMA; the mode whose logits / grads meet the 1e-4 parity bar"}
-        del w32
-        torch.cuda.empty_cache()
+        # the same workload in the parity mode (f32 operands: meets the 1e-4 bar, roofline vs the 157.3 TF f32 MFMA peak) ...
+        extras["parity_mode"] = run_record(a, dev, rank, sync, "f32", False, 20, 3)
+        extras["parity_mode"]["note"] = "f32-in / f32-accumulate MFMA; the mode whose logits / grads meet the 1e-4 parity bar"
         # ... and BASELINE.json configs[1]: forward-only encoders + cosine matrix, bf16
-        wf = Workload(a, dev, rank, "bf16", True, None)
-        ef, pf = wf.run(10, 3, sync)
-        vf = B * 10 / ef
-        extras["fwd_only"] = {"dtype": "bf16", "value": round(vf, 2), "unit": "pairs/s", "steps": 10, "ms_per_step": round(1e3 * ef / 10, 3),
-                              "median_ms_per_step": round(float(np.median(pf)), 3),
-                              "step_mfma_frac": None if gfs is None else round(vf * gfs[1] * 1e9 / (PEAK_TF["bf16"] * 1e12), 4),
-                              "workload": "BASELINE.json configs[1]: ViT-B/16 bs=256 prompt_depth=3 r=4, fwd-only encoder + cosine-sim matrix"}
-        del wf
-        torch.cuda.empty_cache()
+        extras["fwd_only"] = run_record(a, dev, rank, sync, "bf16", True, 20, 3)
+        extras["fwd_only"]["workload"] = "BASELINE.json configs[1]: ViT-B/16 bs=256 prompt_depth=3 r=4, fwd-only encoder + cosine-sim matrix"
         # ... and the f16 operand mode: fp16 MFMA operands / activations in the forward (the reference's own arithmetic type), bf16 backward
-        wh = Workload(a, dev, rank, "f16", False, None)
-        eh, ph = wh.run(10, 3, sync)
-        vh = B * 10 / eh
-        extras["f16_mode"] = {"dtype": "f16", "value": round(vh, 2), "unit": "pairs/s", "steps": 10, "ms_per_step": round(1e3 * eh / 10, 3),
-                              "median_ms_per_step": round(float(np.median(ph)), 3),
-                              "step_mfma_frac": None if gfs is None else round(vh * gfs[0] * 1e9 / (PEAK_TF["f16"] * 1e12), 4),
-                              "note": "compute_dtype='f16': v_mfma_f32_16x16x32_f16 forward, bf16 gradient stream; on the ViT-B/16 fixture 4.6x lower "
+        extras["f16_mode"] = run_record(a, dev, rank, sync, "f16", False, 20, 3)
+        extras["f16_mode"]["note"] = ("compute_dtype='f16': v_mfma_f32_16x16x32_f16 forward, bf16 gradient stream; on the ViT-B/16 fixture 4.6x lower "
                                       "feature error and 4x lower logit error than the bf16 line (tests/test_model_gpu.py); the fp16 MFMA runs "
-                                      "5-9 % slower than the bf16 one on the same GEMM shapes (power-limited clock), hence not the default"}
-        del wh
-        torch.cuda.empty_cache()
+                                      "5-9 % slower than the bf16 one on the same GEMM shapes (power-limited clock), hence not the default")
+        # ... and BASELINE.json configs[4]'s per-GPU workload: ViT-L/14, 512 pairs, prompt_depth 12, r 8, bf16
+        if a.model == "ViT-B/16":
+            extras["vit_l14"] = run_record(a, dev, rank, sync, "bf16", False, 8, 2, model="ViT-L/14", batch=512, depth=12, rank=8, prompt_layers=12)
+            extras["vit_l14"]["workload"] = "BASELINE.json configs[4] on one GPU: ViT-L/14 dual encoder bs=512/GPU prompt_depth=12 r=8, fwd+bwd + SGD step"
         extras["eval_path"] = eval_path(a, dev, rank, sync)
+        extras["packed_ids_host_us_per_batch"] = packed_ids_host_cost(B, dev)
 
     if rank == 0:
         gfs = GFLOP_PER_PAIR.get(a.model)
@@ -476,7 +531,13 @@ def main():
                        "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
                        "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "
                                     "the f32 mode (parity_mode), not of this line" if a.dtype == "bf16" else "f32 MFMA operands and accumulate (parity mode)"},
+            # model-FLOP utilisation (MFU): SURVEY 8(d)'s algorithmic 89.68 GFLOP per pair (77 text rows, whole first and last blocks) / time / peak
             "step_mfma_frac": None if gf is None else round(pairs_s / world * gf * 1e9 / (PEAK_TF[a.dtype] * 1e12), 4),
+            "step_mfma_frac_kind": "MFU: the reference model's algorithmic FLOPs (SURVEY 8(d)); hw_flop_frac counts the FLOPs the kernels execute",
+            # hardware-FLOP utilisation (HFU): what the GEMM launches of a step execute (packed text rows, pooled last block, prompt-row first-block
+            # backward) + the attention kernels' matrix FLOPs, / median step time / peak
+            "hw_flop_frac": None if hw_gflop is None else round(hw_gflop * 1e9 / (median_ms * 1e-3) / (PEAK_TF[a.dtype] * 1e12), 4),
+            "executed_gflop_per_step": None if hw_gflop is None else round(hw_gflop, 1),
             "roofline": roofline,
         }
         out.update(extras)
