@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""The persistent 256x256 GEMM, one bench shape after the other (REPS launches each, fixed order), for rocprofv3 --pmc passes: the counter rows of
+the gemm256p_kernel dispatches are attributed to shapes by dispatch order (tools/gemm_shape_pmc_summary.py).  Prints the shape table (name, M, N, K,
+algorithmic read / write bytes) as JSON on the last line.   usage: python3 tools/gemm_shape_pmc.py"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lpi_amd import engine as E  # noqa: E402
+from lpi_amd._lib import BF16, call  # noqa: E402
+
+REPS = 8
+TD = torch.bfloat16
+dev = "cuda:0"
+Mv, Mt = 54528, 10880          # vision rows (256 x 213) and packed text rows (256 x 42.1 -> whole 128-row tiles)
+shapes = [  # (name, M, N, K, c dtype, epi, residual)
+    ("v.qkv", Mv, 2304, 768, TD, 0, False), ("v.out+res", Mv, 768, 768, torch.float16, 0, True), ("v.fc+gelu", Mv, 3072, 768, TD, 1, False),
+    ("v.proj+res", Mv, 768, 3072, torch.float16, 0, True), ("v.dproj*dgelu", Mv, 3072, 768, TD, 2, False), ("v.dfc", Mv, 768, 3072, TD, 0, False),
+    ("v.dout", Mv, 768, 768, TD, 0, False), ("v.dqkv", Mv, 768, 2304, TD, 0, False),
+    ("t.qkv", Mt, 1536, 512, TD, 0, False), ("t.fc+gelu", Mt, 2048, 512, TD, 1, False), ("t.dproj*dgelu", Mt, 2048, 512, TD, 2, False),
+    ("t.dfc", Mt, 512, 2048, TD, 0, False),
+]
+torch.manual_seed(0)
+table = []
+for name, M, N, K, cdt, epi, res in shapes:
+    a = torch.randn(M, K, device=dev).to(TD)
+    b = (torch.randn(N, K, device=dev) * 0.05).to(TD)
+    c = torch.zeros(M, N, device=dev, dtype=cdt)
+    bias = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev).to(cdt) if res else None
+    aux = torch.randn(M, N, device=dev).to(TD) if epi else None
+    for _ in range(REPS):
+        E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=r, epi=epi, aux=aux)
+    torch.cuda.synchronize()
+    rd = 2 * (M * K + N * K) + (2 * M * N if res else 0) + (2 * M * N if epi == 2 else 0)
+    wr = 2 * M * N + (2 * M * N if epi == 1 else 0)
+    table.append({"name": name, "M": M, "N": N, "K": K, "reads": rd, "writes": wr, "reps": REPS, "gflop": 2.0 * M * N * K / 1e9})
+    del a, b, c, r, aux
+print(json.dumps(table))
