@@ -43,8 +43,10 @@ class Exchange:
         self.timing.append((kind, e0, e1))
         return out
 
-    def gather(self, img_f: torch.Tensor, txt_f: torch.Tensor):
-        """-> (img_all [W*B,E], txt_all [W*B,E] (views of one [W*B, 2E] buffer), first global row of this rank)."""
+    def gather(self, img_f: torch.Tensor, txt_f: torch.Tensor, between=None):
+        """-> (img_all [W*B,E], txt_all [W*B,E] (views of one [W*B, 2E] buffer), first global row of this rank).
+        between: a callable run after the all-gather has been ISSUED and before its result is waited for (step.train_step puts the
+        data-independent alignment-loss kernel there, so that it runs under the collective)."""
         B, E = img_f.shape
         key = (B, E, img_f.device, img_f.dtype)
         local = self._local.get(key)
@@ -61,12 +63,22 @@ class Exchange:
             local[:, E:].copy_(txt_f)
         if self.device_collectives or not local.is_cuda:
             out = torch.empty(self.world * B, 2 * E, dtype=local.dtype, device=local.device)
-            self._timed("all_gather", lambda: dist.all_gather_into_tensor(out, local, group=self.group), local.is_cuda)
+            if between is not None and self.device_collectives:
+                def issue():
+                    work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+                    between()
+                    work.wait()     # the current stream waits for the collective; the host does not
+                self._timed("all_gather (alignment-loss kernel under it)", issue, True)
+                between = None
+            else:
+                self._timed("all_gather", lambda: dist.all_gather_into_tensor(out, local, group=self.group), local.is_cuda)
         else:       # host-staged (gloo with device tensors)
             h = local.cpu()
             oh = torch.empty(self.world * B, 2 * E, dtype=h.dtype)
             dist.all_gather_into_tensor(oh, h, group=self.group)
             out = oh.to(local.device)
+        if between is not None:
+            between()
         return out[:, :E], out[:, E:], self.rank * B
 
     @property

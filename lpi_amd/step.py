@@ -82,9 +82,20 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     world = exchange.world if exchange is not None else 1
     w_base = float(getattr(exchange, "loss_weight", 1.0))
     with torch.no_grad():
-        base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
-        # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again on the host
-        align, dv, dt = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True)
+        al = {}
+
+        def align():
+            # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again below
+            al["r"] = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True)
+
+        if gather is not None and getattr(exchange, "device_collectives", False):
+            # the data-independent alignment kernel runs while the feature all-gather (issued right behind the towers) is in flight
+            g2 = lambda i, t: exchange.gather(i, t, between=align)  # noqa: E731
+            base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, g2, exchange, True)
+        else:
+            base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
+            align()
+        align, dv, dt = al["r"]
         if w_base != 1.0:
             dI, dT = dI * w_base, dT * w_base
     torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 from lpi_amd import synth
 
-W, B = 2, 2
+B = 2
 
 
 def _free_port():
@@ -23,9 +23,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, q):
+def _worker(rank, port, q, W):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
-    torch.set_num_threads(2)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=W)
     from lpi_amd.dp import Exchange
     from oracle import lpi_oracle as O
@@ -60,12 +60,17 @@ def _worker(rank, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_global_batch():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_w_rank_step_equals_global_batch(W):
+    """W = 8: the rank count of BASELINE configs[3] / [4] (8 GPUs), rehearsed as 8 CPU processes."""
     from oracle import lpi_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(W)]
+    procs = [ctx.Process(target=_worker, args=(r, port, q, W)) for r in range(W)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(W)]
@@ -80,6 +85,7 @@ def test_two_rank_step_equals_global_batch():
         for k, g in grads.items():
             r = ref["grad." + k]
             assert np.abs(g - r).max() <= 1e-4 * np.abs(r).max() + 1e-7, (rank, k)
-    # and the two ranks end up with identical gradients
+    # and all ranks end up with identical gradients
     for k in res[0][2]:
-        assert np.array_equal(res[0][2][k], res[1][2][k])
+        for r in range(1, W):
+            assert np.array_equal(res[0][2][k], res[r][2][k])

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 from lpi_amd import synth  # noqa: E402
 
 W, B = 2, 3
+W4 = 4          # the GPU box admits six processes on the card: the test process + 4 ranks (8 ranks are rehearsed on the CPU: tests/test_dp_gloo.py)
 
 
 def _free_port():
@@ -26,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False):
+def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False, W=W, flat=False):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
@@ -44,8 +45,15 @@ def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False):
         img = torch.from_numpy(synth.images(W * B, cfg.image_resolution))[rank * B:(rank + 1) * B].to(dev)
         ids = torch.from_numpy(synth.token_ids(W * B))[rank * B:(rank + 1) * B].to(dev)
         n0 = _lib.launch_count()
-        out = train_step(enc, img, ids, fac, 2, Exchange(local_loss=local_loss, gather_with_grad=gather_with_grad))
+        kw = {}
+        if flat:        # the factors in one flat vector, their gradients in another (optim.flatten): the all-reduce runs on it in place
+            from lpi_amd.optim import flatten
+            _, kw["flat_grad"], kw["grad_views"] = flatten(fac)
+        out = train_step(enc, img, ids, fac, 2, Exchange(local_loss=local_loss, gather_with_grad=gather_with_grad), **kw)
         torch.cuda.synchronize()
+        if flat:
+            for v, p in zip(kw["grad_views"], fac.values()):
+                assert p.grad.data_ptr() == v.data_ptr()
         assert _lib.launch_count() - n0 > 30, "the HIP kernels did not run"
         q.put((rank, float(out["base_loss"]), {k: v.grad.cpu().numpy().copy() for k, v in fac.items()}, out["img_f"].cpu().numpy()))
         dist.barrier()
@@ -109,3 +117,38 @@ def test_two_process_hip_step_with_gradients_through_the_gathered_features(local
     assert abs(mean_loss - float(ref["base_loss"])) < 1e-4
     if not local_loss:
         assert all(abs(b - float(ref["base_loss"])) < 1e-4 for _, b, _, _ in res)
+
+
+@pytest.mark.parametrize("local_loss,gather_with_grad", [(False, False), (True, False), (True, True), (False, True)])
+def test_four_process_hip_step_every_gather_mode_flat_gradients(local_loss, gather_with_grad):
+    """Four ranks on one GPU (gloo, host-staged messages), every mode of the reference's gather_features (sprompt.py:38-82) incl. the
+    reduce-scatter path, with the factor gradients laid out in one flat vector that the all-reduce reduces in place.  With gradients
+    through the gathered features, and in the default mode, the summed factor gradients are the oracle's on the concatenated batch; with
+    local_loss alone they are the reference's partial gradient (checked against the single-process emulation in tests/test_kernels_gpu.py),
+    here: every rank holds the same sum."""
+    from oracle import lpi_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q, "f32", local_loss, gather_with_grad, W4, True)) for r in range(W4)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(W4)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = synth.TINY
+    ref = O.train_step(O.Oracle(cfg, synth.clip_state_dict(cfg)), synth.images(W4 * B, cfg.image_resolution), synth.token_ids(W4 * B),
+                       synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width), depth=2)
+    for rank, base, grads, img_f in res:
+        assert grads is not None, base
+        assert np.abs(img_f - ref["img_f"][rank * B:(rank + 1) * B]).max() < 1e-4
+        if gather_with_grad or not local_loss:
+            for k, g in grads.items():
+                r = ref["grad." + k]
+                assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max() + 1e-6, (rank, k)
+    for k in res[0][2]:
+        for r in range(1, W4):
+            assert np.array_equal(res[0][2][k], res[r][2][k])
+    mean_loss = float(np.mean([b for _, b, _, _ in res]))
+    assert abs(mean_loss - float(ref["base_loss"])) < 1e-4
