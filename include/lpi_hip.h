@@ -361,6 +361,25 @@ int lpi_topk(int n_rows, int n_cols, int k, const float* scores, int ld, int32_t
  * + pair merging of ONE cleaned, lower-cased UTF-8 string (cleaning — ftfy / html.unescape / whitespace — stays with the caller);
  * writes at most max_ids ids and returns the full count.  tokenize = clip.tokenize: row t of out [n, context_length] int64 is
  * SOT, ids, EOT, zero padding; returns 0, or t+1 for the first text that does not fit when truncate == 0 (clip.py:218 raises). */
+/* ---- f4 (optional): low-rank cross-modal interaction of the prompt rows, "InteractModule" ------------------------------------------
+ * replaces: InteractModule.forward (grounding/maskrcnn_benchmark/modeling/bert/modeling_bert.py:616-651; parameters :558-590) and its backward.
+ * xv [N, Dv], xt [N, Dt] f32: the visual / textual prompt rows of the batch ([bs, P, D] flattened).  Per direction the rank-r CP weights
+ * d1 [Lyr, R], d2 [Din + 1, R] (last row = bias), d3 [Dout, R]:  new = x M[:Din] + M[Din],  M[i, j] = mean_r d1[layer, r] d2[i, r] d3[j, r];
+ * out_v = LayerNorm_v((1 - mix) xv + mix new_v), out_t likewise (mix = 0.1, eps = 1e-5 in the reference).  Dv, Dt <= 1024, R <= 8.
+ * stat: [4, N] f32 (mean / rstd of the two LayerNorms).  The backward recomputes the forward; dxv / dxt are overwritten; `grads` receives
+ *   [v2t: dd3 [Dt R] | dd2 [(Dv + 1) R] | dd1 row `layer` [R] | dgamma_t [Dt] | dbeta_t [Dt]] [t2v: dd3 [Dv R] | dd2 [(Dt + 1) R] | dd1 row [R] | dgamma_v [Dv] | dbeta_v [Dv]];
+ * workspace: lpi_interact_workspace_floats(N, Dv, Dt, R) floats (per-workgroup partial sums, added in a fixed order). */
+int lpi_interact_workspace_floats(int N, int Dv, int Dt, int R);
+int lpi_interact_fwd(int N, int Dv, int Dt, int R, int Lyr, int layer, const float* xv, int ldv, const float* xt, int ldt,
+                     const float* d1_v2t, const float* d2_v2t, const float* d3_v2t, const float* d1_t2v, const float* d2_t2v,
+                     const float* d3_t2v, const float* gamma_v, const float* beta_v, const float* gamma_t, const float* beta_t, float mix,
+                     float eps, float* out_v, int ldov, float* out_t, int ldot, float* stat, void* stream);
+int lpi_interact_bwd(int N, int Dv, int Dt, int R, int Lyr, int layer, const float* xv, int ldv, const float* xt, int ldt,
+                     const float* d1_v2t, const float* d2_v2t, const float* d3_v2t, const float* d1_t2v, const float* d2_t2v,
+                     const float* d3_t2v, const float* gamma_v, const float* beta_v, const float* gamma_t, const float* beta_t, float mix,
+                     float eps, const float* g_out_v, int ldgv, const float* g_out_t, int ldgt, float* dxv, int lddv, float* dxt, int lddt,
+                     float* grads, float* workspace, void* stream);
+
 void* lpi_bpe_create(const char* merges_utf8, long nbytes);
 void lpi_bpe_destroy(void* handle);
 int lpi_bpe_encode(void* handle, const char* text_utf8, int32_t* ids, int max_ids);

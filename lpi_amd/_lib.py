@@ -97,6 +97,10 @@ SIGNATURES = {
     # host-side BPE tokenizer (a6)
     "lpi_bpe_create": [_P, _L],
     "lpi_bpe_destroy": [_P],
+    "lpi_interact_workspace_floats": [_I, _I, _I, _I],
+    "lpi_interact_fwd": [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _P, _I, _P, _P],
+    "lpi_interact_bwd": [_I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _P, _I, _P, _I, _P, _I,
+                         _P, _P, _P],
     "lpi_bpe_encode": [_P, _P, _P, _I],
     "lpi_bpe_tokenize": [_P, _P, _I, _I, _I, _P],
 }

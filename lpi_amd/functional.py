@@ -200,3 +200,55 @@ class NtBxentFn(torch.autograd.Function):
         full = torch.zeros(ctx.shape, device=dx.device)
         full[ctx.row] = dx * g
         return full, None, None, None
+
+
+class InteractFn(torch.autograd.Function):
+    """InteractModule.forward (grounding/maskrcnn_benchmark/modeling/bert/modeling_bert.py:616-651): the low-rank cross-modal mix of the visual and
+    textual prompt rows followed by the two LayerNorms — lpi_interact_fwd / lpi_interact_bwd.  Inputs [..., Dv] / [..., Dt] with equal leading
+    dimensions; parameters in the module's order."""
+
+    @staticmethod
+    def forward(ctx, visual_out, textual_out, layer_id, d1v, d2v, d3v, d1t, d2t, d3t, gv, bv, gt, bt, mix=0.1, eps=1e-5):
+        lead = visual_out.shape[:-1]
+        if textual_out.shape[:-1] != lead:
+            raise ValueError("visual and textual prompt rows must have the same leading dimensions")
+        Dv, Dt = visual_out.shape[-1], textual_out.shape[-1]
+        xv = visual_out.detach().reshape(-1, Dv).contiguous().float()
+        xt = textual_out.detach().reshape(-1, Dt).contiguous().float()
+        N, (Lyr, R) = xv.shape[0], d1v.shape
+        ps = [t.detach().contiguous().float() for t in (d1v, d2v, d3v, d1t, d2t, d3t, gv, bv, gt, bt)]
+        if ps[1].shape != (Dv + 1, R) or ps[2].shape != (Dt, R) or ps[4].shape != (Dt + 1, R) or ps[5].shape != (Dv, R) or ps[3].shape != (Lyr, R):
+            raise ValueError("InteractModule factor shapes do not match the inputs")
+        ov, ot = torch.empty_like(xv), torch.empty_like(xt)
+        stat = torch.empty(4, N, device=xv.device)
+        E.call("lpi_interact_fwd", N, Dv, Dt, R, Lyr, int(layer_id), xv, Dv, xt, Dt, *ps, float(mix), float(eps), ov, Dv, ot, Dt, stat, E._stream())
+        ctx.save_for_backward(xv, xt, *ps)
+        ctx.meta = (N, Dv, Dt, R, Lyr, int(layer_id), float(mix), float(eps), lead)
+        return ov.reshape(*lead, Dv), ot.reshape(*lead, Dt)
+
+    @staticmethod
+    def backward(ctx, g_v, g_t):
+        xv, xt, *ps = ctx.saved_tensors
+        N, Dv, Dt, R, Lyr, layer, mix, eps, lead = ctx.meta
+        gv_ = (torch.zeros_like(xv) if g_v is None else g_v.reshape(-1, Dv).contiguous().float())
+        gt_ = (torch.zeros_like(xt) if g_t is None else g_t.reshape(-1, Dt).contiguous().float())
+        dxv, dxt = torch.empty_like(xv), torch.empty_like(xt)
+        la, lb = Dt * R + (Dv + 1) * R + R + 2 * Dt, Dv * R + (Dt + 1) * R + R + 2 * Dv
+        grads = torch.empty(la + lb, device=xv.device)
+        nws = E._lib.load().lpi_interact_workspace_floats(N, Dv, Dt, R)
+        wsp = torch.empty(nws, device=xv.device)
+        E.call("lpi_interact_bwd", N, Dv, Dt, R, Lyr, layer, xv, Dv, xt, Dt, *ps, mix, eps, gv_, Dv, gt_, Dt, dxv, Dv, dxt, Dt, grads, wsp, E._stream())
+
+        def split(v, Din, Dout):
+            o = 0
+            d3 = v[o:o + Dout * R].view(Dout, R); o += Dout * R
+            d2 = v[o:o + (Din + 1) * R].view(Din + 1, R); o += (Din + 1) * R
+            d1row = v[o:o + R]; o += R
+            dg = v[o:o + Dout]; o += Dout
+            db = v[o:o + Dout]
+            d1 = torch.zeros(Lyr, R, device=v.device)
+            d1[layer] = d1row
+            return d1, d2, d3, dg, db
+        d1v, d2v, d3v, dgt, dbt = split(grads[:la], Dv, Dt)          # v2t: its LayerNorm is the textual one
+        d1t, d2t, d3t, dgv, dbv = split(grads[la:], Dt, Dv)
+        return (dxv.reshape(*lead, Dv), dxt.reshape(*lead, Dt), None, d1v, d2v, d3v, d1t, d2t, d3t, dgv, dbv, dgt, dbt, None, None)

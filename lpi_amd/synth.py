@@ -163,3 +163,12 @@ def token_ids(batch: int, context_length: int = 77, n_ctx: int = 16, seed: int =
         row = [SOT] + [X_TOKEN] * n_ctx + body.tolist() + [DOT_TOKEN, EOT]
         ids[b, :len(row)] = row
     return ids
+
+
+INTERACT_SEED = 4000
+
+
+def interact_inputs(bs: int = 2, P: int = 16, Dv: int = 96, Dt: int = 768, seed: int = INTERACT_SEED):
+    """Inputs of the InteractModule fixture (tests/golden/interact.npz): visual / textual prompt rows and the weights of the scalar test loss
+    sum(v_out * wv) + sum(t_out * wt), regenerated from the seed on both sides instead of being stored."""
+    return {k: normal(seed, "interact." + k, (bs, P, D)) for k, D in (("visual_in", Dv), ("textual_in", Dt), ("wv", Dv), ("wt", Dt))}

@@ -72,6 +72,22 @@ def decomposed_prompt(f, scale=1.0):
     return vis, txt
 
 
+def interact(p, visual_out, textual_out, layer_id, a=0.1, eps=1e-5):
+    """InteractModule.forward (grounding/maskrcnn_benchmark/modeling/bert/modeling_bert.py:616-651; optional row (f4) of SURVEY section 8):
+    per direction M = mean_r d1[l, r] d2[i, r] d3[j, r] with a bias row (:617-627, :631-640), both new rows from the ORIGINAL inputs, then
+    LayerNorm((1 - a) x + a x_new) per modality (:641-645; a = 0.1, norm_flag True, scale 1).  p: dict with the module's parameter names."""
+    def m(d1, d2, d3):
+        return torch.einsum("r,ir,jr->ij", d1[layer_id], d2, d3) / d1.shape[1]
+    Dv, Dt = visual_out.shape[-1], textual_out.shape[-1]
+    m_v2t = m(p["dim_1_v2t"], p["dim_2_v2t"], p["dim_3_v2t"])          # [Dv + 1, Dt]
+    m_t2v = m(p["dim_1_t2v"], p["dim_2_t2v"], p["dim_3_t2v"])          # [Dt + 1, Dv]
+    t_new = visual_out @ m_v2t[:Dv] + m_v2t[Dv:]
+    v_new = textual_out @ m_t2v[:Dt] + m_t2v[Dt:]
+    v = layer_norm((1 - a) * visual_out + a * v_new, p["visual_norm.weight"], p["visual_norm.bias"])
+    t = layer_norm((1 - a) * textual_out + a * t_new, p["textual_norm.weight"], p["textual_norm.bias"])
+    return v, t
+
+
 # ----------------------------------------------------------------------------- transformer
 def attention(x, w_in, b_in, w_out, b_out, heads, causal):
     """nn.MultiheadAttention as called at model.py:183-185, batch-first here ([B, L, d]).

@@ -358,13 +358,50 @@ def save(name, res, meta):
     print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def interact_case(bs=2, P=16, Dv=96, Dt=768, layer_num=9, r=4, layer_id=3):
+    """The grounding branch's InteractModule (modeling_bert.py:558-651) imported as it is — two names its module imports from `transformers` are gone
+    from the installed version and are stubbed (ordinary ImportError shims, like the retrieval ones above) — on [bs, P, D] prompt rows: outputs and
+    the gradients of sum(v_out * Wv) + sum(t_out * Wt) w.r.t. every parameter and both inputs."""
+    import types
+    import transformers.pytorch_utils as pu
+    for n in ("apply_chunking_to_forward", "find_pruneable_heads_and_indices", "prune_linear_layer"):
+        if not hasattr(pu, n):
+            setattr(pu, n, lambda *a_, **k_: None)
+    if "transformers.onnx" not in sys.modules:
+        onnx = types.ModuleType("transformers.onnx")
+        onnx.OnnxConfig = object
+        sys.modules["transformers.onnx"] = onnx
+    sys.path.insert(0, os.path.join(os.path.dirname(REF), "grounding"))
+    from maskrcnn_benchmark.modeling.bert.modeling_bert import InteractModule
+    torch.manual_seed(20240607)
+    m = InteractModule(layer_num=layer_num, visual_dim=Dv, textual_dim=Dt, r=r)
+    with torch.no_grad():      # LayerNorm affine away from the identity, so that its gradients are exercised
+        for ln in (m.visual_norm, m.textual_norm):
+            ln.weight.add_(0.1 * torch.randn_like(ln.weight))
+            ln.bias.add_(0.1 * torch.randn_like(ln.bias))
+    inp = synth.interact_inputs(bs, P, Dv, Dt)          # regenerated from the seed by the tests: not stored
+    v = torch.from_numpy(inp["visual_in"]).requires_grad_(True)
+    t = torch.from_numpy(inp["textual_in"]).requires_grad_(True)
+    wv, wt = torch.from_numpy(inp["wv"]), torch.from_numpy(inp["wt"])
+    vo, to = m(v, t, layer_id)
+    ((vo * wv).sum() + (to * wt).sum()).backward()
+    res = {"layer_id": np.int64(layer_id), "shape": np.array([bs, P, Dv, Dt, layer_num, r]),
+           "visual_out": vo.detach().numpy(), "textual_out": to.detach().numpy(), "grad.visual_in": v.grad.numpy(), "grad.textual_in": t.grad.numpy()}
+    for n, p_ in m.named_parameters():
+        res["param." + n] = p_.detach().numpy().copy()
+        res["grad." + n] = p_.grad.numpy().copy()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    install_shims()
     meta_path = os.path.join(HERE, "MANIFEST.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    if a.only in (None, "interact"):      # before the retrieval shims: `transformers` probes the real torchvision's module spec
+        save("interact", interact_case(), meta)
+    install_shims()
     meta["_generator"] = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(),
                           "reference": "Kelvin-ywc/LPI @ 2024-12-23, retrieval/", "dtype": "float32 (CPU)"}
 

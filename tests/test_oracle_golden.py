@@ -158,3 +158,21 @@ def test_tokens_behind_a_captions_own_eot_are_dead_in_the_oracle():
     assert pk.pool_rows.tolist() == (np.cumsum(eot + 1) - 1).tolist()
     assert torch.equal(pk.ids, torch.from_numpy(ids[:, :pk.shape[1]]))
     assert pk[1:3].rows == int((eot[1:3] + 1).sum())
+
+
+def test_interact_module_oracle_vs_reference_fixture(golden):
+    """SURVEY 8 (f4, optional): the oracle's restatement of the grounding branch's InteractModule against outputs and autograd gradients of the
+    imported reference class (tests/golden/interact.npz; inputs regenerated from the seed)."""
+    g = golden("interact")
+    bs, P, Dv, Dt, layer_num, r = (int(x) for x in g["shape"])
+    inp = synth.interact_inputs(bs, P, Dv, Dt)
+    p = {k[6:]: torch.from_numpy(g[k]).double().requires_grad_(True) for k in g if k.startswith("param.")}
+    v = torch.from_numpy(inp["visual_in"]).double().requires_grad_(True)
+    t = torch.from_numpy(inp["textual_in"]).double().requires_grad_(True)
+    vo, to = O.interact(p, v, t, int(g["layer_id"]))
+    assert float((vo.detach() - torch.from_numpy(g["visual_out"])).abs().max()) < 2e-5
+    assert float((to.detach() - torch.from_numpy(g["textual_out"])).abs().max()) < 2e-5
+    ((vo * torch.from_numpy(inp["wv"])).sum() + (to * torch.from_numpy(inp["wt"])).sum()).backward()
+    for name, got in [("visual_in", v.grad), ("textual_in", t.grad)] + [(k, p[k].grad) for k in p]:
+        ref = torch.from_numpy(g["grad." + name]).double()
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name

@@ -202,3 +202,74 @@ def test_flat_sgd_equals_torch_sgd_and_flat_gradients_are_the_autograd_gradients
         assert abs(oa.param_groups[0]["lr"] - ob.param_groups[0]["lr"]) < 1e-9
         for k in fa:
             assert float((fa[k] - fb[k]).abs().max()) <= 1e-6 * float(fb[k].abs().max()), (step, k)
+
+
+def test_interact_module_vs_reference_fixture_and_oracle(golden):
+    """SURVEY 8 (f4, optional): lpi_amd's InteractModule (lpi_interact_fwd / _bwd, rank-r form) with the reference module's parameters against the
+    outputs and autograd gradients of the imported reference class (tests/golden/interact.npz) — outputs 1e-5, every gradient (six factors, both
+    LayerNorms' affine, both inputs) 1e-4 relative — and the reference's parameter names / shapes / initialisation contract."""
+    from lpi_amd.retrieval.models.prompts.prompts import InteractModule
+    g = golden("interact")
+    bs, P, Dv, Dt, layer_num, r = (int(x) for x in g["shape"])
+    inp = synth.interact_inputs(bs, P, Dv, Dt)
+    m = InteractModule(layer_num=layer_num, visual_dim=Dv, textual_dim=Dt, r=r)
+    names = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    assert names == {k[6:]: tuple(g[k].shape) for k in g if k.startswith("param.")}          # the reference's names and shapes
+    bound = 1 / np.sqrt(r)                                                                      # kaiming_uniform_(a = sqrt 5): U(-1/sqrt(fan_in), ..)
+    assert float(m.dim_2_v2t.detach().abs().max()) <= bound + 1e-6 and float(m.dim_3_t2v.detach().abs().max()) <= bound + 1e-6
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(g["param." + n]))
+    m = m.to(DEV)
+    v = torch.from_numpy(inp["visual_in"]).to(DEV).requires_grad_(True)
+    t = torch.from_numpy(inp["textual_in"]).to(DEV).requires_grad_(True)
+    n0 = _lib.launch_count()
+    vo, to = m(v, t, int(g["layer_id"]))
+    ((vo * torch.from_numpy(inp["wv"]).to(DEV)).sum() + (to * torch.from_numpy(inp["wt"]).to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    assert _lib.launch_count() - n0 >= 3
+    assert np.abs(vo.detach().cpu().numpy() - g["visual_out"]).max() < 1e-5
+    assert np.abs(to.detach().cpu().numpy() - g["textual_out"]).max() < 1e-5
+    grads = {"visual_in": v.grad, "textual_in": t.grad, **{n: p.grad for n, p in m.named_parameters()}}
+    for n, got in grads.items():
+        ref = g["grad." + n]
+        e = np.abs(got.cpu().numpy() - ref).max()
+        assert e <= 1e-4 * np.abs(ref).max() + 1e-7, (n, e, np.abs(ref).max())
+
+
+def relerr(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("N,Dv,Dt,r,layer_num,layer", [(1, 64, 128, 1, 2, 0), (37, 96, 768, 4, 9, 8), (300, 1024, 768, 8, 12, 5), (513, 768, 512, 3, 3, 1)])
+def test_interact_kernels_vs_f64(N, Dv, Dt, r, layer_num, layer):
+    """lpi_interact_fwd / _bwd against the oracle's restatement in f64 with autograd, at widths up to the kernels' limit (1024), ranks 1 .. 8, row
+    counts that leave partial workgroups; the backward twice: bitwise the same (fixed summation order, no atomics)."""
+    from lpi_amd.functional import InteractFn
+    from oracle import lpi_oracle as O
+    gen = torch.Generator().manual_seed(N * 7 + r)
+    rn = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    p = {"dim_1_v2t": rn(layer_num, r), "dim_2_v2t": rn(Dv + 1, r) * 0.2, "dim_3_v2t": rn(Dt, r), "dim_1_t2v": rn(layer_num, r),
+         "dim_2_t2v": rn(Dt + 1, r) * 0.2, "dim_3_t2v": rn(Dv, r), "visual_norm.weight": 1 + 0.1 * rn(Dv), "visual_norm.bias": 0.1 * rn(Dv),
+         "textual_norm.weight": 1 + 0.1 * rn(Dt), "textual_norm.bias": 0.1 * rn(Dt)}
+    xv, xt, wv, wt = rn(N, Dv), rn(N, Dt), rn(N, Dv), rn(N, Dt)
+    order = ("dim_1_v2t", "dim_2_v2t", "dim_3_v2t", "dim_1_t2v", "dim_2_t2v", "dim_3_t2v", "visual_norm.weight", "visual_norm.bias",
+             "textual_norm.weight", "textual_norm.bias")
+    runs = []
+    for _ in range(2):
+        pd = {k: v.clone().to(DEV).requires_grad_(True) for k, v in p.items()}
+        a, b = xv.clone().to(DEV).requires_grad_(True), xt.clone().to(DEV).requires_grad_(True)
+        vo, to = InteractFn.apply(a, b, layer, *[pd[k] for k in order])
+        ((vo * wv.to(DEV)).sum() + (to * wt.to(DEV)).sum()).backward()
+        runs.append({"vo": vo.detach(), "to": to.detach(), "xv": a.grad, "xt": b.grad, **{k: pd[k].grad for k in order}})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    a64, b64 = xv.double().requires_grad_(True), xt.double().requires_grad_(True)
+    vr, tr = O.interact(p64, a64, b64, layer)
+    ((vr * wv.double()).sum() + (tr * wt.double()).sum()).backward()
+    assert relerr(runs[0]["vo"], vr.detach()) < 2e-5 and relerr(runs[0]["to"], tr.detach()) < 2e-5
+    assert relerr(runs[0]["xv"], a64.grad) < 1e-4 and relerr(runs[0]["xt"], b64.grad) < 1e-4
+    for k in order:
+        assert relerr(runs[0][k], p64[k].grad) < 1e-4, k

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../lpi_amd/csrc"
 suffix=$1; srcs=",$2,"; shift 2
 mkdir -p build_var
 objs=""
-for f in api gemm gemm256 gemm256p gemm256x128 attention attention4 attn_pooled rowops loss bpe; do
+for f in api gemm gemm256 gemm256p gemm256x128 attention attention4 attn_pooled rowops loss interact bpe; do
   if [[ "$srcs" == *",$f,"* ]]; then
     extra=""
     case $f in attention|attention4) extra="-fno-honor-nans";; esac
