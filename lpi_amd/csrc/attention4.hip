@@ -61,6 +61,25 @@ __device__ __forceinline__ void glds4(const void* src, unsigned lds_addr) {
                  : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 
+// the same with the address as a scalar base + a 32-bit per-lane byte offset: the base of a head is scalar arithmetic once per head, the offset two
+// vector instructions per piece (per-lane 64-bit pointers cost a dozen vector instructions per piece: a sixth of an iteration on the issuing waves)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+__device__ __forceinline__ void glds4s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+// a pointer as a wave-uniform (scalar) value
+__device__ __forceinline__ const void* scalar_ptr(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+
 typedef __attribute__((address_space(3))) short4v* lds_s4p;
 __device__ __forceinline__ uint2 tr_read(const char* p) {
     return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)p));
@@ -71,6 +90,13 @@ __device__ __forceinline__ Chunk tr_pair(const char* p, int second) {
     Chunk c;
     c.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
     return c;
+}
+// 8 bf16 values times a power of two (exact)
+__device__ __forceinline__ void chunk_scale_bf16(Chunk& c, float f) {
+    Chunk o;
+    o.u = make_uint4(pack2((float)c.h[0] * f, (float)c.h[1] * f), pack2((float)c.h[2] * f, (float)c.h[3] * f), pack2((float)c.h[4] * f, (float)c.h[5] * f),
+                     pack2((float)c.h[6] * f, (float)c.h[7] * f));
+    c = o;
 }
 __device__ __forceinline__ void mma(f32x4& acc, const Chunk& a, const Chunk& b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0); }
 
@@ -212,9 +238,13 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     // the dK / dV stores of the head before
     const int nblk = (L + 7) >> 3;
     const int kv_parts = (2 * nblk + 15) >> 4;
-    auto issue_kv_part = [&](const Head& x, int part) {
+    // scalar base of a head's rows in a [B L, ld] matrix (+ a column offset)
+    auto head_base = [&](const T* m, int ld, const Head& x, int col) {
+        return (const T*)scalar_ptr(m + ((size_t)x.b * L * ld + x.h * HD + col));
+    };
+    const T* kv_base = nullptr;           // K columns of the head whose K / V are being fetched
+    auto issue_kv_part = [&](int part) {
         if (wave >= 6) return;                // waves 6, 7 move the O pieces of every slice instead
-        const T* kg = qkv + (size_t)x.b * L * ldqkv + x.h * HD + dm;
         const int r8 = lane >> 3, pc = lane & 7;
         const int np = wave < 4 ? 3 : 2, p0 = wave < 4 ? 3 * wave : 12 + 2 * (wave - 4);      // 16 pieces of a part: 3,3,3,3,2,2
         for (int j = 0; j < np; ++j) {
@@ -222,44 +252,53 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (pi < 2 * nblk) {
                 const int isv = pi >= nblk ? 1 : 0, blk = pi - isv * nblk;
                 const int row = blk * 8 + r8;
-                if (row < L && abl_dma) glds16(kg + (unsigned)(row * ldqkv + isv * dm + ((pc ^ (row & 6)) << 3)), lds0 + isv * Lp * RB + blk * 1024);
+                if (row < L && abl_dma) glds16s(kv_base, (unsigned)(row * ldqkv + isv * dm + ((pc ^ (row & 6)) << 3)) * 2u, lds0 + isv * Lp * RB + blk * 1024);
             }
         }
     };
     auto issue_lse = [&](const Head& x, int buf) {
         const int i = wave * 64 + lane;
         if (wave * 64 < L) {
-            if (i < L && abl_dma) glds4(A.lse + (size_t)(x.b * H + x.h) * L + i, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
+            const float* lb = (const float*)scalar_ptr(A.lse + (size_t)(x.b * H + x.h) * L);
+            if (i < L && abl_dma) glds4s(lb, (unsigned)i * 4u, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
         }
     };
     // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): wave w < 4 moves piece w of Q and of dO, waves 6, 7 two pieces of
     // O each, waves 4, 5 (the longest iteration: staggered, two key units) none (rows behind L: the last row again — finite values; their
     // lse is -inf, so P = 0 there)
-    const T* const sl_base = wave < 4 ? qkv : A.ctx;           // this wave's first source matrix and row stride
-    const int sl_ld = wave < 4 ? ldqkv : A.ldctx;
+    const T* const sl_m0 = wave < 4 ? qkv : A.ctx;             // this wave's first source matrix and row stride
+    const int sl_ld0 = wave < 4 ? ldqkv : A.ldctx;
     const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
     const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : 2) * 32 * RB + sl_blk0 * 1024;
     const int sl_rl = sl_blk0 * 8 + (lane >> 3);
     const int sl_ch = ((lane & 7) ^ (sl_rl & 6)) << 3;         // (row & 6) is the same for rows 8 apart
     const bool sl_mine = wave < 4 || wave >= 6;
-    auto issue_slice = [&](const Head& x, int t, int slot) {
+    const T* sl_b0 = nullptr;             // scalar bases of the prefetch cursor's head: first matrix, and dO for waves 0-3
+    const T* sl_b1 = nullptr;
+    auto slice_bases = [&](const Head& x) {
+        if (!sl_mine) return;
+        sl_b0 = head_base(sl_m0, sl_ld0, x, 0);
+        if (wave < 4) sl_b1 = head_base(dctx, lddctx, x, 0);
+    };
+    auto issue_slice = [&](int t, int slot) {
         if (abl_dma && sl_mine) {
-            const T* hb = sl_base + (size_t)x.b * L * sl_ld + x.h * HD;
             const unsigned dst = sl_dst + slot * SLOT_BYTES;
-            glds16(hb + (unsigned)(min(t * 32 + sl_rl, L - 1) * sl_ld + sl_ch), dst);
-            if (wave < 4) glds16(dctx + (size_t)x.b * L * lddctx + x.h * HD + (unsigned)(min(t * 32 + sl_rl, L - 1) * lddctx + sl_ch), dst + 32 * RB);
-            else glds16(hb + (unsigned)(min(t * 32 + sl_rl + 8, L - 1) * sl_ld + sl_ch), dst + 1024);
+            const int r0 = min(t * 32 + sl_rl, L - 1);
+            glds16s(sl_b0, (unsigned)(r0 * sl_ld0 + sl_ch) * 2u, dst);
+            if (wave < 4) glds16s(sl_b1, (unsigned)(r0 * lddctx + sl_ch) * 2u, dst + 32 * RB);
+            else glds16s(sl_b0, (unsigned)(min(t * 32 + sl_rl + 8, L - 1) * sl_ld0 + sl_ch) * 2u, dst + 1024);
         }
     };
     // prefetch cursor over this workgroup's slice stream
     Head pf{(int)blockIdx.x / H, (int)blockIdx.x % H};
     int pf_t = 0, pf_gs = 0, pf_slot = 0;
+    slice_bases(pf);
     auto issue_next = [&]() {
         if (pf_gs < nslices) {
-            issue_slice(pf, pf_t, pf_slot);
+            issue_slice(pf_t, pf_slot);
             ++pf_gs;
             if (++pf_slot == NSLOT) pf_slot = 0;
-            if (++pf_t == NSL) { pf_t = 0; next_head(pf); }
+            if (++pf_t == NSL) { pf_t = 0; next_head(pf); slice_bases(pf); }
         }
     };
 
@@ -288,7 +327,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         v += dpp_move<0x141>(v);    // the other quad of each 8 lanes
         if ((lane & 7) == 0) {
             const int rl = 8 * wave + (lane >> 3), q = t * 32 + rl;
-            dl_l[par * 32 + rl] = v * SCALE;
+            dl_l[par * 32 + rl] = -v * SCALE;           // the dP' accumulators start from it
 #ifndef LPI_ABL4_STAMPS
             if (q < L && abl_st) drow[q] = v;
 #endif
@@ -314,7 +353,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 da[t2][ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
             }
             nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g);      // -lse log2(e): scaled in place per head
-            dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // delta / 8
+            dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // -delta / 8
         }
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
@@ -324,7 +363,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             }
 #pragma unroll
             for (int u = 0; u < NUW; ++u) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+                // dP' = dO (V / 8)^T - delta / 8: the own V rows carry the 1 / 8 (exact in bf16), the accumulators start from -delta / 8
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = dls[t2];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     mma(s, qa[t2][ks], kk[u][ks]);
@@ -334,7 +374,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     p[r] = exp2_fast(fmaf(s[r], c, nl[t2][r]));
-                    e[r] = p[r] * fmaf(dp[r], SCALE, -dls[t2][r]);
+                    e[r] = p[r] * dp[r];
                 }
                 pw[u][t2][0] = pack2(p[0], p[1]);
                 pw[u][t2][1] = pack2(p[2], p[3]);
@@ -415,7 +455,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 
     // ---- launch prologue: first head's K, V, lse and the first AHEAD slices
     Head cur{(int)blockIdx.x / H, (int)blockIdx.x % H};
-    for (int part = 0; part < kv_parts; ++part) issue_kv_part(cur, part);
+    kv_base = head_base(qkv, ldqkv, cur, dm);
+    for (int part = 0; part < kv_parts; ++part) issue_kv_part(part);
     issue_lse(cur, 0);
     for (int j = 0; j < AHEAD; ++j) issue_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,6 +480,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 kk[u][ks].u = *reinterpret_cast<const uint4*>(k_img + (ub + u) * 16 * RB + rc[ks]);
                 vv[u][ks].u = *reinterpret_cast<const uint4*>(v_img + (ub + u) * 16 * RB + rc[ks]);
                 if constexpr (SV16) { chunk_f16_to_bf16(kk[u][ks]); chunk_f16_to_bf16(vv[u][ks]); }
+                chunk_scale_bf16(vv[u][ks], SCALE);
             }
 #pragma unroll
         for (int kb = 0; kb < (DQN ? (NKB ? NKB : MAXKB) : 0); ++kb) {
@@ -460,9 +502,10 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
+            kv_base = head_base(qkv, ldqkv, nxt, dm);
             issue_lse(nxt, lbuf ^ 1);
             if (!spread_kv)
-                for (int part = 0; part < kv_parts; ++part) issue_kv_part(nxt, part);
+                for (int part = 0; part < kv_parts; ++part) issue_kv_part(part);
         }
         LPI4_STAMP();
         // the last dQ store of a head (slice NSL - 2, in iteration NSL - 1) is what the wait of that iteration may leave in flight
@@ -473,7 +516,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             const int slot1 = slot + 1 == NSLOT ? 0 : slot + 1;
             if (abl_comp && t + 1 < NSL) stage_delta_load(slot1);
             issue_next();         // slice gs + AHEAD -> the slot slice gs - 2 has left (its staggered matrix half ran in the last iteration)
-            if (spread_kv && t < kv_parts && it + 1 < nheads) issue_kv_part(nxt, t);
+            if (spread_kv && t < kv_parts && it + 1 < nheads) issue_kv_part(t);
             LPI4_STAMP();
             const int par = t & 1;
             if (abl_comp) {
