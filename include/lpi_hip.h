@@ -176,8 +176,9 @@ int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, co
 /* ---- a4: prompted multi-head attention, head_dim 64   replaces: models/clip/model.py:183-185 -----------
  * qkv: [B*L, 3*d] `dtype` (q | k | v, heads contiguous by 64).  ctx: [B*L, d] `dtype`.  lse: [B, H, L] f32.
  * softmax(q k^T / 8 + causal mask) v; causal != 0 applies the text tower's strict upper-triangular -inf mask
- * (model.py:347-353).  Backward recomputes P from lse; delta = rowsum(dctx*ctx) is produced into `delta`
- * ([B,H,L] f32 scratch).  dqkv: [B*L, 3*d] `dtype`. L <= 288. */
+ * (model.py:347-353).  Backward recomputes P from lse; `delta` is [B,H,L] f32 SCRATCH: the kernels that make two passes over the scores
+ * leave rowsum(dctx*ctx) there, the streamed single-pass backward (attention4.hip) keeps it in LDS and does not touch the buffer.
+ * dqkv: [B*L, 3*d] `dtype`. L <= 288. */
 int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                  float* lse, int causal, void* stream);
 int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,

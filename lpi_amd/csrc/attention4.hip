@@ -317,7 +317,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         dl_d.u = *reinterpret_cast<const uint4*>(ds_ + dlo);
         dl_o.u = *reinterpret_cast<const uint4*>(ds_ + 32 * RB + dlo);
     };
-    auto stage_delta = [&](float* drow, int t, int par) {
+    auto stage_delta = [&](int par) {
         if (wave >= 4) return;
         float v = 0.f;
 #pragma unroll
@@ -325,18 +325,12 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         v += dpp_move<0xB1>(v);     // lane ^ 1
         v += dpp_move<0x4E>(v);     // lane ^ 2
         v += dpp_move<0x141>(v);    // the other quad of each 8 lanes
-        if ((lane & 7) == 0) {
-            const int rl = 8 * wave + (lane >> 3), q = t * 32 + rl;
-            dl_l[par * 32 + rl] = -v * SCALE;           // the dP' accumulators start from it
-#ifndef LPI_ABL4_STAMPS
-            if (q < L && abl_st) drow[q] = v;
-#endif
-        }
+        if ((lane & 7) == 0) dl_l[par * 32 + 8 * wave + (lane >> 3)] = -v * SCALE;          // the dP' accumulators start from it
     };
 
     Chunk bp[NUA], bs[NUA];              // P and dS of a slice as MFMA B operands: score half -> matrix half
     // score half of slice t: S^T, dP^T -> P, dS = P (dP - delta) / 8; dS^T -> dsb[par]
-    auto stage_s = [&](int t, int slot, int lbuf, int par) {
+    auto stage_s = [&](int t, int slot, int lbuf, int par, bool with_delta) {
         const char* qs_ = ring + slot * SLOT_BYTES;
         const char* ds_ = qs_ + 32 * RB;
         char* dsp = dsb + par * (Lp * 64);
@@ -355,6 +349,9 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g);      // -lse log2(e): scaled in place per head
             dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // -delta / 8
         }
+        // the NEXT slice's delta (waves 0-3; its rows were read in front of the DMA issue): a short dependent chain that runs under this
+        // slice's LDS round trip and first MFMAs
+        if (with_delta) stage_delta(par ^ 1);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             if constexpr (SV16) {
@@ -470,7 +467,6 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         LPI4_STAMP();
         Head nxt = cur;
         next_head(nxt);
-        float* const drow = delta + (size_t)(cur.b * H + cur.h) * L;                   // this head's rows of the outputs
         T* const dqh = dqkv + (size_t)cur.b * L * lddqkv + cur.h * HD;
         // own K, V rows and the K^T fragments out of the images (landed a head ago)
 #pragma unroll
@@ -498,7 +494,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         // this head's lse vector (landed a head ago): -lse log2(e) in place, one entry per thread (the entries behind L stay -inf)
         if ((int)threadIdx.x < L) lse_l[lbuf * Lp + threadIdx.x] *= -LOG2E;
         stage_delta_load(slot);
-        stage_delta(drow, 0, 0);
+        stage_delta(0);
         LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
@@ -510,6 +506,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         LPI4_STAMP();
         // the last dQ store of a head (slice NSL - 2, in iteration NSL - 1) is what the wait of that iteration may leave in flight
         const bool dq_last = DQN > 0 && (NSL - 2) * 32 < rows_hi;
+        const bool dq_all = rows_hi >= L;
 #pragma unroll 1
         for (int t = 0; t < NSL; ++t) {
             LPI4_STAMP();
@@ -520,14 +517,15 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             LPI4_STAMP();
             const int par = t & 1;
             if (abl_comp) {
-                if (t + 1 < NSL) stage_delta(drow, t + 1, par ^ 1);
+                const bool run = own_wanted || t * 32 < rows_hi;
+                if (t + 1 < NSL && (STAG || !run)) stage_delta(par ^ 1);
                 LPI4_STAMP();
                 if constexpr (STAG) {
                     if (t >= 1 && (own_wanted || (t - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);
                     LPI4_STAMP();
-                    if (own_wanted || t * 32 < rows_hi) stage_s(t, slot, lbuf, par);
-                } else if (own_wanted || t * 32 < rows_hi) {
-                    stage_s(t, slot, lbuf, par);
+                    if (run) stage_s(t, slot, lbuf, par, false);
+                } else if (run) {
+                    stage_s(t, slot, lbuf, par, t + 1 < NSL);
                     LPI4_STAMP();
                     stage_m(slot);
                 }
@@ -548,6 +546,12 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                         if (DQN >= 2 && dq_last) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else if (DQN >= 1 && dq_last) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    } else if (t >= 3 && dq_all) {
+                        // younger than the pieces of slice gs + 2 for sure: the 2 x 2 pieces of slices gs + 3, gs + 4 and the DQN dQ stores of each
+                        // of the iterations t - 2, t - 1, t (every row wanted; slices before the last are whole)
+                        if constexpr (DQN >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                        else if constexpr (DQN == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     } else if (t >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 } else if (t == NSL - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next head's K / V pieces (issued 3+ iterations ago)
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1356,8 +1356,7 @@ def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     new, new2, old = out[5][0], out[5][1], out[1][0]
     assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
     assert bool(torch.isfinite(new[0].float()).all())
-    dref = (dctx.double().cpu() * ctx.double().cpu()).reshape(B, L, H, 64).sum(-1).permute(0, 2, 1)
-    assert relerr(new[1], dref) < 1e-5                                             # delta = rowsum(dO o O) of the stored O, f32 sums
+    assert float(new[1].abs().max()) == 0.0                                        # delta (scratch of the C ABI) stays in LDS: the buffer is untouched
     assert relerr(new[0], old[0].double().cpu()) < 2e-2
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         e = relerr(new[0][:, sl], qr.grad[:, sl])

@@ -53,7 +53,7 @@ for dt, TD in ((BF16, torch.bfloat16), (F16, torch.float16)):
         call("lpi_set_tuning", 11, 0)
         e = {k: [relerr(v[0][:, i * d:(i + 1) * d], gref[:, i * d:(i + 1) * d]) for i in range(3)] for k, v in out.items()}
         dref = (dctx.double() * o).reshape(B, L, H, 64).sum(-1).permute(0, 2, 1)
-        ed = relerr(out[5][1], dref)
+        ed = relerr(out[1][1], dref)          # the two-pass kernels leave delta in the scratch; the streamed one keeps it in LDS
         good = max(e[5]) < 4e-2 and ed < 2e-2 and bool(torch.isfinite(out[5][0].float()).all())
         ok &= good
         print(f"dt={dt} B={B} L={L} H={H} cap={cap}: gen4 dq/dk/dv err {e[5][0]:.2e} {e[5][1]:.2e} {e[5][2]:.2e} delta {ed:.2e} | gen1 {e[1][0]:.2e} {e[1][1]:.2e} {e[1][2]:.2e}  {'ok' if good else 'FAIL'}", flush=True)
