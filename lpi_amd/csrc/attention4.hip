@@ -444,8 +444,16 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
             for (int pi = 0; pi < DQN; ++pi) {
                 const int q = t * 32 + (dq_qs + pi) * 16 + r16;
+#ifdef LPI_ABL4_NODQST
+                if (q < L && lddqkv == 12345)
+#else
                 if (q < L && abl_st)
+#endif
+#ifdef LPI_NT_ATTN
+                    st_stream8(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g), pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
+#else
                     *reinterpret_cast<uint2*>(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g)) = make_uint2(pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
+#endif
             }
         }
     };
@@ -565,13 +573,40 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (abl_comp && (own_wanted || (NSL - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);      // the last slice's matrix half
         }
         if ((NSL - 1) * 32 < rows_hi) stage_dq(dqh, NSL - 1, (NSL - 1) & 1);
+        // dK^T / dV^T tiles (16 keys x 64) -> global as WHOLE 128-byte rows: the accumulator layout gives a lane 4 x 8 bytes of its key row; staged
+        // through 1 KiB per wave of the dS^T buffer that is idle now (8 rows at a time, 8-byte slots XOR-ed with 2 (row & 7): conflict-free),
+        // read back as [row][16-byte chunk] — every store instruction writes 8 full rows (straight from the registers it was 16 rows x 64 B:
+        // twice the lines touched per byte)
+        {
+            char* st = dsb + (NSL & 1) * (Lp * 64) + wave * 1024;
+            const int wr = (r16 & 7) * 128, wsw = 2 * (r16 & 7);
+            const int rrow = lane >> 3, rch = lane & 7;
+            const int rd = rrow * 128 + ((rch ^ (rrow & 7)) << 4);
+            auto store_tile = [&](T* tile, const f32x4 (&acc)[4], int row0) {
 #pragma unroll
-        for (int u = 0; u < NUW; ++u) {
-            if ((ub + u) * 16 >= rows_hi) continue;
-            const int kr = (ub + u) * 16 + r16;
-            T* dst = dqh + (unsigned)(kr * lddqkv);
-            store_row_bf16_t(dst + dm, dk[u], g, kr < L && abl_st);
-            store_row_bf16_t(dst + 2 * dm, dv[u], g, kr < L && abl_st);
+                for (int hf = 0; hf < 2; ++hf) {
+                    if ((r16 >> 3) == hf) {
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt)
+                            *reinterpret_cast<uint2*>(st + wr + (((4 * dt + g) ^ wsw) << 3)) = make_uint2(pack2(acc[dt][0], acc[dt][1]), pack2(acc[dt][2], acc[dt][3]));
+                    }
+                    const uint4 v = *reinterpret_cast<const uint4*>(st + rd);
+                    const int kr = row0 + 8 * hf + rrow;
+#ifdef LPI_ABL4_NODKVST
+                    if (kr < L && lddqkv == 12345)
+#else
+                    if (kr < L && abl_st)
+#endif
+                        *reinterpret_cast<uint4*>(tile + (unsigned)((8 * hf + rrow) * lddqkv + 8 * rch)) = v;
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < NUW; ++u) {
+                if ((ub + u) * 16 >= rows_hi) continue;
+                T* dst = dqh + (unsigned)((ub + u) * 16 * lddqkv);
+                store_tile(dst + dm, dk[u], (ub + u) * 16);
+                store_tile(dst + 2 * dm, dv[u], (ub + u) * 16);
+            }
         }
         cur = nxt;
     }
