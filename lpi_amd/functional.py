@@ -44,7 +44,10 @@ class EncodeImageFn(torch.autograd.Function):
         # the backward context (workspace arena + the tower's forward serial) lives on THIS node: a later forward on the same engine
         # makes encode_image_backward raise instead of differentiating the wrong batch
         out, ctx.lpi = enc.encode_image(image, prompts.detach(), depth, train=train, return_ctx=True)
-        return out
+        # a fresh alias: the context holds `out` itself, and a tensor that is BOTH this node's output (grad_fn -> node) and held by the node's
+        # context is a reference cycle through a C++ object — Python's collector cannot break it, and the engine with its workspace arena
+        # (tens of GB) would never be freed
+        return out.detach()
 
     @staticmethod
     def backward(ctx, g):
@@ -63,7 +66,7 @@ class EncodeTextFn(torch.autograd.Function):
         ctx.pshape = prompts.shape
         train = prompts.requires_grad
         out, ctx.lpi = enc.encode_text(ids, prompts.detach(), depth, train=train, return_ctx=True)
-        return out
+        return out.detach()          # see EncodeImageFn.forward
 
     @staticmethod
     def backward(ctx, g):
@@ -86,7 +89,7 @@ class EncodeBothFn(torch.autograd.Function):
         ctx.vshape, ctx.tshape = vis_prompts.shape, txt_prompts.shape
         train = vis_prompts.requires_grad or txt_prompts.requires_grad
         (img_f, ctx.lpi_v), (txt_f, ctx.lpi_t) = enc.encode_both(image, ids, vis_prompts.detach(), txt_prompts.detach(), depth, train=train)
-        return img_f, txt_f
+        return img_f.detach(), txt_f.detach()          # fresh aliases: see EncodeImageFn.forward
 
     @staticmethod
     def backward(ctx, g_img, g_txt):

@@ -4,6 +4,8 @@ for ViT-B/16 (the oracle needs minutes per sample at this size): unit-norm featu
 text batch against the trimmed one, finite gradients of every factor; and, in the f32 parity mode at 128 pairs (the f32 workspace of 512 pairs
 does not fit beside the bf16 one), central finite differences of the total loss against the hand-written backward.
 The architecture itself is pinned against the oracle at batch 2-3 in tests/test_fullsize_gpu.py."""
+import gc
+
 import numpy as np
 import pytest
 import torch
@@ -29,7 +31,14 @@ def weights():
     return synth.clip_state_dict(CFG)
 
 
+def _mem(tag):
+    print(f"[HBM] {tag}: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB")
+
+
 def test_vit_l14_512_pairs_bf16_step_properties_and_packed_text(weights):
+    gc.collect()
+    torch.cuda.empty_cache()
+    _mem("before the 512-pair step")
     img = torch.from_numpy(synth.images(B, CFG.image_resolution)).to(DEV)
     ids_h = synth.token_ids(B)
     ids_t = torch.from_numpy(np.ascontiguousarray(trim_token_ids(ids_h))).to(DEV)
@@ -61,12 +70,16 @@ def test_vit_l14_512_pairs_bf16_step_properties_and_packed_text(weights):
         a, b = res["pack"][1][k].double(), res["trim"][1][k].double()
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), k
     print(f"ViT-L/14, 512 pairs, depth 12, r 8, bf16: base loss {float(out['base_loss']):.4f} (ln 512 = {np.log(512):.4f}); packed text {pk.rows / B:.1f} rows per caption")
-    del enc
+    del enc, fac
+    gc.collect()                # the engine holds reference cycles (towers <-> workspaces): collect them before handing the HBM back
     torch.cuda.empty_cache()
 
 
 def test_vit_l14_finite_difference_of_total_loss_f32(weights):
     """d(base + alignment loss)/d(factor entry) from the hand-written backward against central differences: ViT-L/14, depth 12, r 8, f32 mode."""
+    gc.collect()
+    torch.cuda.empty_cache()
+    _mem("before the finite-difference test")
     Bf = 128
     img = torch.from_numpy(synth.images(Bf, CFG.image_resolution)).to(DEV)
     ids = PackedIds(synth.token_ids(Bf)).to(DEV)
@@ -94,5 +107,6 @@ def test_vit_l14_finite_difference_of_total_loss_f32(weights):
         g = float(grads[name][idx])
         print(f"ViT-L/14 f32 finite difference {name}{idx}: {fd:.6f} vs backward {g:.6f}")
         assert abs(g) > 2e-4 and abs(fd - g) <= 0.05 * abs(g) + 2e-5, (name, idx, fd, g)
-    del enc
+    del enc, fac
+    gc.collect()                # the engine holds reference cycles (towers <-> workspaces): collect them before handing the HBM back
     torch.cuda.empty_cache()

@@ -273,3 +273,28 @@ def test_interact_kernels_vs_f64(N, Dv, Dt, r, layer_num, layer):
     assert relerr(runs[0]["xv"], a64.grad) < 1e-4 and relerr(runs[0]["xt"], b64.grad) < 1e-4
     for k in order:
         assert relerr(runs[0][k], p64[k].grad) < 1e-4, k
+
+
+def test_engine_and_its_workspace_are_freed_after_a_training_step():
+    """The autograd nodes of the towers keep the engine and its workspace arena (tens of GB at full size) in their context; a tensor that is both a
+    node's output and held by that node's context would be a reference cycle through a C++ object that Python's collector cannot break.  After a
+    step, dropping the engine must return its memory."""
+    import gc
+    from lpi_amd.engine import DualEncoder, PackedIds
+    from lpi_amd.step import train_step
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
+    fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+    img = torch.from_numpy(synth.images(64, cfg.image_resolution)).to(DEV)
+    ids = PackedIds(synth.token_ids(64)).to(DEV)
+    out = train_step(enc, img, ids, fac, 2)
+    torch.cuda.synchronize()
+    used = torch.cuda.memory_allocated() - base
+    assert used > (8 << 20)
+    del enc, fac, img, ids, out
+    gc.collect()
+    assert not [o for o in gc.get_objects() if type(o).__name__ == "DualEncoder"]
+    assert torch.cuda.memory_allocated() - base < max(used // 4, 40 << 20)          # module-level caches (split-K scratch, loss workspace) stay
