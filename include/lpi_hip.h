@@ -48,6 +48,12 @@ extern "C" {
                                * carries the LN operand block (f32): mean[ldr] | rstd[ldr] | c1[N] (ldr >= M, a multiple of 4). */
 #define LPI_EPI_LN_QUICKGELU 4 /* ... followed by the QuickGELU epilogue (aux as for LPI_EPI_QUICKGELU).  Both: bf16 / f16 operands, shapes the
                                * persistent 256x256 kernel takes (LPI_ENOSYS otherwise: the caller runs LayerNorm + GEMM). */
+#define LPI_EPI_RES_ROWSTATS 5 /* LPI_EPI_NONE on the fp16 residual stream (c_dtype LPI_F16, residual required), and the ROW STATISTICS of what it
+                               * stores come out with it: `aux` is an f32 buffer of N/128 slots x 2 x ldaux (ldaux >= M, a multiple of 4) and
+                               * aux[(2 j) ldaux + m] = sum, aux[(2 j + 1) ldaux + m] = sum of squares of the 128 stored (fp16-rounded) values
+                               * C[m, 128 j .. 128 j + 127], summed in a fixed order.  lpi_ln_stats_finalize turns them into the mean / rstd the
+                               * LayerNorm-fold epilogues of the NEXT GEMM read (model.py:172-177: x + attn(..) -> ln_2, x + mlp(..) -> the next
+                               * block's ln_1), so no separate pass over the stream is needed.  Same shapes as the LN-fold epilogues. */
 
 int lpi_version(void);   /* the C-ABI version: changes with every change of a signature or of an argument's meaning (bindings check it) */
 /* number of kernels launched by this library since load (tests use it to prove the HIP path ran) */
@@ -121,6 +127,11 @@ int lpi_gemm_last_grouped(void);
 
 /* 1 if lpi_gemm_nt / lpi_gemm_nt_grouped take the LayerNorm-fold epilogues (LPI_EPI_LN, LPI_EPI_LN_QUICKGELU) for this operand type and shape */
 int lpi_gemm_ln_supported(int dtype, int M, int N, int K);
+/* mean[m] = S / d, rstd[m] = 1 / sqrt(Q / d - mean^2 + eps) from the slot sums S, Q an LPI_EPI_RES_ROWSTATS GEMM left in `part` (d / 128 slots,
+ * row stride ld): what nn.LayerNorm (model.py:154-160, biased variance, eps 1e-5) computes from the row.  `_pair`: the two towers' in one launch. */
+int lpi_ln_stats_finalize(int rows, int d, const float* part, int ld, float eps, float* mean, float* rstd, void* stream);
+int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
+                               int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream);
 
 /* TWO few-row GEMMs (lpi_gemm_nt_splitk) in one pair of launches — the two towers' GEMM of the same op on the pooled rows of the last block
  * / the heads: each alone is a ~7 us partial-tile launch plus a ~6 us reduction.  Same operand types and epilogue kind; ksplit[i], scratch_i

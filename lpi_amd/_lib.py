@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LPI_LIB") or os.path.join(_HERE, "csrc", "liblpi_hip.so")
 
 F32, BF16, F16 = 0, 1, 2
-EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU = 0, 1, 2, 3, 4
+EPI_NONE, EPI_QUICKGELU, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS = 0, 1, 2, 3, 4, 5
 
 
 class LpiError(RuntimeError):
@@ -40,6 +40,8 @@ SIGNATURES = {
     "lpi_gemm_nt_grouped": [_I, _I, _I, _F, _I, _P, _P],
     "lpi_gemm_last_grouped": [],
     "lpi_gemm_ln_supported": [_I, _I, _I, _I],
+    "lpi_ln_stats_finalize": [_I, _I, _P, _I, _F, _P, _P, _P],
+    "lpi_ln_stats_finalize_pair": [_I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P],
     "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
@@ -108,7 +110,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 300
+EXPECTED_ABI = 301
 
 _lib = None
 

@@ -6,7 +6,7 @@ static std::atomic<uint64_t> g_launches{0};
 
 extern "C" void lpi_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
-extern "C" int lpi_version(void) { return 300; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
+extern "C" int lpi_version(void) { return 301; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
 
 static thread_local int t_last_gemm_kernel = -1;
 void lpi_note_gemm_kernel(int which) { t_last_gemm_kernel = which; }

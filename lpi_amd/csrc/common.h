@@ -280,6 +280,62 @@ __device__ __forceinline__ float wave_max(float v) {
 #endif
 }
 
+// Row statistics in a GEMM epilogue (LPI_EPI_RES_ROWSTATS): each 32-lane half of a wave holds, per lane, partial sums s[j] / q[j] of EIGHT rows
+// (one row per j, the half's 32 lanes x 4 columns = 128 columns of it).  A halving exchange instead of eight full reductions: at each of three steps a
+// lane keeps half of its rows and receives its partner's partials of those (v_permlane16_swap between the two 16-lane rows, then DPP row_mirror and
+// row_half_mirror inside a row — any pairing that joins the two halves of the undecided lane bit serves, the lanes' sets stay disjoint), then two quad
+// steps.  Every lane ends with the full 128-column sums of row j = (lane >> 2) & 7 of its half: 9 exchanges per quantity, not 40.  Fixed order.
+__device__ __forceinline__ void rowstats8_half_reduce(const float (&s)[8], const float (&q)[8], int lane, float& so, float& qo) {
+    float a[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[4 + i]), false, false);
+        a[0][i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);      // lanes 0-15 of a half: row i; lanes 16-31: row 4 + i
+        r = __builtin_amdgcn_permlane16_swap(__float_as_uint(q[i]), __float_as_uint(q[4 + i]), false, false);
+        a[1][i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const bool b3 = lane & 8, b2 = lane & 4;
+    float o[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        float b[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float keep = b3 ? a[w][2 + k] : a[w][k], send = b3 ? a[w][k] : a[w][2 + k];
+            b[k] = keep + dpp_move<0x140>(send);      // row_mirror: lane 15 - l, the other value of bit 3
+        }
+        const float keep = b2 ? b[1] : b[0], send = b2 ? b[0] : b[1];
+        float c = keep + dpp_move<0x141>(send);       // row_half_mirror: lane 7 - l of the 8, the other value of bit 2
+        c += dpp_move<0xB1>(c);
+        c += dpp_move<0x4E>(c);
+        o[w] = c;
+    }
+    so = o[0];
+    qo = o[1];
+}
+// sum and sum of squares of four values AS fp16 ROUNDS THEM, from the two packed dwords the store writes: v_dot2_f32_f16 against (1, 1) and against
+// itself — four instructions per row instead of eight conversions and seven f32 operations (exact products, f32 accumulation)
+__device__ __forceinline__ void f16x4_sum_sumsq(uint32_t w0, uint32_t w1, float& s, float& q) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_;
+    const h2_ h0 = __builtin_bit_cast(h2_, w0), h1 = __builtin_bit_cast(h2_, w1);
+    const h2_ one = {(_Float16)1.0f, (_Float16)1.0f};
+    s = __builtin_amdgcn_fdot2(h1, one, __builtin_amdgcn_fdot2(h0, one, 0.f, false), false);
+    q = __builtin_amdgcn_fdot2(h1, h1, __builtin_amdgcn_fdot2(h0, h0, 0.f, false), false);
+}
+// the four values as the store of TT rounds them (fp16 / bf16), back in f32
+template <typename TT> __device__ __forceinline__ f32x4 rounded4(f32x4 v);
+template <> __device__ __forceinline__ f32x4 rounded4<float>(f32x4 v) { return v; }
+template <> __device__ __forceinline__ f32x4 rounded4<f16_t>(f32x4 v) {
+    f32x4 r;
+    r[0] = (float)(f16_t)v[0]; r[1] = (float)(f16_t)v[1]; r[2] = (float)(f16_t)v[2]; r[3] = (float)(f16_t)v[3];
+    return r;
+}
+template <> __device__ __forceinline__ f32x4 rounded4<bf16_t>(f32x4 v) {
+    f32x4 r;
+    r[0] = (float)(__bf16)v[0]; r[1] = (float)(__bf16)v[1]; r[2] = (float)(__bf16)v[2]; r[3] = (float)(__bf16)v[3];
+    return r;
+}
+
 // sigmoid through v_rcp_f32 (1 ulp): a plain `/` compiles to the IEEE sequence (2 v_div_scale + v_rcp + 4 fma + v_div_fmas +
 // v_div_fixup per element), which doubled the VALU instructions of the QuickGELU / gelu' GEMM epilogues.  LPI_IEEE_DIV=1 keeps it
 // (A/B switch).

@@ -410,7 +410,12 @@ static int gemm_nt_check(int dtype, int c_dtype, int M, int N, int K, const void
 
     const int esz = dtype == LPI_F32 ? 4 : 2;
     const int csz = c_dtype == LPI_F32 ? 4 : 2;
-    if (c_dtype == LPI_F16 && dtype == LPI_BF16 && (epilogue != LPI_EPI_NONE || !residual)) return LPI_ENOSYS;
+    if (epilogue == LPI_EPI_RES_ROWSTATS) {      // the fp16 residual epilogue + the row statistics of its output: aux = f32 slots, N/128 x 2 x ldaux
+        if (c_dtype != LPI_F16 || dtype == LPI_F32) return LPI_ENOSYS;
+        if (!residual || !aux || ldaux < M || (ldaux & 3) || ((uintptr_t)aux & 15)) return LPI_EINVAL;
+        aux = nullptr;      // the checks below are for an operand-typed [M, N] aux tile
+    }
+    if (c_dtype == LPI_F16 && dtype == LPI_BF16 && ((epilogue != LPI_EPI_NONE && epilogue != LPI_EPI_RES_ROWSTATS) || !residual)) return LPI_ENOSYS;
     if (c_dtype == LPI_F16 && dtype == LPI_F32) return LPI_ENOSYS;
     const bool ln = epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU;
     if (c_dtype == LPI_BF16 && dtype == LPI_F16 && !ln) return LPI_ENOSYS;      // f16 operands write f16 or f32 (bf16: the LN-fold GEMMs of bf16 mode)
@@ -438,7 +443,8 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
     const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
     if (int e = gemm_nt_check(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux)) return e;
     hipStream_t s = (hipStream_t)stream;
-    if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) {      // only the persistent 256x256 kernel has the LN-fold epilogues
+    if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU || epilogue == LPI_EPI_RES_ROWSTATS) {
+        // only the persistent 256x256 kernel has the LN-fold and the row-statistics epilogues
         if (!lpi_gemm256_eligible(dtype, M, N, K)) return LPI_ENOSYS;
         return lpi_gemm256p_launch(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux, alpha, s);
     }
@@ -492,7 +498,7 @@ extern "C" int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float a
         int tiles = 0;
         for (int i = 0; i < 2 && group; ++i) {
             const bool res = d[i].residual != nullptr && epilogue != LPI_EPI_LN && epilogue != LPI_EPI_LN_QUICKGELU;      // LN block: not a tile
-            const bool side16 = (res && c_dtype == LPI_F16) || epilogue == LPI_EPI_DQUICKGELU;
+            const bool side16 = (res && c_dtype == LPI_F16) || epilogue == LPI_EPI_DQUICKGELU;      // LPI_EPI_RES_ROWSTATS: res and fp16 by its checks
             const bool loads = res || epilogue == LPI_EPI_DQUICKGELU;
             group = lpi_gemm256_eligible(dtype, d[i].M, d[i].N, d[i].K) && (!loads || (side16 && g_lpi_tuning[2] != 2));
             tiles += (d[i].M / 256) * (d[i].N / 256);

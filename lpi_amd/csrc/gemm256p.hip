@@ -183,6 +183,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     // vmcnt queue behind a DMA, and the load latency of each pass (exposed four times per tile in the one-tile kernel) is hidden.
     // The bias vector goes to LDS once per launch for the same reason.  No next-tile K prefetch for these (slot 0 is taken).
     constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
+    // STATS (LPI_EPI_RES_ROWSTATS = the residual epilogue with SAVE_U set): the row sums / sums of squares of the stored fp16 values leave with the
+    // tile — `aux` is the f32 slot buffer (include/lpi_hip.h), two more 4-byte stores per wave and pass (NST below counts them in the vmcnt windows)
+    constexpr bool STATS = EPI == LPI_EPI_NONE && RES && SAVE_U && __is_same(TC, f16_t);
+    constexpr int NST = 8 + (STATS ? 2 : 0);
     const char* side_base = nullptr;
     int side_ld = 0;
     float* const bias_lds = reinterpret_cast<float*>(smem + LDS_P);
@@ -386,13 +390,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                     // instructions of the next side tile and the 8 stores of the previous pass, in issue order
                     //   side(0) side(1) | stores(0) side(2) | stores(1) side(3) | stores(2) | stores(3)
                     if (p == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else if (p == 3 && !more_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // p == 3 with a next tile: stores(2) + its 4 A-row DMA instructions
+                    else if (p == 3 && !more_tiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST + 4) : "memory");      // p == 3 with a next tile: stores(2) + its 4 A-row DMA instructions
                 }
                 if constexpr (LNE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mu8), "+s"(rs8) : : "memory");      // the statistics are used after this wait
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                float st_s[8], st_q[8];      // STATS: this lane's partial sums of the pass's eight rows
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
                     const int s_row = wave_e * 8 + rr;
@@ -410,16 +415,45 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         }
                         // streaming store, as gemm_epilogue_store (a RUN-TIME choice per problem was tried: the duplicated store
                         // loops spilled 60 bytes per lane in the QuickGELU instantiations and the step lost 7 %)
+                        if constexpr (STATS) {      // the two packed dwords serve the store and the sums (of the values as stored)
+                            const uint32_t w0 = pack2_t<f16_t>(o[0], o[1]), w1 = pack2_t<f16_t>(o[2], o[3]);
+                            if constexpr (LPI_NTC_DEFAULT) st_stream8(C + (size_t)(m0 + trow) * ldc + ecol, w0, w1);
+                            else *reinterpret_cast<uint2*>(C + (size_t)(m0 + trow) * ldc + ecol) = uint2{w0, w1};
+                            f16x4_sum_sumsq(w0, w1, st_s[rr], st_q[rr]);
+                        } else {
 #ifdef LPI_NO_NT_SIDE16C          /* A/B: the residual-stream outputs (read next by a LayerNorm) with plain stores */
-                        if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                            if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
 #else
-                        if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                            if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
 #endif
-                        else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                            else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
+                        }
                     } else {
                         gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, LNE ? mu8[rr] : 0.f,
                                                                      LNE ? rs8[rr] : 1.f);
                     }
+                }
+#ifdef LPI_EPI_SLEEP      /* timing experiment: the residual epilogue made longer by LPI_EPI_SLEEP x 64 cycles per pass, nothing else changed */
+                if constexpr (SIDE16 && !STATS) __builtin_amdgcn_s_sleep(LPI_EPI_SLEEP);
+#endif
+                if constexpr (STATS) {
+                    // lanes 0-31 hold columns n0 .. n0+127 (slot n0/128), lanes 32-63 the next slot; after the halving exchange every lane has the
+                    // sums of row (lane >> 2) & 7 of the wave's eight: one lane of each quad stores them
+                    float so, qo;
+#ifndef LPI_RS_NOREDUCE      /* ablation: LPI_RS_NOREDUCE = no exchange, LPI_RS_NOSTORE = no statistics stores (timing builds) */
+                    rowstats8_half_reduce(st_s, st_q, lane_e, so, qo);
+#else
+                    so = st_s[0] + st_s[1] + st_s[2] + st_s[3] + st_s[4] + st_s[5] + st_s[6] + st_s[7];
+                    qo = st_q[0] + st_q[1] + st_q[2] + st_q[3] + st_q[4] + st_q[5] + st_q[6] + st_q[7];
+#endif
+                    const int s_row = wave_e * 8 + ((lane_e >> 2) & 7);
+                    const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
+                    float* sp = reinterpret_cast<float*>(aux) + (size_t)(2 * ((n0 >> 7) + (lane_e >> 5))) * ldaux + (m0 + trow);
+#ifndef LPI_RS_NOSTORE
+                    if ((lane_e & 3) == 0) { sp[0] = so; sp[ldaux] = qo; }
+#else
+                    if (so == 12345.678f && qo == 0.f) { sp[0] = so; sp[ldaux] = qo; }
+#endif
                 }
                 // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
                 // all but the 16 youngest operations done.  Passes 2 and 3's barriers then publish it to every wave.
@@ -542,6 +576,12 @@ int dispatchp(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
     case LPI_EPI_NONE:
         if (res) return launchp_impl<T, TC, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
         return launchp_impl<T, TC, LPI_EPI_NONE, false, false>(hp, np, alpha, s);
+    case LPI_EPI_RES_ROWSTATS:
+        if constexpr (sizeof(TC) == 2 && !__is_same(TC, bf16_t)) {
+            if (!res || !ax) return LPI_EINVAL;
+            return launchp_impl<T, TC, LPI_EPI_NONE, true, true>(hp, np, alpha, s);
+        }
+        return LPI_ENOSYS;
     case LPI_EPI_QUICKGELU:
         if (res) return LPI_ENOSYS;
         if (ax) return launchp_impl<T, TC, LPI_EPI_QUICKGELU, false, true>(hp, np, alpha, s);
@@ -577,8 +617,12 @@ int launch_group(int dtype, int c_dtype, int epilogue, const HostProb* hp, int n
     }
     if (dtype == LPI_BF16 && c_dtype == LPI_BF16) return dispatchp<bf16_t, bf16_t>(epilogue, hp, np, alpha, s);
     if (dtype == LPI_BF16 && c_dtype == LPI_F32) return dispatchp<bf16_t, float>(epilogue, hp, np, alpha, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && epilogue == LPI_EPI_NONE && hp[0].residual) {
+    if (dtype == LPI_BF16 && c_dtype == LPI_F16 && (epilogue == LPI_EPI_NONE || epilogue == LPI_EPI_RES_ROWSTATS) && hp[0].residual) {
         for (int i = 1; i < np; ++i) if (!hp[i].residual) return LPI_EINVAL;
+        if (epilogue == LPI_EPI_RES_ROWSTATS) {
+            for (int i = 0; i < np; ++i) if (!hp[i].aux) return LPI_EINVAL;
+            return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, true>(hp, np, alpha, s);
+        }
         return launchp_impl<bf16_t, f16_t, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
     }
     if (dtype == LPI_F16 && c_dtype == LPI_F16) return dispatchp<f16_t, f16_t>(epilogue, hp, np, alpha, s);

@@ -137,13 +137,32 @@ __device__ __forceinline__ void tile(int m0, int n0, int K, const T* __restrict_
         }
         __syncthreads();
         const int r0 = wave * 16 + (lane >> 5);      // this lane's first row within the pass; a wave instruction covers 2 rows
+        // LPI_EPI_RES_ROWSTATS (the fp16 residual epilogue with SAVE_U set, as in gemm256p.hip): a 32-lane half owns one 128-column row per rr, i.e.
+        // the whole slot n0 / 128 of eight rows per pass — the same halving exchange, one lane of each quad stores the sums
+        constexpr bool STATS = EPI == LPI_EPI_NONE && RES && SAVE_U && __is_same(TC, f16_t);
+        if constexpr (STATS) {
+            float st_s[8], st_q[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + 2 * rr;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * ERS + (lane & 31) * 16);
+                const f32x4 o = gemm_epilogue_store<T, TC, EPI, RES, false>(v, m0 + ph * 128 + r, ecol, C, ldc, bv, alpha, residual, ldr, nullptr, 0);
+                f16x4_sum_sumsq(pack2_t<f16_t>(o[0], o[1]), pack2_t<f16_t>(o[2], o[3]), st_s[rr], st_q[rr]);      // of the values as stored
+            }
+            float so, qo;
+            rowstats8_half_reduce(st_s, st_q, lane, so, qo);
+            const int r = r0 + 2 * ((lane >> 2) & 7);
+            float* sp = reinterpret_cast<float*>(aux) + (size_t)(2 * (n0 >> 7)) * ldaux + (m0 + ph * 128 + r);
+            if ((lane & 3) == 0) { sp[0] = so; sp[ldaux] = qo; }
+        } else {
 #pragma unroll 4
-        for (int rr = 0; rr < 8; ++rr) {
-            const int r = r0 + 2 * rr;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * ERS + (lane & 31) * 16);
-            float mu = 0.f, rs = 1.f;
-            if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) { mu = residual[m0 + ph * 128 + r]; rs = residual[(size_t)ldr + m0 + ph * 128 + r]; }
-            gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + ph * 128 + r, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, mu, rs);
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + 2 * rr;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * ERS + (lane & 31) * 16);
+                float mu = 0.f, rs = 1.f;
+                if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) { mu = residual[m0 + ph * 128 + r]; rs = residual[(size_t)ldr + m0 + ph * 128 + r]; }
+                gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + ph * 128 + r, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, mu, rs);
+            }
         }
     }
 }

@@ -19,7 +19,7 @@ template <> struct AuxT<f16_t> { typedef bf16_t type; };
 #define LPI_NTC_DEFAULT false
 #endif
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U = true, bool NTC = LPI_NTC_DEFAULT>
-__device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
+__device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col, TC* __restrict__ C, int ldc, f32x4 bv, float alpha,
                                                     const float* __restrict__ residual, int ldr, typename AuxT<T>::type* __restrict__ aux,
                                                     int ldaux, f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f}, float ln_mu = 0.f, float ln_rs = 1.f) {
     typedef typename AuxT<T>::type TA;
@@ -73,4 +73,5 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 acc, int row, int col,
 #else
     if (v[0] == 12345.678f) Elem<TC>::st4(C + (size_t)row * ldc + col, v);      // ablation build: keeps the arithmetic alive, stores nothing
 #endif
+    return v;      // what was stored, before the rounding to TC (the row-statistics epilogue sums the rounded values)
 }

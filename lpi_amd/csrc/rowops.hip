@@ -1026,6 +1026,43 @@ extern "C" int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float
     return 0;
 }
 
+// ---- statistics of the fp16 residual stream from the slot sums an LPI_EPI_RES_ROWSTATS GEMM epilogue left (include/lpi_hip.h): one thread per row
+// adds the d / 128 slots in order; the variance is E[x^2] - mean^2 in f32 (the stream's rows have |mean| well below their deviation: the relative
+// error of the difference is ~1e-7 (1 + mean^2 / var)), clamped at zero.
+struct StatFinP { int rows, nslot; const float* part; int ld; float* mean; float* rstd; float inv_d; };
+__device__ __forceinline__ void stat_fin_body(const StatFinP& p, int row, float eps) {
+    if (row >= p.rows) return;
+    float s = 0.f, q = 0.f;
+    for (int j = 0; j < p.nslot; ++j) {
+        s += p.part[(size_t)(2 * j) * p.ld + row];
+        q += p.part[(size_t)(2 * j + 1) * p.ld + row];
+    }
+    const float mu = s * p.inv_d;
+    const float var = fmaxf(q * p.inv_d - mu * mu, 0.f);
+    p.mean[row] = mu;
+    p.rstd[row] = 1.0f / sqrtf(var + eps);
+}
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(StatFinP p0, StatFinP p1, int nb0, float eps) {
+    if ((int)blockIdx.x < nb0) stat_fin_body(p0, blockIdx.x * 256 + threadIdx.x, eps);
+    else stat_fin_body(p1, (blockIdx.x - nb0) * 256 + threadIdx.x, eps);
+}
+static bool stat_fin_ok(int rows, int d, const float* part, int ld, const float* mean, const float* rstd) {
+    return rows > 0 && d > 0 && !(d & 127) && part && mean && rstd && ld >= rows;
+}
+extern "C" int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
+                                          int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream) {
+    if (!stat_fin_ok(rows0, d0, part0, ld0, mean0, rstd0) || (rows1 > 0 && !stat_fin_ok(rows1, d1, part1, ld1, mean1, rstd1))) return LPI_EINVAL;
+    const StatFinP p0 = {rows0, d0 / 128, part0, ld0, mean0, rstd0, 1.0f / (float)d0};
+    const StatFinP p1 = {rows1 > 0 ? rows1 : 0, rows1 > 0 ? d1 / 128 : 0, part1, ld1, mean1, rstd1, rows1 > 0 ? 1.0f / (float)d1 : 0.f};
+    const int nb0 = (rows0 + 255) / 256, nb1 = rows1 > 0 ? (rows1 + 255) / 256 : 0;
+    LPI_LAUNCH(ln_stats_finalize_kernel, dim3(nb0 + nb1), dim3(256), 0, S(stream), p0, p1, nb0, eps);
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_ln_stats_finalize(int rows, int d, const float* part, int ld, float eps, float* mean, float* rstd, void* stream) {
+    return lpi_ln_stats_finalize_pair(rows, d, part, ld, mean, rstd, 0, 0, nullptr, 0, nullptr, nullptr, eps, stream);
+}
+
 extern "C" int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream) {
     if (!ids || !idx || B <= 0 || L <= 0) return LPI_EINVAL;
     LPI_LAUNCH(eot_index_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), B, L, ids, idx);

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU, EPI_NONE, EPI_QUICKGELU, F16, F32, call
+from ._lib import BF16, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU, EPI_NONE, EPI_QUICKGELU, EPI_RES_ROWSTATS, F16, F32, call
 from .synth import ClipConfig
 
 import os as _os
@@ -103,6 +103,11 @@ class LnLinear:
 # into c_fc as well.  Measured per layer: the statistics pass saves 18 us against the LayerNorm kernel either way; the fp16-operand in_proj
 # GEMM costs 8 us more than the bf16 one, the c_fc GEMM 18.5 us (profiles/r02_gemm_experiments.md) — so 1 is the default.
 LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "1"))
+# LPI_ROWSTATS=1 / 2: the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
+# LPI_EPI_RES_ROWSTATS) instead of a pass over it; 0 (default) = the statistics pass.  Same values up to the order of an f32 sum.  MEASURED, NOT ADOPTED:
+# the epilogue costs the GEMM more than the 17-20 us pass it replaces (c_proj +13..21 us per launch, out_proj +3 alone and more in the grouped
+# launch, plus a 7 us finalize launch): 23.09 -> 23.11-23.16 ms per step
+ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "0"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
 
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
@@ -146,7 +151,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if ldr is None:
         ldr = residual.stride(0) if residual is not None else 0
     ln = epi in (EPI_LN, EPI_LN_QUICKGELU)      # `residual` is the LN operand block then (include/lpi_hip.h), ldr its vector stride
-    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) and not ln else 0
+    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) and not ln and epi != EPI_RES_ROWSTATS else 0
     if ks:
         call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
              ldr, epi, aux, aux.stride(0) if aux is not None else 0,
@@ -159,7 +164,7 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
         e1.record()
         mr = m_real or M
         nbytes = (mr * K + N * K) * a.element_size() + mr * N * (c.element_size() + (residual.element_size() if residual is not None and not ln else 0)
-                                                                 + (aux.element_size() if aux is not None else 0))
+                                                                 + (aux.element_size() if aux is not None and epi != EPI_RES_ROWSTATS else 0))
         kind = int(_lib.load().lpi_gemm_last_kernel())      # LPI_GEMM_K_*: which kernel the dispatcher launched (same host thread)
         prof.append((e0, e1, 2.0 * mr * N * K, nbytes, kind))
 
@@ -215,6 +220,19 @@ class LnReq:
         call("lpi_layernorm_fwd" if self.kind == "fwd" else "lpi_layernorm_bwd", *self.dts, *self.args, _stream())
 
 
+class StatFinReq:
+    """The row statistics of a residual-stream GEMM output from the slot sums its epilogue left (LPI_EPI_RES_ROWSTATS -> lpi_ln_stats_finalize):
+    args = (rows, d, part, ld, mean, rstd).  The two towers' go out as one launch."""
+    __slots__ = ("tag", "args")
+
+    def __init__(self, tag, *args):
+        self.tag, self.args = tag, args
+
+    def issue(self):
+        rows, d, part, ld, mean, rstd = self.args
+        call("lpi_ln_stats_finalize", rows, d, part, ld, 1e-5, mean, rstd, _stream())
+
+
 def _cdt(c):
     return F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
 
@@ -236,6 +254,14 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             r0.issue()
             r1.issue()
         return
+    if isinstance(r0, StatFinReq) or isinstance(r1, StatFinReq):
+        if GROUP_TOWERS and GROUP_LN and isinstance(r0, StatFinReq) and isinstance(r1, StatFinReq):
+            a, b = r0.args, r1.args
+            call("lpi_ln_stats_finalize_pair", a[0], a[1], a[2], a[3], a[4], a[5], b[0], b[1], b[2], b[3], b[4], b[5], 1e-5, _stream())
+        else:
+            r0.issue()
+            r1.issue()
+        return
     if isinstance(r0, LnReq) or isinstance(r1, LnReq):
         stats_only = [r.kind == "fwd" and r.args[6] is None for r in (r0, r1) if isinstance(r, LnReq)]      # one tower folds its LayerNorms, the other not
         if (GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts
@@ -253,7 +279,8 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
     cdt = _cdt(r0.c)
     # few-row GEMMs (pooled rows of the last block, heads): the two split-K launch pairs as one (lpi_gemm_nt_splitk_pair)
     ks = ([_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)]
-          if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU)) else [0, 0])
+          if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS))
+          else [0, 0])
     few = bool(ks[0] and ks[1])
     if not same or not (few or min(r0.M, r1.M) > 256):
         r0.issue()
@@ -280,7 +307,7 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             res, aux = (None if ln else r.kw.get("residual")), r.kw.get("aux")
             fl += 2.0 * mr * r.N * r.K
             nb += (mr * r.K + r.N * r.K) * r.a.element_size() + mr * r.N * (r.c.element_size() + (res.element_size() if res is not None else 0)
-                                                                         + (aux.element_size() if aux is not None else 0))
+                                                                         + (aux.element_size() if aux is not None and k0.get("epi") != EPI_RES_ROWSTATS else 0))
         prof.append((e0, e1, fl, nb, int(_lib.load().lpi_gemm_last_kernel())))
 
 
@@ -405,6 +432,8 @@ class Tower:
             "lnblk": [z(2, 2 * Mp + 4 * d) for _ in range(nl)],
             "h": z(Mp, d, dtype=T),
             "g": z(Mp, 4 * d, dtype=T),
+            # slot sums of the row statistics a residual GEMM's epilogue leaves (LPI_EPI_RES_ROWSTATS): d/128 slots x (sum, sum of squares) x Mp
+            "rstat": z(2 * max(d // 128, 1), Mp),
             # the LAST block's MLP runs on the B pooled rows only (exact: the heads read nothing else of its output)
             "Bp": Bp, "c_xmid": z(Bp, d), "c_h": z(Bp, d, dtype=T), "c_g": z(Bp, 4 * d, dtype=T),
             "c_u": z(Bp, 4 * d, dtype=TU) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
@@ -455,6 +484,7 @@ class Tower:
         P = prompts.shape[-2] if prompts is not None else 0
         self._check_depth(prompts, depth)
         self.serial += 1
+        have_ln1 = False      # ln_1's statistics of the coming block already written by the previous block's c_proj epilogue
         for i, blk in enumerate(self.blocks):
             lt = "last" if i == len(self.blocks) - 1 else i      # GEMM tag: towers of different depth pair layer i with layer i, last with last
             k = i if train else 0
@@ -466,7 +496,10 @@ class Tower:
             # LayerNorm folded into the GEMM behind it (LnLinear): a statistics pass over the stream, then the GEMM reads the stream itself
             fold = "qkv_ln" in blk and _ln_fold_ok(Mp, d)
             lnb, ln_ld = ws["lnblk"][i], ws["ln_ld"]
-            if fold:
+            rowstats = ROWSTATS if (fold and d % 128 == 0) else 0
+            if fold and have_ln1:
+                pass      # the previous block's c_proj left this LayerNorm's statistics (finalised behind it)
+            elif fold:
                 yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, None, None, None, 0, st[0], st[1])
             else:
                 yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1])
@@ -494,7 +527,13 @@ class Tower:
             else:
                 yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
             yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal))
-            yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
+            ln2_stats = rowstats >= 1 and LN_FOLD >= 2 and not (i == len(self.blocks) - 1 and POOLED_LAST)
+            if ln2_stats:      # x + attn(..) and the slot sums of its rows in one epilogue; ln_2's mean / rstd from them
+                yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M, epi=EPI_RES_ROWSTATS,
+                              aux=ws["rstat"])
+                yield StatFinReq(f"{lt}.fin2", M, d, ws["rstat"], ws["rstat"].stride(0), st[2], st[3])
+            else:
+                yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
             if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
                 Bp, cst = ws["Bp"], ws["c_stat"]
                 call("lpi_gather_rows", xdt, B, Lx, d, xmid, pidx, ws["c_xmid"], s)
@@ -504,12 +543,22 @@ class Tower:
                 return ws["c_xout"]
             if fold and LN_FOLD >= 2:
                 fl = blk["fc_ln"]
-                yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3])
+                if not ln2_stats:
+                    yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3])
                 yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
             else:
                 yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
                 yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
+            # the next block's ln_1 reads x_out as it stands unless deep prompts are written into it first (prompt_add above)
+            nxt = i + 1
+            have_ln1 = (rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt] and not (prompts is not None and 0 < nxt < depth))
+            if have_ln1:
+                yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M,
+                              epi=EPI_RES_ROWSTATS, aux=ws["rstat"])
+                nst = ws["stat"][nxt]
+                yield StatFinReq(f"{lt}.fin1", M, d, ws["rstat"], ws["rstat"].stride(0), nst[0], nst[1])
+            else:
+                yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 

@@ -576,6 +576,73 @@ def test_gemm_layernorm_fold_epilogues(cdt):
         call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], None, 0, E.EPI_LN, None, 0, 1.0, stream())
 
 
+def _slot_stats(c):
+    """f64 slot sums (sum, sum of squares per 128 columns) of the stored values, laid out as the LPI_EPI_RES_ROWSTATS aux buffer."""
+    x = c.double().cpu()
+    M, N = x.shape
+    xs = x.view(M, N // 128, 128)
+    return torch.stack([xs.sum(-1).t(), (xs * xs).sum(-1).t()], 1).reshape(2 * (N // 128), M)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemm_residual_epilogue_with_row_statistics(dt):
+    """LPI_EPI_RES_ROWSTATS: the fp16 residual epilogue leaves the slot sums of the rows it stores (persistent tiles, the hybrid half-tile round,
+    a grouped launch): the output is bit for bit the plain residual epilogue's, the sums are the f64 sums of the STORED values, and
+    lpi_ln_stats_finalize gives the mean / rstd of the statistics pass (lpi_layernorm_fwd with y = NULL)."""
+    td = torch.bfloat16 if dt == BF16 else torch.float16
+
+    def operands(M, N, K, seed):
+        a = rnd(M, K, seed=seed).to(td).to(DEV)
+        b = rnd(N, K, seed=seed + 1, scale=0.05).to(td).to(DEV)
+        bias = rnd(N, seed=seed + 2).to(DEV)
+        res = (rnd(M, N, seed=seed + 3) * 3 + 0.7).half().to(DEV)       # rows with a mean that is not small against their deviation
+        return dict(M=M, N=N, K=K, a=a, b=b, bias=bias, residual=res)
+
+    def check(q, c, part):
+        ref = torch.zeros_like(c)
+        call("lpi_gemm_nt", dt, F16, q["M"], q["N"], q["K"], q["a"], q["K"], q["b"], q["K"], ref, q["N"], q["bias"], q["residual"], q["N"], E.EPI_NONE,
+             None, 0, 1.0, stream())
+        assert torch.equal(c, ref)
+        want = _slot_stats(c)
+        got = part[:, :q["M"]].double().cpu()
+        assert (got - want).abs().max() <= 2e-6 * want.abs().max()
+        M, N = q["M"], q["N"]
+        mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+        call("lpi_ln_stats_finalize", M, N, part, part.stride(0), 1e-5, mean, rstd, stream())
+        m2, r2 = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+        call("lpi_layernorm_fwd", BF16, F16, M, N, c, N, None, None, None, 0, m2, r2, stream())
+        x = c.double().cpu()
+        assert (mean.cpu().double() - x.mean(1)).abs().max() < 1e-5
+        assert ((rstd.cpu().double() * x.std(1, unbiased=False).clamp_min(1e-3) - 1).abs().max()) < 2e-5
+        assert (mean - m2).abs().max().item() < 1e-5 and ((rstd / r2) - 1).abs().max().item() < 2e-5
+
+    # 6 persistent tiles; 300 tiles = one full round + a hybrid round of half tiles (44 leftover ids)
+    for M, N, K, seed in ((512, 768, 768, 1), (25600, 768, 256, 5)):
+        q = operands(M, N, K, seed)
+        c = torch.zeros(M, N, dtype=torch.float16, device=DEV)
+        part = torch.full((2 * (N // 128), M + 256), float("nan"), device=DEV)      # ldaux > M: the row stride is honoured
+        call("lpi_gemm_nt", dt, F16, M, N, K, q["a"], K, q["b"], K, c, N, q["bias"], q["residual"], N, E.EPI_RES_ROWSTATS, part, part.stride(0), 1.0,
+             stream())
+        if M > 20000:
+            assert _lib.load().lpi_gemm_last_kernel() == 2      # LPI_GEMM_K_256_TAIL
+        check(q, c, part)
+    # the two towers' c_proj as one grouped launch
+    p0, p1 = operands(16384, 768, 512, 11), operands(8192, 512, 256, 21)      # 192 + 64 tiles: a grouped launch needs a round of them
+    for q in (p0, p1):
+        q["c"] = torch.zeros(q["M"], q["N"], dtype=torch.float16, device=DEV)
+        q["aux"] = torch.full((2 * (q["N"] // 128), q["M"]), float("nan"), device=DEV)
+    assert _lib.gemm_grouped(dt, F16, E.EPI_RES_ROWSTATS, 1.0, [p0, p1], stream())
+    for q in (p0, p1):
+        check(q, q["c"], q["aux"])
+    q = operands(512, 768, 768, 1)
+    c = torch.zeros(512, 768, dtype=torch.float16, device=DEV)
+    with pytest.raises(_lib.LpiError):      # the slot buffer is required
+        call("lpi_gemm_nt", dt, F16, 512, 768, 768, q["a"], 768, q["b"], 768, c, 768, q["bias"], q["residual"], 768, E.EPI_RES_ROWSTATS, None, 0, 1.0, stream())
+    with pytest.raises(_lib.LpiError):      # 384 rows: not a shape of the persistent kernel
+        call("lpi_gemm_nt", dt, F16, 384, 768, 768, q["a"], 768, q["b"], 768, c, 768, q["bias"], q["residual"], 768, E.EPI_RES_ROWSTATS,
+             torch.zeros(12, 512, device=DEV), 512, 1.0, stream())
+
+
 def test_gemm_256x128_tiles_for_half_empty_launches():
     """Launches with 16..159 256x256 tiles go to the 256x128-tile kernel (twice the workgroups): every epilogue, bit for bit the
     results of the 256x256 kernel (tuning key 5 = 0 disables the rule)."""

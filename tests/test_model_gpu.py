@@ -413,6 +413,7 @@ def test_layernorm_fold_levels_agree_and_do_not_lose_accuracy(monkeypatch, golde
     cfg = synth.VIT_B16
     g = golden("vitb16_d3_patched")
     res, launches = {}, {}
+    monkeypatch.setattr(E, "ROWSTATS", 0)      # the fold levels against each other with the statistics pass; LPI_ROWSTATS has its own test below
     for level in (0, 1, 2):
         monkeypatch.setattr(E, "LN_FOLD", level)
         n0 = _lib.launch_count()
@@ -429,6 +430,35 @@ def test_layernorm_fold_levels_agree_and_do_not_lose_accuracy(monkeypatch, golde
         for k in GRADS:
             assert cos(res[lv][k], res[0][k]) > 0.995, (lv, k)
     assert launches[0] == launches[1] == launches[2]      # a statistics pass replaces each folded LayerNorm: the same number of launches
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_row_statistics_from_the_gemm_epilogue_agree_with_the_statistics_pass(monkeypatch, golden, dtype):
+    """LPI_ROWSTATS: the folded LayerNorms' mean / rstd from the slot sums the producing GEMM's epilogue leaves (LPI_EPI_RES_ROWSTATS + finalize)
+    against the statistics pass over the stream, at both fold levels on the ViT-B/16 bs=8 fixture: the same features, logits and prompt-factor gradients
+    up to the order of an f32 sum (a few output roundings flip), the same error against the reference, one launch for one launch."""
+    from lpi_amd import engine as E
+    cfg = synth.VIT_B16
+    g = golden("vitb16_d3_patched")
+    for level in (1, 2):
+        monkeypatch.setattr(E, "LN_FOLD", level)
+        res, launches = {}, {}
+        for rs in (False, True):
+            monkeypatch.setattr(E, "ROWSTATS", 2 if rs else 0)
+            n0 = _lib.launch_count()
+            res[rs], _ = run_hip(cfg, dtype, 8, g["token_ids"], 3)
+            launches[rs] = _lib.launch_count() - n0
+        d_feat = max(maxerr(res[True]["img_f"], res[False]["img_f"]), maxerr(res[True]["txt_f"], res[False]["txt_f"]))
+        err = {rs: max(maxerr(r["img_f"], g["img_f"]), maxerr(r["txt_f"], g["txt_f"])) for rs, r in res.items()}
+        print(f"{dtype} fold {level}: features differ by {d_feat:.2e}; error against the reference {err}; launches {launches}")
+        assert d_feat <= (1e-3 if dtype == "bf16" else 2e-4)
+        assert err[True] <= 1.25 * err[False] + 1e-5
+        cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+        gd = {k: (round(cos(res[True][k], res[False][k]), 5), round(maxerr(res[True][k], res[False][k]) / np.abs(res[False][k]).max(), 4)) for k in GRADS}
+        print("   factor gradients (cosine, max relative difference):", gd)
+        for k in GRADS:      # the backward's operands are bf16 in both modes: a flipped rounding of the forward moves a gradient entry by percents
+            assert gd[k][0] > 0.999 and gd[k][1] <= 6e-2, (level, k, gd[k])
+        assert launches[True] == launches[False]
 
 
 def test_tiny_f16_close_to_oracle(golden):
