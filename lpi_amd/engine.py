@@ -101,8 +101,10 @@ class LnLinear:
 
 # LPI_LN_FOLD: 0 = LayerNorm as its own kernel in front of in_proj / c_fc (f32 mode always); 1 = ln_1 folded into in_proj; 2 = ln_2 folded
 # into c_fc as well.  Measured per layer: the statistics pass saves 18 us against the LayerNorm kernel either way; the fp16-operand in_proj
-# GEMM costs 8 us more than the bf16 one, the c_fc GEMM 18.5 us (profiles/r02_gemm_experiments.md) — so 1 is the default.
-LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "1"))
+# GEMM costs 8 us more than the bf16 one, the c_fc GEMM 18.5 us (profiles/r02_gemm_experiments.md): a wash in round 2 (24.18 / 24.21 ms per step).
+# Re-measured in round 3 (three interleaved pairs on one box): 22.97 / 22.97 / 23.01 ms with 1 against 22.82 / 22.86 / 22.91 with 2 — 2 is the
+# default now (it is also the more accurate one in bf16 mode: LN(x) is never rounded to bf16; tests/test_model_gpu.py fold-level test).
+LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "2"))
 # LPI_ROWSTATS=1 / 2: the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
 # LPI_EPI_RES_ROWSTATS) instead of a pass over it; 0 (default) = the statistics pass.  Same values up to the order of an f32 sum.  MEASURED, NOT ADOPTED:
 # the epilogue costs the GEMM more than the 17-20 us pass it replaces (c_proj +13..21 us per launch, out_proj +3 alone and more in the grouped
@@ -410,7 +412,10 @@ class Tower:
         ws = self._ws.get(key)
         if ws is not None and ws["Lcap"] >= L:
             return bind(ws, L)
-        self._ws.clear()   # one live shape per tower: the arena is large
+        # one live arena per tower and MODE: the training arena and the evaluation one (a sixth of its size) stay side by side, so that the
+        # train / eval alternation of an epoch loop does not free and re-allocate gigabytes; another batch size of the same mode replaces its arena
+        for k in [k for k in self._ws if k[1] == train]:
+            del self._ws[k]
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
         Lreal, L = L, max(L, cap or L)
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)

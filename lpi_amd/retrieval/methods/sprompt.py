@@ -91,7 +91,8 @@ class SPrompts(BaseLearner):
         if impl == "coco":          # sprompt.py:163-170
             from lpi_amd.retrieval.utils.data import Coco, CocoEval
             return (Coco(image_root=self.args['image_root'], ann_file=self.args['annotation_train_root'], tasks=[i]),
-                    CocoEval(image_root=self.args['image_root'], ann_file=self.args['annotation_val_root'], tasks=np.arange(0, i + 1)))
+                    CocoEval(image_root=self.args['image_root'], ann_file=self.args['annotation_val_root'], tasks=np.arange(0, i + 1),
+                             eval_transform=self.args.get('eval_transform', 'center')))
         if impl != "synthetic":
             raise ValueError(f"unknown dataset_impl {impl!r} (coco | synthetic)")
         res = self._network.clip_cfg.image_resolution
@@ -117,7 +118,8 @@ class SPrompts(BaseLearner):
         self.final_res = final_res
         if _dist_rank() == 0:       # every rank holds the same keys and evaluates the same test set: one writer
             os.makedirs('./res', exist_ok=True)
-            self.save_dict(final_res, f'./res/{datetime.now()}.json')
+            # the evaluation-transform choice travels with the numbers (utils/data.py CocoEval: 'center' | 'reference')
+            self.save_dict({**final_res, 'eval_transform': self.args.get('eval_transform', 'center')}, f'./res/{datetime.now()}.json')
 
     def save_dict(self, dictionary, file_path):
         with open(file_path, 'w') as file:

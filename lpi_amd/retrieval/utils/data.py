@@ -186,14 +186,19 @@ class CocoEval(Dataset):
     """Evaluation images of tasks 0..t with every caption of every image in the lookup tables the scoring loop reads
     (utils/data.py:186-306; sprompt.py:433-548): text, text_cat, image, txt2img, img2txt; item = (image, image index, task)."""
 
-    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, tasks=(0,)):
+    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, tasks=(0,), eval_transform='center'):
         _pil()
         with open(ann_file, 'r') as f:
             records = json.load(f)
         cats = {TASK_CATEGORIES[int(t)] for t in tasks}
-        # the reference's default transform is the TRAINING one (utils/data.py:206, a default-argument slip); evaluation wants the
-        # deterministic Resize + CenterCrop it defines next to it, which is the default here — pass transform=train_transform to get the slip
-        self.transform = transform or test_transform
+        # eval_transform (args['eval_transform'], recorded in the result file): 'center' = the deterministic Resize + CenterCrop the reference
+        # defines for evaluation; 'reference' = what the reference's CocoEval actually applies when constructed as sprompt.py:169 does — its default
+        # argument is the TRAINING transform (utils/data.py:206: RandomResizedCrop + flip), so R@K of a parity run against the reference code as
+        # written needs 'reference'.  An explicit `transform` wins over both.
+        if eval_transform not in ('center', 'reference'):
+            raise ValueError(f"eval_transform must be 'center' or 'reference', not {eval_transform!r}")
+        self.eval_transform = eval_transform
+        self.transform = transform or (test_transform if eval_transform == 'center' else train_transform)
         self.image_root, self.max_words = image_root, max_words
         self.ann = [a for a in records if a['category'] in cats]
         self.text, self.text_cat, self.image = [], [], []

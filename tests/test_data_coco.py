@@ -71,6 +71,10 @@ def test_coco_eval_tables_and_items(coco):
     img, idx, task = ds[3]
     assert img.shape == (3, 224, 224) and idx == 3 and task == 2
     assert torch.equal(img, ds[3][0])                                # evaluation is deterministic
+    ref_default = D.CocoEval(image_root=str(coco), ann_file=str(coco / "val.json"), tasks=[0], eval_transform='reference')
+    assert ref_default.transform is D.train_transform and ds.transform is D.test_transform and ds.eval_transform == 'center'
+    with pytest.raises(ValueError):
+        D.CocoEval(image_root=str(coco), ann_file=str(coco / "val.json"), tasks=[0], eval_transform='random')
     rand = D.CocoEval(transform=D.train_transform, image_root=str(coco), ann_file=str(coco / "val.json"), tasks=[0])
     assert rand[0][0].shape == (3, 224, 224)
 

@@ -298,3 +298,37 @@ def test_engine_and_its_workspace_are_freed_after_a_training_step():
     gc.collect()
     assert not [o for o in gc.get_objects() if type(o).__name__ == "DualEncoder"]
     assert torch.cuda.memory_allocated() - base < max(used // 4, 40 << 20)          # module-level caches (split-K scratch, loss workspace) stay
+
+
+def test_slinet_takes_caption_strings_through_the_native_tokenizer(tmp_path, monkeypatch):
+    """SliNet.forward(image, list[str]) on a box WITHOUT CLIP's merge table (the GPU box): a seeded synthetic table of the same format
+    (tests/bpe_synth.py) stands in through $LPI_BPE_VOCAB.  The C++ tokenizer (lpi_bpe_*) and the Python one give the same ids for the
+    PromptLearner's "X X ... caption." strings (prompt_learner.py:131, clip.py:185-221), and the plugin's features from the strings equal its
+    features from those ids."""
+    import bpe_synth
+    from lpi_amd.retrieval.models.clip import prompt_learner as PL
+    from lpi_amd.retrieval.models.clip import simple_tokenizer as T
+    from lpi_amd.retrieval.models.slinet import SliNet
+    path = bpe_synth.write_table(tmp_path / "synthetic_bpe.txt.gz", seed=5)
+    monkeypatch.setenv("LPI_BPE_VOCAB", path)
+    monkeypatch.setattr(PL, "_tokenizer", None)
+    caps = ["a photo of a dog", "two people riding bicycles down the street", "it's a naïve café, isn't it?", "3 zebras & 2 giraffes 😀"]
+    net = SliNet(tiny_args()).to(DEV)
+    set_factors(net)
+    net.numtask = 1
+    net.eval()
+    img = torch.from_numpy(synth.images(4, 32)).to(DEV)
+    n0 = _lib.launch_count()
+    with torch.no_grad():
+        img_s, txt_s, _, _ = net(img, caps)
+    assert isinstance(PL.get_tokenizer(), T.NativeTokenizer) and _lib.launch_count() > n0
+    prompts = [" ".join(["X"] * 16) + " " + c + "." for c in caps]
+    ids_native = T.tokenize(PL.get_tokenizer(), prompts)
+    ids_py = T.tokenize(T.SimpleTokenizer(path), prompts)
+    assert (ids_native.numpy() == ids_py.numpy()).all()
+    x = int(ids_native[0, 1])
+    assert (ids_native[:, 0] == 49406).all() and (ids_native[:, 1:17] == x).all() and (ids_native.max(1).values == 49407).all()
+    with torch.no_grad():
+        img_i, txt_i, _, _ = net(img, ids_py)
+    assert torch.equal(txt_s, txt_i) and torch.equal(img_s, img_i)
+    monkeypatch.setattr(PL, "_tokenizer", None)      # the next user of the module looks its table up again

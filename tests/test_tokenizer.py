@@ -86,3 +86,25 @@ def test_native_tokenizer_matches_reference_ids_and_python(golden):
     with pytest.raises(RuntimeError):
         T.tokenize(tk, ["word " * 100])
     assert T.tokenize(tk, ["word " * 100], truncate=True)[0, -1] == 49407
+
+
+def test_native_tokenizer_matches_python_on_a_synthetic_merge_table(tmp_path):
+    """No copy of CLIP's merge table needed: a seeded synthetic table of the same format and size (tests/bpe_synth.py).  The C++ BPE and the
+    Python one must agree id for id on the fuzz, on the padded [n, 77] layout, and on the too-long behaviour."""
+    import bpe_synth
+    path = bpe_synth.write_table(tmp_path / "synthetic_bpe.txt.gz", seed=3)
+    tk_py, tk = T.SimpleTokenizer(path), T.NativeTokenizer(path)
+    cases = bpe_synth.fuzz_cases()
+    merged = 0
+    for s in cases:
+        a, b = tk.encode(s), tk_py.encode(s)
+        assert a == b, repr(s)
+        merged += sum(1 for i in a if i >= 512)
+    assert merged > 100      # the table's merges really fire on this text (ids >= 512 are merge results)
+    short = [c for c in cases if len(tk_py.encode(c)) <= 75]
+    ids = T.tokenize(tk, short).numpy()
+    assert (ids == T.tokenize(tk_py, short).numpy()).all()
+    assert (ids[:, 0] == 49406).all() and (ids.max(1) == 49407).all()
+    with pytest.raises(RuntimeError):
+        T.tokenize(tk, ["word " * 100])
+    assert T.tokenize(tk, ["word " * 100], truncate=True)[0, -1] == 49407
