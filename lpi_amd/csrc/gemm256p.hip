@@ -39,7 +39,7 @@ constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
 struct PProb {
     const void* A; const void* B; void* C; const float* bias; const void* residual; void* aux;
     int N, K, lda, ldb, ldc, ldr, ldaux, tiles_m, tiles_n;
-    int vb0;        // first virtual workgroup id (a multiple of 8)
+    int vb0;        // first virtual workgroup id
     int bias_off;   // offset (floats) of its bias vector in the LDS copy (SIDE16 epilogues)
     int group_m;    // order of its tiles inside an XCD's share: group_m row panels at a time, rows fastest (1 = columns fastest)
 };
@@ -535,7 +535,14 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
         P.A = h.A; P.B = h.B; P.C = h.C; P.bias = h.bias; P.residual = h.residual; P.aux = h.aux;
         P.N = h.N; P.K = h.K; P.lda = h.lda; P.ldb = h.ldb; P.ldc = h.ldc; P.ldr = h.ldr; P.ldaux = h.ldaux;
         P.tiles_m = h.M / T256; P.tiles_n = h.N / T256;
-        v = (v + 7) & ~7;                 // a problem starts at a multiple of 8: its ids keep id & 7 = XCD
+        // A problem's ids follow the previous problem's directly.  (They used to start at a multiple of 8 "so that id & 7 stays the XCD"; that is
+        // not needed: coords() gives the ids that share (id - vb0) & 7 a contiguous run of tiles, and those ids share an XCD whatever vb0 is — the
+        // XCDs are merely rotated by vb0 & 7.  The padding ids counted as tiles: the grouped in_proj launch of ViT-B/16 at 256 pairs had 2 178 ids =
+        // 8 rounds + 130, two more than the hybrid half-tile round takes, so its last round ran 130 full tiles on 256 CUs; 2 175 ids end in a round of
+        // 254 half tiles instead.)  LPI_GROUP_PAD8 keeps the padding (A/B switch).
+#ifdef LPI_GROUP_PAD8
+        v = (v + 7) & ~7;
+#endif
         P.vb0 = v;
         v += P.tiles_m * P.tiles_n;
         P.bias_off = nsum;
