@@ -417,14 +417,24 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         // loops spilled 60 bytes per lane in the QuickGELU instantiations and the step lost 7 %)
                         if constexpr (STATS) {      // the two packed dwords serve the store and the sums (of the values as stored)
                             const uint32_t w0 = pack2_t<f16_t>(o[0], o[1]), w1 = pack2_t<f16_t>(o[2], o[3]);
+#ifdef LPI_NT_SIDE16C      /* A/B: streaming stores for the residual stream too (see below) */
                             if constexpr (LPI_NTC_DEFAULT) st_stream8(C + (size_t)(m0 + trow) * ldc + ecol, w0, w1);
                             else *reinterpret_cast<uint2*>(C + (size_t)(m0 + trow) * ldc + ecol) = uint2{w0, w1};
+#else
+                            *reinterpret_cast<uint2*>(C + (size_t)(m0 + trow) * ldc + ecol) = uint2{w0, w1};
+#endif
                             f16x4_sum_sumsq(w0, w1, st_s[rr], st_q[rr]);
                         } else {
-#ifdef LPI_NO_NT_SIDE16C          /* A/B: the residual-stream outputs (read next by a LayerNorm) with plain stores */
-                            if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
-#else
+                            // The fp16 residual stream (84 MB for the vision tower at 256 pairs) is stored with PLAIN stores: the next GEMM reads it
+                            // as its A operand and finds it in the Infinity Cache.  Round 2 measured no difference (24.40 / 24.46 against 24.42 / 24.39 ms)
+                            // because a statistics pass over the stream sat between the two GEMMs and warmed the cache anyway; with the statistics
+                            // coming out of this epilogue (LPI_EPI_RES_ROWSTATS) the pass is gone and the policy decides: 22.81 against 22.95-23.00 ms
+                            // per step (profiles/r03_experiments.md).  d c_proj x gelu' (335 MB, read by one GEMM) stays a streaming store.
+                            // -DLPI_NT_SIDE16C = streaming stores here too (A/B).
+#ifdef LPI_NT_SIDE16C
                             if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
+#else
+                            if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
 #endif
                             else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
                         }

@@ -67,7 +67,8 @@ __device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col
 #ifdef LPI_LN_PLAIN_C      /* A/B: the in_proj output (read next by the attention forward) with plain stores */
     if constexpr (NTC && EPI != LPI_EPI_LN) st4_nt<TC>(C + (size_t)row * ldc + col, v);
 #else
-    if constexpr (NTC) st4_nt<TC>(C + (size_t)row * ldc + col, v);
+    // the fp16 residual stream with plain stores (the next GEMM's A operand: gemm256p.hip has the measurement), everything else streams
+    if constexpr (NTC && !(RES && __is_same(TC, f16_t))) st4_nt<TC>(C + (size_t)row * ldc + col, v);
 #endif
     else Elem<TC>::st4(C + (size_t)row * ldc + col, v);
 #else

@@ -105,11 +105,12 @@ class LnLinear:
 # Re-measured in round 3 (three interleaved pairs on one box): 22.97 / 22.97 / 23.01 ms with 1 against 22.82 / 22.86 / 22.91 with 2 — 2 is the
 # default now (it is also the more accurate one in bf16 mode: LN(x) is never rounded to bf16; tests/test_model_gpu.py fold-level test).
 LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "2"))
-# LPI_ROWSTATS=1 / 2: the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
-# LPI_EPI_RES_ROWSTATS) instead of a pass over it; 0 (default) = the statistics pass.  Same values up to the order of an f32 sum.  MEASURED, NOT ADOPTED:
-# the epilogue costs the GEMM more than the 17-20 us pass it replaces (c_proj +13..21 us per launch, out_proj +3 alone and more in the grouped
-# launch, plus a 7 us finalize launch): 23.09 -> 23.11-23.16 ms per step
-ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "0"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
+# LPI_ROWSTATS=2 (default): the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
+# LPI_EPI_RES_ROWSTATS + a finalize launch) instead of a pass over it; 1 = ln_2's only; 0 = the statistics pass everywhere.  Same values up to the
+# order of an f32 sum.  The epilogue costs the GEMM about as much as the pass it replaces — it pays since the residual stream is stored with plain
+# (Infinity-Cache resident) stores: the pass had been warming the cache for the next GEMM (22.81 against 22.95-23.00 ms per step;
+# profiles/r03_experiments.md).  Blocks whose input rows are rewritten by deep prompts first, and the first block, keep the pass.
+ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "2"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
 
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
