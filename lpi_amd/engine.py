@@ -403,18 +403,22 @@ class Tower:
         row count; the [M, *] buffers are used by their first M rows, the [B, H, L] ones as flat storage.
         packed: a PackedIds (ragged batch: sample b owns rows row_start[b] .. row_start[b+1]-1, M = sum of the lengths, L = the longest)."""
         def bind(ws, L):
+            ws["B"], ws["Bp"] = B, _pad(B)
             ws["L"] = L
             ws["M"] = B * L if packed is None else packed.rows
             ws["Mp"] = _pad(ws["M"], 256)
             ws["rs"] = None if packed is None else packed.row_start_dev
             ws["pool_abs"] = None if packed is None else packed.pool_rows_dev
             return ws
-        key = (B, train)
-        ws = self._ws.get(key)
-        if ws is not None and ws["Lcap"] >= L:
-            return bind(ws, L)
+        # an arena serves any batch of its mode that FITS it (B <= its batch capacity, L <= its token capacity): the odd last batch of an epoch
+        # (DataLoader drop_last=False) and a shorter longest caption only re-bind row counts — every [M, *] buffer is used by its first rows,
+        # the per-sample ones as flat storage; rows past the bound batch hold stale but finite data that no kernel reads into a live row.
+        for (bcap, tr), ws in self._ws.items():
+            if tr == train and bcap >= B and ws["Lcap"] >= L:
+                return bind(ws, L)
         # one live arena per tower and MODE: the training arena and the evaluation one (a sixth of its size) stay side by side, so that the
-        # train / eval alternation of an epoch loop does not free and re-allocate gigabytes; another batch size of the same mode replaces its arena
+        # train / eval alternation of an epoch loop does not free and re-allocate gigabytes; a LARGER batch of the same mode replaces its arena
+        key = (B, train)
         for k in [k for k in self._ws if k[1] == train]:
             del self._ws[k]
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers

@@ -502,6 +502,38 @@ def test_fp16_gradient_storage_of_the_reference_against_the_bf16_backward(golden
     assert all(abs(v[3] - 1.66e-3) < 3e-4 for v in report.values())         # bf16's error does not depend on the magnitude
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_a_smaller_batch_runs_in_the_arena_of_a_larger_one(golden, dtype):
+    """The odd last batch of an epoch (DataLoader drop_last=False) and the train / eval alternation must not free and re-allocate the towers'
+    multi-gigabyte arenas: a batch that fits an arena of its mode (fewer samples, fewer tokens) only re-binds row counts.  A 3-sample step in the arena
+    a 4-sample step left behind gives bit for bit what a fresh encoder gives, and the arena objects are the same ones."""
+    cfg = synth.TINY
+    g = golden("tiny_d2_patched")
+    ids = g["token_ids"]
+
+    def step(enc, n):
+        fac, _ = dev_factors(cfg)
+        img = torch.from_numpy(synth.images(4, cfg.image_resolution)[:n].copy()).to(DEV)
+        out = train_step(enc, img, torch.from_numpy(ids[:n].copy()).to(DEV), fac, 2)
+        torch.cuda.synchronize()
+        res = {k: v.detach().cpu().numpy().copy() for k, v in out.items() if torch.is_tensor(v)}
+        for k in synth.PROMPT_NAMES:
+            res["grad." + k] = fac[k].grad.cpu().numpy().copy()
+        return res
+
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=DEV)
+    step(enc, 4)
+    arenas = {id(w) for t in (enc.vis, enc.txt) for w in t._ws.values()}
+    with torch.no_grad():      # an evaluation pass in between: its own (smaller) arena beside the training one
+        enc.encode_image(torch.from_numpy(synth.images(4, cfg.image_resolution)).to(DEV))
+    got = step(enc, 3)
+    assert arenas <= {id(w) for t in (enc.vis, enc.txt) for w in t._ws.values()}      # the training arenas survived both
+    assert len(enc.vis._ws) == 2 and len(enc.txt._ws) == 1
+    ref = step(DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=DEV), 3)
+    for k in ref:
+        assert np.array_equal(got[k], ref[k]), k
+
+
 def test_tiny_f16_close_to_oracle(golden):
     cfg = synth.TINY
     g = golden("tiny_d2_patched")
