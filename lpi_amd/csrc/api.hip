@@ -8,6 +8,22 @@ extern "C" void lpi_count_launch() { g_launches.fetch_add(1, std::memory_order_r
 extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 extern "C" int lpi_version(void) { return 301; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
 
+// CU count of the CURRENT device (the persistent kernels launch one workgroup per CU), looked up once per device; safe from any host thread (a cached
+// value is written once, every writer writes the same one)
+int lpi_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cache[dev].store(v, std::memory_order_relaxed);
+        n = v;
+    }
+    return n;
+}
+
 static thread_local int t_last_gemm_kernel = -1;
 void lpi_note_gemm_kernel(int which) { t_last_gemm_kernel = which; }
 extern "C" int lpi_gemm_last_kernel(void) { return t_last_gemm_kernel; }

@@ -645,15 +645,7 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
     }
 }
 
-int cu_count4() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
-    }
-    return n;
-}
+int cu_count4() { return lpi_cu_count(); }
 
 size_t lds_bytes4(int Lp) { return (size_t)2 * Lp * RB + (size_t)NSLOT * SLOT_BYTES + (size_t)2 * Lp * 64 + (size_t)2 * 32 * 4 + (size_t)2 * Lp * 4; }
 

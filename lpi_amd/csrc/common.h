@@ -48,6 +48,7 @@ inline int lpi_ensure_lds(LdsOnce& once, const void* kern, int bytes) {
 }
 // which GEMM kernel the last lpi_gemm_nt / lpi_gemm_nt_splitk call of this thread launched (LPI_GEMM_K_*; lpi_gemm_last_kernel)
 void lpi_note_gemm_kernel(int which);
+int lpi_cu_count();      // CUs of the current device (api.hip: cached per device)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

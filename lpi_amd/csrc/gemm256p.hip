@@ -514,15 +514,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     }
 }
 
-int cu_count_p() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n = v;
-    }
-    return n;
-}
+int cu_count_p() { return lpi_cu_count(); }
 
 // ---- host side: one launch for a group of 1 or 2 problems (same T / TC / epilogue kind)
 struct HostProb {
