@@ -251,10 +251,10 @@ int lpi_gather_batch_rows_varlen(int dtype, int B, int L, const int32_t* row_sta
 int lpi_rows_sum_over_batch_varlen(int dtype, int B, int L, const int32_t* row_start, int row0, int P, int d, const void* dx, float* out,
                                    int accumulate, void* stream);
 int lpi_prompt_add_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, void* x, const float* prompt_l, long prompt_bstride,
-                          void* stream);
+                          float* out_mean, float* out_rstd, void* stream);
 /* ids stays the padded [B, L] matrix (clip.tokenize's output); tokens l >= L_b of sample b are not embedded */
 int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
-                             const float* pos, const float* ctx, long ctx_bstride, void* x0, void* stream);
+                             const float* pos, const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream);
 
 /* ---- a1: DecomposedPrompt                          replaces: models/prompts/prompts.py:38-57 -----------
  * out[l,p,d] = scale/r * sum_r d1[l,r]*d2[p,r]*d3[d,r].  bwd: the three factor gradients from dout; scratch: Lyr*P*r floats. */
@@ -270,11 +270,15 @@ int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float
  * prompt0: f32, element (b,p,:) at prompt0 + b*prompt_bstride + p*d (bstride 0 = broadcast, slinet.py:119).
  * bwd (dx0 is `dtype`: f32, or the bf16 gradient stream): applies LN' to rows 1..P of dx0 IN PLACE (dx0 is dead afterwards; the other rows' input gradients are
  *      not needed because the backbone is frozen), then dprompt[p,:] = sum_b dx0[b,1+p,:] (f32 [P,d]; the batch
- *      sum is the gradient of the training-time stride-0 broadcast, slinet.py:119). */
+ *      sum is the gradient of the training-time stride-0 broadcast, slinet.py:119).
+ * out_mean / out_rstd (here, in lpi_txt_embed_fwd and in lpi_prompt_add; both or neither, NULL = not wanted): the LayerNorm statistics of every row
+ *      these kernels WRITE, taken from the row as stored (a wave holds it) and written at the row's index in the stream — the statistics the NEXT
+ *      LayerNorm needs (model.py:172: ln_1 of the block that reads the stream) without a pass over it; lpi_prompt_add overwrites the entries of the
+ *      rows it rewrites, which a GEMM epilogue (LPI_EPI_RES_ROWSTATS) had filled from their old contents. */
 int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream);
 int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
                          const float* pos, const float* prompt0, long prompt_bstride,
-                         const float* gamma, const float* beta, void* x0, float* mean, float* rstd, void* stream);
+                         const float* gamma, const float* beta, void* x0, float* mean, float* rstd, float* out_mean, float* out_rstd, void* stream);
 int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, const float* prompt0, long prompt_bstride,
                          const float* gamma, const float* mean, const float* rstd, float* dprompt, void* stream);
 
@@ -282,13 +286,14 @@ int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void* dx0, cons
  * x0[b,l] = (l in 1..P ? ctx[b,l-1] : tok_emb[ids[b,l]]) + pos[l]      (CLASS_TOKEN_POSITION == "end")
  * bwd: dctx[p,:] (+)= sum_b dx0[b,1+p,:] */
 int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
-                      const float* ctx, long ctx_bstride, void* x0, void* stream);   /* x0 is `x_dtype` */
+                      const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream);   /* x0 is `x_dtype` */
 int lpi_rows_sum_over_batch(int dtype, int B, int L, int row0, int P, int d, const void* dx, float* out, int accumulate,
                             void* stream);   /* dx is `dtype` */
 
 /* ---- F1: deep prompts                               replaces: models/clip/model.py:189-193 -------------
  * x[b, 1..P, :] += prompt_l[b?, p, :]   (in place on the `x_dtype` residual stream; prompt_l f32) */
-int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream);
+int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, float* out_mean, float* out_rstd,
+                   void* stream);
 
 /* ---- a3/a7/a2: pooled head     replaces: model.py:255-257, prompt_learner.py:57-61, slinet.py:122,133 --
  * pool_ln: y[b,:] = LN(x[b*L + idx[b], :]) (x `x_dtype`; idx NULL -> row 0 = CLS; else EOT position) -> y `dtype` [B,d]

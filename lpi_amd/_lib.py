@@ -64,19 +64,19 @@ SIGNATURES = {
     "lpi_layernorm_bwd_rows_varlen": [_I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "lpi_gather_batch_rows_varlen": [_I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
     "lpi_rows_sum_over_batch_varlen": [_I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P],
-    "lpi_prompt_add_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _L, _P],
-    "lpi_txt_embed_fwd_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _L, _P, _P],
+    "lpi_prompt_add_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _L, _P, _P, _P],
+    "lpi_txt_embed_fwd_varlen": [_I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "lpi_scatter_add_rows": [_I, _I, _I, _I, _P, _I, _P, _P, _I, _P],
     "lpi_prompt_cp_fwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P],
     "lpi_prompt_cp_bwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P],
     "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "lpi_nt_bxent_fwd_bwd": [_I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "lpi_patchify": [_I, _I, _I, _I, _P, _P, _I, _P],
-    "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "lpi_vis_assemble_bwd": [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
-    "lpi_txt_embed_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P],
+    "lpi_txt_embed_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P],
     "lpi_rows_sum_over_batch": [_I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "lpi_prompt_add": [_I, _I, _I, _I, _I, _P, _P, _L, _P],
+    "lpi_prompt_add": [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P],
     "lpi_pool_ln_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
     "lpi_pool_ln_bwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "lpi_gather_rows": [_I, _I, _I, _I, _P, _P, _P, _P],
@@ -110,7 +110,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 301
+EXPECTED_ABI = 302
 
 _lib = None
 

@@ -59,6 +59,17 @@ __device__ __forceinline__ void ln_apply_store(const RowT<NC>& r, int d, int lan
     });
 }
 
+// y = LN(r), stored, and left in r as stored (rounded to TY): for the statistics of the OUTPUT row
+template <typename TY, int NC>
+__device__ __forceinline__ void ln_apply_round_store(RowT<NC>& r, int d, int lane, float mu, float rs, const float* gamma, const float* beta, TY* y) {
+    for_chunks_n<NC>(d, lane, [&](int i, int col) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + col);
+        f32x4 b = *reinterpret_cast<const f32x4*>(beta + col);
+        r.v[i] = rounded4<TY>((r.v[i] - mu) * rs * g + b);
+        Elem<TY>::st4(y + col, r.v[i]);
+    });
+}
+
 // dxn = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); x row in `x`, dy row in `dy`; result left in dy
 template <int NC>
 __device__ __forceinline__ void ln_bwd_row(RowT<NC>& dy, const RowT<NC>& x, int d, int lane, float mu, float rs, const float* gamma) {
@@ -373,7 +384,8 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
                                                               int ldpe, const float* __restrict__ cls, const float* __restrict__ pos,
                                                               const float* __restrict__ prompt0, long pbs,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              TX* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                              TX* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd,
+                                                              float* __restrict__ omean, float* __restrict__ orstd) {
     const int L = 1 + P + G2;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -383,8 +395,14 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
     vis_pre_row(r, b, l, G2, P, d, lane, patch_emb, ldpe, cls, pos, prompt0, pbs);
     float mu, rs;
     row_stats(r, d, lane, mu, rs);
-    ln_apply_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (omean) {      // ... and the statistics of the row as STORED: the first block's ln_1 (folded into its in_proj GEMM) needs no pass over x0
+        ln_apply_round_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
+        row_stats(r, d, lane, mu, rs);
+        if (lane == 0) { omean[row] = mu; orstd[row] = rs; }
+    } else {
+        ln_apply_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
+    }
 }
 
 // LN' on the prompt rows only, in place on dx0 (the other rows' input gradients are not needed: frozen weights)
@@ -450,7 +468,8 @@ __global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, co
 template <typename TX>
 __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int* __restrict__ rs, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
-                                                       const float* __restrict__ ctx, long cbs, TX* __restrict__ x0) {
+                                                       const float* __restrict__ ctx, long cbs, TX* __restrict__ x0,
+                                                       float* __restrict__ omean, float* __restrict__ orstd) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, l) over the [B, L] id matrix
     if (row >= B * L) return;
@@ -464,21 +483,38 @@ __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int*
                                                  : tok + (size_t)ids[row] * d;
     const float* pp = pos + (size_t)l * d;
     TX* o = x0 + orow * d;
-    for_chunks(d, lane, [&](int, int col) {
-        Elem<TX>::st4(o + col, *reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col));
+    Row r;
+    for_chunks(d, lane, [&](int i, int col) {
+        r.v[i] = rounded4<TX>(*reinterpret_cast<const f32x4*>(src + col) + *reinterpret_cast<const f32x4*>(pp + col));
+        Elem<TX>::st4(o + col, r.v[i]);
     });
+    if (omean) {      // the statistics of the row as stored (the first block's folded ln_1)
+        float mu, rs_;
+        row_stats(r, d, lane, mu, rs_);
+        if (lane == 0) { omean[orow] = mu; orstd[orow] = rs_; }
+    }
 }
 
 template <typename TX>
 __global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                        const float* __restrict__ pr, long pbs) {
+                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
     const int b = w / P, p = w % P;
-    TX* xr = x + ((rs ? (size_t)rs[b] : (size_t)b * L) + 1 + p) * d;
+    const size_t row = (rs ? (size_t)rs[b] : (size_t)b * L) + 1 + p;
+    TX* xr = x + row * d;
     const float* s = pr + (size_t)b * pbs + (size_t)p * d;
-    for_chunks(d, lane, [&](int, int col) { Elem<TX>::st4(xr + col, Elem<TX>::ld4(xr + col) + *reinterpret_cast<const f32x4*>(s + col)); });
+    Row r;
+    for_chunks(d, lane, [&](int i, int col) {
+        r.v[i] = rounded4<TX>(Elem<TX>::ld4(xr + col) + *reinterpret_cast<const f32x4*>(s + col));
+        Elem<TX>::st4(xr + col, r.v[i]);
+    });
+    if (omean) {      // the rewritten rows' statistics replace the ones the producing GEMM's epilogue left for them (LPI_EPI_RES_ROWSTATS)
+        float mu, rs_;
+        row_stats(r, d, lane, mu, rs_);
+        if (lane == 0) { omean[row] = mu; orstd[row] = rs_; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -869,17 +905,18 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
 
 extern "C" int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls, const float* pos,
                                     const float* prompt0, long prompt_bstride, const float* gamma, const float* beta, void* x0,
-                                    float* mean, float* rstd, void* stream) {
+                                    float* mean, float* rstd, float* out_mean, float* out_rstd, void* stream) {
+    if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!patch_emb || !cls || !pos || !gamma || !beta || !x0 || !mean || !rstd || B <= 0 || G2 <= 0 || P < 0 || bad_row_dim(d) || (ldpe & 3))
         return LPI_EINVAL;
     if (P > 0 && (!prompt0 || (prompt_bstride & 3))) return LPI_EINVAL;
     const long rows = (long)B * (1 + P + G2);
     if (x_dtype == LPI_F32)
         LPI_LAUNCH(vis_assemble_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
-                   prompt0, prompt_bstride, gamma, beta, (float*)x0, mean, rstd);
+                   prompt0, prompt_bstride, gamma, beta, (float*)x0, mean, rstd, out_mean, out_rstd);
     else if (x_dtype == LPI_F16)
         LPI_LAUNCH(vis_assemble_fwd_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
-                   prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd);
+                   prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd, out_mean, out_rstd);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
@@ -929,36 +966,39 @@ extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void
 }
 
 extern "C" int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
-                                        const float* pos, const float* ctx, long ctx_bstride, void* x0, void* stream) {
+                                        const float* pos, const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {
+    if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0);
+        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0, out_mean, out_rstd);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0);
+        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0, out_mean, out_rstd);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
 extern "C" int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
-                                 long ctx_bstride, void* x0, void* stream) {
-    return lpi_txt_embed_fwd_varlen(x_dtype, B, L, nullptr, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0, stream);
+                                 long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {
+    return lpi_txt_embed_fwd_varlen(x_dtype, B, L, nullptr, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0, out_mean, out_rstd, stream);
 }
 
 extern "C" int lpi_prompt_add_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, void* x, const float* prompt_l, long prompt_bstride,
-                                     void* stream) {
+                                     float* out_mean, float* out_rstd, void* stream) {
+    if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (float*)x, prompt_l, prompt_bstride);
+        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (float*)x, prompt_l, prompt_bstride, out_mean, out_rstd);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (f16_t*)x, prompt_l, prompt_bstride);
+        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (f16_t*)x, prompt_l, prompt_bstride, out_mean, out_rstd);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }
-extern "C" int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, void* stream) {
-    return lpi_prompt_add_varlen(x_dtype, B, L, nullptr, P, d, x, prompt_l, prompt_bstride, stream);
+extern "C" int lpi_prompt_add(int x_dtype, int B, int L, int P, int d, void* x, const float* prompt_l, long prompt_bstride, float* out_mean,
+                              float* out_rstd, void* stream) {
+    return lpi_prompt_add_varlen(x_dtype, B, L, nullptr, P, d, x, prompt_l, prompt_bstride, out_mean, out_rstd, stream);
 }
 
 extern "C" int lpi_pool_ln_fwd(int dtype, int x_dtype, int B, int L, int d, const void* x, const int32_t* idx, const float* gamma, const float* beta,

@@ -479,7 +479,15 @@ class Tower:
         return bind(ws, Lreal)
 
     # ------------------------------------------------------------------ forward
-    def forward_gen(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
+    def ln1_stats_out(self, ws):
+        """(mean, rstd) of the first block's ln_1 if the front end should leave them there (its rows pass through a wave: lpi_vis_assemble_fwd /
+        lpi_txt_embed_fwd take them as out_mean / out_rstd), else (None, None): no statistics pass over x_0 then.  Pass ln1_ready=True to forward_gen."""
+        if ROWSTATS >= 2 and self.blocks and "qkv_ln" in self.blocks[0] and _ln_fold_ok(ws["Mp"], self.spec.width):
+            st = ws["stat"][0]
+            return st[0], st[1]
+        return None, None
+
+    def forward_gen(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None, ln1_ready=False):
         """GENERATOR (see GemmReq): runs the blocks over ws['x'][0], yielding its GEMMs; returns the POOLED rows of the output residual stream, [Bp, d] f32: row b is token
         pool_idx[b] of sample b (None: token 0 = CLS).  Only those rows are ever read by the heads (model.py:255,
         prompt_learner.py:61), so the last block's MLP is evaluated on them alone.
@@ -494,7 +502,7 @@ class Tower:
         P = prompts.shape[-2] if prompts is not None else 0
         self._check_depth(prompts, depth)
         self.serial += 1
-        have_ln1 = False      # ln_1's statistics of the coming block already written by the previous block's c_proj epilogue
+        have_ln1 = bool(ln1_ready)      # ln_1's statistics of the coming block already written (by the front end / the previous block's c_proj epilogue)
         for i, blk in enumerate(self.blocks):
             lt = "last" if i == len(self.blocks) - 1 else i      # GEMM tag: towers of different depth pair layer i with layer i, last with last
             k = i if train else 0
@@ -502,7 +510,9 @@ class Tower:
             x_out = ws["x"][i + 1 if train else (i + 1) % 2]
             xmid, qkv, ctx, lse, u, st = ws["xmid"][k], ws["qkv"][k], ws["ctx"][k], ws["lse"][k], ws["u"][k], ws["stat"][i]
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
-                call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, s)
+                # the rows it rewrites get their ln_1 statistics from the same kernel (the epilogue's are of their old contents)
+                so = (st[0], st[1]) if have_ln1 else (None, None)
+                call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, so[0], so[1], s)
             # LayerNorm folded into the GEMM behind it (LnLinear): a statistics pass over the stream, then the GEMM reads the stream itself
             fold = "qkv_ln" in blk and _ln_fold_ok(Mp, d)
             lnb, ln_ld = ws["lnblk"][i], ws["ln_ld"]
@@ -559,9 +569,9 @@ class Tower:
             else:
                 yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
                 yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            # the next block's ln_1 reads x_out as it stands unless deep prompts are written into it first (prompt_add above)
+            # the next block's ln_1 statistics come out of this epilogue; rows that deep prompts rewrite first get theirs from prompt_add (above)
             nxt = i + 1
-            have_ln1 = (rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt] and not (prompts is not None and 0 < nxt < depth))
+            have_ln1 = rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt]
             if have_ln1:
                 yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M,
                               epi=EPI_RES_ROWSTATS, aux=ws["rstat"])
@@ -774,8 +784,8 @@ class DualEncoder:
         call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
         yield GemmReq(None, dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
         call("lpi_vis_assemble_fwd", self.vis.xdt, B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
-             ws["x"][0], fe["stat"][0], fe["stat"][1], s)
-        xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None)      # pooled (CLS) rows [Bp, d]
+             ws["x"][0], fe["stat"][0], fe["stat"][1], *self.vis.ln1_stats_out(ws), s)
+        xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None, ln1_ready=self.vis.ln1_stats_out(ws)[0] is not None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         yield GemmReq("head", dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
@@ -861,8 +871,9 @@ class DualEncoder:
             eot_idx = hw["idx"]
             call("lpi_eot_index", B, L, ids, eot_idx, s)
         ctx = pr if (pr is not None and use_ctx) else None
-        call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0], s)
-        xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx)      # pooled (EOT) rows [Bp, d]
+        call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0],
+             *self.txt.ln1_stats_out(ws), s)
+        xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx, ln1_ready=self.txt.ln1_stats_out(ws)[0] is not None)      # pooled (EOT) rows
         call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
         yield GemmReq("head", dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
         out = torch.empty(B, cfg.embed_dim, device=self.device)

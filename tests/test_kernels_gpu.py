@@ -232,7 +232,7 @@ def test_fp16_residual_stream_kernels():
     P = 4
     pr = rnd(P, d, seed=11)
     xa = x16.clone().to(DEV)
-    call("lpi_prompt_add", F16, B, L, P, d, xa, pr.to(DEV), 0, stream())
+    call("lpi_prompt_add", F16, B, L, P, d, xa, pr.to(DEV), 0, None, None, stream())
     ref = x16.float().reshape(B, L, d).clone()
     ref[:, 1:1 + P] += pr
     assert torch.equal(xa.cpu(), ref.reshape(rows, d).half())
@@ -574,6 +574,66 @@ def test_gemm_layernorm_fold_epilogues(cdt):
         call("lpi_gemm_nt", F16, cdt, 384, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], p["residual"], p["ldr"], E.EPI_LN, None, 0, 1.0, stream())
     with pytest.raises(_lib.LpiError):      # the LN operand block is required
         call("lpi_gemm_nt", F16, cdt, 512, 768, 768, p["a"], 768, p["b"], 768, c, 768, p["bias"], None, 0, E.EPI_LN, None, 0, 1.0, stream())
+
+
+def test_row_kernels_leave_the_layernorm_statistics_of_the_rows_they_write():
+    """out_mean / out_rstd of lpi_vis_assemble_fwd, lpi_txt_embed_fwd(_varlen) and lpi_prompt_add(_varlen): the statistics of every row the kernel
+    writes, taken from the row as stored, at the row's index — equal to what the statistics pass (lpi_layernorm_fwd, y = NULL) finds in the stored stream
+    (up to the order of the sums), and the stored rows themselves are bit for bit those of the calls without statistics."""
+    B, G2, P, d = 3, 9, 4, 768
+    L = 1 + P + G2
+
+    def pass_stats(x16, rows):
+        m, r = torch.zeros(rows, device=DEV), torch.zeros(rows, device=DEV)
+        call("lpi_layernorm_fwd", BF16, F16, rows, d, x16, d, None, None, None, 0, m, r, stream())
+        return m, r
+
+    def close(a, b, what):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), what
+
+    # vision front end
+    pe = (rnd(B * G2, d, seed=1) * 2).to(DEV)
+    cls, pos, pr0 = rnd(d, seed=2).to(DEV), rnd(1 + G2, d, seed=3).to(DEV), rnd(P, d, seed=4).to(DEV)
+    gam, bet = (1 + 0.2 * rnd(d, seed=5)).to(DEV), (0.1 * rnd(d, seed=6)).to(DEV)
+    x0, x1 = torch.zeros(B * L, d, dtype=torch.float16, device=DEV), torch.zeros(B * L, d, dtype=torch.float16, device=DEV)
+    st, st2, so = torch.zeros(2, B * L, device=DEV), torch.zeros(2, B * L, device=DEV), torch.full((2, B * L), float("nan"), device=DEV)
+    call("lpi_vis_assemble_fwd", F16, B, G2, P, d, pe, d, cls, pos, pr0, 0, gam, bet, x0, st[0], st[1], None, None, stream())
+    call("lpi_vis_assemble_fwd", F16, B, G2, P, d, pe, d, cls, pos, pr0, 0, gam, bet, x1, st2[0], st2[1], so[0], so[1], stream())
+    assert torch.equal(x0, x1) and torch.equal(st, st2)
+    m, r = pass_stats(x1, B * L)
+    close(so[0], m, "vis mean"); close(so[1] / r, torch.ones_like(r), "vis rstd")
+    # text front end, uniform and ragged
+    V, Lt = 50, 12
+    ids = torch.randint(0, V, (B, Lt), generator=torch.Generator().manual_seed(7)).to(DEV)
+    tok, tpos, ctx = rnd(V, d, seed=8).to(DEV), rnd(Lt, d, seed=9).to(DEV), rnd(P, d, seed=10).to(DEV)
+    xt = torch.zeros(B * Lt, d, dtype=torch.float16, device=DEV)
+    so = torch.full((2, B * Lt), float("nan"), device=DEV)
+    call("lpi_txt_embed_fwd", F16, B, Lt, P, d, ids, tok, tpos, ctx, 0, xt, so[0], so[1], stream())
+    m, r = pass_stats(xt, B * Lt)
+    close(so[0], m, "txt mean"); close(so[1] / r, torch.ones_like(r), "txt rstd")
+    lens = torch.tensor([12, 7, 9])
+    rs_ = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int().to(DEV)
+    rows = int(lens.sum())
+    xp = torch.zeros(rows, d, dtype=torch.float16, device=DEV)
+    sp = torch.full((2, rows), float("nan"), device=DEV)
+    call("lpi_txt_embed_fwd_varlen", F16, B, Lt, rs_, P, d, ids, tok, tpos, ctx, 0, xp, sp[0], sp[1], stream())
+    m, r = pass_stats(xp, rows)
+    close(sp[0], m, "packed txt mean"); close(sp[1] / r, torch.ones_like(r), "packed txt rstd")
+    # deep-prompt add: only the rewritten rows' entries change
+    prl = rnd(P, d, seed=11).to(DEV)
+    before = sp.clone()
+    xq = xp.clone()
+    call("lpi_prompt_add_varlen", F16, B, Lt, rs_, P, d, xp, prl, 0, sp[0], sp[1], stream())
+    call("lpi_prompt_add_varlen", F16, B, Lt, rs_, P, d, xq, prl, 0, None, None, stream())
+    assert torch.equal(xp, xq)
+    m, r = pass_stats(xp, rows)
+    close(sp[0], m, "prompt rows mean"); close(sp[1] / r, torch.ones_like(r), "prompt rows rstd")
+    touched = torch.zeros(rows, dtype=torch.bool)
+    for b in range(B):
+        touched[int(rs_[b]) + 1:int(rs_[b]) + 1 + P] = True
+    assert torch.equal(sp[:, ~touched.to(DEV)], before[:, ~touched.to(DEV)]) and not torch.equal(sp[:, touched.to(DEV)], before[:, touched.to(DEV)])
+    with pytest.raises(_lib.LpiError):      # both or neither
+        call("lpi_prompt_add_varlen", F16, B, Lt, rs_, P, d, xp, prl, 0, sp[0], None, stream())
 
 
 def _slot_stats(c):
@@ -954,12 +1014,12 @@ def test_row_kernels_varlen():
     tok, pos, ctxp = rnd(64, d, seed=2).to(DEV), rnd(Lmax, d, seed=3).to(DEV), rnd(P, d, seed=4).to(DEV)
     xu = torch.zeros(B * Lmax, d, device=DEV)
     xp = torch.full((M + 7, d), 9.0, device=DEV)
-    call("lpi_txt_embed_fwd", F32, B, Lmax, P, d, ids.to(DEV), tok, pos, ctxp, 0, xu, stream())
-    call("lpi_txt_embed_fwd_varlen", F32, B, Lmax, rs_d, P, d, ids.to(DEV), tok, pos, ctxp, 0, xp, stream())
+    call("lpi_txt_embed_fwd", F32, B, Lmax, P, d, ids.to(DEV), tok, pos, ctxp, 0, xu, None, None, stream())
+    call("lpi_txt_embed_fwd_varlen", F32, B, Lmax, rs_d, P, d, ids.to(DEV), tok, pos, ctxp, 0, xp, None, None, stream())
     assert torch.equal(xp[:M], xu[rows_u]) and bool((xp[M:] == 9.0).all())
     pr = rnd(P, d, seed=5).to(DEV)
-    call("lpi_prompt_add", F32, B, Lmax, P, d, xu, pr, 0, stream())
-    call("lpi_prompt_add_varlen", F32, B, Lmax, rs_d, P, d, xp, pr, 0, stream())
+    call("lpi_prompt_add", F32, B, Lmax, P, d, xu, pr, 0, None, None, stream())
+    call("lpi_prompt_add_varlen", F32, B, Lmax, rs_d, P, d, xp, pr, 0, None, None, stream())
     assert torch.equal(xp[:M], xu[rows_u])
     su, sp = torch.zeros(P, d, device=DEV), torch.zeros(P, d, device=DEV)
     call("lpi_rows_sum_over_batch", F32, B, Lmax, 1, P, d, xu, su, 0, stream())

@@ -436,7 +436,7 @@ def test_layernorm_fold_levels_agree_and_do_not_lose_accuracy(monkeypatch, golde
 def test_row_statistics_from_the_gemm_epilogue_agree_with_the_statistics_pass(monkeypatch, golden, dtype):
     """LPI_ROWSTATS: the folded LayerNorms' mean / rstd from the slot sums the producing GEMM's epilogue leaves (LPI_EPI_RES_ROWSTATS + finalize)
     against the statistics pass over the stream, at both fold levels on the ViT-B/16 bs=8 fixture: the same features, logits and prompt-factor gradients
-    up to the order of an f32 sum (a few output roundings flip), the same error against the reference, one launch for one launch."""
+    up to the order of an f32 sum (a few output roundings flip), the same error against the reference, no more launches."""
     from lpi_amd import engine as E
     cfg = synth.VIT_B16
     g = golden("vitb16_d3_patched")
@@ -458,7 +458,7 @@ def test_row_statistics_from_the_gemm_epilogue_agree_with_the_statistics_pass(mo
         print("   factor gradients (cosine, max relative difference):", gd)
         for k in GRADS:      # the backward's operands are bf16 in both modes: a flipped rounding of the forward moves a gradient entry by percents
             assert gd[k][0] > 0.999 and gd[k][1] <= 6e-2, (level, k, gd[k])
-        assert launches[True] == launches[False]
+        assert launches[False] - 2 <= launches[True] <= launches[False]      # a finalize for a pass; the first block's pass is gone (the front end leaves its statistics)
 
 
 def test_fp16_gradient_storage_of_the_reference_against_the_bf16_backward(golden):
