@@ -395,7 +395,9 @@ def test_f16_operand_mode_is_several_times_closer_to_the_reference_than_bf16(gol
     lb, lh = maxerr(rb["logits"], g["logits"]), maxerr(rh["logits"], g["logits"])
     print(f"feature err bf16 {eb:.2e} / f16 {eh:.2e}; logit err bf16 {lb:.2e} / f16 {lh:.2e}")
     assert eh < 5e-4 and lh < 5e-3
-    assert eh < eb / 2.5 and lh < lb / 2.5
+    # features 5x, logits (a maximum over 64 values: noisy) 2-3x: bf16 mode itself got closer when both LayerNorms were folded into their GEMMs
+    # (LN(x) is no longer rounded to bf16: logit error 8.5e-3 -> 6.5e-3), which narrows the ratio, not the f16 mode's error
+    assert eh < eb / 2.5 and lh < lb / 2
     assert abs(float(rh["base_loss"]) - float(g["base_loss"])) < 2e-3
     cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
     print("f16 mode vs the reference fixture, factor gradients (cosine, max relative error):", {k: (round(cos(rh[k], g[k]), 5), round(relmax(rh[k], g[k]), 4)) for k in GRADS})
