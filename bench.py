@@ -472,11 +472,12 @@ def main():
     pairs_s = world * B * a.steps / el
     median_ms = rank_max(float(np.median(per)))
     collectives = None
-    if exchange is not None and exchange.timing:
+    if exchange is not None:
         torch.cuda.synchronize()
-        tl = exchange.timing[-2 * a.steps:] if not a.fwd_only else exchange.timing[-a.steps:]
+        tl = (exchange.timing or [])[-2 * a.steps:] if not a.fwd_only else (exchange.timing or [])[-a.steps:]
+        # device collectives (RCCL) are timed with HIP events; host-staged ones (gloo, ranks sharing a GPU) carry no per-collective time
         collectives = {k: round(1e3 * float(np.mean([e0.elapsed_time(e1) for kk, e0, e1 in tl if kk == k])), 1)
-                       for k in sorted({kk for kk, _, _ in tl})}
+                       for k in sorted({kk for kk, _, _ in tl})} or None
         collectives = {"mean_us_per_step": collectives, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
                        "messages": "one all_gather_into_tensor of img_f||txt_f [B, 1024] f32 + one all_reduce(SUM) of the 5 284 factor gradients"}
         exchange.timing = None
