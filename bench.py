@@ -20,8 +20,8 @@ The JSON line carries, besides the driver's contract keys:
   roofline     : the dominant kernel (the 256x256 GEMM, MFMA bound): executed FLOPs of its launches / their duration, bracketed by
                  HIP events on the launch stream in an instrumented pass after the timed region; which kernel a launch went to is
                  reported by the library (lpi_gemm_last_kernel), not re-derived here; each launch counts with the
-                 median of five instrumented steps; `traffic` / `mfma_util` come from the committed rocprofv3 --pmc summary
-                 (profiles/r03_pmc.json) when its tuning stamp matches the running build;
+                 median of five instrumented steps; `traffic` / `mfma_util` come from a committed rocprofv3 --pmc summary
+                 (profiles/r*_pmc*.json) of the SAME workload (model / batch / depth), dtype, tuning and library build — else null;
   step_mfma_frac: whole-step fraction of the same peak from SURVEY's 89.68 GFLOP/pair — model-FLOP utilisation (all kernels, not just GEMMs);
   hw_flop_frac : the same with the FLOPs the kernels actually execute (dead text rows, the pooled last block, the prompt-row backward of the
                  first block are skipped exactly, so this is lower);
@@ -116,7 +116,10 @@ def self_launch(a):
 
 def cpu_baseline(cfg, depth, seconds_budget=30.0):
     """Oracle fwd+loss+bwd at bs=8 (BASELINE.json configs[0] shape) on the host cores.  torch's default (all logical CPUs) oversubscribes
-    a bs=8 step, so the thread count is swept first (one step each) and the best one is timed."""
+    a bs=8 step, so the thread count is swept first (one step each, after a warm-up) and the best one is timed: >= 3 warm-up steps, then
+    >= 10 timed steps, the MEDIAN step time is reported (the mean beside it).  When the host has the memory (the oracle keeps
+    ~0.3 GB of autograd state per pair) one bs=256 step — the metric's own batch — is timed as well."""
+    import numpy as np
     import torch
     from lpi_amd import synth
     from oracle import lpi_oracle as O
@@ -142,17 +145,39 @@ def cpu_baseline(cfg, depth, seconds_budget=30.0):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    for _ in range(3):                                              # warm-up at the chosen thread count
         O.train_step(orc, img, ids, fac, depth=depth)
-        n += 1
+    per, t_loop = [], time.perf_counter()
+    while len(per) < 10 or (time.perf_counter() - t_loop < 0.25 * seconds_budget and len(per) < 40):
+        t0 = time.perf_counter()
+        O.train_step(orc, img, ids, fac, depth=depth)
+        per.append(time.perf_counter() - t0)
+    med, mean = float(np.median(per)), float(np.mean(per))
+    out = {"value": round(B / med, 3), "unit": "pairs/s", "cores": best, "kind": "port", "value_at_mean": round(B / mean, 3),
+           "timed_steps": len(per), "warmup_steps": 3,
+           "sample": f"median of {len(per)} timed steps (3 warm-up) of bs={B} fwd+bwd, ViT-B/16 depth={depth} r=4, fp32, oracle/lpi_oracle.py on torch CPU with "
+                     f"{best} threads (best of a one-step sweep {{{', '.join(f'{t}: {B / v:.2f}' for t, v in sweep.items())}}} pairs/s; {ncpu} logical cpus)"}
+    # the metric's own batch: one bs=256 step, when the host can hold it (~80 GB of autograd state; 64 threads: the large batch scales further)
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available / 2**30
+    except Exception:
+        avail = 0.0
+    if avail >= 200.0 and ncpu >= 32 and os.environ.get("LPI_CPU_BASELINE_BS256", "1") != "0":
+        Bl, tl = 256, min(64, ncpu)
+        torch.set_num_threads(tl)
+        imgl, idsl = synth.images(Bl, cfg.image_resolution), synth.token_ids(Bl)
+        t0 = time.perf_counter()
+        O.train_step(orc, imgl, idsl, fac, depth=depth)
         el = time.perf_counter() - t0
-        if el > 0.5 * seconds_budget or n >= 6:
-            break
+        out["bs256_sample"] = {"value": round(Bl / el, 3), "unit": "pairs/s", "cores": tl, "steps": 1, "seconds": round(el, 2),
+                               "sample": f"ONE bs={Bl} step (no warm-up at this size), {tl} threads; host memory available {avail:.0f} GiB"}
+        del imgl, idsl
+    else:
+        out["bs256_sample"] = None
+        out["bs256_skipped"] = f"host memory available {avail:.0f} GiB (< 200) or {ncpu} cpus (< 32)"
     torch.set_num_threads(default_threads)
-    return {"value": round(B * n / el, 3), "unit": "pairs/s", "cores": best, "kind": "port",
-            "sample": f"{n} steps of bs={B} fwd+bwd, ViT-B/16 depth={depth} r=4, fp32, oracle/lpi_oracle.py on torch CPU with {best} threads "
-                      f"(best of a one-step sweep {{{', '.join(f'{t}: {B / s:.2f}' for t, s in sweep.items())}}} pairs/s; {ncpu} logical cpus)"}
+    return out
 
 
 class Workload:
@@ -250,47 +275,62 @@ class Workload:
         else:
             ev_all = [(e[0].elapsed_time(e[1]),) * 2 + tuple(e[2:]) for e in ev_raw]
         bucket = lambda e: GEMM_KERNEL_NAMES.get(e[4], "other")  # noqa: E731
-        # the dominant kernel = the 256x256 GEMM (its two entry kernels); the few-row GEMMs (split-K 128x128 + reduce) and the
-        # half-empty launches that go to the 256x128-tile kernel are reported beside it, not averaged into its launch time
-        ev = [e for e in ev_all if bucket(e) == "k256"] or ev_all
-        small = [e for e in ev_all if bucket(e) in ("few_rows", "k128")]
-        half = [e for e in ev_all if bucket(e) == "k256x128"]
+        # the DOMINANT kernel = the GEMM kernel with the most time in the step: the 256x256 kernel in the bf16 / f16 modes; in the f32 mode most launches
+        # have fewer tiles than its threshold and run the 128x128 kernel (gemm_nt_kernel), which then IS the dominant one and is reported as such.
+        # The other kernels are listed beside it, never averaged into its launch time.
         t_ms = lambda es: sum(e[0] for e in es)  # noqa: E731
-        ms, small_ms, half_ms = t_ms(ev), t_ms(small), t_ms(half)
+        groups = {b: [e for e in ev_all if bucket(e) == b] for b in ("k256", "k128", "k256x128", "few_rows")}
+        dom = max(groups, key=lambda b: t_ms(groups[b]))
+        ev = groups[dom] or ev_all
+        ms = t_ms(ev)
         ms_best = sum(e[1] for e in ev)
         self.gemm_gflop_all = sum(e[2] for e in ev_all) / nprof / 1e9          # every GEMM launch of a step (executed FLOPs)
-        fl, by, half_fl = sum(e[2] for e in ev), sum(e[3] for e in ev), sum(e[2] for e in half)
+        fl, by = sum(e[2] for e in ev), sum(e[3] for e in ev)
         ach = fl / (ms * 1e-3) / 1e12
-        tuning = [int(_lib.load().lpi_get_tuning(k)) for k in range(8)]
+        lib = _lib.load()
+        tuning = [int(lib.lpi_get_tuning(k)) for k in range(8)]
+        KDESC = {"k256": "gemm256p_kernel (the persistent 256x256 GEMM; the vision and the text tower's GEMM of the same layer op go out as ONE grouped launch, a short "
+                         "last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
+                 "k128": "gemm_nt_kernel (128x128 tiles, 4 waves of 64x64, LDS-DMA double buffer: every launch below the 256x256 kernel's tile-count threshold)",
+                 "k256x128": "gemm256x128_kernel (launches with 16..159 256x256 tiles)",
+                 "few_rows": "gemm_nt_splitk(_pair)_kernel + splitk_reduce(_pair)_kernel (M <= 256: split-K partial tiles, fixed-order reduction with the epilogue)"}
         traffic = mfma_util = tsrc = None
-        pmc = os.path.join(REPO, "profiles", "r03_pmc.json")
-        if os.path.exists(pmc):      # separate rocprofv3 --pmc passes of this command, summarised by tools/pmc_summary.py
+        wl = {"model": a.model, "batch": a.batch, "depth": a.depth}
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc*.json")), reverse=True):
+            # separate rocprofv3 --pmc passes of THIS workload (model / batch / depth), dtype, tuning and library build, summarised by tools/pmc_summary.py;
+            # a summary of another workload (or of an older build) is never attached: null instead
             pj = json.load(open(pmc))
-            if pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(_lib.load().lpi_version()):
-                ks = [v for n, v in pj["kernels"].items() if n in ("gemm256_kernel", "gemm256_tail_kernel", "gemm256p_kernel")]
-                if ks:      # the entry kernels of the 256x256 GEMM (persistent / one tile per workgroup / with a half-tile last round), launch-weighted
+            if (pj.get("workload") == wl and pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(lib.lpi_version())):
+                names = {"k256": ("gemm256_kernel", "gemm256_tail_kernel", "gemm256p_kernel"), "k128": ("gemm_nt_kernel",), "k256x128": ("gemm256x128_kernel",),
+                         "few_rows": ("gemm_nt_splitk_kernel", "gemm_nt_splitk_pair_kernel")}[dom]
+                ks = [v for n, v in pj["kernels"].items() if n in names and "hbm_mb_per_launch" in v]
+                if ks:      # launch-weighted over the dominant kernel's entry points
                     w = sum(v["launches"] for v in ks)
                     traffic = round(sum(v["hbm_mb_per_launch"] * v["launches"] for v in ks) / w * 1e6)
                     if all("mfma_busy_frac" in v for v in ks):
                         mfma_util = round(sum(v["mfma_busy_frac"] * v["launches"] for v in ks) / w, 4)
-                    tsrc = "profiles/r03_pmc.json (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES)"
-        return {"bound": "mfma", "kernel": "gemm256p_kernel (the persistent 256x256 GEMM; the vision and the text tower's GEMM of the same layer op go out as ONE "
-                                            "grouped launch, a short last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
-                "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
-                "achieved_fastest_of_n": round(fl / (ms_best * 1e-3) / 1e12, 2),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
-                "algorithmic_bytes_per_launch": round(by / len(ev)),
-                "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
-                "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
-                "few_row_gemms": {"launches_per_step": len(small) // nprof, "ms_per_step": round(small_ms / nprof, 3),
-                                  "kernel": "gemm_nt_kernel: 128x128 tiles (f32 mode: every launch below the 256x256 kernel's tile-count threshold); M <= 256: split-K + splitk_reduce_kernel"},
-                "half_empty_gemms": {"launches_per_step": len(half) // nprof, "ms_per_step": round(half_ms / nprof, 3),
-                                     "achieved_tflops": round(half_fl / (half_ms * 1e-3) / 1e12, 2) if half_ms else None,
-                                     "kernel": "gemm256x128_kernel (launches with 16..159 256x256 tiles)"},
-                "tuning": tuning,
-                "measured": f"HIP events around every GEMM launch of {nrec} extra steps (each launch: the MEDIAN of its {nrec} measurements), towers on one stream "
-                            "(kernel alone on the GPU); "
-                            "kernel attribution from lpi_gemm_last_kernel"}
+                    tsrc = (f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc, separate passes; FETCH_SIZE/WRITE_SIZE corrected per the guide; "
+                            "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024))")
+                    break
+
+        def side(b):
+            es = groups[b]
+            m = t_ms(es)
+            return {"launches_per_step": len(es) // nprof, "ms_per_step": round(m / nprof, 3),
+                    "achieved_tflops": round(sum(e[2] for e in es) / (m * 1e-3) / 1e12, 2) if m else None, "kernel": KDESC[b]}
+        out = {"bound": "mfma", "kernel": KDESC[dom], "dominant_bucket": dom,
+               "achieved": round(ach, 2), "peak": PEAK_TF[self.dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TF[self.dtype], 4),
+               "achieved_fastest_of_n": round(fl / (ms_best * 1e-3) / 1e12, 2),
+               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "mfma_util": mfma_util, "traffic_source": tsrc,
+               "algorithmic_bytes_per_launch": round(by / len(ev)),
+               "launches_per_step": len(ev) // nprof, "avg_launch_us": round(1e3 * ms / len(ev), 2),
+               "gemm_ms_per_step": round(ms / nprof, 3), "gemm_gflop_per_step": round(fl / nprof / 1e9, 1),
+               "other_gemm_kernels": {b: side(b) for b in groups if b != dom and groups[b]},
+               "tuning": tuning,
+               "measured": f"HIP events around every GEMM launch of {nrec} extra steps (each launch: the MEDIAN of its {nrec} measurements), towers on one stream "
+                           "(kernel alone on the GPU); kernel attribution from lpi_gemm_last_kernel"}
+        return out
 
 
 def eval_path(a, dev, rank, sync, tasks=3, centres=5, n_img=5000, n_txt=25000):

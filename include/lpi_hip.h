@@ -243,6 +243,23 @@ int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start
 int lpi_attn_pooled_bwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
                                const int32_t* idx, const void* dctx, int lddctx, const float* lse, void* dq, int lddq, void* dqkv,
                                int lddqkv, int causal, void* stream);
+/* The two towers' pooled-row attention (last block) as ONE launch: d[i] = the arguments of lpi_attn_pooled_fwd_varlen / _bwd_varlen (fwd uses q, qkv, idx,
+ * ctx, lse; bwd q, qkv, idx, dctx, lse, dq, dqkv).  Bit for bit the two single launches. */
+typedef struct lpi_attn_pooled_desc {
+    int B, L, H;
+    const int32_t* row_start;
+    const void* q; int ldq;
+    const void* qkv; int ldqkv;
+    const int32_t* idx;
+    void* ctx; int ldctx;
+    float* lse;
+    const void* dctx; int lddctx;
+    void* dq; int lddq;
+    void* dqkv; int lddqkv;
+    int causal;
+} lpi_attn_pooled_desc;
+int lpi_attn_pooled_fwd_pair(int dtype, const lpi_attn_pooled_desc* d /* [2] */, void* stream);
+int lpi_attn_pooled_bwd_pair(int dtype, const lpi_attn_pooled_desc* d /* [2] */, void* stream);
 int lpi_layernorm_bwd_rows_varlen(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, const int32_t* row_start, int row0, int P, int d,
                                   const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                                   float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);
@@ -263,6 +280,14 @@ int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, const float
 int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3,
                       float scale, const float* dout, float* g1, float* g2, float* g3, int accumulate_g1,
                       float* scratch, void* stream);
+/* Both prompt stacks of a DecomposedPrompt (visual and textual share dim_1_share, prompts.py:38-57) per call (round 4): the forward in ONE launch,
+ * the backward in TWO (lpi_prompt_cp_bwd for the visual stack with g1 overwritten, then for the textual one with g1 accumulated: six launches).
+ * The same arithmetic per value.  scratch: 2 * Lyr * P * r floats. */
+int lpi_prompt_cp_fwd2(int Lyr, int P, int Dv, int Dt, int r, const float* d1, const float* d2v, const float* d2t, const float* d3v, const float* d3t,
+                       float scale, float* outv, float* outt, void* stream);
+int lpi_prompt_cp_bwd2(int Lyr, int P, int Dv, int Dt, int r, const float* d1, const float* d2v, const float* d2t, const float* d3v, const float* d3t,
+                       float scale, const float* doutv, const float* doutt, float* g1, float* g2v, float* g2t, float* g3v, float* g3t, float* scratch,
+                       void* stream);
 
 /* ---- a3: vision front end                          replaces: models/clip/model.py:227-251 --------------
  * patchify: image [B,3,R,R] f32 -> cols [B*G*G (padded rows untouched), Kp] `dtype`, Kp >= 3*ps*ps zero padded.
@@ -318,6 +343,52 @@ int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float* dy, int l
                    float* dx, int lddx, void* stream);
 int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream);   /* ids.argmax(-1), prompt_learner.py:61 */
 
+/* ---- several small row kernels of ONE dependency level in one launch (round 4) ------------------------------------------------------
+ * The tail of a training step — the pooled rows of the last block, the heads, the L2 norms (model.py:255-257, prompt_learner.py:57-61,
+ * slinet.py:122,133), the prompt rows (model.py:189-193, 240-248) — is a chain of few-microsecond launches on B or B*P rows, one per tower
+ * and op.  lpi_row_jobs issues up to LPI_ROW_JOBS_MAX INDEPENDENT ones (the two towers' launch of the same op; independent ops of one tower) as
+ * one launch: every job runs the body of its single-op kernel, so the results are bit for bit those of the entry point named below.
+ * Fields a job does not use are ignored.  dt_*: LPI_F32 / LPI_BF16 / LPI_F16.
+ *   POOL_LN_FWD          lpi_pool_ln_fwd(dt_b, dt_a, B, L, d, a, idx, gamma, beta, out, ld_c, mean, rstd); out2 (optional) = the gathered row itself
+ *                        as f32 [B, d] (lpi_gather_rows(dt_a, B, L, d, a, idx, out2))
+ *   L2NORM_FWD           lpi_l2norm_fwd(B, d, a, ld_a, out, ld_c, mean [inv_norm])
+ *   L2NORM_BWD           lpi_l2norm_bwd(B, d, a [y], ld_a, b [dy], ld_b, mean_in [inv_norm], out, ld_c); out2 (optional, dt_b = BF16) = the bf16
+ *                        copy of out, same row stride (lpi_cast)
+ *   POOL_LN_BWD          lpi_pool_ln_bwd(dt_b, B, L, d, a [dy], ld_a, b [x], idx, gamma, mean_in, rstd_in, out, out2 [cast copy or NULL])
+ *   LN_BWD               lpi_layernorm_bwd(dt_a, dt_b, LPI_F32, B, d, a [dy], ld_a, b [x f32], ld_b, gamma, mean_in, rstd_in, out [dx or NULL], ld_c,
+ *                        out2 [cast], ld_c, flag [accumulate])   with (dt_a, dt_b) = (BF16, BF16) or (F32, F32)
+ *   SCATTER_ADD          lpi_scatter_add_rows(dt_a, B, L, d, a, ld_a, idx, out, ld_c)
+ *   GATHER_BATCH_ROWS    lpi_gather_batch_rows_varlen with d = 16-byte chunks per row and ld_a / ld_c in 16-byte units: (B, L, row_start, row0, P, a, out)
+ *   PROMPT_ADD           lpi_prompt_add_varlen(dt_a, B, L, row_start, P, d, out [x, in place], a [prompt_l], bstride, mean, rstd)
+ *   LN_BWD_ROWS_H16      lpi_layernorm_bwd_rows_varlen(BF16, BF16, F16, B, L, row_start, row0, P, d, a [dy compact], ld_a, b [x], ld_b, gamma, mean_in,
+ *                        rstd_in, NULL, 0, out2 [bf16 gradient stream], ld_c, flag [accumulate])   (the 16-byte half-wave kernel's alignment rules)
+ *   VIS_PROMPT_ROWS_BWD  the LayerNorm part of lpi_vis_assemble_bwd: LN' on rows 1..P of out (dt_a, in place) with the rows of a (prompt0, bstride)   */
+enum { LPI_ROWOP_POOL_LN_FWD = 1, LPI_ROWOP_L2NORM_FWD = 2, LPI_ROWOP_L2NORM_BWD = 3, LPI_ROWOP_POOL_LN_BWD = 4, LPI_ROWOP_LN_BWD = 5,
+       LPI_ROWOP_SCATTER_ADD = 6, LPI_ROWOP_GATHER_BATCH_ROWS = 7, LPI_ROWOP_PROMPT_ADD = 8, LPI_ROWOP_LN_BWD_ROWS_H16 = 9,
+       LPI_ROWOP_VIS_PROMPT_ROWS_BWD = 10 };
+#define LPI_ROW_JOBS_MAX 4
+typedef struct lpi_row_job {
+    int op;
+    int B, L, d;
+    int P, row0;
+    int dt_a, dt_b;
+    int ld_a, ld_b, ld_c;
+    int flag;
+    long bstride;
+    const void* a; const void* b;
+    const int32_t* idx; const int32_t* row_start;
+    const float* gamma; const float* beta; const float* mean_in; const float* rstd_in;
+    void* out; void* out2;
+    float* mean; float* rstd;
+} lpi_row_job;
+int lpi_row_jobs(int n, const lpi_row_job* jobs, void* stream);      /* jobs: HOST array, n <= LPI_ROW_JOBS_MAX */
+typedef struct lpi_rows_sum_desc {
+    int B, L, row0, P, d, accumulate;
+    const int32_t* row_start;
+    const void* dx; float* out;
+} lpi_rows_sum_desc;
+int lpi_rows_sum_over_batch_pair(int dtype, const lpi_rows_sum_desc* d /* [2] */, void* stream);
+
 /* ---- a8: symmetric contrastive loss   replaces: loss/loss.py:75-87 (ClipLoss.forward), slinet.py:139-141
  * logits f32 [n_rows, n_cols] (ld), rows r0..r0+n_local-1 are this rank's pairs; square global matrix
  * (n_rows == n_cols == W*B).  loss[0] = (CE(logits,arange)+CE(logits^T,arange))/2 over ALL rows/cols;
@@ -329,6 +400,11 @@ int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float upstream, fl
  * [nloc, n] row-major, row stride ldg), from the row/column log-sum-exp vectors lpi_clip_loss_fwd_bwd left behind. */
 int lpi_clip_loss_local_grad(int n, const float* logits, int ld, const float* row_lse, const float* col_lse, float upstream,
                              int r0, int nloc, float* g, float* gt, int ldg, void* stream);
+/* lpi_clip_loss_fwd_bwd (dlogits = NULL) + lpi_clip_loss_local_grad as TWO launches instead of four (round 4): the two log-sum-exp vectors in one
+ * launch, the loss value in the first workgroup of the local-gradient kernel.  g / gt NULL: the loss and the lse vectors only.  The same arithmetic
+ * per value: bit for bit the four-launch results (loss/loss.py:75-87, sprompt.py:75-80). */
+int lpi_clip_loss_local(int n, const float* logits, int ld, float upstream, int r0, int nloc, float* loss, float* row_lse, float* col_lse,
+                        float* g, float* gt, int ldg, void* stream);
 /* `local_loss=True` form of the same loss (sprompt.py:278-283 with loss/loss.py:62-73): row-wise cross-entropy of a [rows, n] block of
  * logits (this rank's images against ALL texts, or its texts against all images) whose row i has label label0 + i (= rank * B + i).
  * loss_rows[i] = logsumexp(logits[i, :]) - logits[i, label0 + i]; dlogits (optional, may alias nothing) = upstream * (softmax - onehot).
@@ -354,6 +430,10 @@ int lpi_sgd_step(long n, float* param, const float* grad, float* momentum_buf, f
  * dvis [Lyr,P,Dv], dtxt [Lyr,P,Dt] = dense gradients of loss[0] (both NULL: forward only). */
 int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp,
                            float weight, float* loss, float* dvis, float* dtxt, void* stream);
+/* The same loss and gradients in TWO launches instead of three (round 4): the row means go to `scratch` (2 * Lyr * P floats), and every workgroup of the
+ * second launch recomputes the Lyr x Lyr core from them and writes its own gradient row (workgroup 0 the loss).  Value for value lpi_align_loss_fwd_bwd. */
+int lpi_align_loss_fwd_bwd2(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp, float weight, float* loss, float* dvis,
+                            float* dtxt, float* scratch, void* stream);
 
 /* ---- a9: task loss (nt_bxent over the tasks' flattened prompts)   replaces: loss/loss.py:6-33, models/slinet.py:167-183 ----
  * X f32 [T, D] (row t = prompts of task t, flattened), target int32 [T,T] (task_sim > 0.4), T <= 32.  loss[0] = weight * nt_bxent(X);
@@ -365,6 +445,9 @@ int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const int32_t* t
 /* ---- misc ---------------------------------------------------------------------------------------------- */
 int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, void* stream);
 int lpi_transpose(int dtype, int rows, int cols, const void* src, int lds, void* dst, int ldd, void* stream);
+/* two f32 transposes in one launch (the two feature matrices of the contrastive loss's gradient GEMMs) */
+int lpi_transpose2(int dtype, int rows0, int cols0, const void* src0, int lds0, void* dst0, int ldd0,
+                   int rows1, int cols1, const void* src1, int lds1, void* dst1, int ldd1, void* stream);
 /* per-row descending rank of the best ground-truth column (itm_eval, methods/sprompt.py:558-599):
  * rank[i] = #{j : s[i,j] > s[i,gt] or (s[i,j] == s[i,gt] and j > gt)} minimised over gt in gt_list row i.
  * (np.argsort(score)[::-1] places later indices first among ties.) */

@@ -86,6 +86,15 @@ SIGNATURES = {
     "lpi_eot_index": [_I, _I, _P, _P, _P],
     "lpi_clip_loss_fwd_bwd": [_I, _P, _I, _F, _P, _P, _I, _P, _P, _P],
     "lpi_clip_loss_local_grad": [_I, _P, _I, _P, _P, _F, _I, _I, _P, _P, _I, _P],
+    "lpi_clip_loss_local": [_I, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "lpi_prompt_cp_fwd2": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "lpi_prompt_cp_bwd2": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "lpi_align_loss_fwd_bwd2": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    "lpi_transpose2": [_I, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P],
+    "lpi_row_jobs": [_I, _P, _P],
+    "lpi_rows_sum_over_batch_pair": [_I, _P, _P],
+    "lpi_attn_pooled_fwd_pair": [_I, _P, _P],
+    "lpi_attn_pooled_bwd_pair": [_I, _P, _P],
     "lpi_ce_rows_fwd_bwd": [_I, _I, _P, _I, _I, _F, _P, _P, _I, _P],
     "lpi_sum_scaled": [_I, _P, _P, _F, _P, _P],
     "lpi_zero": [_P, _L, _P],
@@ -110,7 +119,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 302
+EXPECTED_ABI = 400
 
 _lib = None
 
@@ -252,6 +261,80 @@ def gemm_splitk_pair(dt: int, cdt: int, epi: int, alpha: float, problems, ksplit
                                         scratches[1].data_ptr(), stream)
     if rc != 0:
         raise LpiError(f"lpi_gemm_nt_splitk_pair failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+
+
+ROWOP_POOL_LN_FWD, ROWOP_L2NORM_FWD, ROWOP_L2NORM_BWD, ROWOP_POOL_LN_BWD, ROWOP_LN_BWD = 1, 2, 3, 4, 5
+ROWOP_SCATTER_ADD, ROWOP_GATHER_BATCH_ROWS, ROWOP_PROMPT_ADD, ROWOP_LN_BWD_ROWS_H16, ROWOP_VIS_PROMPT_ROWS_BWD = 6, 7, 8, 9, 10
+ROW_JOBS_MAX = 4
+
+
+class RowJob(ctypes.Structure):
+    """``lpi_row_job`` (include/lpi_hip.h): one small row kernel of an lpi_row_jobs launch."""
+    _fields_ = [("op", c_int), ("B", c_int), ("L", c_int), ("d", c_int), ("P", c_int), ("row0", c_int), ("dt_a", c_int), ("dt_b", c_int),
+                ("ld_a", c_int), ("ld_b", c_int), ("ld_c", c_int), ("flag", c_int), ("bstride", c_long),
+                ("a", c_void_p), ("b", c_void_p), ("idx", c_void_p), ("row_start", c_void_p),
+                ("gamma", c_void_p), ("beta", c_void_p), ("mean_in", c_void_p), ("rstd_in", c_void_p),
+                ("out", c_void_p), ("out2", c_void_p), ("mean", c_void_p), ("rstd", c_void_p)]
+
+
+_ROWJOB_PTRS = {"a", "b", "idx", "row_start", "gamma", "beta", "mean_in", "rstd_in", "out", "out2", "mean", "rstd"}
+
+
+def row_job(op, **kw):
+    """A RowJob from keyword fields; tensors become device pointers (None = NULL).  The job keeps a reference to every tensor it points at (`_keep`), so
+    that a tensor the caller drops between building the job and issuing it is not recycled by the allocator under the launch."""
+    j = RowJob()
+    j.op = op
+    j._keep = [v for k, v in kw.items() if k in _ROWJOB_PTRS and v is not None]
+    for k, v in kw.items():
+        setattr(j, k, (_ptr(v) if k in _ROWJOB_PTRS else v))
+    return j
+
+
+def row_jobs(jobs, stream):
+    """lpi_row_jobs: up to ROW_JOBS_MAX independent small row kernels in one launch (more: several launches)."""
+    for i in range(0, len(jobs), ROW_JOBS_MAX):
+        part = jobs[i:i + ROW_JOBS_MAX]
+        arr = (RowJob * len(part))(*part)
+        rc = load().lpi_row_jobs(len(part), ctypes.cast(arr, c_void_p), stream)
+        if rc != 0:
+            raise LpiError(f"lpi_row_jobs failed with code {rc} (ops {[j.op for j in part]})" + (" (invalid argument)" if rc == -22 else ""))
+
+
+class RowsSumDesc(ctypes.Structure):
+    """``lpi_rows_sum_desc``"""
+    _fields_ = [("B", c_int), ("L", c_int), ("row0", c_int), ("P", c_int), ("d", c_int), ("accumulate", c_int), ("row_start", c_void_p),
+                ("dx", c_void_p), ("out", c_void_p)]
+
+
+def rows_sum_pair(dt, a, b, stream):
+    """Two argument tuples (B, L, row_start, row0, P, d, dx, out, accumulate) of lpi_rows_sum_over_batch_varlen in one launch."""
+    arr = (RowsSumDesc * 2)()
+    for q, t in zip(arr, (a, b)):
+        q.B, q.L, q.row_start, q.row0, q.P, q.d, q.dx, q.out, q.accumulate = t[0], t[1], _ptr(t[2]), t[3], t[4], t[5], _ptr(t[6]), _ptr(t[7]), t[8]
+    rc = load().lpi_rows_sum_over_batch_pair(dt, ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_rows_sum_over_batch_pair failed with code {rc}")
+
+
+class AttnPooledDesc(ctypes.Structure):
+    """``lpi_attn_pooled_desc``"""
+    _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("row_start", c_void_p), ("q", c_void_p), ("ldq", c_int), ("qkv", c_void_p), ("ldqkv", c_int),
+                ("idx", c_void_p), ("ctx", c_void_p), ("ldctx", c_int), ("lse", c_void_p), ("dctx", c_void_p), ("lddctx", c_int), ("dq", c_void_p),
+                ("lddq", c_int), ("dqkv", c_void_p), ("lddqkv", c_int), ("causal", c_int)]
+
+
+def attn_pooled_pair(dt, a, b, stream, backward=False):
+    """Two dicts of lpi_attn_pooled_desc fields (tensors or ints) -> lpi_attn_pooled_fwd_pair / _bwd_pair."""
+    arr = (AttnPooledDesc * 2)()
+    ptrs = {"row_start", "q", "qkv", "idx", "ctx", "lse", "dctx", "dq", "dqkv"}
+    for q, t in zip(arr, (a, b)):
+        for k, v in t.items():
+            setattr(q, k, (_ptr(v) if k in ptrs else v))
+    fn = load().lpi_attn_pooled_bwd_pair if backward else load().lpi_attn_pooled_fwd_pair
+    rc = fn(dt, ctypes.cast(arr, c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_attn_pooled_{'bwd' if backward else 'fwd'}_pair failed with code {rc}")
 
 
 def launch_count() -> int:

@@ -25,16 +25,14 @@ __device__ __forceinline__ float reduce16(float v) {
 __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 template <typename T>
-__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
-    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+__device__ __forceinline__ void attn_pooled_fwd_body(
+    int bh, float* sm, int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
     T* __restrict__ ctx, int ldo, float* __restrict__ lse, int causal)
 {
-    extern __shared__ float sm[];
     float* s = sm;                 // scores
     float* p = sm + Lp;            // exp(score - max)
     float* red = sm + 2 * Lp;      // [WPB][64] partial context rows
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H, d = H * DH;
     const int row = idx ? idx[b] : 0;
     // ragged batch (rs = row starts): sample b owns rows rs[b] .. rs[b+1]-1 of qkv
@@ -74,20 +72,37 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
         if (lane == 0) lse[bh] = m + __logf(sum);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_kernel(
+    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const T* __restrict__ q, int ldq, const T* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    T* __restrict__ ctx, int ldo, float* __restrict__ lse, int causal)
+{
+    extern __shared__ float sm[];
+    attn_pooled_fwd_body<T>(blockIdx.x, sm, B, Lmax, rs, H, Lp, q, ldq, qkv, ld, idx, ctx, ldo, lse, causal);
+}
+// the two towers' pooled-row attention of the last block in ONE launch: workgroups [0, nb0) are problem 0's (sample, head) pairs
+struct PoolFwdP { int B, Lmax, H, Lp, ldq, ld, ldo, causal; const int* rs; const void* q; const void* qkv; const int* idx; void* ctx; float* lse; };
+template <typename T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_fwd_pair_kernel(PoolFwdP p0, PoolFwdP p1, int nb0)
+{
+    extern __shared__ float sm[];
+    const bool z = (int)blockIdx.x >= nb0;
+    const PoolFwdP& p = z ? p1 : p0;
+    attn_pooled_fwd_body<T>(z ? blockIdx.x - nb0 : blockIdx.x, sm, p.B, p.Lmax, p.rs, p.H, p.Lp, (const T*)p.q, p.ldq, (const T*)p.qkv, p.ld, p.idx, (T*)p.ctx, p.ldo, p.lse,
+                            p.causal);
+}
 
 // TS: storage type of the SAVED q / qkv (fp16 after an f16-mode forward, else T); dctx, dq, dqkv are T.  All arithmetic is f32.
 template <typename T, typename TS = T>
-__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
-    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
+__device__ __forceinline__ void attn_pooled_bwd_body(
+    int bh, float* sm, int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
     const T* __restrict__ dctx, int ldo, const float* __restrict__ lse, T* __restrict__ dq, int lddq, T* __restrict__ dqkv, int ldg, int causal)
 {
-    extern __shared__ float sm[];
     float* p = sm;                 // softmax row
     float* dp = sm + Lp;           // dctx . V_j
     float* ds = sm + 2 * Lp;       // P_j (dP_j - delta) / 8
     float* red = sm + 3 * Lp;      // [WPB][64] partial dQ rows
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bh = blockIdx.x;
     const int b = bh / H, h = bh - b * H, d = H * DH;
     const int row = idx ? idx[b] : 0;
     const size_t r0 = rs ? (size_t)rs[b] : (size_t)b * Lmax;      // ragged batch: see the forward
@@ -143,6 +158,25 @@ __global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
         for (int w = 0; w < WPB; ++w) t += red[w * DH + lane];
         Elem<T>::st(dq + (size_t)b * lddq + h * DH + lane, t);
     }
+}
+template <typename T, typename TS = T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_kernel(
+    int B, int Lmax, const int* __restrict__ rs, int H, int Lp, const TS* __restrict__ q, int ldq, const TS* __restrict__ qkv, int ld, const int* __restrict__ idx,
+    const T* __restrict__ dctx, int ldo, const float* __restrict__ lse, T* __restrict__ dq, int lddq, T* __restrict__ dqkv, int ldg, int causal)
+{
+    extern __shared__ float sm[];
+    attn_pooled_bwd_body<T, TS>(blockIdx.x, sm, B, Lmax, rs, H, Lp, q, ldq, qkv, ld, idx, dctx, ldo, lse, dq, lddq, dqkv, ldg, causal);
+}
+struct PoolBwdP { int B, Lmax, H, Lp, ldq, ld, ldo, lddq, ldg, causal; const int* rs; const void* q; const void* qkv; const int* idx; const void* dctx; const float* lse;
+                  void* dq; void* dqkv; };
+template <typename T, typename TS = T>
+__global__ __launch_bounds__(WAVE * WPB) void attn_pooled_bwd_pair_kernel(PoolBwdP p0, PoolBwdP p1, int nb0)
+{
+    extern __shared__ float sm[];
+    const bool z = (int)blockIdx.x >= nb0;
+    const PoolBwdP& p = z ? p1 : p0;
+    attn_pooled_bwd_body<T, TS>(z ? blockIdx.x - nb0 : blockIdx.x, sm, p.B, p.Lmax, p.rs, p.H, p.Lp, (const TS*)p.q, p.ldq, (const TS*)p.qkv, p.ld, p.idx, (const T*)p.dctx,
+                                p.ldo, p.lse, (T*)p.dq, p.lddq, (T*)p.dqkv, p.ldg, p.causal);
 }
 
 template <typename T>
@@ -216,6 +250,61 @@ extern "C" int lpi_attn_pooled_bwd_varlen(int dtype, int B, int L, const int32_t
                    (const bf16_t*)dctx, ldo, lse, (bf16_t*)dq, lddq, (bf16_t*)dqkv, ldg, causal);
     else
         return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+// ---- the two towers' pooled attention in one launch (same kernels' bodies, bit for bit); desc[i]: the arguments of the _varlen entry points
+extern "C" int lpi_attn_pooled_fwd_pair(int dtype, const lpi_attn_pooled_desc* d, void* stream)
+{
+    if (!d) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    PoolFwdP p[2];
+    size_t lds = 0;
+    for (int i = 0; i < 2; ++i) {
+        const lpi_attn_pooled_desc& q = d[i];
+        if (!q.q || !q.qkv || !q.ctx || !q.lse || q.B <= 0 || q.L <= 0 || q.H <= 0) return LPI_EINVAL;
+        if (q.ldqkv < 3 * q.H * DH || q.ldq < q.H * DH || q.ldctx < q.H * DH || (q.ldqkv * esz) % 16 || (q.ldq * esz) % 16) return LPI_EINVAL;
+        if (((uintptr_t)q.q | (uintptr_t)q.qkv) & 15) return LPI_EINVAL;
+        const int Lp = (q.L + 63) / 64 * 64;
+        lds = std::max(lds, (size_t)(2 * Lp + WPB * DH) * sizeof(float));
+        p[i] = PoolFwdP{q.B, q.L, q.H, Lp, q.ldq, q.ldqkv, q.ldctx, q.causal, q.row_start, q.q, q.qkv, q.idx, q.ctx, q.lse};
+    }
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb0 = p[0].B * p[0].H;
+    const dim3 grid(nb0 + p[1].B * p[1].H), block(WAVE * WPB);
+    if (dtype == LPI_F32) LPI_LAUNCH((attn_pooled_fwd_pair_kernel<float>), grid, block, lds, s, p[0], p[1], nb0);
+    else if (dtype == LPI_BF16) LPI_LAUNCH((attn_pooled_fwd_pair_kernel<bf16_t>), grid, block, lds, s, p[0], p[1], nb0);
+    else if (dtype == LPI_F16) LPI_LAUNCH((attn_pooled_fwd_pair_kernel<f16_t>), grid, block, lds, s, p[0], p[1], nb0);
+    else return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_attn_pooled_bwd_pair(int dtype, const lpi_attn_pooled_desc* d, void* stream)
+{
+    if (!d) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    PoolBwdP p[2];
+    size_t lds = 0;
+    for (int i = 0; i < 2; ++i) {
+        const lpi_attn_pooled_desc& q = d[i];
+        if (!q.q || !q.qkv || !q.dctx || !q.lse || !q.dq || !q.dqkv || q.B <= 0 || q.L <= 0 || q.H <= 0) return LPI_EINVAL;
+        if (q.ldqkv < 3 * q.H * DH || q.lddqkv < 3 * q.H * DH || q.ldq < q.H * DH || q.lddctx < q.H * DH || q.lddq < q.H * DH) return LPI_EINVAL;
+        if ((q.ldqkv * esz) % 16 || (q.ldq * esz) % 16 || (q.lddctx * esz) % 16) return LPI_EINVAL;
+        if (((uintptr_t)q.q | (uintptr_t)q.qkv | (uintptr_t)q.dctx) & 15) return LPI_EINVAL;
+        const int Lp = (q.L + 63) / 64 * 64;
+        lds = std::max(lds, (size_t)(3 * Lp + WPB * DH) * sizeof(float));
+        p[i] = PoolBwdP{q.B, q.L, q.H, Lp, q.ldq, q.ldqkv, q.lddctx, q.lddq, q.lddqkv, q.causal, q.row_start, q.q, q.qkv, q.idx, q.dctx, q.lse, q.dq, q.dqkv};
+    }
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb0 = p[0].B * p[0].H;
+    const dim3 grid(nb0 + p[1].B * p[1].H), block(WAVE * WPB);
+    if (dtype == LPI_F32) LPI_LAUNCH((attn_pooled_bwd_pair_kernel<float>), grid, block, lds, s, p[0], p[1], nb0);
+    else if (dtype == LPI_BF16) LPI_LAUNCH((attn_pooled_bwd_pair_kernel<bf16_t>), grid, block, lds, s, p[0], p[1], nb0);
+    else if (dtype == LPI_F16) LPI_LAUNCH((attn_pooled_bwd_pair_kernel<bf16_t, f16_t>), grid, block, lds, s, p[0], p[1], nb0);
+    else return LPI_ENOSYS;
     LPI_CHECK_LAST();
     return 0;
 }

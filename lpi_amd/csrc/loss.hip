@@ -51,16 +51,63 @@ __global__ __launch_bounds__(1024) void col_lse_kernel(int n, const float* __res
     }
 }
 
+// row_lse and col_lse in ONE launch (1024-thread blocks): blocks [0, nbr) take 16 rows each (a wave per row: row_lse_kernel's arithmetic), the rest 64
+// columns each (col_lse_kernel's body) — the two are independent, and alone each is a few-microsecond launch
+__device__ __forceinline__ void col_lse_body(int blk, int n, const float* __restrict__ x, int ld, float* __restrict__ out, float (*pm)[64], float (*ps)[64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blk * 64 + lane;
+    float m = -INFINITY, s = 0.f;
+    if (j < n)
+        for (int i = wave; i < n; i += 16) {
+            const float v = x[(size_t)i * ld + j];
+            const float mn = fmaxf(m, v);
+            s = s * expf(m - mn) + expf(v - mn);
+            m = mn;
+        }
+    pm[wave][lane] = m;
+    ps[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < n) {
+        float M = pm[0][lane];
+        for (int w = 1; w < 16; ++w) M = fmaxf(M, pm[w][lane]);
+        float S = 0.f;
+        for (int w = 0; w < 16; ++w) S += ps[w][lane] * expf(pm[w][lane] - M);
+        out[j] = M + logf(S);
+    }
+}
+__global__ __launch_bounds__(1024) void lse_rows_cols_kernel(int n, int nbr, const float* __restrict__ x, int ld, float* __restrict__ rl, float* __restrict__ cl) {
+    __shared__ float pm[16][64], ps[16][64];
+    if ((int)blockIdx.x < nbr) {
+        const int lane = threadIdx.x & 63;
+        const int row = blockIdx.x * 16 + (threadIdx.x >> 6);
+        if (row >= n) return;
+        const float* r = x + (size_t)row * ld;
+        float m = -INFINITY;
+        for (int j = lane; j < n; j += 64) m = fmaxf(m, r[j]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) s += expf(r[j] - m);
+        s = wave_sum(s);
+        if (lane == 0) rl[row] = m + logf(s);
+    } else {
+        col_lse_body(blockIdx.x - nbr, n, x, ld, cl, pm, ps);
+    }
+}
+
 // loss = mean_i( (row_lse[i] + col_lse[i]) / 2 - logits[i,i] )   (single block, fixed-order tree)
-__global__ __launch_bounds__(256) void clip_loss_reduce_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
-                                                              const float* __restrict__ cl, float* __restrict__ loss) {
-    __shared__ float part[4];
+__device__ __forceinline__ void clip_loss_reduce_body(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl, const float* __restrict__ cl,
+                                                      float* __restrict__ loss, float* part) {
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += 0.5f * (rl[i] + cl[i]) - x[(size_t)i * ld + i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)n;
+}
+__global__ __launch_bounds__(256) void clip_loss_reduce_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
+                                                              const float* __restrict__ cl, float* __restrict__ loss) {
+    __shared__ float part[4];
+    clip_loss_reduce_body(n, x, ld, rl, cl, loss, part);
 }
 
 // dlogits[i,j] = up/(2n) * (softmax_row[i,j] + softmax_col[i,j] - 2*delta_ij)
@@ -80,7 +127,9 @@ __global__ __launch_bounds__(256) void clip_loss_grad_kernel(int n, const float*
 // both row-major [nloc, n], so that dI_local = scale * g . T and dT_local = scale * gt . I are plain NT GEMMs.
 __global__ __launch_bounds__(256) void clip_loss_local_grad_kernel(int n, const float* __restrict__ x, int ld, const float* __restrict__ rl,
                                                                   const float* __restrict__ cl, float up, int r0, float* __restrict__ g,
-                                                                  float* __restrict__ gt, int ldg) {
+                                                                  float* __restrict__ gt, int ldg, float* __restrict__ loss) {
+    __shared__ float part[4];
+    if (loss && blockIdx.x == 0 && blockIdx.y == 0) clip_loss_reduce_body(n, x, ld, rl, cl, loss, part);      // the loss value rides in the first block (lpi_clip_loss_local)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= n) return;
@@ -150,13 +199,30 @@ __global__ __launch_bounds__(256) void cp_fwd_kernel(int Lyr, int P, int D, int 
     out[t] = s * sc;
 }
 
+// both prompt stacks (visual and textual share dim_1_share, prompts.py:38-57) in one launch: elements [0, nv) are the visual stack's
+__global__ __launch_bounds__(256) void cp_fwd2_kernel(int Lyr, int P, int Dv, int Dt, int r, const float* __restrict__ d1, const float* __restrict__ d2v,
+                                                     const float* __restrict__ d2t, const float* __restrict__ d3v, const float* __restrict__ d3t, float sc,
+                                                     float* __restrict__ outv, float* __restrict__ outt) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nv = (long)Lyr * P * Dv, nt = (long)Lyr * P * Dt;
+    const bool isv = t < nv;
+    if (!isv) t -= nv;
+    if (!isv && t >= nt) return;
+    const int D = isv ? Dv : Dt;
+    const float* d2 = isv ? d2v : d2t;
+    const float* d3 = isv ? d3v : d3t;
+    const int d = (int)(t % D), p = (int)((t / D) % P), l = (int)(t / ((long)D * P));
+    float s = 0.f;
+    for (int k = 0; k < r; ++k) s += d1[l * r + k] * d2[p * r + k] * d3[d * r + k];   // same product order as prompts.py:49
+    (isv ? outv : outt)[t] = s * sc;
+}
+
 // g3[d,k] = sc * sum_{l,p} dout[l,p,d] * d1[l,k] * d2[p,k].  Block = 64 columns d; 16 waves each take the (l,p) rows
 // w, w+16, ... in order, lanes = columns (coalesced); the 16 partials are added in order (deterministic).
-__global__ __launch_bounds__(1024) void cp_bwd_g3_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
-                                                        float sc, const float* __restrict__ dout, float* __restrict__ g3) {
-    __shared__ float part[16][64][MAXR + 1];
+__device__ __forceinline__ void cp_bwd_g3_body(int blk, int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                               float sc, const float* __restrict__ dout, float* __restrict__ g3, float (*part)[64][MAXR + 1]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int d = blockIdx.x * 64 + lane;
+    const int d = blk * 64 + lane;
     float acc[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) acc[k] = 0.f;
@@ -178,12 +244,16 @@ __global__ __launch_bounds__(1024) void cp_bwd_g3_kernel(int Lyr, int P, int D, 
             g3[d * r + k] = t * sc;
         }
 }
+__global__ __launch_bounds__(1024) void cp_bwd_g3_kernel(int Lyr, int P, int D, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                        float sc, const float* __restrict__ dout, float* __restrict__ g3) {
+    __shared__ float part[16][64][MAXR + 1];
+    cp_bwd_g3_body(blockIdx.x, Lyr, P, D, r, d1, d2, sc, dout, g3, part);
+}
 
 // t[l,p,k] = sum_d dout[l,p,d] * d3[d,k]: one wave per (l,p) row, 4 rows per block -> scratch [Lyr*P*r]
-__global__ __launch_bounds__(256) void cp_bwd_t_kernel(int rows, int D, int r, const float* __restrict__ d3, const float* __restrict__ dout,
-                                                      float* __restrict__ t) {
+__device__ __forceinline__ void cp_bwd_t_body(int row, int rows, int D, int r, const float* __restrict__ d3, const float* __restrict__ dout,
+                                              float* __restrict__ t) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float acc[MAXR];
 #pragma unroll
@@ -202,11 +272,23 @@ __global__ __launch_bounds__(256) void cp_bwd_t_kernel(int rows, int D, int r, c
             if (lane == 0) t[row * r + k] = s;
         }
 }
+__global__ __launch_bounds__(256) void cp_bwd_t_kernel(int rows, int D, int r, const float* __restrict__ d3, const float* __restrict__ dout,
+                                                      float* __restrict__ t) {
+    cp_bwd_t_body(blockIdx.x * 4 + (threadIdx.x >> 6), rows, D, r, d3, dout, t);
+}
+// both stacks' t rows in one launch: rows [0, rows) visual (-> tv), [rows, 2 rows) textual (-> tt)
+__global__ __launch_bounds__(256) void cp_bwd_t2_kernel(int rows, int Dv, int Dt, int r, const float* __restrict__ d3v, const float* __restrict__ d3t,
+                                                       const float* __restrict__ doutv, const float* __restrict__ doutt, float* __restrict__ tv,
+                                                       float* __restrict__ tt) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < rows) cp_bwd_t_body(row, rows, Dv, r, d3v, doutv, tv);
+    else cp_bwd_t_body(row - rows, rows, Dt, r, d3t, doutt, tt);
+}
 
 // g1[l,k] = sc * sum_p t[l,p,k] d2[p,k];  g2[p,k] = sc * sum_l t[l,p,k] d1[l,k]     (tiny, single block)
-__global__ __launch_bounds__(256) void cp_bwd_g12_kernel(int Lyr, int P, int r, const float* __restrict__ d1, const float* __restrict__ d2,
-                                                        float sc, const float* __restrict__ t, float* __restrict__ g1, float* __restrict__ g2,
-                                                        int accumulate_g1) {
+__device__ __forceinline__ void cp_bwd_g12_body(int Lyr, int P, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                float sc, const float* __restrict__ t, float* __restrict__ g1, float* __restrict__ g2,
+                                                int accumulate_g1) {
     for (int i = threadIdx.x; i < Lyr * r; i += blockDim.x) {
         const int l = i / r, k = i % r;
         float s = 0.f;
@@ -219,6 +301,27 @@ __global__ __launch_bounds__(256) void cp_bwd_g12_kernel(int Lyr, int P, int r, 
         float s = 0.f;
         for (int l = 0; l < Lyr; ++l) s += t[(l * P + p) * r + k] * d1[l * r + k];
         g2[i] = s * sc;
+    }
+}
+__global__ __launch_bounds__(256) void cp_bwd_g12_kernel(int Lyr, int P, int r, const float* __restrict__ d1, const float* __restrict__ d2,
+                                                        float sc, const float* __restrict__ t, float* __restrict__ g1, float* __restrict__ g2,
+                                                        int accumulate_g1) {
+    cp_bwd_g12_body(Lyr, P, r, d1, d2, sc, t, g1, g2, accumulate_g1);
+}
+// the g3 blocks of both stacks and ONE block for g1 (visual, then textual added: the shared factor's two contributions in a fixed order) and the two g2
+__global__ __launch_bounds__(1024) void cp_bwd_g2_kernel(int Lyr, int P, int Dv, int Dt, int r, const float* __restrict__ d1, const float* __restrict__ d2v,
+                                                        const float* __restrict__ d2t, float sc, const float* __restrict__ doutv, const float* __restrict__ doutt,
+                                                        const float* __restrict__ tv, const float* __restrict__ tt, float* __restrict__ g1,
+                                                        float* __restrict__ g2v, float* __restrict__ g2t, float* __restrict__ g3v, float* __restrict__ g3t) {
+    __shared__ float part[16][64][MAXR + 1];
+    const int nbv = (Dv + 63) / 64, nbt = (Dt + 63) / 64;
+    const int b = blockIdx.x;
+    if (b < nbv) cp_bwd_g3_body(b, Lyr, P, Dv, r, d1, d2v, sc, doutv, g3v, part);
+    else if (b < nbv + nbt) cp_bwd_g3_body(b - nbv, Lyr, P, Dt, r, d1, d2t, sc, doutt, g3t, part);
+    else {
+        cp_bwd_g12_body(Lyr, P, r, d1, d2v, sc, tv, g1, g2v, 0);
+        __syncthreads();      // g1[i] is rewritten by the thread that wrote it (same loop bounds): the barrier is for clarity only
+        cp_bwd_g12_body(Lyr, P, r, d1, d2t, sc, tt, g1, g2t, 1);
     }
 }
 
@@ -303,6 +406,77 @@ __global__ __launch_bounds__(1024) void align_loss_kernel(int Lyr, int P, int Dv
         dvis[(size_t)i * Dv] = dv[i];
         dtxt[(size_t)i * Dt] = dt[i];
     }
+}
+
+// The alignment loss in TWO launches (lpi_align_loss_fwd_bwd2): align_means2_kernel leaves the 2 Lyr P row means / T in a scratch vector; then EVERY
+// workgroup of align_loss_expand_kernel (one per prompt row, as align_expand_kernel) recomputes the tiny Lyr x Lyr core from them — the same formulas as
+// align_loss_kernel, value for value — and writes its own row of the gradient; workgroup 0 also writes the loss.
+__global__ __launch_bounds__(256) void align_means2_kernel(int nr, int Dv, int Dt, const float* __restrict__ vis, const float* __restrict__ txt,
+                                                          float temp, float* __restrict__ means) {
+    __shared__ float part[4];
+    const bool isv = (int)blockIdx.x < nr;
+    const int row = isv ? blockIdx.x : blockIdx.x - nr;
+    const int D = isv ? Dv : Dt;
+    const float* src = (isv ? vis : txt) + (size_t)row * D;
+    float s = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) s += src[d];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) means[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)D / temp;
+}
+__global__ __launch_bounds__(256) void align_loss_expand_kernel(int Lyr, int P, int Dv, int Dt, const float* __restrict__ means, float temp, float w,
+                                                               float* __restrict__ loss, float* __restrict__ dvis, float* __restrict__ dtxt) {
+    extern __shared__ float sm[];
+    const int nr = Lyr * P;
+    float* v = sm;                 // [Lyr*P]
+    float* t = v + nr;             // [Lyr*P]
+    float* Sm = t + nr;            // [Lyr*Lyr]
+    float* dS = Sm + Lyr * Lyr;    // [Lyr*Lyr]
+    float* rl = dS + Lyr * Lyr;    // [Lyr]
+    float* cl = rl + Lyr;          // [Lyr]
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) { v[i] = means[i]; t[i] = means[nr + i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Lyr * Lyr; i += blockDim.x) {
+        const int a = i / Lyr, b = i % Lyr;
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += v[a * P + p] * t[b * P + p];
+        Sm[i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * Lyr) {
+        const bool row = (int)threadIdx.x < Lyr;
+        const int i = row ? threadIdx.x : threadIdx.x - Lyr;
+        float m = -INFINITY;
+        for (int j = 0; j < Lyr; ++j) m = fmaxf(m, row ? Sm[i * Lyr + j] : Sm[j * Lyr + i]);
+        float s = 0.f;
+        for (int j = 0; j < Lyr; ++j) s += expf((row ? Sm[i * Lyr + j] : Sm[j * Lyr + i]) - m);
+        (row ? rl : cl)[i] = m + logf(s);
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < Lyr; ++i) s += 0.5f * (rl[i] + cl[i]) - Sm[i * Lyr + i];
+        loss[0] = w * s / (float)Lyr;
+    }
+    if (!dvis || !dtxt) return;
+    for (int i = threadIdx.x; i < Lyr * Lyr; i += blockDim.x) {
+        const int a = i / Lyr, b = i % Lyr;
+        float g = expf(Sm[i] - rl[a]) + expf(Sm[i] - cl[b]);
+        if (a == b) g -= 2.f;
+        dS[i] = g * (w / (2.f * (float)Lyr));
+    }
+    __syncthreads();
+    const bool isv = (int)blockIdx.x < nr;
+    const int rr = isv ? blockIdx.x : blockIdx.x - nr;
+    const int a = rr / P, p = rr % P;
+    float s = 0.f;
+    if (isv) for (int b = 0; b < Lyr; ++b) s += dS[a * Lyr + b] * t[b * P + p];
+    else for (int b = 0; b < Lyr; ++b) s += dS[b * Lyr + a] * v[b * P + p];
+    const int D = isv ? Dv : Dt;
+    const float val = s / ((float)D * temp);
+    float* o = (isv ? dvis : dtxt) + (size_t)rr * D;
+    for (int d = threadIdx.x; d < D; d += 256) o[d] = val;
 }
 
 // row means / T, one workgroup per prompt row, parked in the first element of that row of the (not yet written) gradient buffers
@@ -478,7 +652,24 @@ extern "C" int lpi_clip_loss_fwd_bwd(int n, const float* logits, int ld, float u
 extern "C" int lpi_clip_loss_local_grad(int n, const float* logits, int ld, const float* row_lse, const float* col_lse, float upstream,
                                         int r0, int nloc, float* g, float* gt, int ldg, void* stream) {
     if (!logits || !row_lse || !col_lse || !g || !gt || n <= 0 || ld < n || r0 < 0 || nloc <= 0 || r0 + nloc > n || ldg < n) return LPI_EINVAL;
-    LPI_LAUNCH(clip_loss_local_grad_kernel, dim3((n + 255) / 256, nloc), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream, r0, g, gt, ldg);
+    LPI_LAUNCH(clip_loss_local_grad_kernel, dim3((n + 255) / 256, nloc), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream, r0, g, gt, ldg,
+               (float*)nullptr);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+// lpi_clip_loss_fwd_bwd (no dlogits) + lpi_clip_loss_local_grad in TWO launches instead of four: the two log-sum-exp vectors in one, the loss value
+// in the first block of the local-gradient kernel.  The same arithmetic per value (bit for bit the four-launch results).
+extern "C" int lpi_clip_loss_local(int n, const float* logits, int ld, float upstream, int r0, int nloc, float* loss, float* row_lse, float* col_lse,
+                                   float* g, float* gt, int ldg, void* stream) {
+    if (!logits || !loss || !row_lse || !col_lse || n <= 0 || ld < n) return LPI_EINVAL;
+    if (g || gt) {
+        if (!g || !gt || r0 < 0 || nloc <= 0 || r0 + nloc > n || ldg < n) return LPI_EINVAL;
+    }
+    const int nbr = (n + 15) / 16;
+    LPI_LAUNCH(lse_rows_cols_kernel, dim3(nbr + (n + 63) / 64), dim3(1024), 0, S(stream), n, nbr, logits, ld, row_lse, col_lse);
+    if (g) LPI_LAUNCH(clip_loss_local_grad_kernel, dim3((n + 255) / 256, nloc), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, upstream, r0, g, gt, ldg, loss);
+    else LPI_LAUNCH(clip_loss_reduce_kernel, dim3(1), dim3(256), 0, S(stream), n, logits, ld, row_lse, col_lse, loss);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -569,6 +760,34 @@ extern "C" int lpi_prompt_cp_fwd(int Lyr, int P, int D, int r, const float* d1, 
     return 0;
 }
 
+extern "C" int lpi_prompt_cp_fwd2(int Lyr, int P, int Dv, int Dt, int r, const float* d1, const float* d2v, const float* d2t, const float* d3v,
+                                  const float* d3t, float scale, float* outv, float* outt, void* stream) {
+    if (!d1 || !d2v || !d2t || !d3v || !d3t || !outv || !outt || Lyr <= 0 || P <= 0 || Dv <= 0 || Dt <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
+    const long n = (long)Lyr * P * (Dv + Dt);
+    LPI_LAUNCH(cp_fwd2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), Lyr, P, Dv, Dt, r, d1, d2v, d2t, d3v, d3t, scale / (float)r, outv, outt);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+// lpi_prompt_cp_bwd for the visual stack (g1 overwritten) followed by the textual one (g1 accumulated) in TWO launches instead of six; the same
+// arithmetic per value.  scratch: 2 * Lyr * P * r floats.
+extern "C" int lpi_prompt_cp_bwd2(int Lyr, int P, int Dv, int Dt, int r, const float* d1, const float* d2v, const float* d2t, const float* d3v,
+                                  const float* d3t, float scale, const float* doutv, const float* doutt, float* g1, float* g2v, float* g2t, float* g3v,
+                                  float* g3t, float* scratch, void* stream) {
+    if (!d1 || !d2v || !d2t || !d3v || !d3t || !doutv || !doutt || !g1 || !g2v || !g2t || !g3v || !g3t || !scratch || Lyr <= 0 || P <= 0 || Dv <= 0 ||
+        Dt <= 0 || r <= 0 || r > MAXR)
+        return LPI_EINVAL;
+    const float sc = scale / (float)r;
+    const int rows = Lyr * P;
+    float* tv = scratch;
+    float* tt = scratch + (size_t)rows * r;
+    LPI_LAUNCH(cp_bwd_t2_kernel, dim3((2 * rows + 3) / 4), dim3(256), 0, S(stream), rows, Dv, Dt, r, d3v, d3t, doutv, doutt, tv, tt);
+    LPI_LAUNCH(cp_bwd_g2_kernel, dim3((Dv + 63) / 64 + (Dt + 63) / 64 + 1), dim3(1024), 0, S(stream), Lyr, P, Dv, Dt, r, d1, d2v, d2t, sc, doutv, doutt, tv, tt,
+               g1, g2v, g2t, g3v, g3t);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
 extern "C" int lpi_prompt_cp_bwd(int Lyr, int P, int D, int r, const float* d1, const float* d2, const float* d3, float scale,
                                  const float* dout, float* g1, float* g2, float* g3, int accumulate_g1, float* scratch, void* stream) {
     if (!d1 || !d2 || !d3 || !dout || !g1 || !g2 || !g3 || !scratch || Lyr <= 0 || P <= 0 || D <= 0 || r <= 0 || r > MAXR) return LPI_EINVAL;
@@ -590,6 +809,17 @@ extern "C" int lpi_align_loss_fwd_bwd(int Lyr, int P, int Dv, int Dt, const floa
     if (grads) LPI_LAUNCH(align_means_kernel, dim3(2 * Lyr * P), dim3(256), 0, S(stream), Lyr * P, Dv, Dt, vis, txt, temp, dvis, dtxt);
     LPI_LAUNCH(align_loss_kernel, dim3(1), dim3(1024), lds, S(stream), Lyr, P, Dv, Dt, vis, txt, temp, weight, loss, dvis, dtxt, grads);
     if (grads) LPI_LAUNCH(align_expand_kernel, dim3(2 * Lyr * P), dim3(256), 0, S(stream), Lyr * P, Dv, Dt, dvis, dtxt);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_align_loss_fwd_bwd2(int Lyr, int P, int Dv, int Dt, const float* vis, const float* txt, float temp, float weight,
+                                       float* loss, float* dvis, float* dtxt, float* scratch, void* stream) {
+    if (!vis || !txt || !loss || !scratch || Lyr <= 0 || P <= 0 || Dv <= 0 || Dt <= 0 || temp <= 0.f || ((dvis != nullptr) != (dtxt != nullptr))) return LPI_EINVAL;
+    const size_t lds = ((size_t)2 * Lyr * P + 2 * Lyr * Lyr + 2 * Lyr) * sizeof(float);
+    if (lds > 64 * 1024) return LPI_EINVAL;
+    LPI_LAUNCH(align_means2_kernel, dim3(2 * Lyr * P), dim3(256), 0, S(stream), Lyr * P, Dv, Dt, vis, txt, temp, scratch);
+    LPI_LAUNCH(align_loss_expand_kernel, dim3(dvis ? 2 * Lyr * P : 1), dim3(256), lds, S(stream), Lyr, P, Dv, Dt, scratch, temp, weight, loss, dvis, dtxt);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int rows, int d, const TX* 
 }
 
 template <typename TX, typename TDY, typename TCAST, int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
-                                                    const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate,
-                                                    int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
+__device__ __forceinline__ void ln_bwd_body(int blk, int rows, int d, const TDY* __restrict__ dy, int lddy,
+                                            const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                            float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate,
+                                            int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
     const int lane = threadIdx.x & 63;
-    const int crow = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int crow = blk * 4 + (threadIdx.x >> 6);
     if (crow >= rows) return;
     // row map (mapP != 0): dy is COMPACT [B*P, d]; x / statistics / dx live at row (crow / P) * L + row0 + crow % P of the full stream
     const int row = mapP ? (map_rs ? map_rs[crow / mapP] : (crow / mapP) * mapL) + map0 + crow % mapP : crow;      // map_rs: ragged batch (row starts)
@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY*
             Elem<TCAST>::st4(dxr + col, t);
         });
     }
+}
+template <typename TX, typename TDY, typename TCAST, int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int rows, int d, const TDY* __restrict__ dy, int lddy,
+                                                    const TX* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    float* __restrict__ dx, int lddx, TCAST* __restrict__ dx_cast, int ldcast, int accumulate,
+                                                    int mapP, int mapL, int map0, const int* __restrict__ map_rs) {
+    ln_bwd_body<TX, TDY, TCAST, NC>(blockIdx.x, rows, d, dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dx_cast, ldcast, accumulate, mapP, mapL, map0, map_rs);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -420,12 +428,12 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
 
 // LN' on the prompt rows only, in place on dx0 (the other rows' input gradients are not needed: frozen weights)
 template <typename TS>
-__global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, int P, int d, TS* __restrict__ dx0,
-                                                                 const float* __restrict__ prompt0, long pbs,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                 const float* __restrict__ rstd) {
+__device__ __forceinline__ void vis_prompt_rows_bwd_body(int blk, int B, int L, int P, int d, TS* __restrict__ dx0,
+                                                         const float* __restrict__ prompt0, long pbs,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blk * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
     const int b = w / P, p = w % P;
     const int row = b * L + 1 + p;
@@ -439,13 +447,19 @@ __global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, 
     ln_bwd_row(g, x, d, lane, mean[row], rstd[row], gamma);
     for_chunks(d, lane, [&](int i, int col) { Elem<TS>::st4(dxr + col, g.v[i]); });
 }
+template <typename TS>
+__global__ __launch_bounds__(256) void vis_prompt_rows_bwd_kernel(int B, int L, int P, int d, TS* __restrict__ dx0,
+                                                                 const float* __restrict__ prompt0, long pbs,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd) {
+    vis_prompt_rows_bwd_body<TS>(blockIdx.x, B, L, P, d, dx0, prompt0, pbs, gamma, mean, rstd);
+}
 
 // out[p, :] (+)= sum_b dx[(b*L + row0 + p), :]   — deterministic: 16 waves each sum a fixed subset of the batch in order, then
 // the 16 partials are added in order.  Block = (prompt row p, 256-column chunk); lane = one float4 column.
 template <typename TS>
-__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int d, const TS* __restrict__ dx,
-                                                       float* __restrict__ out, int accumulate) {
-    __shared__ f32x4 part[16][64];
+__device__ __forceinline__ void rows_sum_body(int B, int L, const int* __restrict__ rs, int row0, int P, int d, const TS* __restrict__ dx,
+                                              float* __restrict__ out, int accumulate, f32x4 (*part)[64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = blockIdx.x, col = (blockIdx.y * 64 + lane) << 2;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -464,16 +478,35 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, const int*
         *reinterpret_cast<f32x4*>(o) = t;
     }
 }
+template <typename TS>
+__global__ __launch_bounds__(1024) void rows_sum_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int d, const TS* __restrict__ dx,
+                                                       float* __restrict__ out, int accumulate) {
+    __shared__ f32x4 part[16][64];
+    rows_sum_body<TS>(B, L, rs, row0, P, d, dx, out, accumulate, part);
+}
+// the two towers' batch sums of one prompt layer in one launch (blockIdx.z = problem; grid.x / .y cover the larger P / d)
+struct RowsSumP { int B, L, row0, P, d, accumulate; const int* rs; const void* dx; float* out; };
+template <typename TS>
+__global__ __launch_bounds__(1024) void rows_sum_pair_kernel(RowsSumP p0, RowsSumP p1) {
+    __shared__ f32x4 part[16][64];
+    const RowsSumP& q = blockIdx.z ? p1 : p0;
+    if ((int)blockIdx.x >= q.P || (int)blockIdx.y * 256 >= q.d) return;
+    rows_sum_body<TS>(q.B, q.L, q.rs, q.row0, q.P, q.d, (const TS*)q.dx, q.out, q.accumulate, part);
+}
 
 // dst[(b*P + p), 0:cols] = src[(b*L + row0 + p), 0:cols]  in 16-byte chunks (cols * sizeof(T) a multiple of 16)
-__global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
-                                                               uint4* __restrict__ dst, long ldd16) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void gather_batch_rows_body(int blk, int B, int L, const int* __restrict__ rs, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
+                                                       uint4* __restrict__ dst, long ldd16) {
+    const long t = (long)blk * blockDim.x + threadIdx.x;
     if (t >= (long)B * P * chunks) return;
     const int c = (int)(t % chunks);
     const long r = t / chunks;
     const long srow = (rs ? (long)rs[r / P] : (r / P) * L) + row0 + r % P;
     dst[r * ldd16 + c] = src[srow * lds16 + c];
+}
+__global__ __launch_bounds__(256) void gather_batch_rows_kernel(int B, int L, const int* __restrict__ rs, int row0, int P, int chunks, const uint4* __restrict__ src, long lds16,
+                                                               uint4* __restrict__ dst, long ldd16) {
+    gather_batch_rows_body(blockIdx.x, B, L, rs, row0, P, chunks, src, lds16, dst, ldd16);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -509,10 +542,10 @@ __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int*
 }
 
 template <typename TX>
-__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
+__device__ __forceinline__ void prompt_add_body(int blk, int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
+                                                const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blk * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
     const int b = w / P, p = w % P;
     const size_t row = (rs ? (size_t)rs[b] : (size_t)b * L) + 1 + p;
@@ -529,34 +562,47 @@ __global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int
         if (lane == 0) { omean[row] = mu; orstd[row] = rs_; }
     }
 }
+template <typename TX>
+__global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
+                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
+    prompt_add_body<TX>(blockIdx.x, B, L, rs, P, d, x, pr, pbs, omean, orstd);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // pooled heads
 template <typename TX, typename TY>
-__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, const TX* __restrict__ x,
-                                                         const int32_t* __restrict__ idx, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, TY* __restrict__ y, int ldy,
-                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+__device__ __forceinline__ void pool_ln_fwd_body(int blk, int B, int L, int d, const TX* __restrict__ x,
+                                                 const int32_t* __restrict__ idx, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, TY* __restrict__ y, int ldy,
+                                                 float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ raw) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blk * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
     Row r;
     for_chunks(d, lane, [&](int i, int col) { r.v[i] = Elem<TX>::ld4(x + row * d + col); });
+    if (raw) for_chunks(d, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(raw + (size_t)b * d + col) = r.v[i]; });      // the row itself, f32: lpi_gather_rows
     float mu, rs;
     row_stats(r, d, lane, mu, rs);
     ln_apply_store<TY>(r, d, lane, mu, rs, gamma, beta, y + (size_t)b * ldy);
     if (lane == 0) { mean[b] = mu; rstd[b] = rs; }
 }
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(int B, int L, int d, const TX* __restrict__ x,
+                                                         const int32_t* __restrict__ idx, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, TY* __restrict__ y, int ldy,
+                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+    pool_ln_fwd_body<TX, TY>(blockIdx.x, B, L, d, x, idx, gamma, beta, y, ldy, mean, rstd, nullptr);
+}
 
 template <typename TCAST>
-__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, const float* __restrict__ dy, int lddy,
-                                                         const float* __restrict__ x, const int32_t* __restrict__ idx,
-                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, float* __restrict__ dx,
-                                                         TCAST* __restrict__ dx_cast) {
+__device__ __forceinline__ void pool_ln_bwd_body(int blk, int B, int L, int d, const float* __restrict__ dy, int lddy,
+                                                 const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, float* __restrict__ dx,
+                                                 TCAST* __restrict__ dx_cast) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blk * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const size_t row = (size_t)b * L + (idx ? idx[b] : 0);
     Row g, xr;
@@ -569,6 +615,14 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, c
         *reinterpret_cast<f32x4*>(dx + row * d + col) = g.v[i];
         if (dx_cast) Elem<TCAST>::st4(dx_cast + row * d + col, g.v[i]);
     });
+}
+template <typename TCAST>
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(int B, int L, int d, const float* __restrict__ dy, int lddy,
+                                                         const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ dx,
+                                                         TCAST* __restrict__ dx_cast) {
+    pool_ln_bwd_body<TCAST>(blockIdx.x, B, L, d, dy, lddy, x, idx, gamma, mean, rstd, dx, dx_cast);
 }
 
 // dst[b,:] (f32) = src[b*L + idx[b], :]  (idx NULL -> row 0)
@@ -599,10 +653,10 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(int B, int L, int d, 
     });
 }
 
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int B, int E, const float* __restrict__ x, int ldx,
-                                                        float* __restrict__ y, int ldy, float* __restrict__ inv_norm) {
+__device__ __forceinline__ void l2norm_fwd_body(int blk, int B, int E, const float* __restrict__ x, int ldx,
+                                                float* __restrict__ y, int ldy, float* __restrict__ inv_norm) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blk * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     Row r;
     float ss = 0.f;
@@ -614,12 +668,16 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(int B, int E, const flo
     for_chunks(E, lane, [&](int i, int col) { *reinterpret_cast<f32x4*>(y + (size_t)b * ldy + col) = r.v[i] * inv; });
     if (lane == 0) inv_norm[b] = inv;
 }
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(int B, int E, const float* __restrict__ x, int ldx,
+                                                        float* __restrict__ y, int ldy, float* __restrict__ inv_norm) {
+    l2norm_fwd_body(blockIdx.x, B, E, x, ldx, y, ldy, inv_norm);
+}
 
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int B, int E, const float* __restrict__ y, int ldy,
-                                                        const float* __restrict__ dy, int lddy, const float* __restrict__ inv_norm,
-                                                        float* __restrict__ dx, int lddx) {
+__device__ __forceinline__ void l2norm_bwd_body(int blk, int B, int E, const float* __restrict__ y, int ldy,
+                                                const float* __restrict__ dy, int lddy, const float* __restrict__ inv_norm,
+                                                float* __restrict__ dx, int lddx, bf16_t* __restrict__ dx16) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blk * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     Row yr, g;
     float dot = 0.f;
@@ -631,8 +689,15 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(int B, int E, const flo
     dot = wave_sum(dot);
     const float inv = inv_norm[b];
     for_chunks(E, lane, [&](int i, int col) {
-        *reinterpret_cast<f32x4*>(dx + (size_t)b * lddx + col) = (g.v[i] - yr.v[i] * dot) * inv;
+        const f32x4 o = (g.v[i] - yr.v[i] * dot) * inv;
+        *reinterpret_cast<f32x4*>(dx + (size_t)b * lddx + col) = o;
+        if (dx16) Elem<bf16_t>::st4(dx16 + (size_t)b * lddx + col, o);      // the bf16 operand of the head's dgrad GEMM (lpi_cast of dx)
     });
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(int B, int E, const float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ dy, int lddy, const float* __restrict__ inv_norm,
+                                                        float* __restrict__ dx, int lddx) {
+    l2norm_bwd_body(blockIdx.x, B, E, y, ldy, dy, lddy, inv_norm, dx, lddx, nullptr);
 }
 
 __global__ void eot_index_kernel(int B, int L, const int64_t* __restrict__ ids, int32_t* __restrict__ idx) {
@@ -667,6 +732,116 @@ __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, cons
     for (int j = ty; j < 32; j += 8) {
         const int r = bx + j, c = by + tx;  // dst is [cols, rows]
         if (r < cols && c < rows) dst[(size_t)r * ldd + c] = tile[tx][j];
+    }
+}
+
+// two transposes in one launch (blockIdx.z = problem): the two feature matrices of the contrastive loss's gradient GEMMs
+template <typename T>
+__global__ __launch_bounds__(256) void transpose2_kernel(int rows0, int cols0, const T* __restrict__ s0, int lds0, T* __restrict__ d0, int ldd0,
+                                                        int rows1, int cols1, const T* __restrict__ s1, int lds1, T* __restrict__ d1, int ldd1) {
+    __shared__ T tile[32][33];
+    const bool z = blockIdx.z != 0;
+    const int rows = z ? rows1 : rows0, cols = z ? cols1 : cols0, lds = z ? lds1 : lds0, ldd = z ? ldd1 : ldd0;
+    const T* s = z ? s1 : s0;
+    T* dst = z ? d1 : d0;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    if (bx >= cols || by >= rows) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = by + j, c = bx + tx;
+        if (r < rows && c < cols) tile[j][tx] = s[(size_t)r * lds + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = bx + j, c = by + tx;  // dst is [cols, rows]
+        if (r < cols && c < rows) dst[(size_t)r * ldd + c] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lpi_row_jobs: up to LPI_ROW_JOBS_MAX small row kernels of one dependency level in ONE launch.  The tail of a training step (pooled
+// heads, L2 norms, prompt rows: everything that works on B or B*P rows) is a chain of ~5 us launches, one per tower and op; the towers'
+// launches of the same op (and independent ops of one tower) are independent.  Blocks are dealt to the jobs in order (nb[i] blocks of job i); each
+// job runs the BODY of the single-op kernel above with its own block index, so every result is bit for bit the single launch's.
+struct RowJobs { lpi_row_job j[LPI_ROW_JOBS_MAX]; int nb[LPI_ROW_JOBS_MAX]; int n; };
+
+__device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk) {
+    switch (q.op) {
+    case LPI_ROWOP_POOL_LN_FWD: {
+#define PLF(TX, TY) pool_ln_fwd_body<TX, TY>(blk, q.B, q.L, q.d, (const TX*)q.a, q.idx, q.gamma, q.beta, (TY*)q.out, q.ld_c, q.mean, q.rstd, (float*)q.out2)
+        if (q.dt_a == LPI_F32 && q.dt_b == LPI_F32) PLF(float, float);
+        else if (q.dt_a == LPI_F32 && q.dt_b == LPI_BF16) PLF(float, bf16_t);
+        else if (q.dt_a == LPI_F16 && q.dt_b == LPI_BF16) PLF(f16_t, bf16_t);
+        else if (q.dt_a == LPI_F32 && q.dt_b == LPI_F16) PLF(float, f16_t);
+        else PLF(f16_t, f16_t);
+#undef PLF
+        break;
+    }
+    case LPI_ROWOP_L2NORM_FWD:
+        l2norm_fwd_body(blk, q.B, q.d, (const float*)q.a, q.ld_a, (float*)q.out, q.ld_c, q.mean);
+        break;
+    case LPI_ROWOP_L2NORM_BWD:
+        l2norm_bwd_body(blk, q.B, q.d, (const float*)q.a, q.ld_a, (const float*)q.b, q.ld_b, q.mean_in, (float*)q.out, q.ld_c, (bf16_t*)q.out2);
+        break;
+    case LPI_ROWOP_POOL_LN_BWD:
+        if (q.dt_b == LPI_BF16) pool_ln_bwd_body<bf16_t>(blk, q.B, q.L, q.d, (const float*)q.a, q.ld_a, (const float*)q.b, q.idx, q.gamma, q.mean_in, q.rstd_in, (float*)q.out, (bf16_t*)q.out2);
+        else pool_ln_bwd_body<float>(blk, q.B, q.L, q.d, (const float*)q.a, q.ld_a, (const float*)q.b, q.idx, q.gamma, q.mean_in, q.rstd_in, (float*)q.out, (float*)q.out2);
+        break;
+    case LPI_ROWOP_LN_BWD: {      // f32 x rows (the pooled rows of the last block); dy / cast in dt_a / dt_b
+#define LNBJ(TDY, TC, NC) ln_bwd_body<float, TDY, TC, NC>(blk, q.B, q.d, (const TDY*)q.a, q.ld_a, (const float*)q.b, q.ld_b, q.gamma, q.mean_in, q.rstd_in, (float*)q.out, q.ld_c, (TC*)q.out2, q.ld_c, q.flag, 0, 0, 0, nullptr)
+        const int nc = (q.d + 255) / 256;
+        if (q.dt_a == LPI_BF16 && q.dt_b == LPI_BF16) { if (nc <= 1) LNBJ(bf16_t, bf16_t, 1); else if (nc == 2) LNBJ(bf16_t, bf16_t, 2); else if (nc == 3) LNBJ(bf16_t, bf16_t, 3); else if (nc == 4) LNBJ(bf16_t, bf16_t, 4); else LNBJ(bf16_t, bf16_t, 8); }
+        else { if (nc <= 1) LNBJ(float, float, 1); else if (nc == 2) LNBJ(float, float, 2); else if (nc == 3) LNBJ(float, float, 3); else if (nc == 4) LNBJ(float, float, 4); else LNBJ(float, float, 8); }
+#undef LNBJ
+        break;
+    }
+    case LPI_ROWOP_SCATTER_ADD: {      // dst[b*L + idx[b], :] += src[b, :]: one block per sample (the arithmetic of scatter_add_rows_kernel, attn_pooled.hip)
+        const int b = blk;
+        if (b >= q.B) break;
+        const int row = q.idx ? q.idx[b] : 0;
+        auto body = [&](auto* o0, const auto* i0) {
+            typedef typename std::remove_const<typename std::remove_pointer<decltype(o0)>::type>::type T;
+            T* o = o0 + ((size_t)b * q.L + row) * q.ld_c;
+            const T* i = i0 + (size_t)b * q.ld_a;
+            for (int c = threadIdx.x * 4; c < q.d; c += 256 * 4) {
+                f32x4 a = Elem<T>::ld4(o + c), v = Elem<T>::ld4(i + c);
+                a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+                Elem<T>::st4(o + c, a);
+            }
+        };
+        if (q.dt_a == LPI_BF16) body((bf16_t*)q.out, (const bf16_t*)q.a);
+        else body((float*)q.out, (const float*)q.a);
+        break;
+    }
+    case LPI_ROWOP_GATHER_BATCH_ROWS:      // d = 16-byte chunks per row, ld_a / ld_c in 16-byte units
+        gather_batch_rows_body(blk, q.B, q.L, q.row_start, q.row0, q.P, q.d, (const uint4*)q.a, q.ld_a, (uint4*)q.out, q.ld_c);
+        break;
+    case LPI_ROWOP_PROMPT_ADD:
+        if (q.dt_a == LPI_F16) prompt_add_body<f16_t>(blk, q.B, q.L, q.row_start, q.P, q.d, (f16_t*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd);
+        else prompt_add_body<float>(blk, q.B, q.L, q.row_start, q.P, q.d, (float*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd);
+        break;
+    case LPI_ROWOP_LN_BWD_ROWS_H16: {      // compact bf16 dy [B*P, d], fp16 x, bf16 gradient stream (in/out): ln_bwd_h16_kernel with the row map
+#define LNH(NC) ln_bwd_h16_body<NC>(blk, q.B * q.P, q.d, (const bf16_t*)q.a, q.ld_a, (const f16_t*)q.b, q.ld_b, q.gamma, q.mean_in, q.rstd_in, (bf16_t*)q.out2, q.ld_c, q.flag, q.P, q.L, q.row0, q.row_start)
+        const int nc = (q.d + 255) / 256;
+        if (nc <= 1) LNH(1); else if (nc == 2) LNH(2); else if (nc == 3) LNH(3); else LNH(4);
+#undef LNH
+        break;
+    }
+    case LPI_ROWOP_VIS_PROMPT_ROWS_BWD:
+        if (q.dt_a == LPI_BF16) vis_prompt_rows_bwd_body<bf16_t>(blk, q.B, q.L, q.P, q.d, (bf16_t*)q.out, (const float*)q.a, q.bstride, q.gamma, q.mean_in, q.rstd_in);
+        else vis_prompt_rows_bwd_body<float>(blk, q.B, q.L, q.P, q.d, (float*)q.out, (const float*)q.a, q.bstride, q.gamma, q.mean_in, q.rstd_in);
+        break;
+    default: break;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_jobs_kernel(const RowJobs js) {
+    int b = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < LPI_ROW_JOBS_MAX; ++i) {
+        if (i >= js.n) return;
+        if (b < js.nb[i]) { run_row_job(js.j[i], b); return; }
+        b -= js.nb[i];
     }
 }
 
@@ -1116,6 +1291,86 @@ extern "C" int lpi_ln_stats_finalize(int rows, int d, const float* part, int ld,
     return lpi_ln_stats_finalize_pair(rows, d, part, ld, mean, rstd, 0, 0, nullptr, 0, nullptr, nullptr, eps, stream);
 }
 
+// ---- lpi_row_jobs (see row_jobs_kernel): validation per op = the single-op entry point's
+static int row_job_blocks(const lpi_row_job& q) {
+    auto al16 = [](const void* p) { return !((uintptr_t)p & 15); };
+    if (q.B <= 0) return -1;
+    switch (q.op) {
+    case LPI_ROWOP_POOL_LN_FWD:
+        if (!q.a || !q.gamma || !q.beta || !q.out || !q.mean || !q.rstd || q.L < 0 || (q.L == 0 && !q.idx) || bad_row_dim(q.d) || (q.ld_c & 3)) return -1;
+        if (!((q.dt_a == LPI_F32 && (q.dt_b == LPI_F32 || q.dt_b == LPI_BF16 || q.dt_b == LPI_F16)) || (q.dt_a == LPI_F16 && (q.dt_b == LPI_BF16 || q.dt_b == LPI_F16)))) return -1;
+        return rows_grid(q.B);
+    case LPI_ROWOP_L2NORM_FWD:
+        if (!q.a || !q.out || !q.mean || bad_row_dim(q.d) || (q.ld_a & 3) || (q.ld_c & 3)) return -1;
+        return rows_grid(q.B);
+    case LPI_ROWOP_L2NORM_BWD:
+        if (!q.a || !q.b || !q.mean_in || !q.out || bad_row_dim(q.d) || (q.ld_a & 3) || (q.ld_b & 3) || (q.ld_c & 3) || (q.out2 && q.dt_b != LPI_BF16)) return -1;
+        return rows_grid(q.B);
+    case LPI_ROWOP_POOL_LN_BWD:
+        if (!q.a || !q.b || !q.gamma || !q.mean_in || !q.rstd_in || !q.out || bad_row_dim(q.d) || (q.ld_a & 3) || (q.dt_b != LPI_BF16 && q.dt_b != LPI_F32)) return -1;
+        return rows_grid(q.B);
+    case LPI_ROWOP_LN_BWD:
+        if (!q.a || !q.b || !q.gamma || !q.mean_in || !q.rstd_in || (!q.out && !q.out2) || bad_row_dim(q.d) || (q.ld_a & 3) || (q.ld_b & 3) || (q.ld_c & 3)) return -1;
+        if (!((q.dt_a == LPI_BF16 && q.dt_b == LPI_BF16) || (q.dt_a == LPI_F32 && q.dt_b == LPI_F32))) return -1;
+        return rows_grid(q.B);
+    case LPI_ROWOP_SCATTER_ADD: {
+        if (!q.a || !q.out || q.L < 0 || (q.L == 0 && !q.idx) || q.d <= 0 || (q.d & 3) || q.ld_a < q.d || q.ld_c < q.d || (q.dt_a != LPI_BF16 && q.dt_a != LPI_F32)) return -1;
+        const int esz = q.dt_a == LPI_F32 ? 4 : 2;
+        if ((q.ld_a * esz) % 8 || (q.ld_c * esz) % 8 || (((uintptr_t)q.a | (uintptr_t)q.out) & 7)) return -1;
+        return q.B;
+    }
+    case LPI_ROWOP_GATHER_BATCH_ROWS:
+        if (!q.a || !q.out || q.P <= 0 || q.row0 < 0 || q.row0 + q.P > q.L || q.d <= 0 || q.ld_a < q.d || q.ld_c < q.d || !al16(q.a) || !al16(q.out)) return -1;
+        return (int)(((long)q.B * q.P * q.d + 255) / 256);
+    case LPI_ROWOP_PROMPT_ADD:
+        if (!q.out || !q.a || q.P <= 0 || q.P + 1 > q.L || bad_row_dim(q.d) || (q.bstride & 3) || ((q.mean != nullptr) != (q.rstd != nullptr)) || (q.dt_a != LPI_F16 && q.dt_a != LPI_F32)) return -1;
+        return rows_grid((long)q.B * q.P);
+    case LPI_ROWOP_LN_BWD_ROWS_H16:
+        if (!q.a || !q.b || !q.gamma || !q.mean_in || !q.rstd_in || !q.out2 || q.P <= 0 || q.row0 < 0 || q.row0 + q.P > q.L || bad_row_dim(q.d)) return -1;
+        if (!ln_h16_ok(q.d, q.ld_a, q.ld_b, q.a, q.b) || (q.ld_c & 7) || !al16(q.out2)) return -1;
+        return (q.B * q.P + 7) / 8;
+    case LPI_ROWOP_VIS_PROMPT_ROWS_BWD:
+        if (!q.out || !q.a || !q.gamma || !q.mean_in || !q.rstd_in || q.P <= 0 || bad_row_dim(q.d) || (q.bstride & 3) || (q.dt_a != LPI_BF16 && q.dt_a != LPI_F32)) return -1;
+        return rows_grid((long)q.B * q.P);
+    }
+    return -1;
+}
+extern "C" int lpi_row_jobs(int n, const lpi_row_job* jobs, void* stream) {
+    if (!jobs || n <= 0 || n > LPI_ROW_JOBS_MAX) return LPI_EINVAL;
+    RowJobs js = {};
+    js.n = n;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int nb = row_job_blocks(jobs[i]);
+        if (nb <= 0) return LPI_EINVAL;
+        js.j[i] = jobs[i];
+        js.nb[i] = nb;
+        total += nb;
+    }
+    LPI_LAUNCH(row_jobs_kernel, dim3((unsigned)total), dim3(256), 0, S(stream), js);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+// the two towers' lpi_rows_sum_over_batch_varlen of one prompt layer in ONE launch (the same sums, bit for bit)
+extern "C" int lpi_rows_sum_over_batch_pair(int dtype, const lpi_rows_sum_desc* d, void* stream) {
+    if (!d) return LPI_EINVAL;
+    RowsSumP p[2];
+    int gx = 0, gy = 0;
+    for (int i = 0; i < 2; ++i) {
+        const lpi_rows_sum_desc& q = d[i];
+        if (!q.dx || !q.out || q.B <= 0 || q.P <= 0 || q.row0 < 0 || q.row0 + q.P > q.L || bad_row_dim(q.d)) return LPI_EINVAL;
+        p[i] = RowsSumP{q.B, q.L, q.row0, q.P, q.d, q.accumulate, q.row_start, q.dx, q.out};
+        gx = std::max(gx, q.P);
+        gy = std::max(gy, (q.d + 255) / 256);
+    }
+    if (dtype == LPI_F32) LPI_LAUNCH(rows_sum_pair_kernel<float>, dim3(gx, gy, 2), dim3(1024), 0, S(stream), p[0], p[1]);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(rows_sum_pair_kernel<bf16_t>, dim3(gx, gy, 2), dim3(1024), 0, S(stream), p[0], p[1]);
+    else return LPI_EINVAL;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
 extern "C" int lpi_eot_index(int B, int L, const int64_t* ids, int32_t* idx, void* stream) {
     if (!ids || !idx || B <= 0 || L <= 0) return LPI_EINVAL;
     LPI_LAUNCH(eot_index_kernel, dim3((B + 255) / 256), dim3(256), 0, S(stream), B, L, ids, idx);
@@ -1130,6 +1385,19 @@ extern "C" int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, v
     if (src_dtype == LPI_F32 && dst_dtype == LPI_BF16) LPI_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, S(stream), n4, (const float*)src, (bf16_t*)dst);
     else if (src_dtype == LPI_BF16 && dst_dtype == LPI_F32) LPI_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, S(stream), n4, (const bf16_t*)src, (float*)dst);
     else if (src_dtype == LPI_F32 && dst_dtype == LPI_F32) LPI_LAUNCH((cast_kernel<float, float>), g, b, 0, S(stream), n4, (const float*)src, (float*)dst);
+    else return LPI_EINVAL;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_transpose2(int dtype, int rows0, int cols0, const void* src0, int lds0, void* dst0, int ldd0,
+                              int rows1, int cols1, const void* src1, int lds1, void* dst1, int ldd1, void* stream) {
+    if (!src0 || !dst0 || !src1 || !dst1 || rows0 <= 0 || cols0 <= 0 || rows1 <= 0 || cols1 <= 0 || lds0 < cols0 || ldd0 < rows0 || lds1 < cols1 || ldd1 < rows1)
+        return LPI_EINVAL;
+    dim3 g((std::max(cols0, cols1) + 31) / 32, (std::max(rows0, rows1) + 31) / 32, 2), b(256);
+    if (dtype == LPI_F32)
+        LPI_LAUNCH(transpose2_kernel<float>, g, b, 0, S(stream), rows0, cols0, (const float*)src0, lds0, (float*)dst0, ldd0, rows1, cols1, (const float*)src1, lds1,
+                   (float*)dst1, ldd1);
     else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;

@@ -33,45 +33,63 @@ class Exchange:
         self.timing = [] if timing else None      # (kind, start event, end event) per collective, for bench.py
         self._local = {}
 
-    def _timed(self, kind, fn, on_device):
-        if self.timing is None or not on_device:
-            return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = fn()
-        e1.record()
-        self.timing.append((kind, e0, e1))
-        return out
+    def _run(self, kind, issue, on_device, between=None):
+        """Issue one collective and make the CURRENT stream wait for it.  `issue()` returns the c10d Work of an async_op=True call; RCCL runs it on
+        its own stream, ordered behind the current stream's work by an event at issue time.  `between()` (optional) is enqueued on the current
+        stream after the issue and before the wait: it runs UNDER the collective.  Timing (bench.py): the start event is recorded on the current
+        stream right before the issue, the end event right after Work.wait() has put the current stream behind the collective's own end event — the
+        pair brackets the collective itself (stream-ordered through the two waits), i.e. the time the compute stream is held, whichever stream
+        the transport used; a `between` kernel is inside the bracket and is named in `kind`."""
+        t = self.timing is not None and on_device
+        if t:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        work = issue()
+        if between is not None:
+            between()
+        if work is not None:
+            work.wait()     # the current stream waits for the collective; the host does not (device tensors)
+        if t:
+            e1.record()
+            self.timing.append((kind, e0, e1))
+
+    def _buf(self, name, shape, like):
+        """A persistent message buffer (one per name / shape / dtype / device): collectives never allocate or `cat` in the step."""
+        key = (name, tuple(shape), like.dtype, like.device)
+        b = self._local.get(key)
+        if b is None:
+            b = self._local[key] = torch.empty(*shape, dtype=like.dtype, device=like.device)
+        return b
+
+    @staticmethod
+    def _pack2(dst, a, b):
+        """dst[:, :E] = a, dst[:, E:] = b  (lpi_copy_rows on the device: no ATen kernel on the step; plain copies on the host)."""
+        E = a.shape[1]
+        if dst.is_cuda and dst.dtype == torch.float32 and a.dtype == torch.float32 and b.dtype == torch.float32:
+            from . import _lib
+            s = torch.cuda.current_stream().cuda_stream
+            a, b = (a if a.stride(1) == 1 else a.contiguous()), (b if b.stride(1) == 1 else b.contiguous())
+            _lib.call("lpi_copy_rows", a.shape[0], E, a, a.stride(0), dst, 2 * E, s)
+            _lib.call("lpi_copy_rows", b.shape[0], E, b, b.stride(0), dst[:, E:], 2 * E, s)
+        else:
+            dst[:, :E].copy_(a)
+            dst[:, E:].copy_(b)
 
     def gather(self, img_f: torch.Tensor, txt_f: torch.Tensor, between=None):
         """-> (img_all [W*B,E], txt_all [W*B,E] (views of one [W*B, 2E] buffer), first global row of this rank).
         between: a callable run after the all-gather has been ISSUED and before its result is waited for (step.train_step puts the
         data-independent alignment-loss kernel there, so that it runs under the collective)."""
         B, E = img_f.shape
-        key = (B, E, img_f.device, img_f.dtype)
-        local = self._local.get(key)
-        if local is None:
-            local = self._local[key] = torch.empty(B, 2 * E, dtype=img_f.dtype, device=img_f.device)
-        if img_f.is_cuda and img_f.dtype == torch.float32:
-            from . import _lib
-            s = torch.cuda.current_stream().cuda_stream
-            i, t = img_f.contiguous(), txt_f.contiguous()
-            _lib.call("lpi_copy_rows", B, E, i, E, local, 2 * E, s)
-            _lib.call("lpi_copy_rows", B, E, t, E, local[:, E:], 2 * E, s)
-        else:
-            local[:, :E].copy_(img_f)
-            local[:, E:].copy_(txt_f)
+        local = self._buf("gather.local", (B, 2 * E), img_f)
+        self._pack2(local, img_f, txt_f)
         if self.device_collectives or not local.is_cuda:
+            # a fresh output per step: the views handed on are saved by the loss for its backward
             out = torch.empty(self.world * B, 2 * E, dtype=local.dtype, device=local.device)
-            if between is not None and self.device_collectives:
-                def issue():
-                    work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
-                    between()
-                    work.wait()     # the current stream waits for the collective; the host does not
-                self._timed("all_gather (alignment-loss kernel under it)", issue, True)
+            kind = "all_gather" if between is None or not local.is_cuda else "all_gather (alignment-loss kernel under it)"
+            self._run(kind, lambda: dist.all_gather_into_tensor(out, local, group=self.group, async_op=True), local.is_cuda,
+                      between if local.is_cuda else None)
+            if local.is_cuda:
                 between = None
-            else:
-                self._timed("all_gather", lambda: dist.all_gather_into_tensor(out, local, group=self.group), local.is_cuda)
         else:       # host-staged (gloo with device tensors)
             h = local.cpu()
             oh = torch.empty(self.world * B, 2 * E, dtype=h.dtype)
@@ -91,24 +109,25 @@ class Exchange:
         """SUM over ranks of the [W*B, E] key gradients, this rank's B rows of it: the backward of torch.distributed.nn.all_gather
         (sprompt.py:67-69).  One fused message (image || text); reduce_scatter on RCCL, all_reduce + slice where the backend has none."""
         E = dI_all.shape[1]
-        buf = torch.cat([dI_all, dT_all], dim=1).contiguous()
-        if self.world == 1:
-            out = buf
-        elif self.device_collectives:
+        buf = self._buf("rs.in", (dI_all.shape[0], 2 * E), dI_all)
+        self._pack2(buf, dI_all, dT_all)
+        if self.device_collectives and buf.is_cuda:      # RCCL, any world size (W = 1 included: the same call the 8-GPU run makes)
             out = torch.empty(B, 2 * E, dtype=buf.dtype, device=buf.device)
-            self._timed("reduce_scatter", lambda: dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group), buf.is_cuda)
+            self._run("reduce_scatter", lambda: dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True)
+        elif self.world == 1:
+            out = buf.clone()
         else:
             h = buf.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             out = h[self.rank * B:(self.rank + 1) * B].to(buf.device)
-        return out[:, :E].contiguous(), out[:, E:].contiguous()
+        return out[:, :E], out[:, E:]
 
     def allreduce_grads(self, params, flat=None):
         """SUM all-reduce of the (small) prompt-factor gradients as one flat message.  flat: the flat gradient vector the parameters' .grad
         tensors are slices of (optim.flatten): reduced in place, nothing packed or copied back."""
         if flat is not None and all(p.grad is not None and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params):
             if self.device_collectives or not flat.is_cuda:
-                self._timed("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group), flat.is_cuda)
+                self._run("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat.is_cuda)
             else:
                 h = flat.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -117,7 +136,7 @@ class Exchange:
         params = [p for p in params if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in params])
         if self.device_collectives or not flat.is_cuda:
-            self._timed("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group), flat.is_cuda)
+            self._run("all_reduce", lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat.is_cuda)
         else:
             h = flat.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)

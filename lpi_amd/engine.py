@@ -214,10 +214,12 @@ class LnReq:
     """A LayerNorm a tower wants issued (forward: kind "fwd", args of lpi_layernorm_fwd after the two dtypes; backward: "bwd", args of
     lpi_layernorm_bwd after the three dtypes).  Yielded like a GemmReq so that the two towers' LayerNorms of the same layer go out as
     ONE launch (lpi_layernorm_fwd_pair / _bwd_pair): the text tower's alone is a few-microsecond kernel that is mostly launch ramp."""
-    __slots__ = ("tag", "kind", "dts", "args")
+    __slots__ = ("tag", "kind", "dts", "args", "optional")
 
-    def __init__(self, tag, kind, dts, *args):
-        self.tag, self.kind, self.dts, self.args = tag, kind, dts, args
+    def __init__(self, tag, kind, dts, *args, optional=False):
+        # optional: a request this tower emits CONDITIONALLY (the forward LayerNorms / statistics passes: a tower whose statistics come out of a
+        # GEMM epilogue emits a StatFinReq or nothing at that point) — run_lockstep may issue it alone without advancing the partner
+        self.tag, self.kind, self.dts, self.args, self.optional = tag, kind, dts, args, optional
 
     def issue(self):
         call("lpi_layernorm_fwd" if self.kind == "fwd" else "lpi_layernorm_bwd", *self.dts, *self.args, _stream())
@@ -227,6 +229,7 @@ class StatFinReq:
     """The row statistics of a residual-stream GEMM output from the slot sums its epilogue left (LPI_EPI_RES_ROWSTATS -> lpi_ln_stats_finalize):
     args = (rows, d, part, ld, mean, rstd).  The two towers' go out as one launch."""
     __slots__ = ("tag", "args")
+    optional = True      # emitted only by a tower that takes its statistics from the producing GEMM's epilogue (see LnReq.optional)
 
     def __init__(self, tag, *args):
         self.tag, self.args = tag, args
@@ -234,6 +237,47 @@ class StatFinReq:
     def issue(self):
         rows, d, part, ld, mean, rstd = self.args
         call("lpi_ln_stats_finalize", rows, d, part, ld, 1e-5, mean, rstd, _stream())
+
+
+class RowReq:
+    """Small row kernels a tower wants issued (a list of _lib.RowJob of ONE dependency level: lpi_row_jobs).  Yielded like a GemmReq so that the two
+    towers' jobs of the same op go out as ONE launch — each alone is a ~5 us launch on B or B*P rows, and the tail of a step is a chain of them."""
+    __slots__ = ("tag", "jobs", "optional")
+
+    def __init__(self, tag, jobs, optional=False):
+        self.tag, self.jobs, self.optional = tag, list(jobs), optional      # optional: see LnReq
+
+    def issue(self):
+        _lib.row_jobs(self.jobs, _stream())
+
+
+class RowsSumReq:
+    """A batch sum of prompt rows (args of lpi_rows_sum_over_batch_varlen after the dtype, before the stream); the towers' pair = one launch."""
+    __slots__ = ("tag", "dt", "args")
+    optional = True      # emitted by the layers below the prompt depth only: a tower with fewer such layers must not be shifted (run_lockstep)
+
+    def __init__(self, tag, dt, *args):
+        self.tag, self.dt, self.args = tag, dt, args
+
+    def issue(self):
+        call("lpi_rows_sum_over_batch_varlen", self.dt, *self.args, _stream())
+
+
+class PoolAttnReq:
+    """The pooled-row attention of the last block (forward or backward): `desc` = the lpi_attn_pooled_desc fields of this tower."""
+    __slots__ = ("tag", "dt", "bwd", "desc")
+
+    def __init__(self, tag, dt, bwd, **desc):
+        self.tag, self.dt, self.bwd, self.desc = tag, dt, bwd, desc
+
+    def issue(self):
+        q = self.desc
+        if self.bwd:
+            call("lpi_attn_pooled_bwd_varlen", self.dt, q["B"], q["L"], q["row_start"], q["H"], q["q"], q["ldq"], q["qkv"], q["ldqkv"], q["idx"], q["dctx"],
+                 q["lddctx"], q["lse"], q["dq"], q["lddq"], q["dqkv"], q["lddqkv"], q["causal"], _stream())
+        else:
+            call("lpi_attn_pooled_fwd_varlen", self.dt, q["B"], q["L"], q["row_start"], q["H"], q["q"], q["ldq"], q["qkv"], q["ldqkv"], q["idx"], q["ctx"],
+                 q["ldctx"], q["lse"], q["causal"], _stream())
 
 
 def _cdt(c):
@@ -245,11 +289,33 @@ GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
 GROUP_LN = _os.environ.get("LPI_GROUP_LN", "1") != "0"      # ... the towers' LayerNorms of one layer as one launch (A/B switch)
 GROUP_ATTN = _os.environ.get("LPI_GROUP_ATTN", "1") != "0"  # ... and their attention forwards
 GROUP_SPLITK = _os.environ.get("LPI_GROUP_SPLITK", "1") != "0"  # ... and their few-row (split-K) GEMMs
+GROUP_ROWS = _os.environ.get("LPI_GROUP_ROWS", "1") != "0"      # ... and their small row kernels / pooled attention / prompt-row sums (round 4)
 
 
 def _issue_pair(r0: GemmReq, r1: GemmReq):
     """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
     kind), else two launches — the same bits either way."""
+    if isinstance(r0, RowReq) or isinstance(r1, RowReq):
+        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, RowReq) and isinstance(r1, RowReq):
+            _lib.row_jobs(r0.jobs + r1.jobs, _stream())
+        else:
+            r0.issue()
+            r1.issue()
+        return
+    if isinstance(r0, RowsSumReq) or isinstance(r1, RowsSumReq):
+        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, RowsSumReq) and isinstance(r1, RowsSumReq) and r0.dt == r1.dt:
+            _lib.rows_sum_pair(r0.dt, r0.args, r1.args, _stream())
+        else:
+            r0.issue()
+            r1.issue()
+        return
+    if isinstance(r0, PoolAttnReq) or isinstance(r1, PoolAttnReq):
+        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, PoolAttnReq) and isinstance(r1, PoolAttnReq) and r0.dt == r1.dt and r0.bwd == r1.bwd:
+            _lib.attn_pooled_pair(r0.dt, r0.desc, r1.desc, _stream(), backward=r0.bwd)
+        else:
+            r0.issue()
+            r1.issue()
+        return
     if isinstance(r0, AttnFwdReq) or isinstance(r1, AttnFwdReq):
         if GROUP_TOWERS and GROUP_ATTN and isinstance(r0, AttnFwdReq) and isinstance(r1, AttnFwdReq) and r0.dt == r1.dt and r0.dt != F32:
             _lib.attn_fwd_pair(r0.dt, r0.args, r1.args, _stream())
@@ -325,7 +391,10 @@ def run_alone(gen):
 
 def run_lockstep(g0, g1):
     """Drive two tower generators in lock step: requests with EQUAL tags are issued as a pair (_issue_pair); an untagged request is
-    issued alone and only its tower advances; two different tags are issued one after the other.  Returns both return values."""
+    issued alone and only its tower advances.  Two different tags: if exactly one of them is an OPTIONAL request (one a tower emits
+    conditionally: the statistics passes / finalizes, which depend on the tower's fold level, width and LPI_ROWSTATS), it is issued alone and only ITS
+    tower advances — the towers re-align at the next common request instead of running shifted by one (and ungrouped) for the rest of the pass;
+    otherwise both are issued one after the other and both advance.  Returns both return values."""
     gens, cur, done, ret = [g0, g1], [None, None], [False, False], [None, None]
 
     def adv(i):
@@ -346,6 +415,12 @@ def run_lockstep(g0, g1):
         if cur[0].tag == cur[1].tag:
             _issue_pair(cur[0], cur[1])
         else:
+            o0, o1 = bool(getattr(cur[0], "optional", False)), bool(getattr(cur[1], "optional", False))
+            if o0 != o1:
+                i = 0 if o0 else 1
+                cur[i].issue()
+                adv(i)
+                continue
             cur[0].issue()
             cur[1].issue()
         adv(0)
@@ -387,6 +462,7 @@ class Tower:
                 blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device, w8)
             self.blocks.append(blk)
         self._ws = {}
+        self.rowstats = ROWSTATS      # per tower (a test sets one tower to 0: the lock-stepped towers must re-align, run_lockstep)
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
 
     def _check_depth(self, prompts, depth):
@@ -482,7 +558,7 @@ class Tower:
     def ln1_stats_out(self, ws):
         """(mean, rstd) of the first block's ln_1 if the front end should leave them there (its rows pass through a wave: lpi_vis_assemble_fwd /
         lpi_txt_embed_fwd take them as out_mean / out_rstd), else (None, None): no statistics pass over x_0 then.  Pass ln1_ready=True to forward_gen."""
-        if ROWSTATS >= 2 and self.blocks and "qkv_ln" in self.blocks[0] and _ln_fold_ok(ws["Mp"], self.spec.width):
+        if self.rowstats >= 2 and self.blocks and "qkv_ln" in self.blocks[0] and _ln_fold_ok(ws["Mp"], self.spec.width):
             st = ws["stat"][0]
             return st[0], st[1]
         return None, None
@@ -512,17 +588,18 @@ class Tower:
             if prompts is not None and 0 < i < depth:      # model.py:189-193 with the intended guard
                 # the rows it rewrites get their ln_1 statistics from the same kernel (the epilogue's are of their old contents)
                 so = (st[0], st[1]) if have_ln1 else (None, None)
-                call("lpi_prompt_add_varlen", xdt, B, L, rs, P, d, x_in, prompts.view(-1)[i * P * d:], prompt_bstride, so[0], so[1], s)
+                yield RowReq(f"{lt}.padd", [_lib.row_job(_lib.ROWOP_PROMPT_ADD, B=B, L=L, row_start=rs, P=P, d=d, dt_a=xdt, out=x_in,
+                                                         a=prompts.view(-1)[i * P * d:], bstride=prompt_bstride, mean=so[0], rstd=so[1])], optional=True)
             # LayerNorm folded into the GEMM behind it (LnLinear): a statistics pass over the stream, then the GEMM reads the stream itself
             fold = "qkv_ln" in blk and _ln_fold_ok(Mp, d)
             lnb, ln_ld = ws["lnblk"][i], ws["ln_ld"]
-            rowstats = ROWSTATS if (fold and d % 128 == 0) else 0
+            rowstats = self.rowstats if (fold and d % 128 == 0) else 0
             if fold and have_ln1:
                 pass      # the previous block's c_proj left this LayerNorm's statistics (finalised behind it)
             elif fold:
-                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, None, None, None, 0, st[0], st[1])
+                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, None, None, None, 0, st[0], st[1], optional=True)
             else:
-                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1])
+                yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], optional=True)
             if i == len(self.blocks) - 1 and POOLED_ATTN:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
@@ -532,12 +609,15 @@ class Tower:
                     yield GemmReq(f"{lt}.kv", F16, x_in, ql.w[d:], qkv[:, d:], Mp, 2 * d, d, bias=ql.c2[d:], residual=lnb[0], ldr=ln_ld, epi=EPI_LN, m_real=M)
                 else:
                     yield GemmReq(f"{lt}.kv", dt, ws["h"], wq[d:], qkv[:, d:], Mp, 2 * d, d, bias=bq[d:], m_real=M)
-                call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, x_in, pidx, blk["ln_1.w"], blk["ln_1.b"], ws["c_h"], d, cst1[0], cst1[1], s)
+                # ln_1 of the pooled rows and the rows themselves (f32: the residual operand of the pooled out_proj) in one job
+                yield RowReq(f"{lt}.pln1", [_lib.row_job(_lib.ROWOP_POOL_LN_FWD, B=B, L=Lx, d=d, dt_a=xdt, dt_b=dt, a=x_in, idx=pidx, gamma=blk["ln_1.w"],
+                                                         beta=blk["ln_1.b"], out=ws["c_h"], ld_c=d, mean=cst1[0], rstd=cst1[1], out2=ws["c_xin"])])
                 yield GemmReq(f"{lt}.cq", dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
-                call("lpi_attn_pooled_fwd_varlen", dt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_ctx"], d, ws["c_lse"], int(sp.causal), s)
-                call("lpi_gather_rows", xdt, B, Lx, d, x_in, pidx, ws["c_xin"], s)
+                yield PoolAttnReq(f"{lt}.pattn", dt, False, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx, ctx=ws["c_ctx"],
+                                  ldctx=d, lse=ws["c_lse"], causal=int(sp.causal))
                 yield GemmReq(f"{lt}.cout", dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
-                call("lpi_pool_ln_fwd", dt, F32, B, 1, d, ws["c_xmid"], None, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
+                yield RowReq(f"{lt}.pln2", [_lib.row_job(_lib.ROWOP_POOL_LN_FWD, B=B, L=1, d=d, dt_a=F32, dt_b=dt, a=ws["c_xmid"], gamma=blk["ln_2.w"],
+                                                         beta=blk["ln_2.b"], out=ws["c_h"], ld_c=d, mean=cst[0], rstd=cst[1])])
                 yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
@@ -564,10 +644,10 @@ class Tower:
             if fold and LN_FOLD >= 2:
                 fl = blk["fc_ln"]
                 if not ln2_stats:
-                    yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3])
+                    yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3], optional=True)
                 yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
             else:
-                yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3])
+                yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], optional=True)
                 yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
             # the next block's ln_1 statistics come out of this epilogue; rows that deep prompts rewrite first get theirs from prompt_add (above)
             nxt = i + 1
@@ -587,9 +667,10 @@ class Tower:
         return run_alone(self.forward_gen(ws, prompts, prompt_bstride, depth, train, pool_idx))
 
     # ------------------------------------------------------------------ backward (dgrad only)
-    def backward_gen(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
+    def backward_gen(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None, acc=0):
         """GENERATOR (see GemmReq).  ws['c_dx'] (f32 [Bp, d]) [and ws['c_dxT']] hold dL/d(pooled output rows) on entry; ws['dx'] holds dL/dx_0 on exit.
-        dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients."""
+        dprompts: f32 [Lyr, P, d]; rows of layers 1..depth-1 receive the batch-summed deep-prompt gradients (acc = 1: ADDED to what the rows hold — the
+        alignment-loss gradient the step seeded them with, DualEncoder.seed_prompt_grads)."""
         sp, dt, xdt, s = self.spec, self.gdt, self.xdt, _stream()        # dt: the BACKWARD's operand / storage type from here on
         adt = F16 if self.dt == F16 else dt       # attention backward: F16 = "saved q, k, v, ctx are fp16; gradients and operands bf16"
         d, H = sp.width, sp.heads
@@ -616,8 +697,9 @@ class Tower:
                 c_dxT = ws["c_dxT"] if dt != F32 else c_dx
                 yield GemmReq(f"{lt}.cdproj", dt, c_dxT, blk["proj"].wt, ws["c_du"], Bp, 4 * d, d, epi=EPI_DQUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cdfc", dt, ws["c_du"], blk["fc"].wt, ws["c_dh"], Bp, d, 4 * d, m_real=B)
-                call("lpi_layernorm_bwd", dt, dt, F32, B, d, ws["c_dh"], d, ws["c_xmid"], d, blk["ln_2.w"], cst[0], cst[1], c_dx, d,
-                     None if dt == F32 else c_dxT, d, 1, s)
+                yield RowReq(f"{lt}.cdln2", [_lib.row_job(_lib.ROWOP_LN_BWD, B=B, d=d, dt_a=dt, dt_b=dt, a=ws["c_dh"], ld_a=d, b=ws["c_xmid"], ld_b=d,
+                                                          gamma=blk["ln_2.w"], mean_in=cst[0], rstd_in=cst[1], out=c_dx, out2=None if dt == F32 else c_dxT,
+                                                          ld_c=d, flag=1)])
                 if not POOLED_ATTN:
                     call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
                     call("lpi_scatter_rows", dt, B, Lx, d, c_dx, pidx, dx, None if dt == F32 else dxT, s)
@@ -625,18 +707,18 @@ class Tower:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
                 yield GemmReq(f"{lt}.cdout", dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
-                call("lpi_attn_pooled_bwd_varlen", adt, B, L, rs, H, ws["c_q"], d, qkv, 3 * d, pool_idx, ws["c_dctx"], d, ws["c_lse"], ws["c_dq"], d,
-                     dqkv, 3 * d, int(sp.causal), s)
+                yield PoolAttnReq(f"{lt}.pdattn", adt, True, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx,
+                                  dctx=ws["c_dctx"], lddctx=d, lse=ws["c_lse"], dq=ws["c_dq"], lddq=d, dqkv=dqkv, lddqkv=3 * d, causal=int(sp.causal))
                 yield GemmReq(f"{lt}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 yield GemmReq(f"{lt}.cdq", dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
-                call("lpi_scatter_add_rows", dt, B, Lx, d, ws["c_dh"], d, pidx, dh, d, s)
+                yield RowReq(f"{lt}.sadd1", [_lib.row_job(_lib.ROWOP_SCATTER_ADD, B=B, L=Lx, d=d, dt_a=dt, a=ws["c_dh"], ld_a=d, idx=pidx, out=dh, ld_c=d)])
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual
                 # path of the pooled rows is added
                 yield LnReq(f"{lt}.dln1", "bwd", (dt, dt, xdt), M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                             None if dt == F32 else dxT, d, 0)
-                call("lpi_scatter_add_rows", dt, B, Lx, d, c_dxT, d, pidx, dxT, d, s)
+                yield RowReq(f"{lt}.sadd2", [_lib.row_job(_lib.ROWOP_SCATTER_ADD, B=B, L=Lx, d=d, dt_a=dt, a=c_dxT, ld_a=d, idx=pidx, out=dxT, ld_c=d)])
                 if prompts is not None and dprompts is not None and 0 < i < depth:
-                    call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
+                    yield RowsSumReq(f"{lt}.psum", dt, B, L, rs, 1, P, d, dxT, dprompts[i], acc)
                 continue
             if not (i == len(self.blocks) - 1 and POOLED_LAST):
                 du = ws["du"]
@@ -654,21 +736,27 @@ class Tower:
                 # CLS and token embeddings are frozen) -> in_proj dgrad and LN1 backward on the packed B*P prompt rows.  The residual
                 # path of those rows is already in the stream; every other row of it is left without this block's attention term.
                 pq, ph = ws["p_dqkv"], ws["p_dh"]
-                call("lpi_gather_batch_rows_varlen", dt, B, L, rs, 1, P, 3 * d, dqkv, 3 * d, pq, 3 * d, s)
+                esz = 4 if dt == F32 else 2
+                yield RowReq(f"{lt}.gath", [_lib.row_job(_lib.ROWOP_GATHER_BATCH_ROWS, B=B, L=L, row_start=rs, row0=1, P=P, d=3 * d * esz // 16, a=dqkv,
+                                                         ld_a=3 * d * esz // 16, out=pq, ld_c=3 * d * esz // 16)])
                 yield GemmReq(f"{lt}.dqkv_p", dt, pq, blk["qkv"].wt, ph, _pad(B * P, 256), d, 3 * d, m_real=B * P)
-                call("lpi_layernorm_bwd_rows_varlen", dt, dt, xdt, B, L, rs, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
-                     None if dt == F32 else dxT, d, 1, s)
+                if dt == BF16 and xdt == F16 and d % 8 == 0:      # the 16-byte half-wave kernel, with the towers' launches paired
+                    yield RowReq(f"{lt}.dln1p", [_lib.row_job(_lib.ROWOP_LN_BWD_ROWS_H16, B=B, L=L, row_start=rs, row0=1, P=P, d=d, a=ph, ld_a=d, b=x_in, ld_b=d,
+                                                              gamma=blk["ln_1.w"], mean_in=st[0], rstd_in=st[1], out2=dxT, ld_c=d, flag=1)])
+                else:
+                    call("lpi_layernorm_bwd_rows_varlen", dt, dt, xdt, B, L, rs, 1, P, d, ph, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
+                         None if dt == F32 else dxT, d, 1, s)
                 continue
             yield GemmReq(f"{lt}.dqkv", dt, dqkv, blk["qkv"].wt, dh, Mp, d, 3 * d, m_real=M)                                      # d in_proj
             yield LnReq(f"{lt}.dln1", "bwd", (dt, dt, xdt), M, d, dh, d, x_in, d, blk["ln_1.w"], st[0], st[1], dx, d,
                         None if dt == F32 else dxT, d, 1)
             if prompts is not None and dprompts is not None and 0 < i < depth:
-                call("lpi_rows_sum_over_batch_varlen", dt, B, L, rs, 1, P, d, dxT, dprompts[i], 0, s)
+                yield RowsSumReq(f"{lt}.psum", dt, B, L, rs, 1, P, d, dxT, dprompts[i], acc)
         return dxT
 
-    def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None):
+    def backward(self, ws, prompts=None, depth=1, dprompts=None, pool_idx=None, acc=0):
         """backward_gen driven alone."""
-        return run_alone(self.backward_gen(ws, prompts, depth, dprompts, pool_idx))
+        return run_alone(self.backward_gen(ws, prompts, depth, dprompts, pool_idx, acc))
 
 
 class DualEncoder:
@@ -787,29 +875,66 @@ class DualEncoder:
              ws["x"][0], fe["stat"][0], fe["stat"][1], *self.vis.ln1_stats_out(ws), s)
         xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None, ln1_ready=self.vis.ln1_stats_out(ws)[0] is not None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
-        call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_post[0], self.ln_post[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        yield GemmReq("head", dt, hw["pooled"], self.vproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
-        out = torch.empty(B, cfg.embed_dim, device=self.device)
-        if normalise:
-            call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
-        else:
-            out.copy_(hw["feat"][:B])
+        out = yield from self._head_fwd_gen(hw, xo, self.ln_post, self.vproj, B, d, normalise)
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.vis.serial)
         self._vis_ctx = ctx
         return out, ctx
 
-    def _dprompts(self, ws, Lyr, P, d, depth):
-        """The tower's prompt-gradient buffer [Lyr, P, d] f32, kept in the workspace: rows of layers < depth are OVERWRITTEN by every backward
-        (vis_assemble_bwd / rows_sum_over_batch write, they do not accumulate), the rows behind them are zero from the allocation on — no fill
-        kernel in the step.  Re-zeroed if the depth shrinks."""
+    def _head_fwd_gen(self, hw, xo, ln, proj, B, d, normalise):
+        """ln_post / ln_final on the pooled rows, the projection, the L2 normalisation (model.py:255-257, prompt_learner.py:57-63, slinet.py:122,133)."""
+        cfg, dt = self.cfg, self.dt
+        E_ = cfg.embed_dim
+        yield RowReq("head.ln", [_lib.row_job(_lib.ROWOP_POOL_LN_FWD, B=B, L=1, d=d, dt_a=F32, dt_b=dt, a=xo, gamma=ln[0], beta=ln[1], out=hw["pooled"], ld_c=d,
+                                              mean=hw["stat"][0], rstd=hw["stat"][1])])
+        yield GemmReq("head", dt, hw["pooled"], proj.w, hw["feat"], hw["pooled"].shape[0], E_, d)
+        out = torch.empty(B, E_, device=self.device)
+        if normalise:
+            yield RowReq("head.l2", [_lib.row_job(_lib.ROWOP_L2NORM_FWD, B=B, d=E_, a=hw["feat"], ld_a=E_, out=out, ld_c=E_, mean=hw["inv"])])
+        else:
+            out.copy_(hw["feat"][:B])
+        return out
+
+    def _head_bwd_gen(self, hw, ws, out, dout, ln, proj, B, d):
+        """The backward of _head_fwd_gen: leaves dL/d(pooled output rows) in ws['c_dx'] (and its bf16 copy in ws['c_dxT'])."""
+        dt, E_ = self.gdt, self.cfg.embed_dim
+        dout = dout.contiguous().float()
+        # L2-norm backward; in the 2-byte modes the same job leaves the bf16 operand of the dgrad GEMM (no separate cast launch)
+        yield RowReq("dhead.l2", [_lib.row_job(_lib.ROWOP_L2NORM_BWD, B=B, d=E_, a=out, ld_a=E_, b=dout, ld_b=E_, mean_in=hw["inv"], out=hw["dfeat"], ld_c=E_,
+                                               out2=None if dt == F32 else hw["dfeatT"], dt_b=BF16)])
+        dfe = hw["dfeat"] if dt == F32 else hw["dfeatT"]
+        yield GemmReq("dhead", dt, dfe, proj.wt, hw["dpooled"], dfe.shape[0], d, E_)
+        yield RowReq("dhead.ln", [_lib.row_job(_lib.ROWOP_POOL_LN_BWD, B=B, L=1, d=d, dt_b=dt, a=hw["dpooled"], ld_a=d, b=ws["c_xout"], gamma=ln[0],
+                                               mean_in=hw["stat"][0], rstd_in=hw["stat"][1], out=ws["c_dx"], out2=None if dt == F32 else ws["c_dxT"])])
+
+    def _dprompts(self, ws, Lyr, P, d, depth, seeded=False):
+        """The tower's prompt-gradient buffer [Lyr, P, d] f32, kept in the workspace.  Plain mode: rows of layers < depth are OVERWRITTEN by every
+        backward (the prompt-row sums write, they do not accumulate), the rows behind them are zero from the allocation on — no fill kernel in the
+        step; re-zeroed if the depth shrinks or after a seeded use.  Seeded mode (seed_prompt_grads): the caller has written a gradient of ALL rows
+        into it (the alignment loss's) and the backward ADDS the towers' rows to it.
+        The buffer is PERSISTENT: the tensor encode_*_backward returns is this buffer and is overwritten by the engine's next backward — consume it (or
+        clone it) before the next step.  The autograd Functions (functional.py) hand autograd a clone unless the step seeded the buffers."""
         key = (Lyr, P, d)
         ent = ws.get("dprompts")
         if ent is None or ent[0] != key:
-            ent = ws["dprompts"] = [key, torch.zeros(Lyr, P, d, device=self.device), depth]
-        elif depth < ent[2]:
+            ent = ws["dprompts"] = [key, torch.zeros(Lyr, P, d, device=self.device), depth, False]
+        elif not seeded and (depth < ent[2] or ent[3]):
             ent[1].zero_()
-        ent[2] = depth
+        ent[2], ent[3] = depth, seeded
         return ent[1]
+
+    def seed_prompt_grads(self, vis_ctx, txt_ctx):
+        """-> (dvis, dtxt): the two towers' prompt-gradient buffers [Lyr, P, d] for the NEXT backward of these contexts, to be filled by the caller with a
+        gradient the towers' own should be ADDED to (step.train_step: the alignment loss writes its gradient there, so that no separate sum of the
+        two gradients is needed).  One-shot: the next encode_*_backward of each tower accumulates onto the buffer and clears the request."""
+        bufs = []
+        for ctx, d in ((vis_ctx, self.cfg.vision_width), (txt_ctx, self.cfg.transformer_width)):
+            ws, pr, P, depth = ctx[0], ctx[1], ctx[3], ctx[4]
+            if pr is None:
+                raise ValueError("seed_prompt_grads needs a forward with prompts")
+            buf = self._dprompts(ws, pr.shape[-3], P, d, depth, seeded=True)
+            ws["dprompts_seeded"] = True
+            bufs.append(buf)
+        return bufs[0], bufs[1]
 
     def encode_image_backward(self, dout, ctx=None):
         """dL/d(normalised features) [B,E] -> dL/d(prompts) [Lyr,P,d] summed over the batch.
@@ -822,22 +947,18 @@ class DualEncoder:
         self._stale(self.vis, serial, "encode_image_backward")
         d, E = cfg.vision_width, cfg.embed_dim
         hw = self._head("v", B, d)
-        dout = dout.contiguous().float()
-        call("lpi_l2norm_bwd", B, E, out, E, dout, E, hw["inv"], hw["dfeat"], E, s)
-        dfe = hw["dfeat"]
-        if dt != F32:
-            call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
-            dfe = hw["dfeatT"]
-        yield GemmReq("dhead", dt, dfe, self.vproj.wt, hw["dpooled"], dfe.shape[0], d, E)
-        call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_post[0], hw["stat"][0], hw["stat"][1],
-             ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
+        yield from self._head_bwd_gen(hw, ws, out, dout, self.ln_post, self.vproj, B, d)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
-        dpr = self._dprompts(ws, Lyr, P, d, depth)
-        yield from self.vis.backward_gen(ws, pr, depth, dpr, None)
-        call("lpi_vis_assemble_bwd", dt, B, cfg.n_patches, P, d, ws["dx"] if dt == F32 else ws["dxT"], pr, pbs, self.ln_pre[0], ws["front"]["stat"][0],
-             ws["front"]["stat"][1], dpr[0], s)
+        acc = 1 if ws.pop("dprompts_seeded", False) else 0
+        dpr = self._dprompts(ws, Lyr, P, d, depth, seeded=bool(acc))
+        yield from self.vis.backward_gen(ws, pr, depth, dpr, None, acc)
+        # lpi_vis_assemble_bwd as its two kernels: ln_pre's backward on the prompt rows (this tower only), then the batch sum (paired with the text tower's)
+        dx0 = ws["dx"] if dt == F32 else ws["dxT"]
+        yield RowReq(None, [_lib.row_job(_lib.ROWOP_VIS_PROMPT_ROWS_BWD, B=B, L=L, P=P, d=d, dt_a=dt, out=dx0, a=pr, bstride=pbs, gamma=self.ln_pre[0],
+                                         mean_in=ws["front"]["stat"][0], rstd_in=ws["front"]["stat"][1])])
+        yield RowsSumReq("front.psum", dt, B, L, None, 1, P, d, dx0, dpr[0], acc)
         return dpr
 
     # ------------------------------------------------------------------ text
@@ -874,13 +995,7 @@ class DualEncoder:
         call("lpi_txt_embed_fwd_varlen", self.txt.xdt, B, L, ws["rs"], self.n_ctx, d, ids, self.tok, self.tpos, ctx, pbs, ws["x"][0],
              *self.txt.ln1_stats_out(ws), s)
         xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx, ln1_ready=self.txt.ln1_stats_out(ws)[0] is not None)      # pooled (EOT) rows
-        call("lpi_pool_ln_fwd", dt, F32, B, 1, d, xo, None, self.ln_final[0], self.ln_final[1], hw["pooled"], d, hw["stat"][0], hw["stat"][1], s)
-        yield GemmReq("head", dt, hw["pooled"], self.tproj.w, hw["feat"], hw["pooled"].shape[0], cfg.embed_dim, d)
-        out = torch.empty(B, cfg.embed_dim, device=self.device)
-        if normalise:
-            call("lpi_l2norm_fwd", B, cfg.embed_dim, hw["feat"], cfg.embed_dim, out, cfg.embed_dim, hw["inv"], s)
-        else:
-            out.copy_(hw["feat"][:B])
+        out = yield from self._head_fwd_gen(hw, xo, self.ln_final, self.tproj, B, d, normalise)
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial, eot_idx)
         self._txt_ctx = ctx
         return out, ctx
@@ -894,21 +1009,14 @@ class DualEncoder:
         self._stale(self.txt, serial, "encode_text_backward")
         d, E = cfg.transformer_width, cfg.embed_dim
         hw = self._head("t", B, d)
-        dout = dout.contiguous().float()
-        call("lpi_l2norm_bwd", B, E, out, E, dout, E, hw["inv"], hw["dfeat"], E, s)
-        dfe = hw["dfeat"]
-        if dt != F32:
-            call("lpi_cast", F32, dt, dfe.numel(), dfe, hw["dfeatT"], s)
-            dfe = hw["dfeatT"]
-        yield GemmReq("dhead", dt, dfe, self.tproj.wt, hw["dpooled"], dfe.shape[0], d, E)
-        call("lpi_pool_ln_bwd", dt, B, 1, d, hw["dpooled"], d, ws["c_xout"], None, self.ln_final[0], hw["stat"][0], hw["stat"][1],
-             ws["c_dx"], None if dt == F32 else ws["c_dxT"], s)
+        yield from self._head_bwd_gen(hw, ws, out, dout, self.ln_final, self.tproj, B, d)
         if pr is None:
             return None
         Lyr = pr.shape[-3]
-        dpr = self._dprompts(ws, Lyr, P, d, depth)
-        yield from self.txt.backward_gen(ws, pr, depth, dpr, eot_idx)
-        call("lpi_rows_sum_over_batch_varlen", dt, B, L, ws["rs"], 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], 0, s)
+        acc = 1 if ws.pop("dprompts_seeded", False) else 0
+        dpr = self._dprompts(ws, Lyr, P, d, depth, seeded=bool(acc))
+        yield from self.txt.backward_gen(ws, pr, depth, dpr, eot_idx, acc)
+        yield RowsSumReq("front.psum", dt, B, L, ws["rs"], 1, P, d, ws["dx"] if dt == F32 else ws["dxT"], dpr[0], acc)
         return dpr
 
 
@@ -1032,17 +1140,25 @@ def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True, r0: int = 
     A, Bm = ops
     gemm(F32, A, Bm, logits, npad, npad, E, alpha=scale)
     loss = torch.empty(1, device=dev)
-    call("lpi_clip_loss_fwd_bwd", n, logits, npad, 1.0, loss, None, npad, lse[0], lse[1], s)
     if not need_grad:
+        call("lpi_clip_loss_local", n, logits, npad, 1.0, 0, 0, loss, lse[0], lse[1], None, None, 0, s)
         return loss, logits[:n, :n], None, None
-    # dI_loc = scale * g . T,  dT_loc = scale * gt . I  with g / gt the local rows of dlogits / dlogits^T (NT form: B operand = T^T / I^T)
+    # dI_loc = scale * g . T,  dT_loc = scale * gt . I  with g / gt the local rows of dlogits / dlogits^T (NT form: B operand = T^T / I^T).
+    # Two launches for the two log-sum-exp vectors, the loss value and the local rows of both gradients (lpi_clip_loss_local), one for both transposes,
+    # and the two small gradient GEMMs as one split-K pair (round 4: nine launches became five)
     At, Bt, g, gt = ws["At"], ws["Bt"], ws["g"], ws["gt"]
-    call("lpi_clip_loss_local_grad", n, logits, npad, lse[0], lse[1], 1.0, r0, nloc, g, gt, npad, s)
-    call("lpi_transpose", F32, npad if A is ws["A"] else n, E, A, A.stride(0), At, npad, s)
-    call("lpi_transpose", F32, npad if Bm is ws["B"] else n, E, Bm, Bm.stride(0), Bt, npad, s)
+    call("lpi_clip_loss_local", n, logits, npad, 1.0, r0, nloc, loss, lse[0], lse[1], g, gt, npad, s)
+    call("lpi_transpose2", F32, npad if A is ws["A"] else n, E, A, A.stride(0), At, npad, npad if Bm is ws["B"] else n, E, Bm, Bm.stride(0), Bt, npad, s)
     dI, dT = torch.empty(lpad, E, device=dev), torch.empty(lpad, E, device=dev)
-    gemm(F32, g, Bt, dI, lpad, E, npad, alpha=scale)
-    gemm(F32, gt, At, dT, lpad, E, npad, alpha=scale)
+    ks = _splitk_plan(F32, lpad, E, npad) if GROUP_SPLITK else 0
+    if ks and GEMM_PROFILE is None:
+        n0 = (ks * lpad * E + 63) // 64 * 64
+        buf = _splitk_scratch(dev, n0 + ks * lpad * E)
+        probs = [dict(M=lpad, N=E, K=npad, a=g, b=Bt, c=dI), dict(M=lpad, N=E, K=npad, a=gt, b=At, c=dT)]
+        _lib.gemm_splitk_pair(F32, F32, EPI_NONE, scale, probs, [ks, ks], (buf, buf[n0:]), s)
+    else:
+        gemm(F32, g, Bt, dI, lpad, E, npad, alpha=scale)
+        gemm(F32, gt, At, dT, lpad, E, npad, alpha=scale)
     return loss, logits[:n, :n], dI[:nloc], dT[:nloc]
 
 
@@ -1148,6 +1264,34 @@ def score_matrix(img_feats, txt_feats):
     return i2t, t2i
 
 
+def prompt_cp_fwd2(d1, d2v, d2t, d3v, d3t, scale=1.0):
+    """Both prompt stacks of a DecomposedPrompt (prompts.py:38-57) in one launch -> (vis [Lyr,P,Dv], txt [Lyr,P,Dt])."""
+    Lyr, r = d1.shape
+    P, Dv, Dt = d2v.shape[0], d3v.shape[0], d3t.shape[0]
+    outv, outt = torch.empty(Lyr, P, Dv, device=d1.device), torch.empty(Lyr, P, Dt, device=d1.device)
+    call("lpi_prompt_cp_fwd2", Lyr, P, Dv, Dt, r, d1, d2v, d2t, d3v, d3t, float(scale), outv, outt, _stream())
+    return outv, outt
+
+
+_CP_SCRATCH = {}
+
+
+def prompt_cp_bwd2(d1, d2v, d2t, d3v, d3t, doutv, doutt, scale=1.0, out=None):
+    """The five factor gradients from the two stacks' gradients in two launches (lpi_prompt_cp_bwd2).  out: (g1, g2v, g2t, g3v, g3t) to write into
+    (contiguous f32, e.g. the slices of a flat gradient buffer: optim.flatten); default: new tensors."""
+    Lyr, r = d1.shape
+    P, Dv, Dt = d2v.shape[0], d3v.shape[0], d3t.shape[0]
+    g1, g2v, g2t, g3v, g3t = out if out is not None else (torch.empty_like(d1), torch.empty_like(d2v), torch.empty_like(d2t), torch.empty_like(d3v),
+                                                            torch.empty_like(d3t))
+    key = (d1.device, torch.cuda.current_stream().cuda_stream, 2 * Lyr * P * r)
+    scratch = _CP_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _CP_SCRATCH[key] = torch.empty(2 * Lyr * P * r, device=d1.device)
+    call("lpi_prompt_cp_bwd2", Lyr, P, Dv, Dt, r, d1, d2v, d2t, d3v, d3t, float(scale), doutv.contiguous(), doutt.contiguous(), g1, g2v, g2t, g3v, g3t,
+         scratch, _stream())
+    return g1, g2v, g2t, g3v, g3t
+
+
 def prompt_cp_fwd(d1, d2, d3, scale=1.0):
     Lyr, r = d1.shape
     P, D = d2.shape[0], d3.shape[0]
@@ -1166,11 +1310,21 @@ def prompt_cp_bwd(d1, d2, d3, dout, g1, accumulate_g1, scale=1.0, out=None):
     return g2, g3
 
 
-def align_loss_fwd_bwd(vis, txt, temp=0.01, weight=0.1, need_grad=True):
+_ALIGN_SCRATCH = {}
+
+
+def align_loss_fwd_bwd(vis, txt, temp=0.01, weight=0.1, need_grad=True, out=None):
+    """slinet.py:143-158 -> (loss [1], dvis, dtxt).  out: (dvis, dtxt) buffers to write the dense gradients into (contiguous f32 [Lyr, P, D]: the towers'
+    prompt-gradient buffers, DualEncoder.seed_prompt_grads); default: new tensors.  Two launches (lpi_align_loss_fwd_bwd2)."""
     Lyr, P, Dv = vis.shape
     Dt = txt.shape[-1]
     loss = torch.empty(1, device=vis.device)          # written, not accumulated
-    dv = torch.empty_like(vis) if need_grad else None
-    dtx = torch.empty_like(txt) if need_grad else None
-    call("lpi_align_loss_fwd_bwd", Lyr, P, Dv, Dt, vis.contiguous(), txt.contiguous(), float(temp), float(weight), loss, dv, dtx, _stream())
+    dv = dtx = None
+    if need_grad:
+        dv, dtx = out if out is not None else (torch.empty_like(vis), torch.empty_like(txt))
+    key = (vis.device, torch.cuda.current_stream().cuda_stream, 2 * Lyr * P)
+    scratch = _ALIGN_SCRATCH.get(key)
+    if scratch is None:
+        scratch = _ALIGN_SCRATCH[key] = torch.empty(2 * Lyr * P, device=vis.device)
+    call("lpi_align_loss_fwd_bwd2", Lyr, P, Dv, Dt, vis.contiguous(), txt.contiguous(), float(temp), float(weight), loss, dv, dtx, scratch, _stream())
     return loss, dv, dtx

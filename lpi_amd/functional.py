@@ -9,6 +9,15 @@ import torch
 from . import engine as E
 
 
+def _own(dpr, ws):
+    """The prompt gradient an encoder backward returned is the tower's PERSISTENT workspace buffer (engine.DualEncoder._dprompts), overwritten by the
+    engine's next backward: autograd (hooks, torch.autograd.grad, retained .grad tensors) gets a private copy.  The fused step (step.train_step) consumes
+    the buffer at once and sets ws['dprompts_borrow'] to skip the copy: no ATen kernel on its path."""
+    if dpr is None or ws.get("dprompts_borrow", False):
+        return dpr
+    return dpr.clone()
+
+
 class DecomposedPromptFn(torch.autograd.Function):
     """DecomposedPrompt.forward (models/prompts/prompts.py:38-57): (vis [Lyr,P,Dv], txt [Lyr,P,Dt])."""
 
@@ -19,15 +28,18 @@ class DecomposedPromptFn(torch.autograd.Function):
         args = [t.detach().contiguous().float() for t in (d1, d2v, d2t, d3v, d3t)]
         ctx.save_for_backward(*args)
         ctx.scale, ctx.grad_out = scale, grad_out
-        return E.prompt_cp_fwd(args[0], args[1], args[3], scale), E.prompt_cp_fwd(args[0], args[2], args[4], scale)
+        return E.prompt_cp_fwd2(args[0], args[1], args[2], args[3], args[4], scale)
 
     @staticmethod
     def backward(ctx, gvis, gtxt):
         d1, d2v, d2t, d3v, d3t = ctx.saved_tensors
         go = ctx.grad_out
-        g1 = go[0] if go is not None else torch.empty_like(d1)      # the first call overwrites it, the second accumulates (shared dim_1_share)
-        g2v, g3v = E.prompt_cp_bwd(d1, d2v, d3v, gvis.contiguous().float(), g1, False, ctx.scale, out=None if go is None else (go[1], go[3]))
-        g2t, g3t = E.prompt_cp_bwd(d1, d2t, d3t, gtxt.contiguous().float(), g1, True, ctx.scale, out=None if go is None else (go[2], go[4]))
+        if gvis is None:
+            gvis = torch.zeros(d1.shape[0], d2v.shape[0], d3v.shape[0], device=d1.device)
+        if gtxt is None:
+            gtxt = torch.zeros(d1.shape[0], d2t.shape[0], d3t.shape[0], device=d1.device)
+        # both stacks in two launches; dim_1_share's gradient is the visual contribution plus the textual one, in that order
+        g1, g2v, g2t, g3v, g3t = E.prompt_cp_bwd2(d1, d2v, d2t, d3v, d3t, gvis.float(), gtxt.float(), ctx.scale, out=go)
         if go is not None:      # fresh view objects: autograd's AccumulateGrad adopts a gradient it holds the only reference to, and clones one it does not
             g1, g2v, g2t, g3v, g3t = (t.view(t.shape) for t in (g1, g2v, g2t, g3v, g3t))
         return g1, g2v, g2t, g3v, g3t, None, None
@@ -51,7 +63,7 @@ class EncodeImageFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dpr = ctx.enc.encode_image_backward(g, ctx.lpi)
+        dpr = _own(ctx.enc.encode_image_backward(g, ctx.lpi), ctx.lpi[0])
         if len(ctx.pshape) == 4:     # stride-0 expanded [B,Lyr,P,d] view: autograd sums the broadcast itself
             full = torch.zeros(ctx.pshape, device=dpr.device)
             full[0] = dpr
@@ -70,7 +82,7 @@ class EncodeTextFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dpr = ctx.enc.encode_text_backward(g, ctx.lpi)
+        dpr = _own(ctx.enc.encode_text_backward(g, ctx.lpi), ctx.lpi[0])
         if len(ctx.pshape) == 4:
             full = torch.zeros(ctx.pshape, device=dpr.device)
             full[0] = dpr
@@ -98,6 +110,7 @@ class EncodeBothFn(torch.autograd.Function):
         if g_txt is None:
             g_txt = torch.zeros_like(ctx.lpi_t[7])
         dv, dt = ctx.enc.encode_both_backward(g_img, g_txt, ctx.lpi_v, ctx.lpi_t)
+        dv, dt = _own(dv, ctx.lpi_v[0]), _own(dt, ctx.lpi_t[0])
         outs = []
         for dpr, shape in ((dv, ctx.vshape), (dt, ctx.tshape)):
             if len(shape) == 4:     # stride-0 expanded [B,Lyr,P,d] view: autograd sums the broadcast itself

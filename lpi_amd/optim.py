@@ -61,11 +61,24 @@ class FlatSGD:
                 return False
         return True
 
+    def _check_seating(self):
+        """flatten() re-seated every parameter's .data as a view of self.flat; step() updates self.flat.  Anything that re-seats p.data afterwards
+        (module.to(other device / dtype), .half(), load_state_dict(assign=True), a second flatten over the same tensors) would leave the optimiser
+        updating a buffer the model no longer reads — a silent no-op training.  Checked at every step (five pointer compares); raises instead."""
+        o = 0
+        for p in self.params:
+            k = p.numel()
+            if p.data_ptr() != self.flat.data_ptr() + 4 * o or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("FlatSGD: a parameter is no longer a view of the optimiser's flat buffer (its .data was re-seated after the optimiser "
+                                   "was built: .to() / .half() / load_state_dict(assign=True) / a second flatten); build the optimiser after moving the module")
+            o += k
+
     @torch.no_grad()
     def step(self):
         g = self.param_groups[0]
         s = torch.cuda.current_stream().cuda_stream
         first = 1 if self.steps == 0 else 0
+        self._check_seating()
         if self._is_flat():
             _lib.call("lpi_sgd_step", self.flat.numel(), self.flat, self.flat_grad, self.buf, g["lr"], g["momentum"], g["weight_decay"], first, s)
         else:

@@ -141,7 +141,9 @@ class SPrompts(BaseLearner):
         enabled = {n for n, p in network.named_parameters() if p.requires_grad}
         print(f"Parameters to be updated: {enabled}")
         if self.args.get("fused_sgd", True) and str(self._device).startswith("cuda"):
-            # the same SGD / cosine arithmetic (sprompt.py:253-255) as one HIP kernel over the task's five factors (lpi_sgd_step)
+            # the same SGD / cosine arithmetic (sprompt.py:253-255) as one HIP kernel over the task's five factors (lpi_sgd_step).  FlatSGD RE-SEATS the
+            # five parameters' .data as views of one flat buffer: the module must already be on its device (it is: .to() above) and must not be moved
+            # or cast while this optimiser lives — FlatSGD.step() checks the seating and raises if it was lost
             from lpi_amd.optim import CosineLR, FlatSGD
             optimizer = FlatSGD([p for p in network.parameters() if p.requires_grad], lr=self.lrate, momentum=0.9, weight_decay=self.weight_decay)
             scheduler = CosineLR(optimizer, T_max=self.epochs)

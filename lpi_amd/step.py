@@ -81,12 +81,23 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
                                              lockstep, exchange, grad_out=gv, losses=False)
     world = exchange.world if exchange is not None else 1
     w_base = float(getattr(exchange, "loss_weight", 1.0))
+    # The alignment loss's gradient and the towers' gradient of the same prompt stacks are summed WITHOUT a sum kernel: the alignment kernel writes its
+    # (dense, all-layer) gradient into the towers' persistent prompt-gradient buffers and the towers' backward adds its rows (layers < depth) on top
+    # (DualEncoder.seed_prompt_grads).  The stacks then receive ONE gradient each, from the encoder node, so autograd has nothing to accumulate; the node
+    # hands the buffers on without a copy ('dprompts_borrow': DecomposedPromptFn.backward consumes them at once).  Towers on lanes of their own
+    # (overlap_towers) keep the plain path: the stacks are autograd roots too and autograd adds the two gradients.
+    seed = not overlap_towers
+    wss = []
     with torch.no_grad():
         al = {}
+        out_bufs = None
+        if seed:
+            out_bufs = enc.seed_prompt_grads(enc._vis_ctx, enc._txt_ctx)
+            wss = [enc._vis_ctx[0], enc._txt_ctx[0]]
 
         def align():
             # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again below
-            al["r"] = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True)
+            al["r"] = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True, out=out_bufs)
 
         if gather is not None and getattr(exchange, "device_collectives", False):
             # the data-independent alignment kernel runs while the feature all-gather (issued right behind the towers) is in flight
@@ -98,7 +109,17 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
         align, dv, dt = al["r"]
         if w_base != 1.0:
             dI, dT = dI * w_base, dT * w_base
-    torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])
+    if seed:
+        for w in wss:
+            w["dprompts_borrow"] = True
+        try:
+            torch.autograd.backward([img_f, txt_f], [dI, dT])
+        finally:
+            for w in wss:
+                w.pop("dprompts_borrow", None)
+                w.pop("dprompts_seeded", None)
+    else:
+        torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])
     if exchange is not None:
         if gv is not None:
             exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES], flat=flat_grad)

@@ -58,7 +58,12 @@ def main():
                 counters[k][c] = (n, v)
                 if c == "GRBM_GUI_ACTIVE" and k in dur:
                     durs[k] = dur[k]
-    out = {"command": cmd, "dtype": dtype, "tuning": [int(x) for x in tuning.split(",") if x], "lib_version": int(libv),
+    # the workload the passes ran (bench.py attaches the summary only to a record of the SAME model / batch / depth): read off the command line
+    def opt(name, default, conv=str):
+        m = re.search(r"--" + name + r"[ =](\S+)", cmd)
+        return conv(m.group(1)) if m else default
+    workload = {"model": opt("model", "ViT-B/16"), "batch": opt("batch", 256, int), "depth": opt("depth", 3, int)}
+    out = {"command": cmd, "workload": workload, "dtype": dtype, "tuning": [int(x) for x in tuning.split(",") if x], "lib_version": int(libv),
            "formulas": {"hbm_mb_per_launch": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes (gfx950 FETCH_SIZE half-count corrected; separate passes)",
                         "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)",
                         "clock_ghz": "GRBM_GUI_ACTIVE / 8 / kernel duration of the same pass"},
@@ -98,7 +103,7 @@ def main():
             e["lds_bank_conflict_frac"] = round((per("SQ_LDS_BANK_CONFLICT") or 0.0) / per("SQ_LDS_IDX_ACTIVE"), 4)
         out["kernels"][k] = e
     json.dump(out, open(out_path, "w"), indent=1)
-    for k in ("gemm256_kernel", "gemm256_tail_kernel", "attn_bwd_fused_kernel", "attn_fwd_kernel"):
+    for k in ("gemm256p_kernel", "attn_bwd4_kernel", "attn_fwd_pair_kernel"):
         print(k, json.dumps(out["kernels"].get(k)))
 
 
