@@ -121,6 +121,10 @@ struct Args4 {
     T* dqkv; int lddqkv;
     int rows_hi;      // only dQ / dK / dV of token rows < rows_hi are wanted (lpi_attn_bwd_prefix); >= L: all
     int flags;        // A/B switches (tuning key 12): 1 = K / V of the next head as one burst after the prologue
+    // key WINDOW (round 4; template WIN): the launch covers keys kw0 .. kw0 + Lk - 1 of every head (Lkp = Lk rounded up to 32) against ALL L queries
+    // (Lp = L rounded up to 32 = 32 x the query slices).  A sequence longer than 224 tokens (ViT-L/14: 273) runs as two launches — keys 0 .. 223 on
+    // the Lp = 224 configuration, the rest (<= 64 keys) on the generic one with acc_dq: its dQ is ADDED to what the first launch stored.
+    int kw0, Lk, Lkp, acc_dq;
 };
 
 // LDS map (byte offsets from the dynamic region; Lp <= 224: 161 792 B):
@@ -134,10 +138,21 @@ struct Args4 {
 // STAG: this wave runs the matrix half of a slice (dV, dK) one iteration late, IN FRONT of the next slice's score half: the two waves of a
 // SIMD (w and w + 4) run the same program between the same barriers, so unstaggered they want the matrix pipe together and the vector
 // pipe together; with waves 4-7 half an iteration behind, one wave's MFMAs run beside the other's exponentials.
-template <int NUW, bool SV16, int NKB, int DQN, bool STAG>
+// NQS: the query slices at compile time (= NKB for the whole-sequence launches of Lp = 224), 0 = read A.Lp.  WIN: key-window launch (Args4): without it
+// the window is the whole sequence and every window quantity folds into the old one (the same code as before the window existed).
+// WIN: 0 = the whole sequence; 1 = first key window of a long sequence; 2 = a later window: its dQ share is added to what the first launch stored — the
+// stored rows of a slice come in by LDS-DMA as a FOURTH piece of the slice's ring slot (waves 4, 5, which move no piece otherwise), are read there when the
+// slice's dQ pieces are complete, and the sum leaves as a plain store (a no-return packed-bf16 atomic was tried first: its 8-byte segments in 16 rows per
+// wave instruction ran the launch at 0.3 TB/s)
+template <int NUW, bool SV16, int NKB, int DQN, bool STAG, int NQS = NKB, int WIN = 0>
 __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, int ub, int dq_dt, int dq_qs) {
     const int lane = threadIdx.x & 63, g = lane >> 4, r16 = lane & 15;
-    const int L = A.L, Lp = NKB ? 32 * NKB : A.Lp, H = A.H, NSL = NKB ? NKB : (A.Lp >> 5), total = A.total;
+    // Lp: padded KEY rows of the launch (images, units, dS^T rows); Lqp: padded query rows (slices, lse vector); L: the sequence (queries, row addressing)
+    const int L = A.L, Lp = NKB ? 32 * NKB : (WIN ? A.Lkp : A.Lp), H = A.H, total = A.total;
+    const int NSL = NQS ? NQS : (A.Lp >> 5);                       // query slices of a head
+    const int NKBr = NKB ? NKB : (Lp >> 5);                        // 32-key blocks of the window
+    const int Lqp = WIN ? 32 * NSL : Lp;
+    const int kw0 = WIN ? A.kw0 : 0, Lk = WIN ? A.Lk : L;
     const T* const qkv = A.qkv; const int ldqkv = A.ldqkv;
     const T* const dctx = A.dctx; const int lddctx = A.lddctx;
     float* const delta = A.delta;
@@ -147,17 +162,20 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int nheads = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this workgroup
     const int nslices = nheads * NSL;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem);
-    const int o_ring = 2 * Lp * RB, o_dsb = o_ring + NSLOT * SLOT_BYTES, o_dl = o_dsb + 2 * Lp * 64, o_lse = o_dl + 2 * 32 * 4;
+    constexpr int SLOTB = (WIN == 2 ? 4 : 3) * 32 * RB;      // ring slot: Q, dO, O (and the stored dQ rows) of a slice
+    const int o_ring = 2 * Lp * RB, o_dsb = o_ring + NSLOT * SLOTB, o_dl = o_dsb + 2 * Lp * 64, o_lse = o_dl + 2 * 32 * 4;      // lse: 2 x Lqp floats
+    const int o_dlt = o_lse + 2 * Lqp * 4;                   // WIN == 2: -delta / 8 of the head's queries, 2 x Lqp floats (written by the first window's launch)
     char* const k_img = smem;
     char* const v_img = smem + Lp * RB;
     char* const ring = smem + o_ring;
     char* const dsb = smem + o_dsb;
     float* const dl_l = reinterpret_cast<float*>(smem + o_dl);
     float* const lse_l = reinterpret_cast<float*>(smem + o_lse);
+    float* const dlt_l = reinterpret_cast<float*>(smem + o_dlt);
     // prefix mode: dQ of the slices that hold rows < rows_hi (every wave works on those: dQ sums over all keys), dK / dV of the units that
     // hold such rows (their waves work on every slice); delta for every row
     const int rows_hi = A.rows_hi;
-    const bool own_wanted = NUW > 0 && ub * 16 < rows_hi;
+    const bool own_wanted = NUW > 0 && kw0 + ub * 16 < rows_hi;
     // ablation builds (timing only, wrong results): a run-time condition that is never true keeps the code alive
 #ifdef LPI_ABL4_NOCOMPUTE
     const bool abl_comp = lddqkv == 12345;
@@ -236,7 +254,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     // K and V rows of a head -> their images, in PARTS of 16 pieces of 8 rows (2 per wave): the images are free from a head's prologue
     // on and needed at the next one, so the parts go out over the first iterations of a head instead of as one 57 KB burst per CU beside
     // the dK / dV stores of the head before
-    const int nblk = (L + 7) >> 3;
+    const int nblk = (Lk + 7) >> 3;
     const int kv_parts = (2 * nblk + 15) >> 4;
     // scalar base of a head's rows in a [B L, ld] matrix (+ a column offset)
     auto head_base = [&](const T* m, int ld, const Head& x, int col) {
@@ -252,7 +270,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             if (pi < 2 * nblk) {
                 const int isv = pi >= nblk ? 1 : 0, blk = pi - isv * nblk;
                 const int row = blk * 8 + r8;
-                if (row < L && abl_dma) glds16s(kv_base, (unsigned)(row * ldqkv + isv * dm + ((pc ^ (row & 6)) << 3)) * 2u, lds0 + isv * Lp * RB + blk * 1024);
+                if (row < Lk && abl_dma) glds16s(kv_base, (unsigned)((kw0 + row) * ldqkv + isv * dm + ((pc ^ (row & 6)) << 3)) * 2u, lds0 + isv * Lp * RB + blk * 1024);
             }
         }
     };
@@ -260,19 +278,30 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         const int i = wave * 64 + lane;
         if (wave * 64 < L) {
             const float* lb = (const float*)scalar_ptr(A.lse + (size_t)(x.b * H + x.h) * L);
-            if (i < L && abl_dma) glds4s(lb, (unsigned)i * 4u, lds0 + o_lse + (buf * Lp + wave * 64) * 4);
+            if (i < L && abl_dma) glds4s(lb, (unsigned)i * 4u, lds0 + o_lse + (buf * Lqp + wave * 64) * 4);
+        }
+    };
+    // WIN == 2: the head's -delta / 8 vector, which the first window's launch left in the C ABI's delta scratch ([B, H, L] f32): no O rows are read
+    auto issue_dlt = [&](const Head& x, int buf) {
+        if constexpr (WIN == 2) {
+            const int i = wave * 64 + lane;
+            if (wave * 64 < L) {
+                const float* db = (const float*)scalar_ptr(delta + (size_t)(x.b * H + x.h) * L);
+                if (i < L && abl_dma) glds4s(db, (unsigned)i * 4u, lds0 + o_dlt + (buf * Lqp + wave * 64) * 4);
+            }
         }
     };
     // slice t of a head -> ring slot: 12 pieces of 8 rows (Q, dO, O x 4): wave w < 4 moves piece w of Q and of dO, waves 6, 7 two pieces of
     // O each, waves 4, 5 (the longest iteration: staggered, two key units) none (rows behind L: the last row again — finite values; their
     // lse is -inf, so P = 0 there)
-    const T* const sl_m0 = wave < 4 ? qkv : A.ctx;             // this wave's first source matrix and row stride
-    const int sl_ld0 = wave < 4 ? ldqkv : A.ldctx;
+    const bool mv_dq = WIN == 2 && wave >= 4 && wave < 6;      // WIN == 2: waves 4, 5 move the stored dQ rows of every slice (piece 3 of the slot)
+    const T* const sl_m0 = wave < 4 ? qkv : (mv_dq ? (const T*)dqkv : A.ctx);             // this wave's first source matrix and row stride
+    const int sl_ld0 = wave < 4 ? ldqkv : (mv_dq ? lddqkv : A.ldctx);
     const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
-    const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : 2) * 32 * RB + sl_blk0 * 1024;
+    const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : (mv_dq ? 3 : 2)) * 32 * RB + sl_blk0 * 1024;
     const int sl_rl = sl_blk0 * 8 + (lane >> 3);
     const int sl_ch = ((lane & 7) ^ (sl_rl & 6)) << 3;         // (row & 6) is the same for rows 8 apart
-    const bool sl_mine = wave < 4 || wave >= 6;
+    const bool sl_mine = wave < 4 || (wave >= 6 && WIN != 2) || mv_dq;      // WIN == 2: nobody moves O (delta comes from the scratch)
     const T* sl_b0 = nullptr;             // scalar bases of the prefetch cursor's head: first matrix, and dO for waves 0-3
     const T* sl_b1 = nullptr;
     auto slice_bases = [&](const Head& x) {
@@ -282,7 +311,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     };
     auto issue_slice = [&](int t, int slot) {
         if (abl_dma && sl_mine) {
-            const unsigned dst = sl_dst + slot * SLOT_BYTES;
+            const unsigned dst = sl_dst + slot * SLOTB;
             const int r0 = min(t * 32 + sl_rl, L - 1);
             glds16s(sl_b0, (unsigned)(r0 * sl_ld0 + sl_ch) * 2u, dst);
             if (wave < 4) glds16s(sl_b1, (unsigned)(r0 * lddctx + sl_ch) * 2u, dst + 32 * RB);
@@ -311,27 +340,34 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     // delta of slice t's rows 8 wave .. 8 wave + 7 = rowsum(dO o O) -> dl[par] (/ 8) and the C ABI's delta scratch; waves 0-3 (they have the
     // slack: waves 4-7 run the longer iteration), 8 lanes of 8 elements per row
     Chunk dl_d, dl_o;
+    float* dlt_g = nullptr;      // WIN == 1: this head's row of the delta scratch
     auto stage_delta_load = [&](int slot) {         // issued in front of the iteration's DMA: the LDS round trip runs under it
-        if (wave >= 4) return;
-        const char* ds_ = ring + slot * SLOT_BYTES + 32 * RB;
+        if (wave >= 4 || WIN == 2) return;
+        const char* ds_ = ring + slot * SLOTB + 32 * RB;
         dl_d.u = *reinterpret_cast<const uint4*>(ds_ + dlo);
         dl_o.u = *reinterpret_cast<const uint4*>(ds_ + 32 * RB + dlo);
     };
-    auto stage_delta = [&](int par) {
-        if (wave >= 4) return;
+    auto stage_delta = [&](int par, int tq) {         // tq: the slice whose rows 8 wave .. 8 wave + 7 these are
+        if (wave >= 4 || WIN == 2) return;
         float v = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v = fmaf((float)dl_d.h[e], SV16 ? (float)dl_o.hh[e] : (float)dl_o.h[e], v);
         v += dpp_move<0xB1>(v);     // lane ^ 1
         v += dpp_move<0x4E>(v);     // lane ^ 2
         v += dpp_move<0x141>(v);    // the other quad of each 8 lanes
-        if ((lane & 7) == 0) dl_l[par * 32 + 8 * wave + (lane >> 3)] = -v * SCALE;          // the dP' accumulators start from it
+        if ((lane & 7) == 0) {
+            dl_l[par * 32 + 8 * wave + (lane >> 3)] = -v * SCALE;          // the dP' accumulators start from it
+            if constexpr (WIN == 1) {      // ... and the later windows' launches read it instead of the O rows
+                const int q = tq * 32 + 8 * wave + (lane >> 3);
+                if (q < L) dlt_g[q] = -v * SCALE;
+            }
+        }
     };
 
     Chunk bp[NUA], bs[NUA];              // P and dS of a slice as MFMA B operands: score half -> matrix half
     // score half of slice t: S^T, dP^T -> P, dS = P (dP - delta) / 8; dS^T -> dsb[par]
     auto stage_s = [&](int t, int slot, int lbuf, int par, bool with_delta) {
-        const char* qs_ = ring + slot * SLOT_BYTES;
+        const char* qs_ = ring + slot * SLOTB;
         const char* ds_ = qs_ + 32 * RB;
         char* dsp = dsb + par * (Lp * 64);
         uint32_t pw[NUA][2][2], sw[NUA][2][2];
@@ -346,12 +382,13 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 qa[t2][ks].u = *reinterpret_cast<const uint4*>(qs_ + t2 * 16 * RB + rc[ks]);
                 da[t2][ks].u = *reinterpret_cast<const uint4*>(ds_ + t2 * 16 * RB + rc[ks]);
             }
-            nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lp + t * 32 + t2 * 16 + 4 * g);      // -lse log2(e): scaled in place per head
-            dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // -delta / 8
+            nl[t2] = *reinterpret_cast<const f32x4*>(lse_l + lbuf * Lqp + t * 32 + t2 * 16 + 4 * g);      // -lse log2(e): scaled in place per head
+            if constexpr (WIN == 2) dls[t2] = *reinterpret_cast<const f32x4*>(dlt_l + lbuf * Lqp + t * 32 + t2 * 16 + 4 * g);
+            else dls[t2] = *reinterpret_cast<const f32x4*>(dl_l + par * 32 + t2 * 16 + 4 * g);                 // -delta / 8
         }
         // the NEXT slice's delta (waves 0-3; its rows were read in front of the DMA issue): a short dependent chain that runs under this
         // slice's LDS round trip and first MFMAs
-        if (with_delta) stage_delta(par ^ 1);
+        if (with_delta) stage_delta(par ^ 1, t + 1);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             if constexpr (SV16) {
@@ -388,7 +425,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     };
     // matrix half of the slice in ring slot `slot`: dV^T += dO^T P, dK^T += Q^T dS
     auto stage_m = [&](int slot) {
-        const char* qs_ = ring + slot * SLOT_BYTES;
+        const char* qs_ = ring + slot * SLOTB;
         const char* ds_ = qs_ + 32 * RB;
         // the transposing reads of two head-dim blocks are in flight together
 #pragma unroll
@@ -412,7 +449,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     };
 
     // dQ^T[16 dq_dt .., 16 queries of half dq_qs (+ piece)] of slice t = K^T (all keys) . dS^T -> global
-    auto stage_dq = [&](T* dqh, int t, int par) {
+    auto stage_dq = [&](T* dqh, int t, int par, int slot_t) {      // slot_t: the ring slot of slice t (WIN == 2: its piece 3 holds the stored dQ rows)
         if constexpr (DQN > 0) {
             const char* dsp = dsb + par * (Lp * 64);
             f32x4 dq[DQN];
@@ -426,7 +463,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 Chunk bq[GRP][DQN];
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
+                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NKBr) && abl_comp) {
 #pragma unroll
                         for (int pi = 0; pi < DQN; ++pi) {
                             const uint2 lo = tr_read(dsp + (k0 + j) * 2048 + dsr[pi][0]), hi = tr_read(dsp + (k0 + j) * 2048 + dsr[pi][1]);
@@ -435,7 +472,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                     }
 #pragma unroll
                 for (int j = 0; j < GRP; ++j)
-                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NSL) && abl_comp) {
+                    if (k0 + j < (NKB ? NKB : MAXKB) && (NKB || k0 + j < NKBr) && abl_comp) {
 #pragma unroll
                         for (int pi = 0; pi < DQN; ++pi) mma(dq[pi], kT[k0 + j], bq[j][pi]);
                     }
@@ -452,7 +489,17 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #ifdef LPI_NT_ATTN
                     st_stream8(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g), pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
 #else
+                {
+                    if constexpr (WIN == 2) {
+                        // this window's share + what the first launch stored (exactly two addends per element, the first in memory since the launch
+                        // before: bitwise reproducible): the stored row came with the slice (piece 3 of its slot, the images' chunk swizzle)
+                        const int rl = (dq_qs + pi) * 16 + r16;
+                        const uint2 old = *reinterpret_cast<const uint2*>(ring + slot_t * SLOTB + 3 * 32 * RB + rl * RB + (((2 * dq_dt + (g >> 1)) ^ (rl & 6)) << 4) + (g & 1) * 8);
+                        dq[pi][0] += __uint_as_float(old.x << 16); dq[pi][1] += __uint_as_float(old.x & 0xFFFF0000u);
+                        dq[pi][2] += __uint_as_float(old.y << 16); dq[pi][3] += __uint_as_float(old.y & 0xFFFF0000u);
+                    }
                     *reinterpret_cast<uint2*>(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g)) = make_uint2(pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
+                }
 #endif
             }
         }
@@ -463,6 +510,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     kv_base = head_base(qkv, ldqkv, cur, dm);
     for (int part = 0; part < kv_parts; ++part) issue_kv_part(part);
     issue_lse(cur, 0);
+    issue_dlt(cur, 0);
     for (int j = 0; j < AHEAD; ++j) issue_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -476,6 +524,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         Head nxt = cur;
         next_head(nxt);
         T* const dqh = dqkv + (size_t)cur.b * L * lddqkv + cur.h * HD;
+        if constexpr (WIN == 1) dlt_g = delta + (size_t)(cur.b * H + cur.h) * L;
         // own K, V rows and the K^T fragments out of the images (landed a head ago)
 #pragma unroll
         for (int u = 0; u < NUW; ++u)
@@ -489,7 +538,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
         for (int kb = 0; kb < (DQN ? (NKB ? NKB : MAXKB) : 0); ++kb) {
             kT[kb].u = make_uint4(0, 0, 0, 0);
-            if (NKB || kb < NSL) {
+            if (NKB || kb < NKBr) {
                 kT[kb] = tr_pair(k_img + kb * 32 * RB + trw, 16 * RB);
                 if constexpr (SV16) chunk_f16_to_bf16(kT[kb]);
             }
@@ -500,14 +549,15 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             for (int i = 0; i < 4; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
         // this head's lse vector (landed a head ago): -lse log2(e) in place, one entry per thread (the entries behind L stay -inf)
-        if ((int)threadIdx.x < L) lse_l[lbuf * Lp + threadIdx.x] *= -LOG2E;
+        if ((int)threadIdx.x < L) lse_l[lbuf * Lqp + threadIdx.x] *= -LOG2E;
         stage_delta_load(slot);
-        stage_delta(0);
+        stage_delta(0, 0);
         LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
             kv_base = head_base(qkv, ldqkv, nxt, dm);
             issue_lse(nxt, lbuf ^ 1);
+            issue_dlt(nxt, lbuf ^ 1);
             if (!spread_kv)
                 for (int part = 0; part < kv_parts; ++part) issue_kv_part(part);
         }
@@ -526,7 +576,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             const int par = t & 1;
             if (abl_comp) {
                 const bool run = own_wanted || t * 32 < rows_hi;
-                if (t + 1 < NSL && (STAG || !run)) stage_delta(par ^ 1);
+                if (t + 1 < NSL && (STAG || !run)) stage_delta(par ^ 1, t + 1);
                 LPI4_STAMP();
                 if constexpr (STAG) {
                     if (t >= 1 && (own_wanted || (t - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);
@@ -540,7 +590,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                 LPI4_STAMP();
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1);
+            if (t >= 1 && (t - 1) * 32 < rows_hi) stage_dq(dqh, t - 1, par ^ 1, slot == 0 ? NSLOT - 1 : slot - 1);
             LPI4_STAMP();
             // End of an iteration: this wave's pieces of slice gs + 2 (the next iteration's delta pass reads it) have landed — all but the
             // pieces of the AHEAD - 2 younger slices (2 per slice from each of waves 0-3, 6, 7; stores and K / V pieces issued in between only
@@ -572,7 +622,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         if constexpr (STAG) {
             if (abl_comp && (own_wanted || (NSL - 1) * 32 < rows_hi)) stage_m(slot == 0 ? NSLOT - 1 : slot - 1);      // the last slice's matrix half
         }
-        if ((NSL - 1) * 32 < rows_hi) stage_dq(dqh, NSL - 1, (NSL - 1) & 1);
+        if ((NSL - 1) * 32 < rows_hi) stage_dq(dqh, NSL - 1, (NSL - 1) & 1, slot == 0 ? NSLOT - 1 : slot - 1);
         // dK^T / dV^T tiles (16 keys x 64) -> global as WHOLE 128-byte rows: the accumulator layout gives a lane 4 x 8 bytes of its key row; staged
         // through 1 KiB per wave of the dS^T buffer that is idle now (8 rows at a time, 8-byte slots XOR-ed with 2 (row & 7): conflict-free),
         // read back as [row][16-byte chunk] — every store instruction writes 8 full rows (straight from the registers it was 16 rows x 64 B:
@@ -591,19 +641,19 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                             *reinterpret_cast<uint2*>(st + wr + (((4 * dt + g) ^ wsw) << 3)) = make_uint2(pack2(acc[dt][0], acc[dt][1]), pack2(acc[dt][2], acc[dt][3]));
                     }
                     const uint4 v = *reinterpret_cast<const uint4*>(st + rd);
-                    const int kr = row0 + 8 * hf + rrow;
+                    const int kr = row0 + 8 * hf + rrow;      // key row inside the window
 #ifdef LPI_ABL4_NODKVST
-                    if (kr < L && lddqkv == 12345)
+                    if (kr < Lk && lddqkv == 12345)
 #else
-                    if (kr < L && abl_st)
+                    if (kr < Lk && abl_st)
 #endif
                         *reinterpret_cast<uint4*>(tile + (unsigned)((8 * hf + rrow) * lddqkv + 8 * rch)) = v;
                 }
             };
 #pragma unroll
             for (int u = 0; u < NUW; ++u) {
-                if ((ub + u) * 16 >= rows_hi) continue;
-                T* dst = dqh + (unsigned)((ub + u) * 16 * lddqkv);
+                if (kw0 + (ub + u) * 16 >= rows_hi) continue;
+                T* dst = dqh + (unsigned)((kw0 + (ub + u) * 16) * lddqkv);
                 store_tile(dst + dm, dk[u], (ub + u) * 16);
                 store_tile(dst + 2 * dm, dv[u], (ub + u) * 16);
             }
@@ -612,10 +662,12 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     }
 }
 
-template <bool SV16, int NKB>
+template <bool SV16, int NKB, int WIN = 0>
 __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int L = A.L, Lp = A.Lp;
+    // the KEY rows of the launch (whole sequence, or the window) decide the images and the units; the lse vectors cover the queries
+    const int L = WIN ? A.Lk : A.L, Lp = WIN ? A.Lkp : A.Lp;
+    const int Lq = A.L, Lqp = A.Lp;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int NU = Lp >> 4;
     const int base = NU / NWV, rem = NU % NWV;
@@ -629,43 +681,77 @@ __global__ __launch_bounds__(512) void attn_bwd4_kernel(Args4 A) {
             const int im = i / per, rch = i % per;
             *reinterpret_cast<uint4*>(smem + (size_t)im * Lp * RB + (size_t)L * RB + rch * 16) = make_uint4(0, 0, 0, 0);
         }
-        float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * SLOT_BYTES + 2 * Lp * 64 + 2 * 32 * 4);
-        for (int i = threadIdx.x; i < 2 * (Lp - L); i += blockDim.x) lse_l[(i / (Lp - L)) * Lp + L + i % (Lp - L)] = -INFINITY;
+        float* lse_l = reinterpret_cast<float*>(smem + 2 * Lp * RB + NSLOT * ((WIN == 2 ? 4 : 3) * 32 * RB) + 2 * Lp * 64 + 2 * 32 * 4);
+        for (int i = threadIdx.x; i < 2 * (Lqp - Lq); i += blockDim.x) lse_l[(i / (Lqp - Lq)) * Lqp + Lq + i % (Lqp - Lq)] = -INFINITY;
+        if constexpr (WIN == 2) {      // the padded queries' delta entries: finite (P = 0 there)
+            float* dlt_l = lse_l + 2 * Lqp;
+            for (int i = threadIdx.x; i < 2 * (Lqp - Lq); i += blockDim.x) dlt_l[(i / (Lqp - Lq)) * Lqp + Lq + i % (Lqp - Lq)] = 0.f;
+        }
     }
+    constexpr int NQS = WIN ? 0 : NKB;      // a window launch reads its query slices from A.Lp
     if constexpr (NKB == 7) {       // Lp == 224: 14 units = 2 x 6 + 1 x 2
-        if (wave < 4) bwd4_body<2, SV16, 7, 1, false>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);     // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
-        else if (wave < 6) bwd4_body<2, SV16, 7, 0, true>(A, smem, wave, ub, 0, 0);
-        else bwd4_body<1, SV16, 7, 2, true>(A, smem, wave, ub, wave - 4, 0);                             // head-dim blocks 2, 3: both query halves
+        if (wave < 4) bwd4_body<2, SV16, 7, 1, false, NQS, WIN>(A, smem, wave, ub, (wave >> 1) ^ 1, wave & 1);     // head-dim blocks 1, 1, 0, 0; query halves 0, 1, 0, 1
+        else if (wave < 6) bwd4_body<2, SV16, 7, 0, true, NQS, WIN>(A, smem, wave, ub, 0, 0);
+        else bwd4_body<1, SV16, 7, 2, true, NQS, WIN>(A, smem, wave, ub, wave - 4, 0);                             // head-dim blocks 2, 3: both query halves
     } else {
         switch (nu) {
-            case 2: bwd4_body<2, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
-            case 1: bwd4_body<1, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
-            default: bwd4_body<0, SV16, 0, 1, false>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            case 2: bwd4_body<2, SV16, 0, 1, false, 0, WIN>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            case 1: bwd4_body<1, SV16, 0, 1, false, 0, WIN>(A, smem, wave, ub, wave & 3, wave >> 2); break;
+            default: bwd4_body<0, SV16, 0, 1, false, 0, WIN>(A, smem, wave, ub, wave & 3, wave >> 2); break;
         }
     }
 }
 
 int cu_count4() { return lpi_cu_count(); }
 
-size_t lds_bytes4(int Lp) { return (size_t)2 * Lp * RB + (size_t)NSLOT * SLOT_BYTES + (size_t)2 * Lp * 64 + (size_t)2 * 32 * 4 + (size_t)2 * Lp * 4; }
+// Lkp: padded key rows of the launch, Lqp: padded query rows
+size_t lds_bytes4(int Lkp, int Lqp, int win = 0) {
+    return (size_t)2 * Lkp * RB + (size_t)NSLOT * ((win == 2 ? 4 : 3) * 32 * RB) + (size_t)2 * Lkp * 64 + (size_t)2 * 32 * 4 + (size_t)(win == 2 ? 4 : 2) * Lqp * 4;
+}
+constexpr int WIN0 = 224;      // keys of the first window of a long sequence: the Lp = 224 configuration (14 key units over 8 waves)
 
 }  // namespace
 
 // true if the fourth-generation backward takes this shape (bf16 operands, non-causal, at most 8 x 2 key units)
 bool lpi_attn4_bwd_ok(int L, int causal) {
     const int Lp = (L + 31) / 32 * 32;
-    return !causal && L >= 1 && Lp <= 32 * MAXKB && Lp / 16 <= NWV * MAXU && lds_bytes4(Lp) <= 160 * 1024;
+    if (causal || L < 1) return false;
+    if (Lp <= 32 * MAXKB) return Lp / 16 <= NWV * MAXU && lds_bytes4(Lp, Lp) <= 160 * 1024;
+    // two key windows: 224 keys + the rest (<= 64) against all queries
+    return L - WIN0 <= 64 && lds_bytes4(WIN0, Lp) <= 160 * 1024;
 }
 
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
                   float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi) {
     const int Lp = (L + 31) / 32 * 32;
-    const size_t lds = lds_bytes4(Lp);
     const int total = B * H;
     int grid = std::min(total, cu_count4());
     if (g_lpi_tuning[11] > 0) grid = std::min(grid, g_lpi_tuning[11]);      // tests: several heads per workgroup at small B H
-    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12]};
-    static LdsOnce o0, o1, o2, o3;
+    static LdsOnce o0, o1, o2, o3, w0, w1, w2, w3;
+    if (Lp > 32 * MAXKB) {
+        // a sequence of more than 224 tokens (ViT-L/14: 273) as TWO launches over all queries: keys 0 .. 223 (the Lp = 224 configuration), then keys
+        // 224 .. L - 1 (generic configuration, 4 units at most) whose dQ share is added to the first launch's.  lse and delta are per query, so the two
+        // key windows are independent; dK / dV of a window are complete.  Every query slice streams through twice (the price of not fitting 18 key
+        // units on 8 waves: three units per wave spill).
+#define BWD4W(S, K, W, O, ARGS, LDS)                                                                       \
+    do {                                                                                                   \
+        if (int e = lpi_ensure_lds(O, (const void*)attn_bwd4_kernel<S, K, W>, 160 * 1024)) return e;       \
+        LPI_LAUNCH((attn_bwd4_kernel<S, K, W>), dim3(grid), dim3(64 * NWV), LDS, s, ARGS);                 \
+    } while (0)
+        const int Lk1 = L - WIN0, Lkp1 = (Lk1 + 31) / 32 * 32;
+        const Args4 A0{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
+                       0, WIN0, WIN0, 0};
+        const Args4 A1{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
+                       WIN0, Lk1, Lkp1, 1};
+        if (saved_f16) { BWD4W(true, 7, 1, w0, A0, lds_bytes4(WIN0, Lp)); BWD4W(true, 0, 2, w1, A1, lds_bytes4(Lkp1, Lp, 2)); }
+        else { BWD4W(false, 7, 1, w2, A0, lds_bytes4(WIN0, Lp)); BWD4W(false, 0, 2, w3, A1, lds_bytes4(Lkp1, Lp, 2)); }
+#undef BWD4W
+        LPI_CHECK_LAST();
+        return 0;
+    }
+    const size_t lds = lds_bytes4(Lp, Lp);
+    const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
+                  0, L, Lp, 0};
 #define BWD4(S, K, O)                                                                               \
     do {                                                                                            \
         if (int e = lpi_ensure_lds(O, (const void*)attn_bwd4_kernel<S, K>, 160 * 1024)) return e;   \

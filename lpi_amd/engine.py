@@ -120,6 +120,9 @@ GEMM_PROFILE = None
 
 # Split-K for GEMMs with a few rows (pooled rows of the last block, heads): LPI_SPLITK=0 disables it (A/B switch).
 SPLITK = _os.environ.get("LPI_SPLITK", "1") != "0"
+# workgroups a split-K launch aims at (slices = this // tiles, a divisor of the K-tile count): more slices shorten the partial kernel's K loop and
+# lengthen the reduction (slices x M x N f32 partials); LPI_SPLITK_WGS: A/B switch
+SPLITK_WGS = int(_os.environ.get("LPI_SPLITK_WGS", "384"))
 _SPLITK_SCRATCH = {}
 
 
@@ -130,7 +133,7 @@ def _splitk_plan(dt, M, N, K):
         return 0
     nk = K // (32 if dt == F32 else 64)
     tiles = (M // 128) * (N // 128)
-    cap = max(1, 384 // tiles)
+    cap = max(1, SPLITK_WGS // tiles)
     ks = max((d for d in range(1, nk + 1) if nk % d == 0 and d <= cap), default=1)
     return ks if ks > 1 else 0
 

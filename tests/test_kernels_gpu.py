@@ -1448,7 +1448,10 @@ def test_attention_forward_pair_launch_equals_two_launches(dt):
 
 
 @pytest.mark.parametrize("saved", ["bf16", "f16"])
-@pytest.mark.parametrize("B,L,H,cap", [(2, 213, 3, 0), (3, 213, 2, 1), (24, 213, 12, 0), (3, 197, 2, 2), (2, 224, 2, 1), (2, 161, 1, 1), (5, 64, 4, 3), (4, 21, 2, 1), (2, 100, 2, 1)])
+@pytest.mark.parametrize("B,L,H,cap", [(2, 213, 3, 0), (3, 213, 2, 1), (24, 213, 12, 0), (3, 197, 2, 2), (2, 224, 2, 1), (2, 161, 1, 1), (5, 64, 4, 3), (4, 21, 2, 1), (2, 100, 2, 1),
+                                       # round 4: sequences of 225 .. 288 tokens as TWO key windows (224 keys + the rest) over all queries, the second
+                                       # window's dQ added to the first's: ViT-L/14's L = 273, the window edges 225 / 257 / 288, several heads per workgroup
+                                       (2, 273, 2, 0), (3, 273, 2, 1), (20, 273, 16, 0), (2, 225, 1, 1), (2, 257, 2, 1), (3, 288, 1, 2)])
 def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     """attention4.hip (one pass over the scores; 8 waves own 16-32 keys each; Q / dO / O stream through an LDS ring in 32-query slices,
     across head boundaries; dS^T crosses LDS once and every wave contracts it over ALL keys for its piece of dQ) against f64 autograd,
@@ -1483,7 +1486,11 @@ def test_attention_streamed_single_pass_backward(saved, B, L, H, cap):
     new, new2, old = out[5][0], out[5][1], out[1][0]
     assert torch.equal(new[0], new2[0]) and torch.equal(new[1], new2[1])
     assert bool(torch.isfinite(new[0].float()).all())
-    assert float(new[1].abs().max()) == 0.0                                        # delta (scratch of the C ABI) stays in LDS: the buffer is untouched
+    if L <= 224:
+        assert float(new[1].abs().max()) == 0.0                                    # delta (scratch of the C ABI) stays in LDS: the buffer is untouched
+    else:       # two key windows: the first launch leaves -delta / 8 = -rowsum(dO o O) / 8 there for the second (which then reads no O row)
+        dref = -(dctx.double().cpu() * ctx.double().cpu()).view(B, L, H, 64).sum(-1).permute(0, 2, 1) / 8
+        assert float((new[1].double().cpu() - dref).abs().max()) <= 2e-3 * float(dref.abs().max()) + 1e-6
     assert relerr(new[0], old[0].double().cpu()) < 2e-2
     for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
         e = relerr(new[0][:, sl], qr.grad[:, sl])

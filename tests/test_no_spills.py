@@ -46,6 +46,10 @@ def test_streamed_attention_backward_of_the_vision_tower_does_not_spill(tmp_path
     ks = _kernel_scratch("attention4.o", tmp_path)
     # attn_bwd4_kernel<SV16, NKB = 7>: the vision tower's backward (Lp = 224) in bf16 and f16 mode — a scratch reload's vmcnt(0) would drain
     # the ring's LDS-DMA every iteration
-    vision = {k: v for k, v in ks.items() if re.search(r"attn_bwd4_kernelILb[01]ELi7E", k)}
-    assert len(vision) == 2, sorted(ks)
+    # ... <SV16, NKB, WIN>: the key-window launches of a sequence longer than 224 tokens (ViT-L/14: L = 273 = 224 keys on the NKB = 7 configuration +
+    # 49 on the generic one, round 4) must not spill either
+    vision = {k: v for k, v in ks.items() if re.search(r"attn_bwd4_kernelILb[01]ELi7ELi[01]E", k)}
+    assert len(vision) == 4, sorted(ks)
     assert all(v == 0 for v in vision.values()), vision
+    window_rest = {k: v for k, v in ks.items() if re.search(r"attn_bwd4_kernelILb[01]ELi0ELi2E", k)}
+    assert len(window_rest) == 2 and all(v == 0 for v in window_rest.values()), window_rest
