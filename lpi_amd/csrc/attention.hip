@@ -54,7 +54,10 @@ template <> struct AT<bf16_t> {
 // (the qkv buffer is far larger than the caches), and a one-load-at-a-time loop costs a full HBM round trip per iteration.
 // CV0 / CV1: the matrix is stored as fp16 (saved by an f16-mode forward) and is converted to bf16 on its way into LDS (the backward's
 // operands are bf16: gradients do not fit fp16's range)
-template <typename T, bool CV0 = false, bool CV1 = false>
+// SW: the images have UNPADDED 128-byte rows (2-byte types) with the 16-byte chunk index XOR-ed with (row & 6) — conflict-free for the row-fragment and
+// the transposing reads alike (tools/lds_swizzle_check.py; the layout of attention4.hip's images) — instead of rows padded to 160 bytes: a head of
+// 257 .. 288 tokens (ViT-L/14: 273) then takes 72 KiB instead of 90, so that TWO workgroups fit a CU's 160 KiB like they do at L = 213
+template <typename T, bool CV0 = false, bool CV1 = false, bool SW = false>
 __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1, const T* g1, int ld0, int ld1, int L, int Lp) {
     constexpr int NCH = HD * (int)sizeof(T) / 16;
     const int n = Lp * NCH, nt = blockDim.x;
@@ -80,8 +83,9 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
             if (i < n) {
                 if constexpr (CV0) { Chunk t; t.u = v0[j]; chunk_f16_to_bf16(t); v0[j] = t.u; }
                 if constexpr (CV1) { Chunk t; t.u = v1[j]; chunk_f16_to_bf16(t); v1[j] = t.u; }
-                *reinterpret_cast<uint4*>(lds0 + row * AT<T>::RS + c * 16) = v0[j];
-                *reinterpret_cast<uint4*>(lds1 + row * AT<T>::RS + c * 16) = v1[j];
+                const int lo = SW ? row * 128 + ((c ^ (row & 6)) << 4) : row * AT<T>::RS + c * 16;
+                *reinterpret_cast<uint4*>(lds0 + lo) = v0[j];
+                *reinterpret_cast<uint4*>(lds1 + lo) = v1[j];
             }
         }
     }
@@ -174,6 +178,38 @@ __device__ __forceinline__ void mma_transposed(f32x4 (&acc)[NB][4], const char* 
     }
 }
 
+// the same two products on the swizzled images (SW): `base` = the image row block (rows r0 .. r0 + 15, r0 a multiple of 16), ro[ks] / to[dt] = this lane's
+// byte offsets of its row chunk of k-step ks / of its transposing read of head-dim block dt (16 rows further: + 16 * 128, same swizzle)
+template <typename T>
+__device__ __forceinline__ void mma_lds_rows_sw(f32x4 (&acc)[NB], const char* base, const int (&ro)[AT<T>::KS], const Chunk (&b)[NB][AT<T>::KS]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < AT<T>::KS; ++ks) {
+        Chunk a;
+        a.u = *reinterpret_cast<const uint4*>(base + ro[ks]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mma_chunk<T>(acc[j], a, b[j][ks]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void mma_transposed_sw(f32x4 (&acc)[NB][4], const char* base, const int (&to)[4], const f32x4 (&p0)[NB], const f32x4 (&p1)[NB]) {
+    Chunk b[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+        b[j].u = make_uint4(pack2_t<T>(p0[j][0], p0[j][1]), pack2_t<T>(p0[j][2], p0[j][3]), pack2_t<T>(p1[j][0], p1[j][1]), pack2_t<T>(p1[j][2], p1[j][3]));
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + to[dt]));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(base + 16 * 128 + to[dt]));
+        Chunk a;
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+        a.u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mma_chunk<T>(acc[j][dt], a, b[j]);
+    }
+}
+
 template <typename T> __device__ __forceinline__ int row_ptr_off(int lane) { return (lane & 15) * AT<T>::RS + (lane >> 4) * 16; }
 template <typename T> __device__ __forceinline__ int tr_ptr_off(int lane) {
     if constexpr (sizeof(T) == 2) return (4 * (lane >> 4) + ((lane & 15) >> 2)) * AT<T>::RS + (lane & 3) * 8;
@@ -197,7 +233,7 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SW = false>
 __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                               T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
     const int b = bh / H, h = bh % H;
@@ -213,8 +249,10 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
     const T* qg = qkv + row0 * ldqkv + h * HD;
+    constexpr int RSX = SW ? 128 : AT<T>::RS;      // image row stride (SW: see stage_rows2)
+    static_assert(!SW || sizeof(T) == 2, "the swizzled images are for the 2-byte operand types");
     char* k_lds = smem;
-    char* v_lds = smem + Lp * AT<T>::RS;
+    char* v_lds = smem + Lp * RSX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int g = lane >> 4;
     // the wave's first query blocks are fetched before the staging so that their HBM latency hides under it
@@ -224,12 +262,20 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         const int qr = (wave * NB + j) * 16 + (lane & 15);
         load_row_chunks<T>(q[j], qg, qr, ldqkv, g, qr < L);
     }
-    stage_rows2<T>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    stage_rows2<T, false, false, SW>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const float c = SCALE * LOG2E;
     const char* const kp0 = k_lds + row_ptr_off<T>(lane);
     const char* const vt0 = v_lds + tr_ptr_off<T>(lane);
+    int ro[AT<T>::KS], to[4];      // SW: this lane's swizzled offsets inside a 16-row block of an image
+    {
+        const int r = lane & 15, rr = 4 * g + (r >> 2), pq = lane & 3;
+#pragma unroll
+        for (int ks = 0; ks < AT<T>::KS; ++ks) ro[ks] = r * 128 + (((g + 4 * ks) ^ (r & 6)) << 4);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) to[dt] = rr * 128 + (((2 * dt + (pq >> 1)) ^ (rr & 6)) << 4) + (pq & 1) * 8;
+    }
     for (int q0 = wave * 16 * NB; q0 < L; q0 += nw * 16 * NB) {
         int qrow[NB];
 #pragma unroll
@@ -250,12 +296,20 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         // one 32-key tile; MASKED only for tiles that can contain padded keys (last tile) or the causal diagonal
         auto tile = [&](int kb, auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-            const char* kp = kp0 + kb * AT<T>::RS;
             f32x4 s0[NB], s1[NB];
-            mma_lds_rows<T>(s0, kp, q);
-            mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
-            attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
-            mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
+            if constexpr (SW) {
+                const char* kb_ = k_lds + kb * 128;
+                mma_lds_rows_sw<T>(s0, kb_, ro, q);
+                mma_lds_rows_sw<T>(s1, kb_ + 16 * 128, ro, q);
+                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
+                mma_transposed_sw<T>(o, v_lds + kb * 128, to, s0, s1);
+            } else {
+                const char* kp = kp0 + kb * AT<T>::RS;
+                mma_lds_rows<T>(s0, kp, q);
+                mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
+                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
+                mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
+            }
         };
         const int qlast = q0 + 16 * NB - 1;
         const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
@@ -288,11 +342,11 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
     }
 }
 
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, bool SW = false>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                       T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_fwd_body<T, CAUSAL>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse);
+    attn_fwd_body<T, CAUSAL, SW>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse);
 }
 // TWO attention forwards in one launch (the vision tower's and the text tower's of the same layer): workgroups [0, nb0) run problem 0, the
 // rest problem 1.  The text tower's forward alone is a 15 us kernel — a chain of dependent HBM round trips with the chip nearly idle; here its
@@ -302,10 +356,10 @@ struct AttnFwdP {
     int L, Lp, H, ldqkv, ldctx;
     const int* rs; const T* qkv; T* ctx; float* lse;
 };
-template <typename T, bool C0, bool C1>
+template <typename T, bool C0, bool C1, bool SW0 = false>
 __global__ __launch_bounds__(512) void attn_fwd_pair_kernel(AttnFwdP<T> p0, AttnFwdP<T> p1, int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse);
+    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0, SW0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse);
     else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse);
 }
 
@@ -752,11 +806,23 @@ int set_lds(const void* kern, size_t bytes) {
     return lpi_ensure_lds(once[slot], kern, 160 * 1024);
 }
 
+// the padded images of two workgroups do not fit a CU's 160 KiB but the unpadded ones do (tuning key 13 = 1: never; A/B switch)
+static bool fwd_swizzled(int Lp) { return g_lpi_tuning[13] != 1 && (size_t)2 * 2 * Lp * 160 > (size_t)160 * 1024 && (size_t)2 * 2 * Lp * 128 <= (size_t)160 * 1024; }
+
 template <typename T, bool CAUSAL>
 int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)2 * Lp * AT<T>::RS;
     const int thr = 64 * pick_waves(L);
+    if constexpr (sizeof(T) == 2 && !CAUSAL) {
+        if (fwd_swizzled(Lp) && !rs) {      // 257 .. 288 tokens: unpadded swizzled images, two workgroups per CU (stage_rows2)
+            const size_t lsw = (size_t)2 * Lp * 128;
+            if (int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL, true>, lsw)) return e;
+            LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL, true>), dim3(B * H), dim3(thr), lsw, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+            LPI_CHECK_LAST();
+            return 0;
+        }
+    }
     int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL>, lds);
     if (e) return e;
     LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
@@ -843,6 +909,13 @@ static int fwd_pair_launch(const lpi_attn_fwd_desc* d, hipStream_t s) {
         thr = std::max(thr, 64 * pick_waves(d[i].L));
     }
     const int nb0 = d[0].B * d[0].H, nb1 = d[1].B * d[1].H;
+    if (!d[0].causal && d[1].causal && !d[0].row_start && fwd_swizzled(p[0].Lp)) {      // a long vision sequence beside the text tower: problem 0 on the swizzled images
+        const size_t lsw = std::max((size_t)2 * p[0].Lp * 128, (size_t)2 * p[1].Lp * AT<T>::RS);
+        if (int e = set_lds((const void*)attn_fwd_pair_kernel<T, false, true, true>, lsw)) return e;
+        LPI_LAUNCH((attn_fwd_pair_kernel<T, false, true, true>), dim3(nb0 + nb1), dim3(thr), lsw, s, p[0], p[1], nb0);
+        LPI_CHECK_LAST();
+        return 0;
+    }
 #define FP(C0, C1)                                                                                                              \
     do {                                                                                                                        \
         if (int e = set_lds((const void*)attn_fwd_pair_kernel<T, C0, C1>, lds)) return e;                                       \

@@ -1410,12 +1410,13 @@ def test_layernorm_pair_launch_equals_two_launches(d0, d1):
     assert torch.equal(y0, y1) and relerr(y0, torch.nn.functional.layer_norm(x.double().cpu(), (256,), g.double().cpu(), b.double().cpu(), 1e-5)) < 2e-5
 
 
+@pytest.mark.parametrize("Lv", [213, 273])      # 273 (ViT-L/14): the vision problem on the unpadded swizzled K / V images (two workgroups per CU), round 4
 @pytest.mark.parametrize("dt", [BF16, F16, F32])
-def test_attention_forward_pair_launch_equals_two_launches(dt):
+def test_attention_forward_pair_launch_equals_two_launches(dt, Lv):
     """lpi_attn_fwd_pair: the vision tower's (non-causal, uniform length) and the text tower's (causal, packed batch) attention forward of one
     layer in ONE launch: same bits as the two launches (f32 runs as two launches behind the same entry point)."""
     TDX = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
-    Bv, Lv, Hv = 3, 213, 3
+    Bv, Hv = 3, 3
     Bt, Lt, Ht = 5, 59, 2
     lens, rs = _ragged(Bt, Lt, 11, 18)
     rs_d = rs.int().to(DEV)
@@ -1445,6 +1446,31 @@ def test_attention_forward_pair_launch_equals_two_launches(dt):
     _lib.attn_fwd_pair(dt, (Bt, Lt, rs_d, Ht, qt, 3 * Ht * 64, ct, Ht * 64, lt_, 1), (Bv, Lv, None, Hv, qv, 3 * Hv * 64, cv, Hv * 64, lv, 0), stream())
     torch.cuda.synchronize()
     assert torch.equal(cv, res["single"][0]) and torch.equal(ct, res["single"][1])
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("L", [257, 273, 288])
+def test_attention_forward_swizzled_images_equal_the_padded_ones(dt, L):
+    """Sequences of 257 .. 288 tokens stage K and V as unpadded 128-byte rows with swizzled 16-byte chunks (72 KiB per head: two workgroups per CU)
+    instead of rows padded to 160 bytes (90 KiB: one).  The same products in the same order: bit for bit the padded kernel (tuning key 13 = 1),
+    which test_attention_fwd_bwd holds against f64."""
+    td = torch.bfloat16 if dt == BF16 else torch.float16
+    B, H = 3, 2
+    d = H * 64
+    qkv = rnd(B * L, 3 * d, seed=L).to(td).to(DEV)
+    outs = []
+    try:
+        for key13 in (0, 1):
+            call("lpi_set_tuning", 13, key13)
+            ctx = torch.zeros(B * L, d, device=DEV, dtype=td)
+            lse = torch.zeros(B, H, L, device=DEV)
+            call("lpi_attn_fwd", dt, B, L, H, qkv, 3 * d, ctx, d, lse, 0, stream())
+            torch.cuda.synchronize()
+            outs.append((ctx, lse))
+    finally:
+        call("lpi_set_tuning", 13, 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].float().abs().max()) > 0
 
 
 @pytest.mark.parametrize("saved", ["bf16", "f16"])
