@@ -75,6 +75,11 @@ def parse_args():
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
+    ap.add_argument("--local-loss", action="store_true",
+                    help="N > 1: the row-sharded contrastive loss (gather_features local_loss=True, sprompt.py:278-283): a rank evaluates its B x W B logit "
+                         "blocks only, labels offset by rank * B")
+    ap.add_argument("--gather-with-grad", action="store_true",
+                    help="N > 1: gradients through the gathered features (sprompt.py:67-69): the key gradients are reduce-scattered to their owners")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU with a gloo group (messages staged through the host): exercises the multi-rank path on a 1-GPU box")
     return ap.parse_args()
@@ -489,7 +494,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         from lpi_amd.dp import Exchange
-        exchange = Exchange(timing=True)
+        exchange = Exchange(timing=True, local_loss=a.local_loss, gather_with_grad=a.gather_with_grad)
     if os.environ.get("LPI_MAIN_STREAM") == "side":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # A/B: the step on a side stream instead of the (blocking) null stream
 
@@ -514,15 +519,24 @@ def main():
     collectives = None
     if exchange is not None:
         torch.cuda.synchronize()
-        tl = (exchange.timing or [])[-2 * a.steps:] if not a.fwd_only else (exchange.timing or [])[-a.steps:]
+        tt = exchange.timing or []
+        per_step = max(1, len(tt) // max(1, a.steps + a.warmup))      # collectives per step: 2 (3 with gradients through the gathered features; 1 forward only)
+        tl = tt[-per_step * a.steps:]
         # device collectives (RCCL) are timed with HIP events; host-staged ones (gloo, ranks sharing a GPU) carry no per-collective time
         collectives = {k: round(1e3 * float(np.mean([e0.elapsed_time(e1) for kk, e0, e1 in tl if kk == k])), 1)
                        for k in sorted({kk for kk, _, _ in tl})} or None
         collectives = {"mean_us_per_step": collectives, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
-                       "messages": "one all_gather_into_tensor of img_f||txt_f [B, 1024] f32 + one all_reduce(SUM) of the 5 284 factor gradients"}
+                       "messages": "one all_gather_into_tensor of img_f||txt_f [B, 1024] f32 + one all_reduce(SUM) of the 5 284 factor gradients"
+                                   + (" + one reduce_scatter_tensor of the key gradients [W B, 1024] f32" if a.gather_with_grad else "")}
         exchange.timing = None
 
     roofline = None if a.no_roofline else wl.gemm_roofline()
+    from lpi_amd import _lib as _L
+    torch.cuda.synchronize()
+    n0 = _L.launch_count()
+    wl.step()
+    torch.cuda.synchronize()
+    launches_per_step = _L.launch_count() - n0      # library launches of one steady-state step (no other kernel runs in it: tests/test_round4_gpu.py)
 
     hw_gflop = None
     if roofline is not None and not a.fwd_only:
@@ -569,6 +583,8 @@ def main():
                        "text_layout": "77 columns" if a.no_text_trim else ("cut at the longest caption" if a.no_text_pack else "packed (engine.PackedIds)"),
                        "towers": "one after the other" if (a.no_lockstep or a.overlap) else "lock step, GEMMs of one layer op grouped in one launch",
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
+                       "dp_mode": None if world == 1 and exchange is None else
+                       f"gather_features(local_loss={a.local_loss}, gather_with_grad={a.gather_with_grad})",
                        "weights": "synthetic (numpy Philox, CLIP-init scales), frozen",
                        "precision": "bf16 MFMA operands, f32 accumulate, fp16 residual stream, bf16 gradient stream; parity at 1e-4 is a property of "
                                     "the f32 mode (parity_mode), not of this line" if a.dtype == "bf16" else "f32 MFMA operands and accumulate (parity mode)"},
@@ -580,6 +596,7 @@ def main():
             "hw_flop_frac": None if hw_gflop is None else round(hw_gflop * 1e9 / (median_ms * 1e-3) / (PEAK_TF[a.dtype] * 1e12), 4),
             "executed_gflop_per_step": None if hw_gflop is None else round(hw_gflop, 1),
             "roofline": roofline,
+            "launches_per_step": launches_per_step,
         }
         out.update(extras)
         if collectives is not None:

@@ -110,6 +110,7 @@ LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "2"))
 # order of an f32 sum.  The epilogue costs the GEMM about as much as the pass it replaces — it pays since the residual stream is stored with plain
 # (Infinity-Cache resident) stores: the pass had been warming the cache for the next GEMM (22.81 against 22.95-23.00 ms per step;
 # profiles/r03_experiments.md).  Blocks whose input rows are rewritten by deep prompts first, and the first block, keep the pass.
+MLP_SPLIT = int(_os.environ.get("LPI_MLP_SPLIT", "0"))      # see Tower.mlp_split
 ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "2"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
 
 
@@ -193,10 +194,11 @@ class GemmReq:
     """A GEMM a tower wants issued: the towers' forward / backward are generators that YIELD their GEMMs instead of launching them, so
     that a driver (run_lockstep) can launch the vision and the text tower's GEMM of the same layer op as ONE grouped launch
     (lpi_gemm_nt_grouped).  `tag` names the op ("3.qkv", "last.kv", ...): only requests with equal tags are paired; None = never."""
-    __slots__ = ("tag", "dt", "a", "b", "c", "M", "N", "K", "kw")
+    __slots__ = ("tag", "dt", "a", "b", "c", "M", "N", "K", "kw", "optional")
 
-    def __init__(self, tag, dt, a, b, c, M, N, K, **kw):
-        self.tag, self.dt, self.a, self.b, self.c, self.M, self.N, self.K, self.kw = tag, dt, a, b, c, M, N, K, kw
+    def __init__(self, tag, dt, a, b, c, M, N, K, optional=False, **kw):
+        # optional: a request only THIS tower emits (a later row chunk of its MLP, Tower.mlp_split): run_lockstep issues it alone
+        self.tag, self.dt, self.a, self.b, self.c, self.M, self.N, self.K, self.kw, self.optional = tag, dt, a, b, c, M, N, K, kw, optional
 
     def issue(self):
         gemm(self.dt, self.a, self.b, self.c, self.M, self.N, self.K, **self.kw)
@@ -468,6 +470,14 @@ class Tower:
         self.rowstats = ROWSTATS      # per tower (a test sets one tower to 0: the lock-stepped towers must re-align, run_lockstep)
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
 
+    def mlp_split(self, Mp):
+        """Rows of the FIRST row chunk of the MLP (a multiple of 256), 0 = the MLP runs over all rows at once.  LPI_MLP_SPLIT = row panels (of 256 rows)
+        of the first chunk (A/B switch; only the wider tower splits)."""
+        p = MLP_SPLIT
+        if p <= 0 or self.spec.causal or p * 256 >= Mp - 256 * 32:
+            return 0
+        return p * 256
+
     def _check_depth(self, prompts, depth):
         """model.py:191 indexes prompts[:, layer_id]: the reference raises IndexError past the stack; so do we (before any kernel)."""
         if prompts is not None and not (1 <= depth <= prompts.shape[-3]):
@@ -518,7 +528,8 @@ class Tower:
             "lse": [z(B, H, L) for _ in range(keep)],
             "u": [z(Mp, 4 * d, dtype=TU) for _ in range(keep)] if train else [None],
             # per layer, per LayerNorm: mean[Mp] | rstd[Mp] | c1[<= 4d] (the LN operand block of the LN-fold GEMM epilogues, include/lpi_hip.h)
-            "lnblk": [z(2, 2 * Mp + 4 * d) for _ in range(nl)],
+            # (+ Mp: a row CHUNK of the MLP passes the block shifted by its first row, and reads c1 shifted by as much: a copy of c1 sits there)
+            "lnblk": [z(2, 3 * Mp + 4 * d) for _ in range(nl)],
             "h": z(Mp, d, dtype=T),
             "g": z(Mp, 4 * d, dtype=T),
             # slot sums of the row statistics a residual GEMM's epilogue leaves (LPI_EPI_RES_ROWSTATS): d/128 slots x (sum, sum of squares) x Mp
@@ -554,6 +565,9 @@ class Tower:
                     c1 = c1[d:]
                 ws["lnblk"][i][0, 2 * Mp:2 * Mp + c1.numel()].copy_(c1)
                 ws["lnblk"][i][1, 2 * Mp:2 * Mp + 4 * d].copy_(blk["fc_ln"].c1)
+                r1 = self.mlp_split(Mp)
+                if r1:
+                    ws["lnblk"][i][1, 2 * Mp + r1:2 * Mp + r1 + 4 * d].copy_(blk["fc_ln"].c1)
         self._ws[key] = ws
         return bind(ws, Lreal)
 
@@ -644,24 +658,37 @@ class Tower:
                 yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
                 yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
                 return ws["c_xout"]
+            # the next block's ln_1 statistics come out of c_proj's epilogue; rows that deep prompts rewrite first get theirs from prompt_add (above)
+            nxt = i + 1
+            have_ln1 = rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt]
+            # MLP in row chunks (mlp_split): c_fc and c_proj of the first rows, then of the rest — same tiles, same bits; the first chunk keeps the
+            # op's tags (it pairs with the other tower's GEMMs), the later ones are this tower's alone
+            r1 = self.mlp_split(Mp) if (fold and LN_FOLD >= 2) else 0
+            chunks = [(0, r1), (r1, Mp - r1)] if r1 else [(0, Mp)]
+
+            def proj_req(ci, r0, n):
+                kw = dict(bias=blk["proj"].b, residual=xmid[r0:r0 + n], m_real=max(0, min(n, M - r0)))
+                if have_ln1:
+                    kw.update(epi=EPI_RES_ROWSTATS, aux=ws["rstat"][:, r0:])
+                yield GemmReq(f"{lt}.proj" + ("" if ci == 0 else f"#{ci}"), dt, ws["g"][r0:r0 + n], blk["proj"].w, x_out[r0:r0 + n], n, d, 4 * d, optional=ci > 0, **kw)
+
             if fold and LN_FOLD >= 2:
                 fl = blk["fc_ln"]
                 if not ln2_stats:
                     yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3], optional=True)
-                yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
+                for ci, (r0, n) in enumerate(chunks):
+                    yield GemmReq(f"{lt}.fc" + ("" if ci == 0 else f"#{ci}"), F16, xmid[r0:r0 + n], fl.w, ws["g"][r0:r0 + n], n, 4 * d, d, optional=ci > 0, bias=fl.c2,
+                                  residual=lnb[1][r0:], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u[r0:r0 + n], m_real=max(0, min(n, M - r0)))
+                    if len(chunks) > 1:
+                        yield from proj_req(ci, r0, n)
             else:
                 yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], optional=True)
                 yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            # the next block's ln_1 statistics come out of this epilogue; rows that deep prompts rewrite first get theirs from prompt_add (above)
-            nxt = i + 1
-            have_ln1 = rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt]
+            if len(chunks) == 1:
+                yield from proj_req(0, 0, Mp)
             if have_ln1:
-                yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M,
-                              epi=EPI_RES_ROWSTATS, aux=ws["rstat"])
                 nst = ws["stat"][nxt]
                 yield StatFinReq(f"{lt}.fin1", M, d, ws["rstat"], ws["rstat"].stride(0), nst[0], nst[1])
-            else:
-                yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, bias=blk["proj"].b, residual=xmid, m_real=M)
         call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
         return ws["c_xout"]
 

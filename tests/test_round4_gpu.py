@@ -426,3 +426,24 @@ def test_single_sweep_statistics_accuracy_envelope():
         m2, r2 = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
         call("lpi_layernorm_fwd", BF16, F16, M, d, x16.to(DEV), d, None, None, None, 0, m2, r2, s)
         assert float(((r2.double().cpu() / ref_rstd) - 1).abs().max()) <= 2e-6, name
+
+
+def test_bench_multi_rank_line_on_one_gpu_reports_the_observed_world_size():
+    """`bench.py --gpus 2 --share-gpu` (two ranks on this GPU, gloo group, host-staged messages): the ranks are started as a CHILD torch.distributed.run
+    before anything touches the GPU in the launcher, rank 0's JSON line carries the world size the process group observed and the whole-job value —
+    the multi-rank path of the bench is exercised on a one-GPU box (the 8-GPU run is the driver's)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in ([], ["--local-loss", "--gather-with-grad"]):
+        p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--share-gpu", "--batch", "16", "--steps", "2", "--warmup", "1",
+                            "--no-cpu-baseline", "--no-roofline", "--no-extras"] + extra, capture_output=True, text=True, env=env, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+        j = json.loads(line)
+        assert j["n_gpus"] == 2 and j["collectives"]["observed_world_size"] == 2 and j["collectives"]["backend"] == "gloo"
+        assert j["config"]["global_batch"] == 32 and j["value"] > 0 and j["scaling"] == "weak"
+        assert ("local_loss=True" in j["config"]["dp_mode"]) == bool(extra)
