@@ -1,28 +1,31 @@
-// Prompted multi-head attention backward, bf16 operands, fourth generation: ONE pass over the scores, 4 fat waves, query slices STREAMED.
+// Prompted multi-head attention backward, bf16 operands, fourth generation: ONE pass over the scores, 8 waves, query slices STREAMED.
 //
 // replaces: the autograd backward of nn.MultiheadAttention as called from ResidualAttentionBlock.attention
-// (retrieval/models/clip/model.py:183-185) for the vision tower (non-causal, L = 1 + P + 196 = 213), like attn_bwd2_kernel of attention2.hip.
+// (retrieval/models/clip/model.py:183-185) for the vision tower (non-causal; ViT-B/16: L = 1 + P + 196 = 213, ViT-L/14: L = 273).
 //
-// Why a fourth generation (profiles/r02_pmc.json, DESIGN section 4 "what bounds attention"): the two-phase persistent backward evaluates S, P, dP
-// and dS twice (56 MFMAs and two exponentials per score), keeps a whole head's Q, K, V, dO (and O) in LDS, and its 7 waves (2 / 2 / 2 / 1 per
-// SIMD) overlap neither their loads with their arithmetic (157 us + 177 us -> 228 us) nor one wave's vector work with another's matrix work.
-// Here:
-//   * a workgroup = 4 waves, one per SIMD, each with the whole 512-register file; wave w OWNS 3-4 blocks of 16 keys ("units": 14 for L = 213,
-//     split 4 / 4 / 3 / 3) for a whole head: their K and V rows (MFMA B operands) and their dK^T, dV^T accumulators stay in registers;
-//   * the head's queries stream through LDS in SLICES of 32 rows (Q and dO, 8 KiB per slice) from an 8-slot ring filled by LDS-DMA seven
-//     slices ahead, across head boundaries — every global read of the kernel is an LDS-DMA issued a whole head before its use, so the memory
-//     pipe never waits for the arithmetic nor the arithmetic for it;
-//   * per slice ONE evaluation: S^T = Q K_own^T and dP^T = dO V_own^T (key on the lane), P = exp2(c S - lse), dS = P (dP - delta) / 8;
-//     P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS straight from the accumulators; dS^T crosses LDS once ([key][query]
-//     bf16, 14 KiB per slice) and wave w contracts it over ALL keys with the K^T fragments of its 16 head-dim columns: dQ^T of the slice is
-//     complete (no partial sums across waves, no atomics, no f32 read-modify-write) and is stored at once;
-//   * delta_i = sum_j P_ij dP_ij (== rowsum(dO o O)) comes from the same accumulators: the O rows are never read (-12.5 % bytes), the
-//     per-wave partial sums meet in a 1 KiB LDS table, summed in a fixed order;
-//   * software pipeline over slices, one barrier per slice: iteration t runs stage 1 of slice t + 1 (S, dP, P, partial delta), stage 2 of
-//     slice t (delta, dS, dV, dK) and stage 3 of slice t - 1 (dQ) as independent instruction streams.
-// 40 MFMAs and one exponential per score instead of 56 and two; 586 MB instead of 670 MB per vision layer at B = 256.
-// Results are bitwise reproducible (fixed summation orders), but differ in the last bits from the earlier generations (delta from P dP
-// instead of dO O; dQ summed over keys inside one MFMA chain).
+// Why ("what bounds attention"): the two-phase persistent backward of round 2 evaluated S, P, dP and dS twice (56 MFMAs and two
+// exponentials per score), kept a whole head's Q, K, V, dO (and O) in LDS and overlapped neither its loads with its arithmetic nor one wave's vector
+// work with another's matrix work.  Here:
+//   * a persistent workgroup per CU = 8 waves (two per SIMD, <= 248 VGPRs so that MFMA results land in VGPRs); wave w OWNS one or two 16-key "units"
+//     of a head (14 units at Lp = 224: 2,2,2,2,2,2,1,1): their K and V rows (MFMA B operands, V pre-scaled by 1/8) and their dK^T, dV^T
+//     accumulators stay in registers for the whole head;
+//   * the head's queries stream through LDS in SLICES of 32 rows (Q, dO, O: 12 KiB) from a 6-slot ring filled by LDS-DMA four slices ahead,
+//     across head boundaries — every global read is an LDS-DMA (scalar head base + 32-bit lane offset) issued long before its use; K / V of the
+//     NEXT head arrive in their images spread over the head's first iterations;
+//   * per slice: delta = rowsum(dO o O) (waves 0-3, eight lanes per row, kept in LDS); S^T = Q K_own^T and dP' = dO (V/8)^T - delta/8 (the
+//     accumulators start from -delta/8) with the key on the lane; P = exp2(c S - lse'), dS = P dP' are, packed, the B operands of dV^T += dO^T P
+//     and dK^T += Q^T dS; dS^T crosses LDS once ([key][query] bf16, double-buffered) and each wave contracts it over ALL keys with the K^T
+//     fragments of its 16 head-dim columns: a piece of dQ^T is complete in one MFMA chain — no partial sums across waves, no atomics;
+//   * one barrier per slice; waves 4-7 run a slice's matrix half (dV, dK) one iteration late, in front of the next slice's score half (stagger:
+//     SIMD partners are in complementary phases); dQ pieces 1,1,3,3 over the SIMDs, DMA issue and the delta pass on the waves with barrier slack;
+//   * vmcnt is ONE in-order counter over loads, stores and DMA: the waits name exactly the operations that may stay in flight.
+// 40 MFMAs and one exponential per score instead of 56 and two.  Results are bitwise reproducible (fixed summation orders).
+//
+// Round 4 — sequences of 225 .. 288 tokens (ViT-L/14: 273 = 18 key units, two more than 8 waves x 2; three units per wave spill): the head's keys
+// run as TWO launches over all queries (template WIN, Args4): keys 0 .. 223 on the tuned Lp = 224 configuration, which also leaves -delta/8 in the
+// C ABI's delta scratch; then keys 224 .. L-1 on the generic configuration, which reads that vector instead of the O rows and ADDS its dQ share to
+// the stored one — the stored dQ rows of a slice arrive by LDS-DMA as a fourth piece of the slice's ring slot.  lse and delta are per query, so the
+// two windows are independent; dK / dV of a window are complete; two addends per dQ element in a fixed order: still bitwise reproducible.
 #include <type_traits>
 #include "common.h"
 
