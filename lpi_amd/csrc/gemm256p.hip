@@ -31,6 +31,24 @@ constexpr int NTHR = 512;
 constexpr int OFF_A0 = 0, OFF_A1 = HALF_BYTES, OFF_B0 = 2 * HALF_BYTES, OFF_B1 = 3 * HALF_BYTES;
 constexpr int STG = BUF_BYTES;            // epilogue staging = ring slot 1 (the odd K-tiles'), 64 rows x 1024 B
 constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
+// Internal epilogue kind (never in the C ABI): LPI_EPI_NONE with NO bias, alpha = 1, a 2-byte output and no residual / aux — the dgrad GEMMs of the
+// backward (d c_fc, d out_proj, d in_proj, d K/V: a fifth of the step).  The stamps of the diagnostic build (tools/gemm_stamps.py,
+// profiles/r04_gemm_stamps.json) show where a store-only epilogue's 7 600 cycles per tile go: 48 % is the f32 staging WRITE (256 KiB per tile through the
+// CU's ~79 B/clk ds_write_b128 path: 8 waves wait for it at the barrier behind the writes) and 14 % the barrier in front of it (the staging buffer is
+// single: a pass may not overwrite what the pass before is still reading).  With nothing to add per column or per row the accumulators can be rounded to
+// the output type BEFORE the staging: half the bytes (ds_write_b64, 32 KiB per pass), so two passes' buffers fit the staging slot (double buffer: ONE
+// barrier per pass), whole rows leave as 16-byte stores (half the store instructions).  The same roundings of the same values: bit for bit the generic
+// epilogue (acc * 1 + 0 is kept as acc + 0, which turns a -0 into the +0 the generic form stores).
+constexpr int EPI_PLAIN16 = 100;
+// ... and the same for LPI_EPI_LN (in_proj with ln_1 folded in; no aux) — OPT-IN (tuning key 14 = 3): on the whole step it measured no faster than the generic
+// LN-fold epilogue (22.44-22.49 ms against 22.44-22.46; EPI_PLAIN16 alone 22.35-22.42).  v = (acc alpha - mean c1) rstd + c2 is evaluated on the accumulators — a lane's four column
+// groups' c1 / c2 and its eight rows' mean / rstd are loaded once per tile (plain loads: 24 per lane) — and staged in the output type.  The same
+// expression on the same values as gemm_epilogue_store: bit for bit the generic epilogue (tests/test_round4_gpu.py).
+constexpr int EPI_LN16 = 101;
+#ifndef LPI_EPI_DB
+#define LPI_EPI_DB false     /* -DLPI_EPI_DB=true: eight double-buffered passes of 32 rows for the store-only epilogues with arithmetic — measured SLOWER on the whole
+                                step (22.66-22.71 ms with the four single-buffer passes against 22.78-22.82: twice the barriers for half the work per pass) */
+#endif
 
 // One GEMM of a launch.  A launch takes one or two of them (a GROUPED launch: the same operand types and epilogue kind, e.g. the
 // vision and the text tower's in_proj of the same layer): the second problem's tiles follow the first's in the virtual workgroup order
@@ -54,6 +72,14 @@ struct PGroup {
     float alpha;
 };
 
+// Diagnostic build only (-DLPI_GEMM_STAMPS, tools/gemm_stamps.py; no stamp executes in the product build): per workgroup the shader cycles
+// (s_memtime, wave 0) spent in the K loops, in the epilogues and in the hand-over to the next tile, and the tile count — where a tile's time goes per
+// instantiation (MI355X_MICROARCH.md, 'DVFS give-back' item 6: stamps go to memory of their own, no output depends on them)
+#ifdef LPI_GEMM_STAMPS
+__device__ unsigned long long g_gemm_stamps[1024][8];      // K loop, epilogue, hand-over, tiles | epilogue split: pre-barrier, staging writes, post-write barrier, read + store
+#define GS_NOW() __builtin_amdgcn_s_memtime()
+#endif
+
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 {
@@ -70,6 +96,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     typedef typename AuxT<T>::type TA;
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     constexpr bool LNE = EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU;
+    constexpr bool P16 = EPI == EPI_PLAIN16, L16 = EPI == EPI_LN16;
+    constexpr int EPIX = P16 ? LPI_EPI_NONE : (L16 ? LPI_EPI_LN : EPI);      // the epilogue kind the half-tile body sees
     // the CURRENT problem's operands and geometry (wave-uniform; re-bound by bind() when the workgroup moves on to the next problem)
     const T* A = nullptr; const T* B = nullptr; TC* C = nullptr;
     const float* bias = nullptr; const float* residual = nullptr; TA* aux = nullptr;
@@ -222,6 +250,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
         }
     };
 
+#ifdef LPI_GEMM_STAMPS
+    unsigned long long gs_main = 0, gs_epi = 0, gs_next = 0, gs_tiles = 0, gs_t0 = 0, gs_t1 = 0, gs_t2 = 0;
+    unsigned long long gs_e[4] = {0, 0, 0, 0}, gs_a = 0, gs_b = 0;
+#endif
     const int n_full = grp.n_full;
     int vbv = blockIdx.x;          // virtual id of the workgroup's next tile: blockIdx.x, + G, ...
     bool lds_used = false;
@@ -319,6 +351,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                 mma_quadrant(acc, 0, 1, fb0);
                 PHASE_SYNC_OUT();
             };
+#ifdef LPI_GEMM_STAMPS
+            gs_t0 = GS_NOW();
+            if (gs_tiles) gs_next += gs_t0 - gs_t2;
+#endif
             ktile(0, 0, !first);
             ktile(1, 1, false);
             for (int kt = 2; kt < nk; kt += 2) {
@@ -326,6 +362,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                 ktile(kt + 1, 1, false);
             }
             if (wm == 0) __builtin_amdgcn_s_barrier();
+#ifdef LPI_GEMM_STAMPS
+            gs_t1 = GS_NOW();
+            gs_main += gs_t1 - gs_t0;
+#endif
 
             // ---- epilogue: four passes of 64 rows through slot 1 (pass p: mh = p >> 1, mi in {2 (p & 1), 2 (p & 1) + 1}, both wm).
             // Staging row s = wm * 32 + (mi & 1) * 16 + lrow holds tile row mh * 128 + wm * 64 + mi * 16 + lrow as 64 16-byte chunks
@@ -339,6 +379,66 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             asm volatile("" : "+s"(wave_e));
             const int lrow = lane_e & 15, lslot = lane_e >> 4;
             const int wm_e = wave_e >> 2, wn_e = wave_e & 3;
+            if constexpr (P16 || L16) {
+                // four passes of 64 rows x 512 B through the two halves of slot 1, alternating (see EPI_PLAIN16).  Staging row s = wm 32 + mi2 16 + lrow;
+                // its 64 8-byte chunks (chunk c8 = output columns 4 c8 .. 4 c8 + 3) sit at c8 ^ 2 (s & 15): the 16 lanes of a ds_write_b64 group (16 rows, one
+                // chunk) spread over 16 bank pairs, a row's 16-byte chunks stay whole (the XOR is even) and a read group's 16 chunks cover all banks once
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+                const int l5 = lane_e & 31, lh = lane_e >> 5;
+                TC* const cbase = C + (size_t)m0 * ldc + n0 + l5 * 8;
+                f32x4 c1g[2][2], c2g[2][2];
+                float mug[2][4], rsg[2][4];
+                if constexpr (L16) {
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const int col = n0 + nh * 128 + wn_e * 32 + ni * 16 + lslot * 4;
+                            c1g[nh][ni] = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + col);
+                            c2g[nh][ni] = *reinterpret_cast<const f32x4*>(bias + col);
+                        }
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi) {
+                            const int row = m0 + mh * 128 + wm_e * 64 + mi * 16 + lrow;
+                            mug[mh][mi] = residual[row];
+                            rsg[mh][mi] = residual[(size_t)ldr + row];
+                        }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int mh = p >> 1;
+                    char* const sb = smem + STG + (p & 1) * 32768;
+#pragma unroll
+                    for (int mi2 = 0; mi2 < 2; ++mi2) {
+                        const int s_row = wm_e * 32 + mi2 * 16 + lrow;
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const int c8 = nh * 32 + wn_e * 8 + ni * 4 + lslot;
+                                f32x4 a;
+                                if constexpr (L16) a = (acc[nh][ni][mh][(p & 1) * 2 + mi2] * alpha - mug[mh][(p & 1) * 2 + mi2] * c1g[nh][ni]) * rsg[mh][(p & 1) * 2 + mi2] + c2g[nh][ni];
+                                else a = acc[nh][ni][mh][(p & 1) * 2 + mi2] + 0.0f;
+                                *reinterpret_cast<uint2*>(sb + s_row * 512 + ((c8 ^ (2 * lrow)) << 3)) = uint2{pack2_t<TC>(a[0], a[1]), pack2_t<TC>(a[2], a[3])};
+                            }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {      // two rows per wave instruction: lanes 0-31 / 32-63, 16 bytes each
+                        const int s_row = wave_e * 8 + 2 * i + lh;
+                        const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
+                        const u32x4_ v = *reinterpret_cast<const u32x4_*>(sb + s_row * 512 + (((2 * l5) ^ (2 * (s_row & 15))) << 3));
+                        if constexpr (LPI_NTC_DEFAULT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_*>(cbase + (size_t)trow * ldc));
+                        else *reinterpret_cast<u32x4_*>(cbase + (size_t)trow * ldc) = v;
+                    }
+                    // after two passes (8 stores of this wave since then) the next tile's K-tile 0, issued before them, must have landed
+                    if (p == 1 && has_next) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                }
+            } else {
             const int ecol = n0 + lane_e * 4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SIDE16) bv = *reinterpret_cast<const f32x4*>(bias_lds + bias_off + ecol);
@@ -346,13 +446,65 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f};      // LayerNorm-fold epilogues: c1 sits behind the two statistics vectors
             if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) c1v = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + ecol);
             char* const stg = smem + STG;
+            // Store-only epilogues with arithmetic (bias, LayerNorm fold, QuickGELU: nothing is LOADED per element): EIGHT passes of 32 rows through the two
+            // halves of slot 1, alternating — a pass may write its staging while the pass before is still being read and stored, so the barrier in front of
+            // the staging writes is gone (the stamps of the four-pass form, tools/gemm_stamps.py: for c_fc + QuickGELU that barrier alone was a quarter of the
+            // epilogue: every wave waited there for the slowest wave's sixteen stores).  Pass q: mh = q >> 2, mi = q & 3; staging row s = wm 16 + lrow holds
+            // tile row mh 128 + wm 64 + mi 16 + lrow; wave w reads back rows 4 w .. 4 w + 3.  Same values, same arithmetic per element: the same bits.
+            constexpr bool DB = !LATE && LPI_EPI_DB;
+            if constexpr (DB) {
+                typedef float f32x4s __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int mh = q >> 2, mi = q & 3;
+                    char* const sb = stg + (q & 1) * 32768;
+                    f32x4s mu4, rs4;
+                    if constexpr (LNE) {
+                        const int sr0 = wave_e * 4;
+                        const int trow0 = mh * 128 + (sr0 >> 4) * 64 + mi * 16 + (sr0 & 15);
+                        const float* pm = residual + (m0 + trow0);
+                        const float* pr = pm + ldr;
+                        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(mu4), "=&s"(rs4) : "s"(pm), "s"(pr));
+                    }
+                    {
+                        const int s_row = wm_e * 16 + lrow;
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                const int chunk = nh * 32 + wn_e * 8 + ni * 4 + lslot;
+                                *reinterpret_cast<f32x4*>(sb + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][mi];
+                            }
+                    }
+                    if constexpr (LNE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mu4), "+s"(rs4) : : "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int s_row = wave_e * 4 + rr;
+                        const int trow = mh * 128 + (s_row >> 4) * 64 + mi * 16 + (s_row & 15);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + s_row * 1024 + ((lane_e ^ (s_row & 7)) << 4));
+                        gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, LNE ? mu4[rr] : 0.f,
+                                                                     LNE ? rs4[rr] : 1.f);
+                    }
+                    // after four passes (>= 16 stores of this wave since then) the next tile's K-tile 0, issued before them, must have landed
+                    if (q == 3 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                }
+            } else
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int mh = p >> 1;
+#ifdef LPI_GEMM_STAMPS
+                gs_a = GS_NOW();
+#endif
                 if (p) {          // the previous pass's staging reads are done before this pass overwrites them
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 }
+#ifdef LPI_GEMM_STAMPS
+                gs_b = GS_NOW(); gs_e[0] += gs_b - gs_a;
+#endif
                 if constexpr (SIDE16) {      // pass p+1's side tile -> the half pass p-1 has just finished reading (passes 0, 1: main loop)
                     if (p >= 1 && p <= 2) stage_side(m0, n0, p + 1);
                     // pass 2 was the last reader of half 0 = the A0 | A1 halves of ring slot 0: the next tile's K-tile 0 A rows (the ones
@@ -395,8 +547,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                 }
                 if constexpr (LNE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mu8), "+s"(rs8) : : "memory");      // the statistics are used after this wait
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef LPI_GEMM_STAMPS
+                gs_a = GS_NOW(); gs_e[1] += gs_a - gs_b;
+#endif
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifdef LPI_GEMM_STAMPS
+                gs_b = GS_NOW(); gs_e[2] += gs_b - gs_a;
+#endif
                 float st_s[8], st_q[8];      // STATS: this lane's partial sums of the pass's eight rows
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
@@ -465,6 +623,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                     if (so == 12345.678f && qo == 0.f) { sp[0] = so; sp[ldaux] = qo; }
 #endif
                 }
+#ifdef LPI_GEMM_STAMPS
+                gs_a = GS_NOW(); gs_e[3] += gs_a - gs_b;
+#endif
                 // after two passes (>= 16 vector-memory instructions of this wave since then) the next tile's K-tile 0 must have landed:
                 // all but the 16 youngest operations done.  Passes 2 and 3's barriers then publish it to every wave.
                 if (p == 1 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -476,6 +637,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                     if (p == 3 && more_tiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 }
             }
+            }      // generic epilogue (else of P16)
+#ifdef LPI_GEMM_STAMPS
+            gs_t2 = GS_NOW();
+            gs_epi += gs_t2 - gs_t1;
+            ++gs_tiles;
+#endif
             if (!more_tiles) { vbv = nvb + vb0; break; }
             // the staging slot is free again once every wave has read its rows: K-tile 1's three early halves of the next tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -496,6 +663,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 #undef PHASE_SYNC_IN
 #undef PHASE_SYNC_OUT
 
+#ifdef LPI_GEMM_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_gemm_stamps[blockIdx.x][0] = gs_main; g_gemm_stamps[blockIdx.x][1] = gs_epi; g_gemm_stamps[blockIdx.x][2] = gs_next; g_gemm_stamps[blockIdx.x][3] = gs_tiles;
+        for (int i = 0; i < 4; ++i) g_gemm_stamps[blockIdx.x][4 + i] = gs_e[i];
+    }
+#endif
     // ---- hybrid short last round: the leftover virtual ids [n_full, ...) as two 256x128 half tiles each (mapping of gemm256_tail_kernel:
     // work item j -> leftover id k = (j >> 4) * 8 + (j & 7), half (j >> 3) & 1, so both halves of a tile stay on one XCD)
     if (grp.tail_blocks > 0) {
@@ -509,7 +682,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             __syncthreads();      // LDS hand-over between tile bodies
             int m0, n0;
             coords(lv, m0, n0);
-            t128::tile<T, TC, EPI, RES, SAVE_U>(m0, n0 + half * 128, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, smem);
+            t128::tile<T, TC, EPIX, RES, SAVE_U>(m0, n0 + half * 128, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, smem);
         }
     }
 }
@@ -526,6 +699,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
 {
     constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
+    static_assert((EPI != EPI_PLAIN16 && EPI != EPI_LN16) || (!RES && !SAVE_U && sizeof(TC) == 2), "EPI_PLAIN16 / EPI_LN16: store-only, 2-byte output");
     const int ncu = cu_count_p();
     PGroup g = {};
     g.nprob = np;
@@ -584,6 +758,11 @@ int dispatchp(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
     switch (epi) {
     case LPI_EPI_NONE:
         if (res) return launchp_impl<T, TC, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
+        if constexpr (sizeof(TC) == 2) {      // nothing to add per column or row: the half-width staging (EPI_PLAIN16; tuning key 14 = 1: the generic epilogue, A/B)
+            bool plain = alpha == 1.0f && !ax && g_lpi_tuning[14] != 1;      // key 14 (A/B): 1 = the generic epilogue everywhere, 3 = EPI_LN16 as well
+            for (int i = 0; i < np; ++i) plain = plain && hp[i].bias == nullptr;
+            if (plain) return launchp_impl<T, TC, EPI_PLAIN16, false, false>(hp, np, alpha, s);
+        }
         return launchp_impl<T, TC, LPI_EPI_NONE, false, false>(hp, np, alpha, s);
     case LPI_EPI_RES_ROWSTATS:
         if constexpr (sizeof(TC) == 2 && !__is_same(TC, bf16_t)) {
@@ -610,7 +789,15 @@ int dispatchp_ln(int epi, const HostProb* hp, int np, float alpha, hipStream_t s
     const bool ax = hp[0].aux != nullptr;
     for (int i = 0; i < np; ++i)
         if (!hp[i].residual || (hp[i].aux != nullptr) != ax) return LPI_EINVAL;
-    if (epi == LPI_EPI_LN) return ax ? LPI_EINVAL : launchp_impl<T, TC, LPI_EPI_LN, false, false>(hp, np, alpha, s);
+    if (epi == LPI_EPI_LN) {
+        if (ax) return LPI_EINVAL;
+        if constexpr (sizeof(TC) == 2) {
+            bool fast = g_lpi_tuning[14] == 3;      // opt-in: measured no faster than the generic LN-fold epilogue on the whole step (profiles/r04_experiments.md)
+            for (int i = 0; i < np; ++i) fast = fast && hp[i].bias != nullptr;
+            if (fast) return launchp_impl<T, TC, EPI_LN16, false, false>(hp, np, alpha, s);
+        }
+        return launchp_impl<T, TC, LPI_EPI_LN, false, false>(hp, np, alpha, s);
+    }
     if (ax) return launchp_impl<T, TC, LPI_EPI_LN_QUICKGELU, false, true>(hp, np, alpha, s);
     return launchp_impl<T, TC, LPI_EPI_LN_QUICKGELU, false, false>(hp, np, alpha, s);
 }
@@ -640,6 +827,13 @@ int launch_group(int dtype, int c_dtype, int epilogue, const HostProb* hp, int n
 }
 
 }  // namespace
+
+#ifdef LPI_GEMM_STAMPS
+// diagnostic build: copy the last launch's stamps ([1024][4] u64: K-loop cycles, epilogue cycles, hand-over cycles, tiles) to the host
+extern "C" int lpi_gemm_stamps_read(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // bf16 / f16 operands only (the f32 path is MFMA-bound: its prologue share is small and its K-tile geometry differs)
 int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

@@ -447,3 +447,68 @@ def test_bench_multi_rank_line_on_one_gpu_reports_the_observed_world_size():
         assert j["n_gpus"] == 2 and j["collectives"]["observed_world_size"] == 2 and j["collectives"]["backend"] == "gloo"
         assert j["config"]["global_batch"] == 32 and j["value"] > 0 and j["scaling"] == "weak"
         assert ("local_loss=True" in j["config"]["dp_mode"]) == bool(extra)
+
+
+@pytest.mark.parametrize("tm,N,K", [(3, 512, 128), (43, 1536, 512), (213, 768, 768), (100, 768, 3072), (30, 3072, 256), (90, 768, 2304)])
+def test_gemm_half_width_staging_epilogue_equals_the_generic_one(tm, N, K):
+    """EPI_PLAIN16 (gemm256p.hip): a store-only GEMM with no bias, alpha = 1 and a 2-byte output rounds its accumulators BEFORE the LDS staging (half the
+    staging bytes, double-buffered passes, 16-byte row stores).  Bit for bit the generic epilogue (tuning key 14 = 1) — persistent tiles, the hybrid
+    half-tile round, a grouped launch — and the generic one is held against f64 by test_kernels_gpu.py."""
+    M = tm * 256
+    a = rnd(M, K, seed=tm).bfloat16().to(DEV)
+    a[5] = 0                                        # a row of exact zeros (the sign of a stored zero)
+    b = (rnd(N, K, seed=tm + 1) * 0.05).bfloat16().to(DEV)
+    outs = []
+    try:
+        for key in (0, 1):
+            call("lpi_set_tuning", 14, key)
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            E.gemm(BF16, a, b, c, M, N, K)
+            torch.cuda.synchronize()
+            outs.append(c)
+        # grouped with a second problem
+        a2 = rnd(1024, 512, seed=9).bfloat16().to(DEV)
+        b2 = (rnd(512, 512, seed=10) * 0.05).bfloat16().to(DEV)
+        grp = []
+        for key in (0, 1):
+            call("lpi_set_tuning", 14, key)
+            c, c2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV), torch.zeros(1024, 512, dtype=torch.bfloat16, device=DEV)
+            _lib.gemm_grouped(BF16, BF16, E.EPI_NONE, 1.0, [dict(M=M, N=N, K=K, a=a, b=b, c=c), dict(M=1024, N=512, K=512, a=a2, b=b2, c=c2)], stream())
+            torch.cuda.synchronize()
+            grp.append((c, c2))
+    finally:
+        call("lpi_set_tuning", 14, 0)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(grp[0][0].view(torch.int16), grp[1][0].view(torch.int16)) and torch.equal(grp[0][1].view(torch.int16), grp[1][1].view(torch.int16))
+    assert torch.equal(grp[0][0].view(torch.int16), outs[0].view(torch.int16))
+    ref = a.double().cpu() @ b.double().cpu().t()
+    assert float((outs[0].double().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cdt", [BF16, F16])
+@pytest.mark.parametrize("tm,N,K", [(43, 1536, 512), (213, 2304, 768), (30, 1536, 768)])
+def test_gemm_layernorm_fold_fast_epilogue_equals_the_generic_one(cdt, tm, N, K):
+    """EPI_LN16 (gemm256p.hip): the LayerNorm-fold epilogue of in_proj evaluated on the accumulators and staged in the output type — bit for bit the generic
+    LN-fold epilogue (tuning key 14 = 1), which test_kernels_gpu.py::test_gemm_layernorm_fold_epilogues holds against f64 LN(x) W^T + b."""
+    M = tm * 256
+    td = torch.bfloat16 if cdt == BF16 else torch.float16
+    x = (rnd(M, K, seed=tm) * 1.3 + 0.2).half().to(DEV)
+    w = (rnd(N, K, seed=tm + 1) * 0.05).half().to(DEV)
+    c2 = rnd(N, seed=tm + 2).to(DEV)
+    xf = x.float()
+    lnb = torch.zeros(2 * M + N, device=DEV)
+    lnb[:M] = xf.mean(1)
+    lnb[M:2 * M] = 1.0 / (xf.var(1, unbiased=False) + 1e-5).sqrt()
+    lnb[2 * M:] = w.float().sum(1)
+    outs = []
+    try:
+        for key in (3, 1):      # 3: the opt-in fast LN-fold epilogue, 1: the generic one
+            call("lpi_set_tuning", 14, key)
+            c = torch.full((M, N), float("nan"), dtype=td, device=DEV)
+            E.gemm(F16, x, w, c, M, N, K, bias=c2, residual=lnb, ldr=M, epi=E.EPI_LN)
+            torch.cuda.synchronize()
+            outs.append(c)
+    finally:
+        call("lpi_set_tuning", 14, 0)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert bool(torch.isfinite(outs[0].float()).all())
