@@ -420,6 +420,18 @@ int lpi_copy_rows(int rows, int cols, const float* src, long lds, float* dst, lo
  * dist (optional) [n, T] receives the per-task minima. */
 int lpi_l1_task_id(int n, int E, int T, int C, const float* feat, int ldf, const float* keys, int32_t* sel, float* dist,
                    void* stream);
+/* ---- a10/f3: the task keys — KMeans(n_clusters=5, random_state=0).fit(features)   replaces: methods/sprompt.py:370-397 (clustering), round 4 -----------
+ * The device parts of scikit-learn's fit (k-means++ seeding + Lloyd iterations, sklearn/cluster/_kmeans.py), driven by lpi_amd/kmeans.py, which keeps the
+ * random draws (numpy RandomState) and the convergence logic on the host on vectors of n floats at most: the features X [n, E] f32 stay on the device.
+ *   lpi_kmeans_sqdist   out[c, i] = |x_i - x_cand[c]|^2, c < nc (the distances of every point to candidate centres, which are points)
+ *   lpi_kmeans_assign   labels[i] = argmin_c |x_i - centers[c]|^2 (first minimum; labels in / out), *changed = 1 if any label changed (never cleared here)
+ *   lpi_kmeans_update   new_centers[c] = mean of the points labelled c (0 for an empty cluster), counts[c] = their number; fixed summation order
+ *   lpi_kmeans_colstats colsum[e] = sum_i x[i, e], colsq[e] = sum_i x[i, e]^2 (the tolerance mean_e var_i x[i, e] * tol) */
+int lpi_kmeans_sqdist(int n, int E, int nc, const float* X, int ldx, const int32_t* cand, float* out, void* stream);
+int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, void* stream);
+int lpi_kmeans_update(int n, int E, int k, const float* X, int ldx, const int32_t* labels, float* new_centers, float* counts, void* stream);
+int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, float* colsum, float* colsq, void* stream);
+
 /* a10 optimiser step, replaces optim.SGD(momentum, weight_decay).step() (methods/sprompt.py:253,311) on one flat f32 vector:
  * d = grad + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf. */
 int lpi_sgd_step(long n, float* param, const float* grad, float* momentum_buf, float lr, float momentum, float weight_decay,

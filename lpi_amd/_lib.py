@@ -100,6 +100,10 @@ SIGNATURES = {
     "lpi_zero": [_P, _L, _P],
     "lpi_copy_rows": [_I, _I, _P, _L, _P, _L, _P],
     "lpi_l1_task_id": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "lpi_kmeans_sqdist": [_I, _I, _I, _P, _I, _P, _P, _P],
+    "lpi_kmeans_assign": [_I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "lpi_kmeans_update": [_I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "lpi_kmeans_colstats": [_I, _I, _P, _I, _P, _P, _P],
     "lpi_sgd_step": [_L, _P, _P, _P, _F, _F, _F, _I, _P],
     "lpi_cast": [_I, _I, _L, _P, _P, _P],
     "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],
@@ -119,7 +123,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 400
+EXPECTED_ABI = 401
 
 _lib = None
 

@@ -6,7 +6,7 @@ static std::atomic<uint64_t> g_launches{0};
 
 extern "C" void lpi_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
-extern "C" int lpi_version(void) { return 400; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
+extern "C" int lpi_version(void) { return 401; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
 
 // CU count of the CURRENT device (the persistent kernels launch one workgroup per CU), looked up once per device; safe from any host thread (a cached
 // value is written once, every writer writes the same one)

@@ -575,6 +575,89 @@ __global__ __launch_bounds__(256) void nt_bxent_dx_kernel(int T, int D, int r, c
     dx[d] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------- task keys: KMeans (methods/sprompt.py:370-397)
+// The heavy parts of scikit-learn's KMeans fit (k-means++ seeding + Lloyd iterations; lpi_amd/kmeans.py drives them and keeps the random draws and the
+// convergence logic on the host, on vectors of n floats at most): the features [n, E] never leave the device.  All sums run in a fixed order.
+// out[c, i] = |x_i - cand_c|^2 (cand_c = row cand[c] of X): one wave per point, differences in f32
+__global__ __launch_bounds__(256) void kmeans_sqdist_kernel(int n, int E, int nc, const float* __restrict__ X, int ldx, const int32_t* __restrict__ cand,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* x = X + (size_t)i * ldx;
+    for (int c = 0; c < nc; ++c) {
+        const float* y = X + (size_t)cand[c] * ldx;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) { const float d = x[e] - y[e]; s = fmaf(d, d, s); }
+        s = wave_sum(s);
+        if (lane == 0) out[(size_t)c * n + i] = s;
+    }
+}
+// labels[i] = argmin_c |x_i - C_c|^2 (first minimum); *changed = 1 if any label differs from the one stored before (labels is in / out)
+__global__ __launch_bounds__(256) void kmeans_assign_kernel(int n, int E, int k, const float* __restrict__ X, int ldx, const float* __restrict__ C,
+                                                           int32_t* __restrict__ labels, int32_t* __restrict__ changed) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float* x = X + (size_t)i * ldx;
+    float best = INFINITY;
+    int bc = 0;
+    for (int c = 0; c < k; ++c) {
+        const float* y = C + (size_t)c * E;
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) { const float d = x[e] - y[e]; s = fmaf(d, d, s); }
+        s = wave_sum(s);
+        if (s < best) { best = s; bc = c; }
+    }
+    if (lane == 0) {
+        if (labels[i] != bc) { labels[i] = bc; *changed = 1; }
+    }
+}
+// Cnew[c, cols] = mean of the points labelled c; counts[c] (written by the column chunk 0 blocks).  Block = (cluster, 64 columns) x 16 waves: wave w scans
+// the points w, w + 16, ... in order, the 16 partial sums and counts are added in order.
+__global__ __launch_bounds__(1024) void kmeans_update_kernel(int n, int E, int k, const float* __restrict__ X, int ldx, const int32_t* __restrict__ labels,
+                                                            float* __restrict__ Cnew, float* __restrict__ counts) {
+    __shared__ float part[16][64];
+    __shared__ int pcnt[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x, col = blockIdx.y * 64 + lane;
+    float s = 0.f;
+    int cnt = 0;
+    for (int i = wave; i < n; i += 16)
+        if (labels[i] == c) {
+            ++cnt;
+            if (col < E) s += X[(size_t)i * ldx + col];
+        }
+    part[wave][lane] = s;
+    if (lane == 0) pcnt[wave] = cnt;
+    __syncthreads();
+    if (wave == 0) {
+        float t = part[0][lane];
+        int m = pcnt[0];
+        for (int w = 1; w < 16; ++w) { t += part[w][lane]; m += pcnt[w]; }
+        if (col < E) Cnew[(size_t)c * E + col] = m > 0 ? t / (float)m : 0.f;
+        if (blockIdx.y == 0 && lane == 0) counts[c] = (float)m;
+    }
+}
+// colsum[e] = sum_i x[i, e], colsq[e] = sum_i x[i, e]^2 (for the tolerance mean_e var_i x[i, e] * tol): block = 64 columns x 16 waves, fixed order
+__global__ __launch_bounds__(1024) void kmeans_colstats_kernel(int n, int E, const float* __restrict__ X, int ldx, float* __restrict__ colsum, float* __restrict__ colsq) {
+    __shared__ float ps[16][64], pq[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float s = 0.f, q = 0.f;
+    if (col < E)
+        for (int i = wave; i < n; i += 16) { const float v = X[(size_t)i * ldx + col]; s += v; q = fmaf(v, v, q); }
+    ps[wave][lane] = s;
+    pq[wave][lane] = q;
+    __syncthreads();
+    if (wave == 0 && col < E) {
+        float a = ps[0][lane], b = pq[0][lane];
+        for (int w = 1; w < 16; ++w) { a += ps[w][lane]; b += pq[w][lane]; }
+        colsum[col] = a;
+        colsq[col] = b;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- retrieval
 // rank of the best ground-truth column under np.argsort(score)[::-1] (later index first among equal scores)
 __global__ __launch_bounds__(256) void retrieval_rank_kernel(int n_rows, int n_cols, const float* __restrict__ s, int ld,
@@ -832,6 +915,31 @@ extern "C" int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const
     LPI_LAUNCH(gram_kernel, dim3(T * T), dim3(256), 0, S(stream), T, D, X, G);
     LPI_LAUNCH(nt_bxent_kernel, dim3(1), dim3(64), 0, S(stream), T, G, target, temp, weight, loss, dcos);
     if (dx_row && row >= 0) LPI_LAUNCH(nt_bxent_dx_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), T, D, row, X, G, dcos, dx_row);
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_kmeans_sqdist(int n, int E, int nc, const float* X, int ldx, const int32_t* cand, float* out, void* stream) {
+    if (!X || !cand || !out || n <= 0 || E <= 0 || nc <= 0 || ldx < E) return LPI_EINVAL;
+    LPI_LAUNCH(kmeans_sqdist_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, E, nc, X, ldx, cand, out);
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, void* stream) {
+    if (!X || !centers || !labels || !changed || n <= 0 || E <= 0 || k <= 0 || ldx < E) return LPI_EINVAL;
+    LPI_LAUNCH(kmeans_assign_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, E, k, X, ldx, centers, labels, changed);
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_kmeans_update(int n, int E, int k, const float* X, int ldx, const int32_t* labels, float* new_centers, float* counts, void* stream) {
+    if (!X || !labels || !new_centers || !counts || n <= 0 || E <= 0 || k <= 0 || ldx < E) return LPI_EINVAL;
+    LPI_LAUNCH(kmeans_update_kernel, dim3(k, (E + 63) / 64), dim3(1024), 0, S(stream), n, E, k, X, ldx, labels, new_centers, counts);
+    LPI_CHECK_LAST();
+    return 0;
+}
+extern "C" int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, float* colsum, float* colsq, void* stream) {
+    if (!X || !colsum || !colsq || n <= 0 || E <= 0 || ldx < E) return LPI_EINVAL;
+    LPI_LAUNCH(kmeans_colstats_kernel, dim3((E + 63) / 64), dim3(1024), 0, S(stream), n, E, X, ldx, colsum, colsq);
     LPI_CHECK_LAST();
     return 0;
 }

@@ -11,7 +11,9 @@ What changed, and why:
   * the per-row ``np.argsort`` rank search of ``itm_eval`` (sprompt.py:558-599) runs on the GPU (lpi_retrieval_rank);
   * datasets: ``args['dataset_impl']`` = 'coco' (utils/data.py's Coco / CocoEval on image_root + the two annotation files; default when
     image_root exists) or 'synthetic' (default when image_root is missing: COCO is not available offline; loaders with the same
-    item structure).  KMeans task keys stay on the host (sklearn), as in the reference.
+    item structure);
+  * the KMeans task keys (sprompt.py:370-397) are fitted on the GPU (lpi_amd/kmeans.py: scikit-learn's algorithm, the features stay in HBM;
+    args['kmeans_impl'] = 'sklearn' keeps the reference's host call).
 """
 import collections
 import json
@@ -208,24 +210,39 @@ class SPrompts(BaseLearner):
             return self._task_id(self._network.extract_textual_vector(inputs), self.textual_all_keys)
 
     def clustering(self, dataloader):
-        from sklearn.cluster import KMeans
+        """sprompt.py:370-397: the un-prompted features of the task's training set, L2-normalised, KMeans(n_clusters=5, random_state=0) per modality ->
+        the task's keys.  args['kmeans_impl'] = 'hip' (default: lpi_amd.kmeans — scikit-learn's algorithm with the features left on the GPU, pinned to the
+        reference's centres by tests/golden/kmeans.npz) | 'sklearn' (the reference's own call on the host)."""
+        impl = self.args.get("kmeans_impl", "hip")
+        if impl not in ("hip", "sklearn"):
+            raise ValueError(f"unknown kmeans_impl {impl!r} (hip | sklearn)")
         vf, tf = [], []
+        s = torch.cuda.current_stream().cuda_stream
         for inputs, captions, _, _ in dataloader:
             with torch.no_grad():
-                v = self._network.extract_vector(inputs.to(self._device))
-                t = self._network.extract_textual_vector(captions if torch.is_tensor(captions) else list(captions))
-            vf.append(v / v.norm(dim=-1, keepdim=True))
-            tf.append(t / t.norm(dim=-1, keepdim=True))
-        vf = torch.cat(vf, 0).cpu().numpy()
-        tf = torch.cat(tf, 0).cpu().numpy()
+                v = self._network.extract_vector(inputs.to(self._device)).float().contiguous()
+                t = self._network.extract_textual_vector(captions if torch.is_tensor(captions) else list(captions)).float().contiguous()
+            for f, acc in ((v, vf), (t, tf)):      # v / v.norm(dim=-1, keepdim=True): lpi_l2norm_fwd
+                o, inv = torch.empty_like(f), torch.empty(f.shape[0], device=f.device)
+                _lib.call("lpi_l2norm_fwd", f.shape[0], f.shape[1], f, f.shape[1], o, f.shape[1], inv, s)
+                acc.append(o)
+        vf, tf = torch.cat(vf, 0), torch.cat(tf, 0)
         if _dist_world() > 1:       # every rank clusters the features of ALL shards, so the task keys are identical everywhere
             import torch.distributed as dist
             parts = [None] * _dist_world()
-            dist.all_gather_object(parts, (vf, tf))
-            vf = np.concatenate([p[0] for p in parts])
-            tf = np.concatenate([p[1] for p in parts])
-        vc = KMeans(n_clusters=5, random_state=0).fit(vf)
-        tc = KMeans(n_clusters=5, random_state=0).fit(tf)
+            dist.all_gather_object(parts, (vf.cpu().numpy(), tf.cpu().numpy()))
+            vf = torch.from_numpy(np.concatenate([p[0] for p in parts])).to(self._device)
+            tf = torch.from_numpy(np.concatenate([p[1] for p in parts])).to(self._device)
+        if impl == "hip":
+            from lpi_amd.kmeans import kmeans_fit
+            vc, _, _ = kmeans_fit(vf, 5, random_state=0)
+            tc, _, _ = kmeans_fit(tf, 5, random_state=0)
+            self.all_keys.append(vc)
+            self.textual_all_keys.append(tc)
+            return
+        from sklearn.cluster import KMeans
+        vc = KMeans(n_clusters=5, random_state=0).fit(vf.cpu().numpy())
+        tc = KMeans(n_clusters=5, random_state=0).fit(tf.cpu().numpy())
         self.all_keys.append(torch.tensor(vc.cluster_centers_).to(self._device))
         self.textual_all_keys.append(torch.tensor(tc.cluster_centers_).to(self._device))
 

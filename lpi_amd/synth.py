@@ -172,3 +172,22 @@ def interact_inputs(bs: int = 2, P: int = 16, Dv: int = 96, Dt: int = 768, seed:
     """Inputs of the InteractModule fixture (tests/golden/interact.npz): visual / textual prompt rows and the weights of the scalar test loss
     sum(v_out * wv) + sum(t_out * wt), regenerated from the seed on both sides instead of being stored."""
     return {k: normal(seed, "interact." + k, (bs, P, D)) for k, D in (("visual_in", Dv), ("textual_in", Dt), ("wv", Dv), ("wt", Dt))}
+
+
+KMEANS_SEED = 20240707
+
+
+def clustering_features(n: int = 600, dim: int = 512, modes: int = 7, seed: int = KMEANS_SEED):
+    """Un-normalised synthetic features for the task-key clustering (methods/sprompt.py:370-397): a mixture of `modes` Gaussian blobs of unequal size and
+    spread around random directions — more blobs than the five KMeans centres, so that the fit has real decisions to make — regenerated from the seed on
+    both sides (the fixture tests/golden/kmeans.npz holds only the centres the imported reference found).  -> (visual [n, dim], textual [n, dim]) f32."""
+    out = []
+    for name in ("visual", "textual"):
+        g = _rng(seed, "kmeans." + name)
+        centres = g.standard_normal((modes, dim)) * 1.5
+        sizes = g.dirichlet(np.full(modes, 2.0))
+        which = g.choice(modes, size=n, p=sizes)
+        spread = 0.6 + 0.8 * g.random(modes)
+        x = centres[which] + g.standard_normal((n, dim)) * spread[which][:, None]
+        out.append(x.astype(np.float32))
+    return out[0], out[1]

@@ -314,3 +314,71 @@ def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt, category_i, category_t, t
         r = ranks[category_t == task]
         t2i[task] = [100.0 * (r < k).sum() / len(r) for k in (1, 5, 10)]
     return {"mscoco": {"i2t": i2t, "t2i": t2i}}
+
+
+# ----------------------------------------------------------------------------- task keys (KMeans)
+def kmeans_fit(X, n_clusters=5, random_state=0, max_iter=300, tol=1e-4):
+    """The fit behind the reference's task keys — ``KMeans(n_clusters=5, random_state=0).fit(features)`` (methods/sprompt.py:393-394) — restated in numpy.
+    The algorithm is a third-party dependency that is not under /root/reference: scikit-learn (unpinned by the reference; 1.7.2 in the build
+    container), `sklearn/cluster/_kmeans.py`: KMeans.fit with init='k-means++', n_init='auto' (= 1), algorithm='lloyd' —
+      * the data are centred (X -= X.mean(0)) and the centres shifted back at the end; tol = mean(var(X, 0)) * 1e-4;
+      * k-means++ seeding with 2 + int(log k) local trials per centre, driven by numpy's RandomState(random_state): choice(n, p=uniform), then per centre
+        uniform(size=trials) * potential -> searchsorted in the float64 cumulative sum of the closest squared distances -> the candidate with the
+        smallest new potential; squared distances evaluated in float64 and rounded to float32 (sklearn's float32 path upcasts in chunks);
+      * Lloyd iterations: labels = argmin_c (|c|^2 - 2 x.c) in float32, centres = means of their points, until the labels repeat (strict convergence)
+        or sum_c |c_new - c_old|^2 <= tol, then (if not strictly converged) one more labelling pass.
+    Pinned by tests/golden/kmeans.npz (the imported reference's clustering() on synthetic features).  Test infrastructure only.
+    X: [n, E] array-like (float32) -> (centers [k, E] float32, labels [n] int32, n_iter)."""
+    import numpy as np
+    X = np.array(X, dtype=np.float32, order="C", copy=True)
+    n = X.shape[0]
+    tol_ = np.mean(np.var(X, axis=0)) * tol
+    rs = np.random.RandomState(random_state)
+    w = np.ones(n, dtype=np.float32)
+    X_mean = X.mean(axis=0)
+    X -= X_mean
+
+    def sqdist(C):      # [c, n] float32: exact differences in float64, rounded once
+        d = ((C.astype(np.float64)[:, None, :] - X.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+        return np.maximum(d, 0).astype(np.float32)
+
+    trials = 2 + int(np.log(n_clusters))
+    centers = np.empty((n_clusters, X.shape[1]), dtype=np.float32)
+    cid = rs.choice(n, p=w / w.sum())
+    centers[0] = X[cid]
+    closest = sqdist(centers[0:1])
+    pot = closest @ w
+    for c in range(1, n_clusters):
+        rand_vals = rs.uniform(size=trials) * pot
+        cand = np.searchsorted(np.cumsum(w * closest, dtype=np.float64).ravel(), rand_vals.ravel())
+        np.clip(cand, None, n - 1, out=cand)
+        dc = sqdist(X[cand])
+        np.minimum(closest, dc, out=dc)
+        pots = dc @ w.reshape(-1, 1)
+        best = int(np.argmin(pots))
+        pot, closest = pots[best], dc[best:best + 1]
+        centers[c] = X[cand[best]]
+    labels, labels_old = np.full(n, -1, np.int32), np.full(n, -2, np.int32)
+    strict = False
+    for it in range(max_iter):
+        d = (centers * centers).sum(1)[None, :] - 2.0 * (X @ centers.T)          # float32, as the chunked Cython loop
+        labels = d.argmin(1).astype(np.int32)
+        new = np.zeros_like(centers)
+        cnt = np.zeros(n_clusters, dtype=np.float32)
+        np.add.at(new, labels, X)
+        np.add.at(cnt, labels, 1.0)
+        if (cnt == 0).any():
+            raise RuntimeError("empty cluster: the relocation step of scikit-learn is not restated")
+        new /= cnt[:, None]
+        shift = np.sqrt(((new - centers) ** 2).sum(1))
+        centers = new
+        if np.array_equal(labels, labels_old):
+            strict = True
+            break
+        if (shift ** 2).sum() <= tol_:
+            break
+        labels_old = labels.copy()
+    if not strict:
+        d = (centers * centers).sum(1)[None, :] - 2.0 * (X @ centers.T)
+        labels = d.argmin(1).astype(np.int32)
+    return (centers + X_mean).astype(np.float32), labels, it + 1

@@ -351,6 +351,34 @@ def eval_shard(net, cfg, n_img, caps_per_img, n_tasks):
             "itm_t2i": np.array([final_res["mscoco"]["t2i"][t] for t in range(n_tasks)])}
 
 
+def kmeans_case(n=600, dim=512):
+    """The reference's task-key clustering (methods/sprompt.py:370-397 `clustering`: un-prompted features of the task's training set, L2-normalised,
+    KMeans(n_clusters=5, random_state=0) per modality; scikit-learn as installed here) run through the IMPORTED method on synthetic features
+    (lpi_amd.synth.clustering_features): the network is a stand-in that returns rows of the feature matrices, everything else is the reference's code."""
+    from methods.sprompt import SPrompts
+    import sklearn
+    fv, ft = (torch.from_numpy(x) for x in synth.clustering_features(n, dim))
+
+    class Net:
+        def extract_vector(self, idx):
+            return fv[idx]
+
+        def extract_textual_vector(self, idx):
+            return ft[torch.as_tensor(idx)]
+
+    class Loader:
+        def __iter__(self):
+            for i in range(0, n, 128):
+                idx = torch.arange(i, min(n, i + 128))
+                yield idx, idx.tolist(), None, None
+
+    sp = object.__new__(SPrompts)
+    sp._network, sp._device, sp.all_keys, sp.textual_all_keys = Net(), torch.device("cpu"), [], []
+    sp.clustering(Loader())
+    return {"shape": np.array([n, dim]), "centers_visual": sp.all_keys[0].numpy(), "centers_textual": sp.textual_all_keys[0].numpy(),
+            "sklearn_version": np.array(sklearn.__version__)}
+
+
 def save(name, res, meta):
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **res)
@@ -404,6 +432,9 @@ def main():
     install_shims()
     meta["_generator"] = {"torch": torch.__version__, "numpy": np.__version__, "threads": torch.get_num_threads(),
                           "reference": "Kelvin-ywc/LPI @ 2024-12-23, retrieval/", "dtype": "float32 (CPU)"}
+
+    if a.only in (None, "kmeans"):
+        save("kmeans", kmeans_case(), meta)
 
     if a.only in (None, "tokenizer"):
         from models.clip.clip import tokenize

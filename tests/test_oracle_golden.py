@@ -176,3 +176,19 @@ def test_interact_module_oracle_vs_reference_fixture(golden):
     for name, got in [("visual_in", v.grad), ("textual_in", t.grad)] + [(k, p[k].grad) for k in p]:
         ref = torch.from_numpy(g["grad." + name]).double()
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name
+
+
+def test_oracle_kmeans_equals_the_reference_clustering(golden):
+    """oracle.kmeans_fit (a numpy restatement of scikit-learn's KMeans fit as the reference calls it, sprompt.py:393-394) against the centres the IMPORTED
+    reference's clustering() found on the synthetic features (tests/golden/kmeans.npz, generated by tests/golden/gen_golden.py --only kmeans)."""
+    import numpy as np
+    from lpi_amd import synth
+    from oracle import lpi_oracle as O
+    g = golden("kmeans")
+    n, dim = (int(x) for x in g["shape"])
+    fv, ft = synth.clustering_features(n, dim)
+    for name, f in (("visual", fv), ("textual", ft)):
+        x = f / np.linalg.norm(f, axis=-1, keepdims=True)
+        centers, labels, iters = O.kmeans_fit(x)
+        assert np.abs(centers - g["centers_" + name]).max() < 1e-6, name
+        assert labels.min() == 0 and labels.max() == 4 and iters < 50

@@ -282,10 +282,18 @@ def test_engine_and_its_workspace_are_freed_after_a_training_step():
     import gc
     from lpi_amd.engine import DualEncoder, PackedIds
     from lpi_amd.step import train_step
+    cfg = synth.TINY
+    # what a process keeps after its FIRST engine is not the engine's: the vendor BLAS handle's workspace (the weight folding at construction multiplies
+    # in f64 on the device: ~128 MB on first use) and the module-level scratch (split-K partials, loss workspace).  Build and run one engine first, so
+    # that this test measures the same thing whether it runs alone or behind the other files
+    warm = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
+    wf = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+    train_step(warm, torch.from_numpy(synth.images(64, cfg.image_resolution)).to(DEV), PackedIds(synth.token_ids(64)).to(DEV), wf, 2)
+    torch.cuda.synchronize()
+    del warm, wf
     gc.collect()
     torch.cuda.empty_cache()
     base = torch.cuda.memory_allocated()
-    cfg = synth.TINY
     enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
     fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
     img = torch.from_numpy(synth.images(64, cfg.image_resolution)).to(DEV)
@@ -297,7 +305,7 @@ def test_engine_and_its_workspace_are_freed_after_a_training_step():
     del enc, fac, img, ids, out
     gc.collect()
     assert not [o for o in gc.get_objects() if type(o).__name__ == "DualEncoder"]
-    assert torch.cuda.memory_allocated() - base < max(used // 4, 40 << 20)          # module-level caches (split-K scratch, loss workspace) stay
+    assert torch.cuda.memory_allocated() - base < max(used // 8, 8 << 20)          # the caches existed before `base`: (almost) everything comes back
 
 
 def test_slinet_takes_caption_strings_through_the_native_tokenizer(tmp_path, monkeypatch):

@@ -18,6 +18,15 @@ from lpi_amd._lib import BF16, F16, F32, call  # noqa: E402
 DEV = "cuda:0"
 
 
+@pytest.fixture(scope="module")
+def golden():
+    import os
+
+    def load(name):
+        return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"), allow_pickle=False))
+    return load
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -512,3 +521,46 @@ def test_gemm_layernorm_fold_fast_epilogue_equals_the_generic_one(cdt, tm, N, K)
         call("lpi_set_tuning", 14, 0)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
     assert bool(torch.isfinite(outs[0].float()).all())
+
+
+def test_device_kmeans_equals_the_reference_clustering_and_the_oracle(golden):
+    """lpi_amd.kmeans.kmeans_fit (HIP passes over the features, scikit-learn's seeding and convergence logic on the host) on the synthetic features of the
+    fixture: the centres the IMPORTED reference's clustering() found (sprompt.py:370-397, tests/golden/kmeans.npz) to 1e-5, the oracle's labels exactly —
+    and through the plugin's SPrompts.clustering, which normalises with lpi_l2norm_fwd."""
+    from lpi_amd.kmeans import kmeans_fit
+    from oracle import lpi_oracle as O
+    g = golden("kmeans")
+    n, dim = (int(x) for x in g["shape"])
+    feats = synth.clustering_features(n, dim)
+    n0 = _lib.launch_count()
+    for name, f in zip(("visual", "textual"), feats):
+        x = f / np.linalg.norm(f, axis=-1, keepdims=True)
+        centers, labels, iters = kmeans_fit(torch.from_numpy(x).to(DEV), 5, random_state=0)
+        oc, ol, oi = O.kmeans_fit(x)
+        assert np.abs(centers.cpu().numpy() - g["centers_" + name]).max() < 1e-5, name
+        assert np.array_equal(labels.cpu().numpy(), ol) and iters == oi, name
+    assert _lib.launch_count() - n0 >= 2 * (1 + 5 + 2)
+    with pytest.raises(_lib.LpiError):
+        kmeans_fit(torch.from_numpy(feats[0]), 5)              # host tensor: no CPU fallback
+    # ... and as the plugin calls it
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    fv, ft = (torch.from_numpy(x).to(DEV) for x in feats)
+
+    class Net:
+        def extract_vector(self, idx):
+            return fv[idx]
+
+        def extract_textual_vector(self, idx):
+            return ft[torch.as_tensor(idx, device=DEV)]
+
+    class Loader:
+        def __iter__(self):
+            for i in range(0, n, 128):
+                idx = torch.arange(i, min(n, i + 128))
+                yield idx, idx, None, None
+
+    sp = object.__new__(SPrompts)
+    sp._network, sp._device, sp.all_keys, sp.textual_all_keys, sp.args = Net(), torch.device(DEV), [], [], {}
+    sp.clustering(Loader())
+    assert np.abs(sp.all_keys[0].cpu().numpy() - g["centers_visual"]).max() < 1e-5
+    assert np.abs(sp.textual_all_keys[0].cpu().numpy() - g["centers_textual"]).max() < 1e-5
