@@ -10,7 +10,7 @@ The algorithm is scikit-learn's (a dependency of the reference that is not under
     (the reference moves them to the host with .cpu().numpy(), sprompt.py:391-392).
 The data are NOT centred here: scikit-learn centres them only to keep its |c|^2 - 2 x.c distance form accurate, and distances between points, label
 assignments and centre means are the same on the raw data (the kernels take differences directly).
-Pinned (through oracle.lpi_oracle.kmeans_fit and directly) by tests/golden/kmeans.npz: the centres the imported reference's clustering() found.
+Pinned by tests/golden/kmeans.npz: the centres the imported reference's clustering() found (tests/test_round4_gpu.py, next to the CPU restatement the tests keep).
 There is no CPU fallback: without the library or a GPU this raises.
 """
 from __future__ import annotations
