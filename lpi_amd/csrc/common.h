@@ -362,18 +362,34 @@ __device__ __forceinline__ f32x4 fast_sigmoid1702_x4(f32x4 u) {
     return f32x4{__builtin_amdgcn_rcpf(d0[0]), __builtin_amdgcn_rcpf(d0[1]), __builtin_amdgcn_rcpf(d1[0]), __builtin_amdgcn_rcpf(d1[1])};
 }
 __device__ __forceinline__ f32x4 quick_gelu_x4(f32x4 u) { return u * fast_sigmoid1702_x4(u); }
-// value and derivative from ONE sigmoid: g = u s, g' = s (1 + 1.702 u (1 - s))
+// value and derivative from ONE sigmoid: g = u s, g' = s (1 + 1.702 u (1 - s)) = s + 1.702 (g - g s): with g in hand the derivative is two
+// fused multiply-adds per element instead of three operations on u (the QuickGELU epilogue of the c_fc GEMM is bound by its vector
+// instructions: tools/isa_count.py gives 18 packed operations + 8 transcendentals per four elements before this form, 16 + 8 with it)
+// g - g s for two values as ONE packed multiply-add with the negation as an operand modifier (hipcc negates with a v_xor per element)
+__device__ __forceinline__ f32x2_t pk_g_minus_gs(f32x2_t g, f32x2_t s) {
+    f32x2_t d;
+    asm("v_pk_fma_f32 %0, %1, %2, %1 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(d) : "v"(g), "v"(s));
+    return d;
+}
+__device__ __forceinline__ f32x4 quick_gelu_grad_from(f32x4 g, f32x4 s) {
+    const f32x2_t d0 = pk_g_minus_gs((f32x2_t){g[0], g[1]}, (f32x2_t){s[0], s[1]}), d1 = pk_g_minus_gs((f32x2_t){g[2], g[3]}, (f32x2_t){s[2], s[3]});
+    return 1.702f * f32x4{d0[0], d0[1], d1[0], d1[1]} + s;
+}
 __device__ __forceinline__ void quick_gelu_both_x4(f32x4 u, f32x4& g, f32x4& dg) {
     const f32x4 s = fast_sigmoid1702_x4(u);
     g = u * s;
+#ifdef LPI_GELU_GRAD_V1      /* A/B: the round-3 expression */
     dg = s * (1.0f + (1.702f * u) * (1.0f - s));
+#else
+    dg = quick_gelu_grad_from(g, s);
+#endif
 }
 __device__ __forceinline__ f32x4 quick_gelu_grad_x4(f32x4 u) {
     const f32x4 s = fast_sigmoid1702_x4(u);
-    return s * (1.0f + (1.702f * u) * (1.0f - s));
+    return quick_gelu_grad_from(u * s, s);
 }
 __device__ __forceinline__ float quick_gelu(float u) { return u * fast_sigmoid1702(u); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
-    const float s = fast_sigmoid1702(u);
-    return s * (1.0f + 1.702f * u * (1.0f - s));
+    const float s = fast_sigmoid1702(u), g = u * s;
+    return fmaf(1.702f, fmaf(g, -s, g), s);
 }

@@ -27,6 +27,8 @@ __device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col
     if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) {
         // LayerNorm folded into the GEMM (include/lpi_hip.h): c1v = this lane's four c1 values, (ln_mu, ln_rs) = the row's mean and 1/std —
         // the caller loads them (`residual` = mean[ldr] | rstd[ldr] | c1[N]): the persistent kernel with scalar loads, eight rows at a time.
+        // ((alpha rstd) acc + (bias - (mean rstd) c1) was tried: two packed operations fewer per four elements, three more plain ones for the
+        // per-row products, which a lane uses for only four elements - no gain)
         v = (acc * alpha - ln_mu * c1v) * ln_rs + bv;
     } else {
         v = acc * alpha + bv;

@@ -57,6 +57,9 @@ def mk(M, N, K, kind):
 shapes = [("in_proj (LN fold)", Mv, 2304, 768, "qkv"), ("out_proj + res + rowstats", Mv, 768, 768, "res"), ("c_fc (LN fold) + QuickGELU", Mv, 3072, 768, "fc"),
           ("c_proj + res + rowstats", Mv, 768, 3072, "res"), ("d c_proj x gelu'", Mv, 3072, 768, "dgelu"), ("d c_fc", Mv, 768, 3072, "plain"),
           ("d out_proj", Mv, 768, 768, "plain"), ("d in_proj", Mv, 768, 2304, "plain")]
+only = os.environ.get("LPI_STAMP_ONLY")      # e.g. "dgelu": just the shapes of that kind (quick A/B runs with LPI_TUNING)
+if only:
+    shapes = [sh for sh in shapes if sh[4] in only.split(",")]
 rows = []
 for name, M, N, K, kind in shapes:
     fn = mk(M, N, K, kind)
