@@ -678,7 +678,7 @@ class Tower:
                     yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3], optional=True)
                 for ci, (r0, n) in enumerate(chunks):
                     yield GemmReq(f"{lt}.fc" + ("" if ci == 0 else f"#{ci}"), F16, xmid[r0:r0 + n], fl.w, ws["g"][r0:r0 + n], n, 4 * d, d, optional=ci > 0, bias=fl.c2,
-                                  residual=lnb[1][r0:], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u[r0:r0 + n], m_real=max(0, min(n, M - r0)))
+                                  residual=lnb[1][r0:], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=None if u is None else u[r0:r0 + n], m_real=max(0, min(n, M - r0)))
                     if len(chunks) > 1:
                         yield from proj_req(ci, r0, n)
             else:

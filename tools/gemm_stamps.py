@@ -13,15 +13,18 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lpi_amd._lib as L  # noqa: E402
-L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lpi_amd/csrc/liblpi_hip_stamps.so")
+PRODUCT = os.environ.get("LPI_STAMP_PRODUCT") == "1"      # 1: the PRODUCT library, launch times only (no stamp executes there): the table's `us_product` column
+if not PRODUCT:
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lpi_amd/csrc/liblpi_hip_stamps.so")
 from lpi_amd import engine as E  # noqa: E402
 from lpi_amd._lib import BF16, F16, EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS  # noqa: E402
 
 dev = "cuda:0"
 Mv, Mt = 54528, 11008
 lib = L.load()
-rd = lib.lpi_gemm_stamps_read
-rd.argtypes = [ctypes.c_void_p]
+if not PRODUCT:
+    rd = lib.lpi_gemm_stamps_read
+    rd.argtypes = [ctypes.c_void_p]
 buf = np.zeros((1024, 8), dtype=np.uint64)
 TD = torch.bfloat16
 torch.manual_seed(0)
@@ -73,6 +76,10 @@ for name, M, N, K, kind in shapes:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
+    if PRODUCT:
+        rows.append({"gemm": name, "M": M, "N": N, "K": K, "us_product": round(us, 1), "tflops_product": round(2.0 * M * N * K / us / 1e6, 1)})
+        print(f"{name:28s} {us:7.1f} us {rows[-1]['tflops_product']:7.1f} TF (product library)", flush=True)
+        continue
     assert rd(buf.ctypes.data) == 0
     st = buf[:256].astype(np.float64)
     tot = st[:, 0] + st[:, 1] + st[:, 2]

@@ -68,7 +68,7 @@ def main():
                         "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)",
                         "clock_ghz": "GRBM_GUI_ACTIVE / 8 / kernel duration of the same pass"},
            "kernels": {}}
-    keep = ("gemm", "attn", "ln_", "vis_", "txt_", "pool", "rows_sum", "patchify", "splitk")
+    keep = ("gemm", "attn", "ln_", "vis_", "txt_", "pool", "rows_sum", "patchify", "splitk", "row_jobs", "clip_loss", "lse_rows", "align_", "cp_", "transpose2", "sgd_step")
     order = sorted(counters, key=lambda k: -counters[k].get("FETCH_SIZE", (0, 0.0))[1])
     for k in order:
         if not k.startswith(keep):
