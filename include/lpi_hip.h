@@ -43,7 +43,7 @@ extern "C" {
                                * DERIVATIVE, evaluated here from the same sigmoid and saved for the backward                          */
 #define LPI_EPI_DQUICKGELU 2  /* C = acc * aux, aux = the derivative the forward saved          (backward of the activation)          */
 #define LPI_EPI_LN 3          /* LayerNorm FOLDED into the GEMM: A is the LayerNorm's INPUT x, B = gamma o W (columns scaled), and
-                               * C = rstd[row] * (alpha*acc - mean[row] * c1[col]) + bias[col], c1[n] = sum_k B[n,k], bias = W beta + b — i.e.
+                               * C = rstd[row] * (acc - mean[row] * c1[col]) + bias[col] (alpha must be 1: LPI_EINVAL otherwise), c1[n] = sum_k B[n,k], bias = W beta + b — i.e.
                                * LN(x) W^T + b without ever writing LN(x) (model.py:172-177: ln_1 -> attn in_proj, ln_2 -> c_fc).  `residual`
                                * carries the LN operand block (f32): mean[ldr] | rstd[ldr] | c1[N] (ldr >= M, a multiple of 4). */
 #define LPI_EPI_LN_QUICKGELU 4 /* ... followed by the QuickGELU epilogue (aux as for LPI_EPI_QUICKGELU).  Both: bf16 / f16 operands, shapes the

@@ -442,6 +442,7 @@ extern "C" int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K, const vo
 {
     const float* residual = (const float*)residual_;      // fp16 when c_dtype == LPI_F16 (re-typed in the epilogue)
     if (int e = gemm_nt_check(dtype, c_dtype, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, epilogue, aux, ldaux)) return e;
+    if ((epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) && alpha != 1.0f) return LPI_EINVAL;      // LN(x) W^T + b has no scale (the epilogue does not multiply by one)
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU || epilogue == LPI_EPI_RES_ROWSTATS) {
         // only the persistent 256x256 kernel has the LN-fold and the row-statistics epilogues
@@ -486,6 +487,7 @@ extern "C" int lpi_gemm_last_grouped(void) { return t_last_grouped; }
 
 extern "C" int lpi_gemm_nt_grouped(int dtype, int c_dtype, int epilogue, float alpha, int count, const lpi_gemm_desc* d, void* stream)
 {
+    if ((epilogue == LPI_EPI_LN || epilogue == LPI_EPI_LN_QUICKGELU) && alpha != 1.0f) return LPI_EINVAL;
     if (count <= 0 || !d) return LPI_EINVAL;
     t_last_grouped = 0;
     for (int i = 0; i < count; ++i)

@@ -419,7 +419,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                             for (int ni = 0; ni < 2; ++ni) {
                                 const int c8 = nh * 32 + wn_e * 8 + ni * 4 + lslot;
                                 f32x4 a;
-                                if constexpr (L16) a = (acc[nh][ni][mh][(p & 1) * 2 + mi2] * alpha - mug[mh][(p & 1) * 2 + mi2] * c1g[nh][ni]) * rsg[mh][(p & 1) * 2 + mi2] + c2g[nh][ni];
+                                if constexpr (L16) {      // the two multiply-adds of gemm_epilogue_store
+                                    const float nm = -mug[mh][(p & 1) * 2 + mi2], rs = rsg[mh][(p & 1) * 2 + mi2];
+                                    a = __builtin_elementwise_fma(__builtin_elementwise_fma(f32x4{nm, nm, nm, nm}, c1g[nh][ni], acc[nh][ni][mh][(p & 1) * 2 + mi2]), f32x4{rs, rs, rs, rs}, c2g[nh][ni]);
+                                }
                                 else a = acc[nh][ni][mh][(p & 1) * 2 + mi2] + 0.0f;
                                 *reinterpret_cast<uint2*>(sb + s_row * 512 + ((c8 ^ (2 * lrow)) << 3)) = uint2{pack2_t<TC>(a[0], a[1]), pack2_t<TC>(a[2], a[3])};
                             }

@@ -29,7 +29,18 @@ __device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col
         // the caller loads them (`residual` = mean[ldr] | rstd[ldr] | c1[N]): the persistent kernel with scalar loads, eight rows at a time.
         // ((alpha rstd) acc + (bias - (mean rstd) c1) was tried: two packed operations fewer per four elements, three more plain ones for the
         // per-row products, which a lane uses for only four elements - no gain)
-        v = (acc * alpha - ln_mu * c1v) * ln_rs + bv;
+        // alpha is 1 for these epilogues (lpi_gemm_nt refuses anything else): no multiply by it — one vector operation per element less in an epilogue
+        // that is bound by them.  The two multiply-adds are written out (no contraction choice left to the compiler): every instantiation rounds alike, so
+        // the forward that saves gelu' and the one that does not (evaluation) give the same bits.  The QuickGELU instantiation that saves nothing keeps an
+        // (exact) multiply by alpha = 1 in front: without it hipcc's allocation of the persistent kernel spills 40 bytes per lane there
+        // (tests/test_no_spills.py).  -DLPI_LN_ALPHA_MUL=true: the multiply everywhere (A/B).
+#ifndef LPI_LN_ALPHA_MUL
+#define LPI_LN_ALPHA_MUL false
+#endif
+        f32x4 a0 = acc;
+        if constexpr (LPI_LN_ALPHA_MUL || (EPI == LPI_EPI_LN_QUICKGELU && !SAVE_U)) a0 = acc * alpha;
+        const f32x4 nmu = f32x4{-ln_mu, -ln_mu, -ln_mu, -ln_mu}, rs4 = f32x4{ln_rs, ln_rs, ln_rs, ln_rs};
+        v = __builtin_elementwise_fma(__builtin_elementwise_fma(nmu, c1v, a0), rs4, bv);
     } else {
         v = acc * alpha + bv;
     }
