@@ -90,39 +90,36 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     # hands the buffers on without a copy ('dprompts_borrow': DecomposedPromptFn.backward consumes them at once).  Towers on lanes of their own
     # (overlap_towers) keep the plain path: the stacks are autograd roots too and autograd adds the two gradients.
     seed = not overlap_towers and SEED_GRADS
-    wss = []
-    with torch.no_grad():
-        al = {}
-        out_bufs = None
+    wss = [enc._vis_ctx[0], enc._txt_ctx[0]] if seed else []
+    try:      # the workspaces' seeding flags never outlive this step, whatever raises between the seeding and the backward
+        with torch.no_grad():
+            al = {}
+            out_bufs = enc.seed_prompt_grads(enc._vis_ctx, enc._txt_ctx) if seed else None
+
+            def align():
+                # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again below
+                al["r"] = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True, out=out_bufs)
+
+            if gather is not None and getattr(exchange, "device_collectives", False):
+                # the data-independent alignment kernel runs while the feature all-gather (issued right behind the towers) is in flight
+                g2 = lambda i, t: exchange.gather(i, t, between=align)  # noqa: E731
+                base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, g2, exchange, True)
+            else:
+                base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
+                align()
+            align, dv, dt = al["r"]
+            if w_base != 1.0:
+                dI, dT = dI * w_base, dT * w_base
         if seed:
-            out_bufs = enc.seed_prompt_grads(enc._vis_ctx, enc._txt_ctx)
-            wss = [enc._vis_ctx[0], enc._txt_ctx[0]]
-
-        def align():
-            # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again below
-            al["r"] = E.align_loss_fwd_bwd(vis.detach().float(), txt.detach().float(), 0.01, align_weight / world, True, out=out_bufs)
-
-        if gather is not None and getattr(exchange, "device_collectives", False):
-            # the data-independent alignment kernel runs while the feature all-gather (issued right behind the towers) is in flight
-            g2 = lambda i, t: exchange.gather(i, t, between=align)  # noqa: E731
-            base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, g2, exchange, True)
-        else:
-            base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
-            align()
-        align, dv, dt = al["r"]
-        if w_base != 1.0:
-            dI, dT = dI * w_base, dT * w_base
-    if seed:
-        for w in wss:
-            w["dprompts_borrow"] = True
-        try:
-            torch.autograd.backward([img_f, txt_f], [dI, dT])
-        finally:
             for w in wss:
-                w.pop("dprompts_borrow", None)
-                w.pop("dprompts_seeded", None)
-    else:
-        torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])
+                w["dprompts_borrow"] = True
+            torch.autograd.backward([img_f, txt_f], [dI, dT])
+        else:
+            torch.autograd.backward([img_f, txt_f, vis, txt], [dI, dT, dv, dt])
+    finally:
+        for w in wss:
+            w.pop("dprompts_borrow", None)
+            w.pop("dprompts_seeded", None)
     if exchange is not None:
         if gv is not None:
             exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES], flat=flat_grad)
