@@ -33,7 +33,7 @@ constexpr int STG = BUF_BYTES;            // epilogue staging = ring slot 1 (the
 constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
 // Internal epilogue kind (never in the C ABI): LPI_EPI_NONE with NO bias, alpha = 1, a 2-byte output and no residual / aux — the dgrad GEMMs of the
 // backward (d c_fc, d out_proj, d in_proj, d K/V: a fifth of the step).  The stamps of the diagnostic build (tools/gemm_stamps.py,
-// profiles/r04_gemm_stamps.json) show where a store-only epilogue's 7 600 cycles per tile go: 48 % is the f32 staging WRITE (256 KiB per tile through the
+// profiles/r04_gemm_shapes.json) show where a store-only epilogue's 7 600 cycles per tile go: 48 % is the f32 staging WRITE (256 KiB per tile through the
 // CU's ~79 B/clk ds_write_b128 path: 8 waves wait for it at the barrier behind the writes) and 14 % the barrier in front of it (the staging buffer is
 // single: a pass may not overwrite what the pass before is still reading).  With nothing to add per column or per row the accumulators can be rounded to
 // the output type BEFORE the staging: half the bytes (ds_write_b64, 32 KiB per pass), so two passes' buffers fit the staging slot (double buffer: ONE
