@@ -27,7 +27,36 @@ def _free_port():
     return p
 
 
-def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False, W=W, flat=False):
+def _device_collective_adapters(dist):
+    """The three c10d calls of dp.Exchange's DEVICE-collective branch (the one RCCL takes) on a backend that cannot move device memory: the same
+    signatures, device tensors in and out, the transport staged through the host.  With them the branch an 8-GPU run takes — device message buffers,
+    async_op calls, reduce_scatter_tensor — runs at world size 2 on one GPU (RCCL itself gives one rank per device: tests/test_dp_rccl_gpu.py)."""
+    real_ag, real_ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        assert out.is_cuda and inp.is_cuda and async_op
+        oh = torch.empty(out.shape, dtype=out.dtype)
+        real_ag(oh, inp.cpu(), group=group)
+        out.copy_(oh)
+
+    def reduce_scatter_tensor(out, inp, op=None, group=None, async_op=False):
+        assert out.is_cuda and inp.is_cuda and async_op and op == dist.ReduceOp.SUM
+        h = inp.cpu()
+        real_ar(h, op=dist.ReduceOp.SUM, group=group)
+        n, r = out.shape[0], dist.get_rank(group)
+        out.copy_(h[r * n:(r + 1) * n])
+
+    def all_reduce(t, op=None, group=None, async_op=False):
+        if not t.is_cuda:
+            return real_ar(t, op=op, group=group, async_op=async_op)
+        h = t.cpu()
+        real_ar(h, op=op, group=group)
+        t.copy_(h)
+
+    return all_gather_into_tensor, reduce_scatter_tensor, all_reduce
+
+
+def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False, W=W, flat=False, device_branch=False):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
@@ -49,8 +78,20 @@ def _worker(rank, port, q, dtype, local_loss=False, gather_with_grad=False, W=W,
         if flat:        # the factors in one flat vector, their gradients in another (optim.flatten): the all-reduce runs on it in place
             from lpi_amd.optim import flatten
             _, kw["flat_grad"], kw["grad_views"] = flatten(fac)
-        out = train_step(enc, img, ids, fac, 2, Exchange(local_loss=local_loss, gather_with_grad=gather_with_grad), **kw)
+        ex = Exchange(local_loss=local_loss, gather_with_grad=gather_with_grad)
+        if device_branch:
+            import lpi_amd.dp as dp_mod
+            ag, rs, ar = _device_collective_adapters(dist)
+            dp_mod.dist.all_gather_into_tensor, dp_mod.dist.reduce_scatter_tensor, dp_mod.dist.all_reduce = ag, rs, ar
+            ex.device_collectives = True
+            first = train_step(enc, img, ids, fac, 2, ex, **kw)      # a first step: the second one reuses the persistent message buffers
+            torch.cuda.synchronize()
+            g1 = {k: v.grad.clone() for k, v in fac.items()}
+        out = train_step(enc, img, ids, fac, 2, ex, **kw)
         torch.cuda.synchronize()
+        if device_branch:
+            assert float(first["base_loss"]) == float(out["base_loss"])
+            assert all(torch.equal(g1[k], fac[k].grad) for k in fac), "the second step through the reused message buffers differs from the first"
         if flat:
             for v, p in zip(kw["grad_views"], fac.values()):
                 assert p.grad.data_ptr() == v.data_ptr()
@@ -117,6 +158,36 @@ def test_two_process_hip_step_with_gradients_through_the_gathered_features(local
     assert abs(mean_loss - float(ref["base_loss"])) < 1e-4
     if not local_loss:
         assert all(abs(b - float(ref["base_loss"])) < 1e-4 for _, b, _, _ in res)
+
+
+@pytest.mark.parametrize("local_loss,gather_with_grad", [(False, False), (True, True), (False, True)])
+def test_two_process_device_collective_branch_equals_oracle(local_loss, gather_with_grad):
+    """The DEVICE-collective branch of dp.Exchange (device message buffers, async_op calls, all_gather_into_tensor / reduce_scatter_tensor / in-place
+    all_reduce on device tensors — what an N-GPU RCCL run executes) at WORLD SIZE 2: two processes on GPU 0 with the three c10d calls replaced by
+    host-staging adapters of the same signatures (_device_collective_adapters).  Two steps (the second reuses the persistent buffers) with flat
+    gradients; the summed factor gradients equal the oracle's on the concatenated batch, in the modes whose gradients are complete."""
+    from oracle import lpi_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q, "f32", local_loss, gather_with_grad, W, True, True)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(W)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = synth.TINY
+    ref = O.train_step(O.Oracle(cfg, synth.clip_state_dict(cfg)), synth.images(W * B, cfg.image_resolution), synth.token_ids(W * B),
+                       synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width), depth=2)
+    for rank, base, grads, img_f in res:
+        assert grads is not None, base
+        for k, g in grads.items():
+            r = ref["grad." + k]
+            assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max() + 1e-6, (rank, k)
+    assert abs(float(np.mean([b for _, b, _, _ in res])) - float(ref["base_loss"])) < 1e-4
+    for k in res[0][2]:
+        assert np.array_equal(res[0][2][k], res[1][2][k])
 
 
 @pytest.mark.parametrize("local_loss,gather_with_grad", [(False, False), (True, False), (True, True), (False, True)])
