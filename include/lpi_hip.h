@@ -188,7 +188,8 @@ int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, co
  * qkv: [B*L, 3*d] `dtype` (q | k | v, heads contiguous by 64).  ctx: [B*L, d] `dtype`.  lse: [B, H, L] f32.
  * softmax(q k^T / 8 + causal mask) v; causal != 0 applies the text tower's strict upper-triangular -inf mask
  * (model.py:347-353).  Backward recomputes P from lse; `delta` is [B,H,L] f32 SCRATCH: the kernels that make two passes over the scores
- * leave rowsum(dctx*ctx) there, the streamed single-pass backward (attention4.hip) keeps it in LDS and does not touch the buffer.
+ * leave rowsum(dctx*ctx) there, the streamed single-pass backward (attention4.hip) keeps it in LDS and does not touch the buffer at L <= 224; at
+ * 224 < L <= 288 (two key-window launches) its first launch leaves -rowsum(dctx*ctx)/8 there for the second.  The contents are unspecified after the call.
  * dqkv: [B*L, 3*d] `dtype`. L <= 288. */
 int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                  float* lse, int causal, void* stream);
