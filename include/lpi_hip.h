@@ -80,7 +80,10 @@ uint64_t lpi_launch_count(void);
  *   key 8      != 0: lpi_gemm_nt_grouped never groups (issues its problems one after the other; A/B switch, same bits).
  *   key 11     > 0: the streamed attention backward launches at most this many workgroups (tests: several heads per workgroup at small B H).
  *   key 12     A/B switches of the streamed attention backward (bit 0: K / V of the next head as one burst instead of spread over the head).
- *   keys 9, 10, 13..15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
+ *   key 13     != 0: the attention forward keeps padded (160-byte) K / V image rows where it would use the swizzled unpadded ones (Lp = 288; A/B, same bits).
+ *   key 14     1: the generic epilogue of the persistent GEMM everywhere (no half-width staging for store-only 2-byte outputs); 3: also the opt-in
+ *              half-width LayerNorm-fold epilogue (A/B switches, same bits).
+ *   keys 9, 10, 15 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */
 
