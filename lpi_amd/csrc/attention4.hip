@@ -110,9 +110,12 @@ __device__ __forceinline__ void mma(f32x4& acc, const Chunk& a, const Chunk& b) 
         asm volatile("" ::: "memory");                             \
     } while (0)
 
-// dS^T scratch: 64-byte rows (32 queries x bf16); the 8-byte slot index is XOR-ed with ((row >> 2 & 1) << 2 | (row >> 3 & 1) << 1): conflict-free
-// for the transposing reads (tools/lds_swizzle_check.py)
-__device__ __forceinline__ int ds_sw(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1); }
+// dS^T scratch: 64-byte rows (32 queries x bf16); the 8-byte slot index is XOR-ed with (row >> 2 & 1) << 2 | (row >> 3 & 1) << 1 | (row >> 1 & 1).
+// Bits 2 and 1 keep the transposing reads conflict-free (2 x 32 lanes on 64 banks: rows r and r + 4 of a half land in different slot groups); bit 0
+// (round 4) does the same for the STORES, which the LDS serves as 4 x 16 contiguous lanes on 32 banks: the 8 rows of one parity that a 16-lane group
+// writes then use 8 distinct slots — without it they shared 4 (two-way: 2.25 M extra LDS cycles per launch, profiles/r03_pmc.json; the model:
+// tools/lds_swizzle_check.py, dS^T section)
+__device__ __forceinline__ int ds_sw(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
 
 struct Args4 {
     int L, Lp, H, total;

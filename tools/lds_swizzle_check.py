@@ -42,8 +42,40 @@ def swizzled(f):
     return extra_cycles(rc, tr)
 
 
+def dst_scratch(sw):
+    """The dS^T scratch of attention4.hip: 64-byte rows ([key][32 queries] bf16), 8-byte slot index ^ sw(row).  -> (extra LDS cycles per 16-lane group of
+    the ds_write_b64 stores: 4 x 16 contiguous lanes on 32 banks; extra cycles per 32-lane half of the ds_read_b64_tr_b16 reads on 64 banks)."""
+    worst_w = worst_r = 0
+    for ug in (0, 1):
+        for t2 in (0, 1):
+            for grp in range(4):
+                banks = {}
+                for lane in range(16 * grp, 16 * grp + 16):
+                    rowb = 16 * (ug & 1) + (lane & 15)
+                    a = rowb * 64 + (((4 * t2 + (lane >> 4)) ^ sw(rowb)) << 3)
+                    for d in range(2):
+                        banks.setdefault((a // 4 + d) % 32, set()).add(a // 4 + d)
+                worst_w = max(worst_w, max(len(v) for v in banks.values()) - 1)
+    for q4 in (0, 1):
+        for hi in (0, 1):
+            for half in (0, 1):
+                banks = {}
+                for lane in range(32 * half, 32 * half + 32):
+                    row = 16 * hi + 4 * (lane >> 4) + ((lane & 15) >> 2)
+                    a = row * 64 + (((4 * q4 + (lane & 3)) ^ sw(row)) << 3)
+                    for d in range(2):
+                        banks.setdefault((a // 4 + d) % 64, set()).add(a // 4 + d)
+                worst_r = max(worst_r, max(len(v) for v in banks.values()) - 1)
+    return worst_w, worst_r
+
+
 if __name__ == "__main__":
     for RS in (128, 144, 160, 176):
         print(f"padded rows, stride {RS:3d} B: extra cycles (row fragments, transposed reads) = {padded(RS)}")
     print("128-B rows, chunk ^ (row & 6)        :", swizzled(lambda r: r & 6))
     print("128-B rows, chunk ^ ((row >> 1) & 7)  :", swizzled(lambda r: (r >> 1) & 7), "(the GEMM's swizzle: fine for row fragments only)")
+
+    print("dS^T scratch, slot ^ (b2<<2 | b3<<1)      (round 3): extra cycles (stores, transposing reads) =",
+          dst_scratch(lambda r: (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1)))
+    print("dS^T scratch, slot ^ (b2<<2 | b3<<1 | b1) (round 4): extra cycles (stores, transposing reads) =",
+          dst_scratch(lambda r: (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 1) & 1)))
