@@ -453,10 +453,11 @@ int lpi_align_loss_fwd_bwd2(int Lyr, int P, int Dv, int Dt, const float* vis, co
 
 /* ---- a9: task loss (nt_bxent over the tasks' flattened prompts)   replaces: loss/loss.py:6-33, models/slinet.py:167-183 ----
  * X f32 [T, D] (row t = prompts of task t, flattened), target int32 [T,T] (task_sim > 0.4), T <= 32.  loss[0] = weight * nt_bxent(X);
- * dx_row [D] = d loss / d X[row,:] (only the current task's prompts train; NULL or row < 0: forward only).
+ * dx_row [D] = d loss / d X[row,:] (only the current task's prompts train; NULL or row < 0: forward only); accumulate != 0: ADDED to what dx_row
+ * holds (the fused training step adds the task term onto the alignment gradient already sitting in the towers' prompt-gradient buffers).
  * scratch: 2*T*T floats. */
 int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const int32_t* target, float temp, float weight,
-                         float* loss, float* dx_row, float* scratch, void* stream);
+                         float* loss, float* dx_row, int accumulate, float* scratch, void* stream);
 
 /* ---- misc ---------------------------------------------------------------------------------------------- */
 int lpi_cast(int src_dtype, int dst_dtype, long n, const void* src, void* dst, void* stream);
@@ -495,6 +496,11 @@ int lpi_interact_bwd(int N, int Dv, int Dt, int R, int Lyr, int layer, const flo
                      const float* d3_t2v, const float* gamma_v, const float* beta_v, const float* gamma_t, const float* beta_t, float mix,
                      float eps, const float* g_out_v, int ldgv, const float* g_out_t, int ldgt, float* dxv, int lddv, float* dxt, int lddt,
                      float* grads, float* workspace, void* stream);
+
+/* ---- host side: batch assembly for the input pipeline      replaces: the DataLoader's default_collate (torch.stack of the decoded images) + the pageable
+ * `images.cuda()` copy of methods/sprompt.py:166-167, 301.  HOST pointers, no stream: dst[i * bytes_each ..] = srcs[i][0 .. bytes_each) for i < n on
+ * `threads` host threads (dst: the pinned staging buffer the H2D DMA reads; 154 MB of f32 pixels per 256-pair step).  lpi_amd/pipeline.py. */
+int lpi_host_gather(void* dst, const void* const* srcs, int n, long bytes_each, int threads);
 
 void* lpi_bpe_create(const char* merges_utf8, long nbytes);
 void lpi_bpe_destroy(void* handle);

@@ -70,7 +70,7 @@ SIGNATURES = {
     "lpi_prompt_cp_fwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P],
     "lpi_prompt_cp_bwd": [_I, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P, _P],
     "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
-    "lpi_nt_bxent_fwd_bwd": [_I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
+    "lpi_nt_bxent_fwd_bwd": [_I, _I, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P],
     "lpi_patchify": [_I, _I, _I, _I, _P, _P, _I, _P],
     "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "lpi_vis_assemble_bwd": [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
@@ -109,7 +109,8 @@ SIGNATURES = {
     "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],
     "lpi_retrieval_rank": [_I, _I, _P, _I, _P, _I, _P, _P],
     "lpi_topk": [_I, _I, _I, _P, _I, _P, _P, _P],
-    # host-side BPE tokenizer (a6)
+    # host side: batch assembly of the input pipeline (pipeline.py), BPE tokenizer (a6)
+    "lpi_host_gather": [_P, _P, _I, _L, _I],
     "lpi_bpe_create": [_P, _L],
     "lpi_bpe_destroy": [_P],
     "lpi_interact_workspace_floats": [_I, _I, _I, _I],
@@ -123,7 +124,8 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 401
+EXPECTED_ABI = 500
+VARIANT_OFFSET = 1000000      # lpi_version() of a tools/build_variant.sh build = EXPECTED_ABI + this
 
 _lib = None
 
@@ -150,6 +152,11 @@ def load() -> ctypes.CDLL:
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
     got = int(lib.lpi_version())
+    if got == EXPECTED_ABI + VARIANT_OFFSET and os.path.abspath(LIB_PATH) != os.path.join(_HERE, "csrc", "liblpi_hip.so"):
+        # a diagnostic / ablation build (tools/build_variant.sh) of THIS ABI, asked for by name (LPI_LIB / a tool's LIB_PATH): never picked up silently
+        import sys
+        print(f"lpi_amd: loaded the VARIANT library {LIB_PATH} (diagnostic build; not the product library)", file=sys.stderr)
+        got = EXPECTED_ABI
     if got != EXPECTED_ABI:
         raise LpiError(f"{LIB_PATH} has C-ABI version {got}, this binding expects {EXPECTED_ABI}: rebuild it (lpi_amd/csrc/build.sh)")
     _lib = lib

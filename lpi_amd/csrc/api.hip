@@ -6,7 +6,16 @@ static std::atomic<uint64_t> g_launches{0};
 
 extern "C" void lpi_count_launch() { g_launches.fetch_add(1, std::memory_order_relaxed); }
 extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
-extern "C" int lpi_version(void) { return 401; }      // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI)
+// bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI).  Diagnostic / ablation builds (tools/build_variant.sh)
+// report LPI_ABI_VERSION + 1 000 000: the binding loads such a library only when LPI_LIB names it, and says so on stderr.
+#ifndef LPI_ABI_VERSION
+#define LPI_ABI_VERSION 500
+#endif
+#ifdef LPI_VARIANT_BUILD
+extern "C" int lpi_version(void) { return LPI_ABI_VERSION + 1000000; }
+#else
+extern "C" int lpi_version(void) { return LPI_ABI_VERSION; }
+#endif
 
 // CU count of the CURRENT device (the persistent kernels launch one workgroup per CU), looked up once per device; safe from any host thread (a cached
 // value is written once, every writer writes the same one)

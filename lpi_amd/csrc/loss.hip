@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void nt_bxent_kernel(int T, const float* __rest
 
 // dX[r,:] = sum_j (dcos[r,j] + dcos[j,r]) * ( x_j / (|x_r||x_j|) - cos_rj * x_r / |x_r|^2 )   for one row r
 __global__ __launch_bounds__(256) void nt_bxent_dx_kernel(int T, int D, int r, const float* __restrict__ X, const float* __restrict__ G,
-                                                         const float* __restrict__ dcos, float* __restrict__ dx) {
+                                                         const float* __restrict__ dcos, float* __restrict__ dx, int accumulate) {
     const int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= D) return;
     const float nr = fmaxf(sqrtf(G[r * T + r]), 1e-8f);
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void nt_bxent_dx_kernel(int T, int D, int r, c
         const float w = dcos[r * T + j] + dcos[j * T + r];
         acc += w * (X[(size_t)j * D + d] / (nr * nj) - c * xr / (nr * nr));
     }
-    dx[d] = acc;
+    dx[d] = accumulate ? dx[d] + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------------- task keys: KMeans (methods/sprompt.py:370-397)
@@ -908,13 +908,13 @@ extern "C" int lpi_align_loss_fwd_bwd2(int Lyr, int P, int Dv, int Dt, const flo
 }
 
 extern "C" int lpi_nt_bxent_fwd_bwd(int T, int D, int row, const float* X, const int32_t* target, float temp, float weight, float* loss,
-                                    float* dx_row, float* scratch, void* stream) {
+                                    float* dx_row, int accumulate, float* scratch, void* stream) {
     if (!X || !target || !loss || !scratch || T <= 0 || T > MAXT || D <= 0 || temp <= 0.f || row >= T) return LPI_EINVAL;
     float* G = scratch;            // [T*T]
     float* dcos = scratch + T * T; // [T*T]
     LPI_LAUNCH(gram_kernel, dim3(T * T), dim3(256), 0, S(stream), T, D, X, G);
     LPI_LAUNCH(nt_bxent_kernel, dim3(1), dim3(64), 0, S(stream), T, G, target, temp, weight, loss, dcos);
-    if (dx_row && row >= 0) LPI_LAUNCH(nt_bxent_dx_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), T, D, row, X, G, dcos, dx_row);
+    if (dx_row && row >= 0) LPI_LAUNCH(nt_bxent_dx_kernel, dim3((D + 255) / 256), dim3(256), 0, S(stream), T, D, row, X, G, dcos, dx_row, accumulate);
     LPI_CHECK_LAST();
     return 0;
 }

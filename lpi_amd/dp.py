@@ -19,6 +19,29 @@ import torch
 import torch.distributed as dist
 
 
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenation over ranks of the row blocks t [n_r, E] (n_r may differ per rank: the last shard of a DistributedSampler without drop_last, or
+    shards of a dataset whose size is not a multiple of W).  Two collectives: the row counts, then ONE all_gather_into_tensor of the blocks padded to the
+    largest — device to device on RCCL; staged through the host (as tensors, not pickles) where the backend cannot move device memory.  Used by the
+    task-key clustering (methods/sprompt.py:370-397 under data parallelism: every rank clusters the features of all shards)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    on_dev = dist.get_backend(group) == "nccl" or not t.is_cuda
+    w = t if on_dev else t.cpu()
+    counts = torch.zeros(world, dtype=torch.int64, device=w.device)
+    mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=w.device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts = [int(c) for c in counts.cpu()]
+    nmax = max(counts)
+    pad = torch.zeros(nmax, t.shape[1], dtype=w.dtype, device=w.device)
+    pad[:t.shape[0]].copy_(w)
+    out = torch.empty(world * nmax, t.shape[1], dtype=w.dtype, device=w.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    rows = torch.cat([out[r * nmax:r * nmax + c] for r, c in enumerate(counts)], 0)
+    return rows.to(t.device)
+
+
 class Exchange:
     def __init__(self, group=None, timing: bool = False, local_loss: bool = False, gather_with_grad: bool = False):
         """local_loss / gather_with_grad: the modes of the reference's gather_features / get_logits (sprompt.py:38-82, 272-288),

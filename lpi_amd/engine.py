@@ -1103,6 +1103,12 @@ class PackedIds:
         self.on(device)
         return self
 
+    def record_stream(self, stream):
+        """The device arrays were allocated on the stream that uploaded them (lpi_amd.pipeline: a side stream); tell the allocator who else reads them."""
+        for t in (self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev):
+            if t is not None:
+                t.record_stream(stream)
+
     def slice(self, lo, hi):
         """The sub-batch of samples lo .. hi-1 (data-parallel shards, micro-batches)."""
         return PackedIds(self.ids[lo:hi])

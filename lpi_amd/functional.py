@@ -204,7 +204,7 @@ class NtBxentFn(torch.autograd.Function):
         dx = torch.empty(D, device=X.device) if need else None
         scratch = torch.empty(2 * T * T, device=X.device)
         E.call("lpi_nt_bxent_fwd_bwd", T, D, int(row) if need else -1, Xc, target.to(device=X.device, dtype=torch.int32).contiguous(),
-               float(temp), 1.0, loss, dx, scratch, E._stream())
+               float(temp), 1.0, loss, dx, 0, scratch, E._stream())
         ctx.row, ctx.shape = int(row), (T, D)
         if need:
             ctx.save_for_backward(dx)

@@ -13,7 +13,11 @@ What changed, and why:
     image_root exists) or 'synthetic' (default when image_root is missing: COCO is not available offline; loaders with the same
     item structure);
   * the KMeans task keys (sprompt.py:370-397) are fitted on the GPU (lpi_amd/kmeans.py: scikit-learn's algorithm, the features stay in HBM;
-    args['kmeans_impl'] = 'sklearn' keeps the reference's host call).
+    args['kmeans_impl'] = 'sklearn' keeps the reference's host call);
+  * the hot loop runs the step FUSED (SliNet.train_step: forward -> losses -> backward in one call, the loss kernels seed the backward) on batches an
+    input pipeline prepared one step ahead (lpi_amd/pipeline.py: pinned staging, H2D on a side stream, tokenisation off the critical path) and never
+    synchronises the host with the device inside an epoch except where it prints the loss (every 50 batches; the reference calls loss.item() every
+    step, sprompt.py:313).  args['fused_step'] = False / args['prefetch'] = False give the reference-shaped loop (net(...) -> cal_loss -> backward).
 """
 import collections
 import json
@@ -31,6 +35,26 @@ from lpi_amd.retrieval.loss.loss import ClipLoss
 from lpi_amd.retrieval.methods.base import BaseLearner
 from lpi_amd.retrieval.models.slinet import SliNet
 from lpi_amd.retrieval.utils.data import SyntheticCoco, SyntheticCocoEval
+
+
+class LossLog:
+    """The per-key AverageMeters of the hot loop (sprompt.py:294-323) without a device synchronisation or an arithmetic kernel per step: the step's loss
+    tensors are only REFERENCED here and averaged when the line is printed."""
+
+    def __init__(self):
+        self.items = collections.defaultdict(list)
+
+    def add(self, losses):
+        for k, v in losses.items():
+            self.items[k].append(v)
+
+    def flush(self):
+        out = {}
+        for k, vs in self.items.items():
+            vals = [sum(float(p) for p in v) if isinstance(v, (tuple, list)) else float(v) for v in vs]
+            out[k] = sum(vals) / max(1, len(vals))
+        self.items.clear()
+        return out
 
 
 class AverageMeter(object):
@@ -113,15 +137,37 @@ class SPrompts(BaseLearner):
             if _dist_world() > 1:
                 from torch.utils.data.distributed import DistributedSampler
                 sampler = DistributedSampler(train_dataset, shuffle=True, drop_last=True)
+            # single-process loading: the images stay a list and the pipeline gathers them straight into pinned memory (one copy); with worker
+            # processes the batch arrives stacked in shared memory and the pipeline's gather is its pinning copy (no pin_memory thread needed)
+            from lpi_amd.retrieval.utils.data import collate_keep_images
             self.train_loader = DataLoader(train_dataset, batch_size=self.batch_size, shuffle=sampler is None, sampler=sampler,
-                                           num_workers=self.num_workers, drop_last=sampler is not None)
-            self.test_loader = DataLoader(test_dataset, batch_size=128, shuffle=False, num_workers=self.num_workers)
+                                           num_workers=self.num_workers, drop_last=sampler is not None,
+                                           collate_fn=collate_keep_images if self.num_workers == 0 else None,
+                                           persistent_workers=self.num_workers > 0)
+            self.test_loader = DataLoader(test_dataset, batch_size=128, shuffle=False, num_workers=self.num_workers, pin_memory=True)
             final_res[i] = self._train(self.train_loader, self.test_loader)
         self.final_res = final_res
         if _dist_rank() == 0:       # every rank holds the same keys and evaluates the same test set: one writer
             os.makedirs('./res', exist_ok=True)
             # the evaluation-transform choice travels with the numbers (utils/data.py CocoEval: 'center' | 'reference')
             self.save_dict({**final_res, 'eval_transform': self.args.get('eval_transform', 'center')}, f'./res/{datetime.now()}.json')
+
+    def state_dict(self):
+        """What a continual run carries from task to task besides the frozen backbone (the reference's BaseLearner.save_checkpoint,
+        methods/base.py:57-63, is never called and saves the whole network): the prompt factors, numtask, the KMeans task keys of both modalities."""
+        return {"network": self._network.trainable_state_dict(), "cur_id": self.cur_id,
+                "all_keys": [k.detach().float().cpu() for k in self.all_keys],
+                "textual_all_keys": [k.detach().float().cpu() for k in self.textual_all_keys]}
+
+    def load_state_dict(self, sd):
+        self._network.load_trainable_state_dict(sd["network"])
+        self.cur_id = int(sd.get("cur_id", self.cur_id))
+        self.all_keys = [k.to(self._device) for k in sd["all_keys"]]
+        self.textual_all_keys = [k.to(self._device) for k in sd["textual_all_keys"]]
+        return self
+
+    def save_checkpoint(self, filename):
+        torch.save(self.state_dict(), '{}_{}.pkl'.format(filename, self.cur_id))      # the reference's file name pattern (base.py:63)
 
     def save_dict(self, dictionary, file_path):
         with open(file_path, 'w') as file:
@@ -156,35 +202,59 @@ class SPrompts(BaseLearner):
         return self.train_function(train_loader, test_loader, optimizer, scheduler)
 
     # ------------------------------------------------------------------ sprompt.py:290-334 (hot loop)
-    def train_function(self, train_loader, test_loader, optimizer, scheduler):
-        loss_meter = collections.defaultdict(AverageMeter)
+    def _batches(self, train_loader):
+        """The epoch's batches as objects with .images / .text on the device.  Default: lpi_amd.pipeline.BatchPipeline (batch i+1 gathered into pinned
+        memory, tokenised and copied on a side stream while batch i trains); args['prefetch'] = False: the reference's order — `images.cuda()` and the
+        tokenizer inside the step (sprompt.py:301-303)."""
         net = self._network
+        if self.args.get("prefetch", True) and torch.device(self._device).type == "cuda":
+            from lpi_amd.pipeline import BatchPipeline
+            pipe = getattr(self, "_pipeline", None)
+            if pipe is None or pipe.loader is not train_loader:
+                pipe = self._pipeline = BatchPipeline(train_loader, self._device, net.prepare_text, depth=int(self.args.get("prefetch_depth", 3)),
+                                                      threads=int(self.args.get("prefetch_threads", 8)), timing=bool(self.args.get("pipeline_timing", False)))
+            return iter(pipe)
+
+        def plain():
+            from types import SimpleNamespace
+            for item in train_loader:
+                images, captions = item[0], item[1]
+                if not torch.is_tensor(images):
+                    images = torch.stack(list(images))
+                yield SimpleNamespace(images=images.to(self._device, non_blocking=True), text=captions if torch.is_tensor(captions) else list(captions))
+        return plain()
+
+    def train_function(self, train_loader, test_loader, optimizer, scheduler):
+        log = LossLog()
+        net = self._network
+        fused = bool(self.args.get("fused_step", True)) and torch.device(self._device).type == "cuda"
+        flat_grad, grad_views = getattr(optimizer, "flat_grad", None), getattr(optimizer, "grad_views", None)
         for epoch in range(self.run_epoch):
             net.train()
             if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
                 train_loader.sampler.set_epoch(epoch)          # DistributedSampler: a new shuffle every epoch
-            for i, (images, captions, _, _) in enumerate(train_loader):
-                images = images.to(self._device, non_blocking=True)
-                captions = captions if torch.is_tensor(captions) else list(captions)
-                image_features, text_features, visual_prompt, textual_prompt = net(images, captions)
-                model_out = net.cal_loss(image_features, text_features, visual_prompt, textual_prompt)
-                world = net.exchange.world if net.exchange is not None else 1
-                # data-independent terms are identical on every rank: count them once under the SUM all-reduce
-                bw = net.exchange.loss_weight if net.exchange is not None else 1.0
-                loss = sum(v * bw if k == "base_loss" else v / world for k, v in model_out['loss'].items())
-                optimizer.zero_grad()
-                loss.backward()
-                if net.exchange is not None:
-                    net.exchange.allreduce_grads([p for p in net.parameters() if p.requires_grad])
+            for i, batch in enumerate(self._batches(train_loader)):
+                if fused:
+                    # forward -> cal_loss -> sum -> backward (sprompt.py:303-310) in one call; data parallel: the all-gather / all-reduce are inside it
+                    model_out = net.train_step(batch.images, batch.text, flat_grad=flat_grad, grad_views=grad_views)
+                else:
+                    image_features, text_features, visual_prompt, textual_prompt = net(batch.images, batch.text)
+                    model_out = net.cal_loss(image_features, text_features, visual_prompt, textual_prompt)
+                    world = net.exchange.world if net.exchange is not None else 1
+                    # data-independent terms are identical on every rank: count them once under the SUM all-reduce
+                    bw = net.exchange.loss_weight if net.exchange is not None else 1.0
+                    loss = sum(v * bw if k == "base_loss" else v / world for k, v in model_out['loss'].items())
+                    optimizer.zero_grad()
+                    loss.backward()
+                    if net.exchange is not None:
+                        net.exchange.allreduce_grads([p for p in net.parameters() if p.requires_grad])
                 optimizer.step()
-                for k, v in model_out['loss'].items():
-                    loss_meter[k].update(v.detach())
+                log.add({k: (v.detach() if torch.is_tensor(v) else v) for k, v in model_out['loss'].items()})
                 if i % 50 == 0:
                     info = 'Task {}, Epoch {}/{}, Batch {}, lr {:.4f} =>, '.format(
                         self.cur_id, epoch + 1, self.run_epoch, i, optimizer.param_groups[0]["lr"])
-                    for k, v in loss_meter.items():
-                        info += '{} = {:.4f}, '.format(k, float(v.avg))
-                        v.reset()
+                    for k, v in log.flush().items():         # the one place of the loop where the host waits for the device
+                        info += '{} = {:.4f}, '.format(k, v)
                     logging.info(info)
             scheduler.step()
         self.clustering(dataloader=train_loader)
@@ -217,22 +287,26 @@ class SPrompts(BaseLearner):
         if impl not in ("hip", "sklearn"):
             raise ValueError(f"unknown kmeans_impl {impl!r} (hip | sklearn)")
         vf, tf = [], []
-        s = torch.cuda.current_stream().cuda_stream
-        for inputs, captions, _, _ in dataloader:
+        for item in dataloader:
+            inputs, captions = item[0], item[1]
+            if not torch.is_tensor(inputs):
+                inputs = torch.stack(list(inputs))
             with torch.no_grad():
-                v = self._network.extract_vector(inputs.to(self._device)).float().contiguous()
-                t = self._network.extract_textual_vector(captions if torch.is_tensor(captions) else list(captions)).float().contiguous()
-            for f, acc in ((v, vf), (t, tf)):      # v / v.norm(dim=-1, keepdim=True): lpi_l2norm_fwd
+                v = self._network.extract_vector(inputs.to(self._device))
+                t = self._network.extract_textual_vector(captions if torch.is_tensor(captions) else list(captions))
+            if impl == "sklearn":      # the reference's lines verbatim (sprompt.py:380-388): torch normalisation, host features
+                vf.append((v / v.norm(dim=-1, keepdim=True)).cpu())
+                tf.append((t / t.norm(dim=-1, keepdim=True)).cpu())
+                continue
+            s = torch.cuda.current_stream().cuda_stream
+            for f, acc in ((v.float().contiguous(), vf), (t.float().contiguous(), tf)):      # v / v.norm(dim=-1, keepdim=True): lpi_l2norm_fwd
                 o, inv = torch.empty_like(f), torch.empty(f.shape[0], device=f.device)
                 _lib.call("lpi_l2norm_fwd", f.shape[0], f.shape[1], f, f.shape[1], o, f.shape[1], inv, s)
                 acc.append(o)
         vf, tf = torch.cat(vf, 0), torch.cat(tf, 0)
         if _dist_world() > 1:       # every rank clusters the features of ALL shards, so the task keys are identical everywhere
-            import torch.distributed as dist
-            parts = [None] * _dist_world()
-            dist.all_gather_object(parts, (vf.cpu().numpy(), tf.cpu().numpy()))
-            vf = torch.from_numpy(np.concatenate([p[0] for p in parts])).to(self._device)
-            tf = torch.from_numpy(np.concatenate([p[1] for p in parts])).to(self._device)
+            from lpi_amd.dp import all_gather_rows
+            vf, tf = all_gather_rows(vf), all_gather_rows(tf)      # one padded all_gather_into_tensor each: no pickling, no host trip on RCCL
         if impl == "hip":
             from lpi_amd.kmeans import kmeans_fit
             vc, _, _ = kmeans_fit(vf, 5, random_state=0)
@@ -241,8 +315,8 @@ class SPrompts(BaseLearner):
             self.textual_all_keys.append(tc)
             return
         from sklearn.cluster import KMeans
-        vc = KMeans(n_clusters=5, random_state=0).fit(vf.cpu().numpy())
-        tc = KMeans(n_clusters=5, random_state=0).fit(tf.cpu().numpy())
+        vc = KMeans(n_clusters=5, random_state=0).fit(vf.numpy())
+        tc = KMeans(n_clusters=5, random_state=0).fit(tf.numpy())
         self.all_keys.append(torch.tensor(vc.cluster_centers_).to(self._device))
         self.textual_all_keys.append(torch.tensor(tc.cluster_centers_).to(self._device))
 

@@ -3,6 +3,7 @@
 embedding lookup, the ctx splice over positions 1..n_ctx (CLASS_TOKEN_POSITION == "end") and the positional add in one
 kernel (lpi_txt_embed_fwd).  Accepts a LongTensor of ready token ids in place of the caption list (bench / tests)."""
 import torch
+from torch import nn
 
 from .simple_tokenizer import NativeTokenizer, SimpleTokenizer, tokenize
 
@@ -27,8 +28,9 @@ class cfgc(object):
     CLASS_TOKEN_POSITION = 'end'
 
 
-class PromptLearner:
-    def __init__(self, cfg, context_length=77):
+class PromptLearner(nn.Module):
+    def __init__(self, cfg, context_length=77, ctx_dim=None):
+        super().__init__()
         if cfg.CLASS_TOKEN_POSITION != "end":
             raise ValueError("only CLASS_TOKEN_POSITION='end' (every LPI config) is built")   # prompt_learner.py:155-163
         if cfg.CTXINIT:
@@ -37,6 +39,11 @@ class PromptLearner:
         self.prompt_prefix = " ".join(["X"] * self.n_ctx)
         self.context_length = context_length
         self.n_cls = None
+        if ctx_dim is not None:
+            # the module's own context vectors (prompt_learner.py:100-110: normal(std 0.02), "to be optimized"): never read on the LPI path — the ctx comes
+            # from the DecomposedPrompt (slinet.py:130) — and frozen by the trainable filter (sprompt.py:230-237); kept because they are part of the
+            # reference network's state (12 x [n_ctx, d_t] of the 149.78 M parameters trainer.py:50 logs)
+            self.ctx = nn.Parameter(torch.randn(self.n_ctx, ctx_dim) * 0.02, requires_grad=False)
 
     def token_ids(self, captions) -> torch.Tensor:
         if torch.is_tensor(captions):
@@ -45,4 +52,4 @@ class PromptLearner:
         prompts = [self.prompt_prefix + " " + c + "." for c in captions]          # prompt_learner.py:131
         return tokenize(get_tokenizer(), prompts, self.context_length)
 
-    __call__ = token_ids
+    forward = token_ids

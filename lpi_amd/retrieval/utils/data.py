@@ -31,19 +31,46 @@ def pre_caption(caption, max_words):
 
 
 class SyntheticCoco(Dataset):
-    """Training pairs of one task: N(0,1) images and random caption token ids (SURVEY.md section 8(d) recipe)."""
+    """Training pairs of one task: N(0,1) images and random captions (SURVEY.md section 8(d) recipe).
 
-    def __init__(self, n, tasks, resolution=224, seed=0):
+    captions = 'ids' (default): a caption is its row of ready token ids [77] (no tokenizer, no merge table needed); 'strings': a caption is a STRING of
+    COCO-like words (lpi_amd.synth_bpe.captions) — the item then has exactly the reference's structure (utils/data.py:376-382: f32 image, str, 0, task) and
+    the step tokenises it like PromptLearner.forward does.
+    image_pool = K > 0: the K distinct images are generated once and item i returns pool image i % K (a VIEW: the collate / pipeline copies it) — an
+    item costs nothing, so that a throughput measurement of the training loop times the loop and not numpy's generator (150 k normals per image)."""
+
+    def __init__(self, n, tasks, resolution=224, seed=0, captions="ids", image_pool=0):
+        if captions not in ("ids", "strings"):
+            raise ValueError(f"captions must be 'ids' or 'strings', not {captions!r}")
         self.n, self.tasks, self.res = n, list(tasks), resolution
-        self.ids = torch.from_numpy(synth.token_ids(n, seed=synth.TOKEN_SEED + 17 * seed))
         self.seed = seed
+        if captions == "ids":
+            self.ids = torch.from_numpy(synth.token_ids(n, seed=synth.TOKEN_SEED + 17 * seed))
+            self.captions = None
+        else:
+            from lpi_amd.synth_bpe import captions as make
+            self.ids, self.captions = None, make(n, seed=synth.TOKEN_SEED + 17 * seed)
+        k = min(int(image_pool), n) if image_pool else 0
+        self.pool = None if k <= 0 else torch.from_numpy(synth.normal(synth.IMAGE_SEED + seed, f"pool{k}", (k, 3, resolution, resolution)))
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
-        img = torch.from_numpy(synth.normal(synth.IMAGE_SEED + self.seed, f"img{i}", (3, self.res, self.res)))
-        return img, self.ids[i], 0, self.tasks[0]
+        if self.pool is not None:
+            img = self.pool[i % self.pool.shape[0]]
+        else:
+            img = torch.from_numpy(synth.normal(synth.IMAGE_SEED + self.seed, f"img{i}", (3, self.res, self.res)))
+        return img, (self.ids[i] if self.captions is None else self.captions[i]), 0, self.tasks[0]
+
+
+def collate_keep_images(batch):
+    """default_collate for everything but the images, which stay a LIST of [3,R,R] tensors: lpi_amd.pipeline gathers them straight into its pinned staging
+    buffer (one copy, several threads) instead of torch.stack into pageable memory followed by a second copy (single-process loaders only: tensors that
+    cross a worker boundary must be stacked there)."""
+    from torch.utils.data import default_collate
+    cols = list(zip(*batch))
+    return [list(cols[0])] + [default_collate(list(c)) for c in cols[1:]]
 
 
 class SyntheticCocoEval(Dataset):

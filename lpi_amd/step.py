@@ -65,7 +65,7 @@ def forward_loss(enc, images, ids, factors: dict, depth: int = 1, gather=None, a
 
 
 def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, align_weight: float = 0.1, overlap_towers: bool = False,
-               vision_lanes: int = 1, text_lanes: int = 1, lockstep: bool = True, flat_grad=None, grad_views=None):
+               vision_lanes: int = 1, text_lanes: int = 1, lockstep: bool = True, flat_grad=None, grad_views=None, task_term=None, marks=None):
     """forward + losses + backward; leaves the gradients in factors[k].grad and returns the forward outputs.
 
     exchange: a ``dp.Exchange`` for data-parallel runs (features all-gathered for the global contrastive matrix, factor
@@ -75,13 +75,29 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
 
     The loss kernels produce the loss values AND their gradients w.r.t. features / prompts in one pass, so the towers' backward is seeded with
     those gradients directly (torch.autograd.backward on the features and the prompt stacks): no scalar loss graph, no `grad * g` kernels.  The
-    weights of the sum (sprompt.py:308: the plain sum of the dict; data parallel: see above) are host numbers folded into the seeds."""
+    weights of the sum (sprompt.py:308: the plain sum of the dict; data parallel: see above) are host numbers folded into the seeds.
+
+    task_term: callable(vis, txt, dvis_buf, dtxt_buf, weight_scale) -> loss tensor(s) — the task loss of a continual session (slinet.py:160-162, 167-183: only when
+    numtask != 1).  It is data-independent like the alignment term: it ADDS its dense gradient onto the seeded prompt-gradient buffers (needs the seeded
+    path) and is scaled by 1/W under data parallelism; its (unscaled) value comes back as out["task_loss"].
+    marks: a list that receives (name, HIP event) pairs at the phase boundaries (bench.py's split of the plugin step); None = no events.
+
+    Seeded mode hands autograd the towers' PERSISTENT prompt-gradient buffers: gradients of vis_prompt / txt_prompt must not be retained (hooks,
+    retain_grad) across this call, and no other forward may run on `enc` between this call's forward and backward (it does not: both are in here)."""
+
+    def mark(name):
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+
     for k in PROMPT_NAMES:
         factors[k].grad = None
     gather = exchange.gather if exchange is not None else None
     gv = None if grad_views is None else [grad_views[list(factors).index(k)] for k in _CP_ORDER]
     _, img_f, txt_f, vis, txt = forward_loss(enc, images, ids, factors, depth, gather, align_weight, overlap_towers, vision_lanes, text_lanes,
                                              lockstep, exchange, grad_out=gv, losses=False)
+    mark("forward")
     world = exchange.world if exchange is not None else 1
     w_base = float(getattr(exchange, "loss_weight", 1.0))
     # The alignment loss's gradient and the towers' gradient of the same prompt stacks are summed WITHOUT a sum kernel: the alignment kernel writes its
@@ -90,11 +106,16 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     # hands the buffers on without a copy ('dprompts_borrow': DecomposedPromptFn.backward consumes them at once).  Towers on lanes of their own
     # (overlap_towers) keep the plain path: the stacks are autograd roots too and autograd adds the two gradients.
     seed = not overlap_towers and SEED_GRADS
-    wss = [enc._vis_ctx[0], enc._txt_ctx[0]] if seed else []
+    if task_term is not None and not seed:
+        raise ValueError("task_term needs the seeded prompt-gradient path (one stream, LPI_SEED_GRADS=1)")
+    # the contexts of THIS call's forward (EncodeBothFn keeps them on its node; the lock-step / separate-node paths leave them on the engine)
+    vis_ctx, txt_ctx = (enc._vis_ctx, enc._txt_ctx) if seed else (None, None)
+    wss = [vis_ctx[0], txt_ctx[0]] if seed else []
+    task_out = None
     try:      # the workspaces' seeding flags never outlive this step, whatever raises between the seeding and the backward
         with torch.no_grad():
             al = {}
-            out_bufs = enc.seed_prompt_grads(enc._vis_ctx, enc._txt_ctx) if seed else None
+            out_bufs = enc.seed_prompt_grads(vis_ctx, txt_ctx) if seed else None
 
             def align():
                 # the alignment weight / W goes into the kernel: loss value and gradients come out scaled; the reported value is unscaled again below
@@ -108,9 +129,14 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
                 base, dI, dT, _ = contrastive_loss_and_grads(img_f, txt_f, enc.logit_scale_exp, gather, exchange, True)
                 align()
             align, dv, dt = al["r"]
+            if task_term is not None:      # after the alignment kernel has WRITTEN the buffers: the task term adds onto them
+                task_out = task_term(vis.detach(), txt.detach(), out_bufs[0], out_bufs[1], 1.0 / world)
             if w_base != 1.0:
                 dI, dT = dI * w_base, dT * w_base
+        mark("losses")
         if seed:
+            if vis_ctx[8] != enc.vis.serial or txt_ctx[8] != enc.txt.serial:
+                raise RuntimeError("train_step: another forward ran on this engine between the step's forward and its backward")
             for w in wss:
                 w["dprompts_borrow"] = True
             torch.autograd.backward([img_f, txt_f], [dI, dT])
@@ -120,11 +146,15 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
         for w in wss:
             w.pop("dprompts_borrow", None)
             w.pop("dprompts_seeded", None)
+    mark("backward")
     if exchange is not None:
         if gv is not None:
             exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES], flat=flat_grad)
         else:
             exchange.allreduce_grads([factors[k] for k in PROMPT_NAMES])
     align_out = align[0] if world == 1 else align[0] * float(world)
-    return {"img_f": img_f.detach(), "txt_f": txt_f.detach(), "vis_prompt": vis.detach(), "txt_prompt": txt.detach(),
-            "base_loss": base[0], "alignment_loss": align_out}
+    out = {"img_f": img_f.detach(), "txt_f": txt_f.detach(), "vis_prompt": vis.detach(), "txt_prompt": txt.detach(),
+           "base_loss": base[0], "alignment_loss": align_out}
+    if task_out is not None:
+        out["task_loss"] = task_out
+    return out

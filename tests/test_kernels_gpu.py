@@ -423,7 +423,7 @@ def test_nt_bxent_task_loss():
     loss = torch.zeros(1, device=DEV)
     dx = torch.zeros(D, device=DEV)
     scratch = torch.zeros(2 * T * T, device=DEV)
-    call("lpi_nt_bxent_fwd_bwd", T, D, row, X.to(DEV), tgt.to(DEV), temp, 1.0, loss, dx, scratch, stream())
+    call("lpi_nt_bxent_fwd_bwd", T, D, row, X.to(DEV), tgt.to(DEV), temp, 1.0, loss, dx, 0, scratch, stream())
     assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
     assert relerr(dx, Xr.grad[row]) < 1e-4
 

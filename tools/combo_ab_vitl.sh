@@ -8,7 +8,7 @@ A="--model ViT-L/14 --batch 512 --depth 12 --rank 8 --steps 6 --warmup 2 --no-cp
 for rep in $(seq 1 $reps); do
   for cfg in "${cfgs[@]}"; do
     set -- $cfg; v=$1; shift; e="$*"
-    lib=$R/lpi_amd/csrc/liblpi_hip.so; [ "$v" != base ] && lib=$R/lpi_amd/csrc/liblpi_hip_$v.so
+    lib=$R/lpi_amd/csrc/liblpi_hip.so; [ "$v" != base ] && lib=$R/lpi_amd/csrc/variants/liblpi_hip_$v.so
     env LPI_LIB=$lib $e timeout -k 10 300 python3 "$R/bench.py" $A 2>/dev/null | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%40s: %.3f ms  %.0f pairs/s' % ('$cfg', r['ms_per_step'], r['value']), flush=True)"

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lpi_amd._lib as L  # noqa: E402
 PRODUCT = os.environ.get("LPI_STAMP_PRODUCT") == "1"      # 1: the PRODUCT library, launch times only (no stamp executes there): the table's `us_product` column
 if not PRODUCT:
-    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lpi_amd/csrc/liblpi_hip_stamps.so")
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lpi_amd/csrc/variants/liblpi_hip_stamps.so")
 from lpi_amd import engine as E  # noqa: E402
 from lpi_amd._lib import BF16, F16, EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS  # noqa: E402
 

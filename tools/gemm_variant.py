@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time (and fingerprint) the eight vision-layer GEMMs of the bench with an alternate build of the library:
-   python tools/gemm_variant.py base|<suffix>      (suffix -> lpi_amd/csrc/liblpi_hip_<suffix>.so)
+   python tools/gemm_variant.py base|<suffix>      (suffix -> lpi_amd/csrc/variants/liblpi_hip_<suffix>.so)
 Used for A/B-ing kernel variants compiled with -D switches; each variant runs in its own process."""
 import hashlib
 import os
@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.getcwd())
 import lpi_amd._lib as L  # noqa: E402
 if sys.argv[1] != "base":
-    L.LIB_PATH = os.path.join(os.getcwd(), "lpi_amd/csrc/liblpi_hip_%s.so" % sys.argv[1])
+    L.LIB_PATH = os.path.join(os.getcwd(), "lpi_amd/csrc/variants/liblpi_hip_%s.so" % sys.argv[1])
 from lpi_amd import engine as E  # noqa: E402
 from lpi_amd._lib import BF16, F32, call  # noqa: E402
 
