@@ -31,6 +31,9 @@ The JSON line carries, besides the driver's contract keys:
   eval_path    : (N = 1) the reference's evaluation path per batch (task-id pass, L1 task selection, per-sample prompted forward), images/s and
                  captions/s, and the score matrix + ranks at COCO 5k-test size;
   f16_mode     : (N = 1) the same step with fp16 MFMA operands in the forward (the reference's arithmetic type): 4x lower logit error;
+  plugin_step  : (N = 1) the reference's real caller loop — SPrompts.train_epoch (methods/sprompt.py:290-334) built from configs/lpi/coco_lpi.json, fed by a
+                 DataLoader over a synthetic Coco that yields HOST f32 images and caption STRINGS: H2D copy, tokenisation, forward, losses, backward, SGD
+                 step; pairs/s from the wall clock around K loop iterations, its ratio to the bare step (`value`) and the split of a step;
   collectives  : (N > 1) mean microseconds of the feature all-gather and the factor-gradient all-reduce per step;
   cpu_baseline : the oracle (oracle/lpi_oracle.py, "port") timed on this host's cores on a bounded bs=8 sample, thread count swept.
 """
@@ -456,6 +459,92 @@ def run_record(a, dev, proc_rank, sync, dtype, fwd_only, steps, warm, roofline=T
     return rec
 
 
+def plugin_step(a, dev, sync, steps=60, warm=10, **over):
+    """The plugin's hot loop as the reference's caller runs it (methods/sprompt.py:290-334: DataLoader batch -> images.cuda() -> SliNet.forward on caption
+    strings -> cal_loss -> backward -> optimizer.step), timed like every other record: wall clock around exactly `steps` iterations of SPrompts.train_epoch,
+    synchronised on both sides.  The dataset yields host f32 images (views of a pool of 512 distinct N(0,1) images: generating 150 k normals per item
+    would time numpy) and caption strings; tokenisation uses CLIP's merge table if the box has one, else a synthetic table of the same format."""
+    import gc
+    import numpy as np
+    import torch
+    from torch.utils.data import DataLoader
+    from lpi_amd import _lib
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    from lpi_amd.retrieval.utils.data import SyntheticCoco, collate_keep_images
+    from lpi_amd.synth_bpe import ensure_vocab
+    vocab = ensure_vocab()
+    gc.collect()
+    torch.cuda.empty_cache()
+    B = a.batch
+    args = json.load(open(os.path.join(REPO, "lpi_amd", "retrieval", "configs", "lpi", "coco_lpi.json")))
+    args.update(device=[dev], compute_dtype=a.dtype, honor_prompt_depth=True, prompt_depth=a.depth, batch_size=B, epochs=1, num_workers=0, r=a.rank,
+                backbonename=a.model, pipeline_timing=True)
+    args.update(over)
+    m = SPrompts(args)
+    net = m._network
+    net.update_fc(0)                                            # task 0 (numtask = 1), as incremental_train does
+    ds = SyntheticCoco((steps + warm + 8) * B, [0], net.clip_cfg.image_resolution, seed=0, captions="strings", image_pool=512)
+    loader = DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
+    optimizer, _ = m._setup_training()
+    t, host, h2d, rows = {}, [], [], []
+
+    def on_step(i, batch, out):
+        if i == warm - 1:
+            sync()
+            t["n0"] = _lib.launch_count()
+            t["t0"] = time.perf_counter()
+        elif i >= warm:
+            if hasattr(batch, "host_ms"):
+                host.append(batch.host_ms)
+                h2d.append(batch.h2d)
+                rows.append(getattr(batch.text, "rows", 0))
+            if i == warm + steps - 1:
+                t["n1"] = _lib.launch_count()
+                sync()
+                t["t1"] = time.perf_counter()
+                return True
+        return False
+
+    m.train_epoch(loader, optimizer, 0, None, on_step)
+    el = t["t1"] - t["t0"]
+    rec = {"dtype": a.dtype, "value": round(B * steps / el, 2), "unit": "pairs/s", "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * el / steps, 3),
+           "launches_per_step": (t["n1"] - t["n0"]) // steps,
+           "loop": "SPrompts.train_epoch: " + ("BatchPipeline (pinned staging, side-stream H2D, tokenise ahead) + fused SliNet.train_step + FlatSGD"
+                                               if args.get("prefetch", True) else "images.to(device) + net(images, captions) -> cal_loss -> backward + FlatSGD (reference order)"),
+           "input": f"DataLoader(SyntheticCoco: host f32 images [3,{net.clip_cfg.image_resolution},{net.clip_cfg.image_resolution}] from a pool of 512, caption strings), bs={B}, "
+                    "num_workers=0", "bpe_table": "synthetic" if "lpi_synthetic_bpe" in vocab else "clip"}
+    if host:
+        rec["producer_ms_per_batch"] = {k: round(float(np.mean([h[k] for h in host])), 3) for k in host[0]}
+        rec["producer_ms_per_batch"]["total_without_waits"] = round(sum(v for k, v in rec["producer_ms_per_batch"].items() if k not in ("slot_wait",)), 3)
+        rec["h2d_ms_per_batch"] = round(float(np.mean([e0.elapsed_time(e1) for e0, e1 in h2d if e0 is not None])), 3)
+        rec["h2d_bytes_per_batch"] = B * 3 * net.clip_cfg.image_resolution ** 2 * 4
+        rec["text_rows_computed"] = round(float(np.mean(rows)) / B, 2)
+    # the split of one step on the device (HIP events at the phase boundaries of a few more steps, on the loop's own batches)
+    marks_all = []
+    it = iter(DataLoader(ds, batch_size=B, shuffle=False, num_workers=0))
+    for _ in range(5):
+        img, caps = next(it)[:2]
+        img = img.to(dev)
+        ids = net.prepare_text(list(caps)).to(dev)
+        marks = []
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(("start", e))
+        net.train_step(img, ids, flat_grad=optimizer.flat_grad, grad_views=optimizer.grad_views, marks=marks)
+        optimizer.step()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(("optimiser", e))
+        marks_all.append(marks)
+    torch.cuda.synchronize()
+    rec["device_ms"] = {name: round(float(np.median([mk[j][1].elapsed_time(mk[j + 1][1]) for mk in marks_all])), 3)
+                        for j, name in enumerate(n for n, _ in marks_all[0][1:])}
+    del m, net, optimizer, loader, ds
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def packed_ids_host_cost(B, dev, n=20):
     """Per-batch host cost of the packed text layout (engine.PackedIds: argmax / cumsum over the tokenizer's [B, 77] ids and the upload of the index
     arrays) — host work next to tokenisation, outside the timed step like it, reported so that it is not hidden."""
@@ -565,6 +654,12 @@ def main():
         if a.model == "ViT-B/16":
             extras["vit_l14"] = run_record(a, dev, rank, sync, "bf16", False, 8, 2, model="ViT-L/14", batch=512, depth=12, rank=8, prompt_layers=12)
             extras["vit_l14"]["workload"] = "BASELINE.json configs[4] on one GPU: ViT-L/14 dual encoder bs=512/GPU prompt_depth=12 r=8, fwd+bwd + SGD step"
+        # ... and the step inside the reference's caller loop: DataLoader -> H2D -> tokenise -> SliNet -> FlatSGD (methods/sprompt.py:290-334)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):       # the learner prints its trainable set: stdout carries the ONE JSON line only
+            extras["plugin_step"] = plugin_step(a, dev, sync)
+            extras["plugin_step"]["vs_bare_step"] = round(extras["plugin_step"]["value"] / pairs_s, 4)
+            extras["plugin_step_reference_order"] = plugin_step(a, dev, sync, steps=15, warm=4, prefetch=False, fused_step=False)
         extras["eval_path"] = eval_path(a, dev, rank, sync)
         extras["packed_ids_host_us_per_batch"] = packed_ids_host_cost(B, dev)
 

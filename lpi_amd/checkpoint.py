@@ -116,7 +116,7 @@ class ParamTree(nn.Module):
                 if p not in node._modules:
                     node.add_module(p, ParamTree())
                 node = node._modules[p]
-            t = _as_tensor(t)
+            t = (t if torch.is_tensor(t) else torch.as_tensor(np.asarray(t))).detach()      # dtype and device as given
             node.register_parameter(leaf, nn.Parameter(t, requires_grad=False)) if t.is_floating_point() else node.register_buffer(leaf, t)
 
     def forward(self):          # a container: never called (present so that torch.jit.script accepts the tree in the checkpoint tests)

@@ -124,7 +124,11 @@ class SPrompts(BaseLearner):
         res = self._network.clip_cfg.image_resolution
         n_train = int(self.args.get("synthetic_train_size", 4 * self.batch_size))
         n_eval = int(self.args.get("synthetic_eval_images_per_task", 16))
-        return (SyntheticCoco(n_train, [i], res, seed=i), SyntheticCocoEval(n_eval, np.arange(0, i + 1), 2, res, seed=i))
+        # synthetic_captions = 'strings': items carry caption STRINGS like the reference's Coco (needs a BPE merge table: lpi_amd.synth_bpe.ensure_vocab
+        # supplies a synthetic one where CLIP's is absent); synthetic_image_pool = K: K distinct images, generated once (items are views)
+        return (SyntheticCoco(n_train, [i], res, seed=i, captions=self.args.get("synthetic_captions", "ids"),
+                              image_pool=int(self.args.get("synthetic_image_pool", 0))),
+                SyntheticCocoEval(n_eval, np.arange(0, i + 1), 2, res, seed=i))
 
     def incremental_train(self):
         final_res = {}
@@ -175,6 +179,12 @@ class SPrompts(BaseLearner):
 
     # ------------------------------------------------------------------ sprompt.py:197-256
     def _train(self, train_loader, test_loader):
+        optimizer, scheduler = self._setup_training()
+        self.run_epoch = self.epochs
+        return self.train_function(train_loader, test_loader, optimizer, scheduler)
+
+    def _setup_training(self):
+        """sprompt.py:197-255 up to the hot loop: device, trainable filter, optimiser, scheduler."""
         self._network.to(self._device)
         if _dist_world() > 1 and self._network.exchange is None:
             from lpi_amd.dp import Exchange
@@ -199,7 +209,7 @@ class SPrompts(BaseLearner):
             optimizer = optim.SGD(network.parameters(), momentum=0.9, lr=self.lrate, weight_decay=self.weight_decay)
             scheduler = optim.lr_scheduler.CosineAnnealingLR(optimizer=optimizer, T_max=self.epochs)
         self.run_epoch = self.epochs
-        return self.train_function(train_loader, test_loader, optimizer, scheduler)
+        return optimizer, scheduler
 
     # ------------------------------------------------------------------ sprompt.py:290-334 (hot loop)
     def _batches(self, train_loader):
@@ -226,14 +236,25 @@ class SPrompts(BaseLearner):
 
     def train_function(self, train_loader, test_loader, optimizer, scheduler):
         log = LossLog()
+        for epoch in range(self.run_epoch):
+            self.train_epoch(train_loader, optimizer, epoch, log)
+            scheduler.step()
+        self.clustering(dataloader=train_loader)
+        _, _, final_res = self._evaluate_retrieval(test_loader)
+        return final_res
+
+    def train_epoch(self, train_loader, optimizer, epoch=0, log=None, on_step=None):
+        """One epoch of the hot loop (sprompt.py:296-323).  on_step(i, batch, model_out) -> True stops the epoch (bench.py times the loop through it)."""
+        log = LossLog() if log is None else log
         net = self._network
         fused = bool(self.args.get("fused_step", True)) and torch.device(self._device).type == "cuda"
         flat_grad, grad_views = getattr(optimizer, "flat_grad", None), getattr(optimizer, "grad_views", None)
-        for epoch in range(self.run_epoch):
-            net.train()
-            if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
-                train_loader.sampler.set_epoch(epoch)          # DistributedSampler: a new shuffle every epoch
-            for i, batch in enumerate(self._batches(train_loader)):
+        net.train()
+        if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(epoch)          # DistributedSampler: a new shuffle every epoch
+        batches = self._batches(train_loader)
+        try:
+            for i, batch in enumerate(batches):
                 if fused:
                     # forward -> cal_loss -> sum -> backward (sprompt.py:303-310) in one call; data parallel: the all-gather / all-reduce are inside it
                     model_out = net.train_step(batch.images, batch.text, flat_grad=flat_grad, grad_views=grad_views)
@@ -256,10 +277,11 @@ class SPrompts(BaseLearner):
                     for k, v in log.flush().items():         # the one place of the loop where the host waits for the device
                         info += '{} = {:.4f}, '.format(k, v)
                     logging.info(info)
-            scheduler.step()
-        self.clustering(dataloader=train_loader)
-        _, _, final_res = self._evaluate_retrieval(test_loader)
-        return final_res
+                if on_step is not None and on_step(i, batch, model_out):
+                    break
+        finally:
+            if hasattr(batches, "close"):
+                batches.close()          # an early exit (on_step, an exception) stops the pipeline's producer thread
 
     # ------------------------------------------------------------------ sprompt.py:336-397
     def _task_id(self, feature, all_keys):

@@ -1,0 +1,235 @@
+"""Round-5 additions on a real MI355X:
+  * the FUSED plugin step (SliNet.train_step: what SPrompts.train_epoch runs) against the reference's fixtures — losses and factor gradients, with and
+    without the task term of a continual session (tiny_d1 / tiny_task2), and against the reference-ordered loop (net -> cal_loss -> backward);
+  * the input pipeline (lpi_amd/pipeline.py): batches arrive bit for bit, in order, over several epochs, with a ragged last batch; a loader error
+    reaches the consumer; an early exit stops the producer;
+  * the plugin's hot loop on caption STRINGS and HOST images at the benchmarked size issues exactly the launches of the bare step and no other kernel;
+  * a CLIP checkpoint file (TorchScript archive / saved state dict, fp16) gives the same features, bit for bit, as the in-memory state dict."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from lpi_amd import _lib, synth  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RET = os.path.join(REPO, "lpi_amd", "retrieval")
+DEV = torch.device("cuda:0")
+
+
+def tiny_args(**over):
+    args = json.load(open(os.path.join(RET, "configs", "lpi", "coco_lpi.json")))
+    args.update(backbonename="tiny", visual_dim=128, textual_dim=128, device=[DEV], compute_dtype="f32", batch_size=4, epochs=1, num_workers=0)
+    args.update(over)
+    return args
+
+
+def set_factors(net):
+    for t in range(len(net.prompts)):
+        for k, v in synth.prompt_factors(9, 16, 128, 128, task=t).items():
+            getattr(net.prompts[t], k).data = torch.from_numpy(v.copy()).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ fused step vs the reference's fixtures
+@pytest.mark.parametrize("name,numtask", [("tiny_d1", 1), ("tiny_task2", 2)])
+def test_fused_plugin_step_matches_reference(golden, name, numtask):
+    from lpi_amd.retrieval.models.slinet import SliNet
+    g = golden(name)
+    net = SliNet(tiny_args()).to(DEV)
+    set_factors(net)
+    net.numtask = numtask
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad_("prompts." + str(numtask - 1) + "." in n)
+        p.grad = None
+    img = torch.from_numpy(synth.images(4, 32)).to(DEV)
+    n0 = _lib.launch_count()
+    out = net.train_step(img, torch.from_numpy(g["token_ids"]))
+    torch.cuda.synchronize()
+    assert _lib.launch_count() - n0 > 30
+    assert np.abs(out["image_features"].cpu().numpy() - g["img_f"]).max() < 1e-4
+    assert np.abs(out["text_features"].cpu().numpy() - g["txt_f"]).max() < 1e-4
+    losses = out["loss"]
+    assert set(losses) == ({"base_loss", "alignment_loss"} | ({"task_loss"} if numtask != 1 else set()))
+    for k, v in losses.items():
+        got = sum(float(p) for p in v) if isinstance(v, tuple) else float(v)
+        assert abs(got - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, got, float(g[k]))
+    for k in synth.PROMPT_NAMES:
+        got = getattr(net.prompts[numtask - 1], k).grad.cpu().numpy()
+        ref = g["grad." + k]
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-5, k
+    # a second step on the same network: the task term's cached rows / the seeded buffers carry nothing over (same inputs, same gradients)
+    g1 = {k: getattr(net.prompts[numtask - 1], k).grad.clone() for k in synth.PROMPT_NAMES}
+    net.train_step(img, torch.from_numpy(g["token_ids"]))
+    for k in synth.PROMPT_NAMES:
+        assert torch.equal(getattr(net.prompts[numtask - 1], k).grad, g1[k]), k
+
+
+@pytest.mark.parametrize("numtask", [1, 2])
+def test_pipelined_fused_loop_equals_the_reference_ordered_loop(numtask, monkeypatch):
+    """SPrompts._train three epochs of two batches: (pipeline + fused step + FlatSGD) and (images.to(device) -> net -> cal_loss -> sum -> backward ->
+    FlatSGD, the reference's order) move the parameters to the same place (same kernels for forward / backward; the fused path only skips the scalar loss
+    graph: one multiplication by 1.0 less per gradient)."""
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    ids = torch.from_numpy(synth.token_ids(8, seed=5))
+    img = torch.from_numpy(synth.images(8, 32, seed=11))
+    loader = [(img[:4], ids[:4], 0, 0), (img[4:], ids[4:], 0, 0)]
+    got = []
+    for fast in (True, False):
+        m = SPrompts(tiny_args(epochs=3, prefetch=fast, fused_step=fast))
+        net = m._network.to(DEV)
+        set_factors(net)
+        net.numtask = numtask
+        monkeypatch.setattr(m, "clustering", lambda dataloader: None)
+        monkeypatch.setattr(m, "_evaluate_retrieval", lambda loader: (None, None, {}))
+        m._train(loader, None)
+        torch.cuda.synchronize()
+        got.append({k: getattr(net.prompts[numtask - 1], k).detach().clone() for k in synth.PROMPT_NAMES})
+    for k in synth.PROMPT_NAMES:
+        start = torch.from_numpy(synth.prompt_factors(9, 16, 128, 128, task=numtask - 1)[k]).to(DEV)
+        moved = float((got[1][k] - start).abs().max())
+        assert moved > 0
+        assert float((got[0][k] - got[1][k]).abs().max()) <= 1e-5 * moved + 1e-7, k
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline
+def test_pipeline_batches_arrive_bit_for_bit_in_order_over_epochs():
+    from lpi_amd.engine import PackedIds
+    from lpi_amd.pipeline import BatchPipeline
+    g = torch.Generator().manual_seed(3)
+    n, B = 22, 4                                   # 5 full batches and a ragged last one of 2
+    imgs = torch.randn(n, 3, 32, 32, generator=g)
+    ids = torch.from_numpy(synth.token_ids(n, seed=9))
+    # three loader flavours: a stacked tensor, a list of per-item views (collate_keep_images), a non-contiguous stacked tensor
+    loaders = [[(imgs[i:i + B], ids[i:i + B], 0, 7) for i in range(0, n, B)],
+               [([imgs[j] for j in range(i, min(n, i + B))], ids[i:i + B], 0, 7) for i in range(0, n, B)],
+               [(imgs[i:i + B].transpose(2, 3).contiguous().transpose(2, 3), ids[i:i + B], 0, 7) for i in range(0, n, B)]]
+    for loader in loaders:
+        pipe = BatchPipeline(loader, DEV, lambda c: PackedIds(c), depth=2, threads=3, timing=True)
+        for epoch in range(3):
+            seen = 0
+            for b in pipe:
+                lo = b.index * B
+                hi = min(n, lo + B)
+                assert b.images.shape == (hi - lo, 3, 32, 32) and b.images.is_cuda
+                # consume on the CURRENT stream, like the step does (the pipeline made it wait for the copy)
+                assert torch.equal(b.images.cpu(), imgs[lo:hi])
+                assert isinstance(b.text, PackedIds) and torch.equal(b.text._dev.cpu(), PackedIds(ids[lo:hi]).ids)
+                assert b.rest == (0, 7) and set(b.host_ms) >= {"gather", "tokenise_pack"}
+                assert b.h2d[0].elapsed_time(b.h2d[1]) >= 0.0 if epoch else True
+                seen += 1
+            assert seen == 6
+    assert not pipe._thread.is_alive()
+
+
+def test_pipeline_passes_loader_errors_on_and_stops_on_early_exit():
+    from lpi_amd.pipeline import BatchPipeline
+
+    def bad():
+        yield torch.zeros(2, 3, 8, 8), torch.zeros(2, 77, dtype=torch.long)
+        raise OSError("disk gone")
+    got = 0
+    with pytest.raises(OSError, match="disk gone"):
+        for b in BatchPipeline(bad(), DEV, None):
+            got += 1
+    assert got == 1
+    many = [(torch.zeros(2, 3, 8, 8), torch.zeros(2, 77, dtype=torch.long)) for _ in range(50)]
+    pipe = BatchPipeline(many, DEV, None, depth=2)
+    it = iter(pipe)
+    next(it)
+    it.close()                                     # the consumer leaves after one batch
+    pipe._thread.join(timeout=5.0)
+    assert not pipe._thread.is_alive()
+    assert not [t for t in threading.enumerate() if t.name == "lpi-batch-pipeline" and t.is_alive()]
+
+
+# ------------------------------------------------------------------------------------------------ the plugin's hot loop at the benchmarked size
+def test_plugin_loop_on_strings_issues_the_bare_steps_launches_and_no_other_kernel(tmp_path, monkeypatch):
+    """SPrompts.train_epoch over a DataLoader of HOST f32 images and caption STRINGS (ViT-B/16, 256 pairs, bf16, depth 3): per iteration exactly the
+    library launches of the bare step (lpi_amd.step.train_step + FlatSGD on resident tensors: <= 230, tests/test_round4_gpu.py) and NO other device
+    kernel — the H2D copies are DMA (Memcpy), the tokenizer is host code, the loss log holds references."""
+    from torch.profiler import ProfilerActivity, profile
+    from torch.utils.data import DataLoader
+    from lpi_amd import synth_bpe
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    from lpi_amd.retrieval.models.clip import prompt_learner as PL
+    from lpi_amd.retrieval.utils.data import SyntheticCoco, collate_keep_images
+    monkeypatch.setenv("LPI_BPE_VOCAB", synth_bpe.write_table(tmp_path / "bpe.txt.gz", seed=1))
+    monkeypatch.setattr(PL, "_tokenizer", None)
+    B = 256
+    args = json.load(open(os.path.join(RET, "configs", "lpi", "coco_lpi.json")))
+    args.update(device=[DEV], compute_dtype="bf16", honor_prompt_depth=True, prompt_depth=3, batch_size=B, epochs=1, num_workers=0)
+    m = SPrompts(args)
+    net = m._network
+    net.update_fc(0)
+    ds = SyntheticCoco(12 * B, [0], 224, captions="strings", image_pool=64)
+    loader = DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
+    opt, _ = m._setup_training()
+    counts = []
+
+    def on_step(i, batch, out):
+        counts.append(_lib.launch_count())
+        return i == 5
+    m.train_epoch(loader, opt, 0, None, on_step)            # warm-up pass: arenas, pinned slots, tokenizer tables
+    torch.cuda.synchronize()
+    counts.clear()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        m.train_epoch(loader, opt, 0, None, on_step)
+        torch.cuda.synchronize()
+    per = sorted({b - a for a, b in zip(counts, counts[1:])})
+    print(f"\n    library launches per iteration of the plugin loop: {per}")
+    # the bare step on resident tensors of the same batch
+    from lpi_amd.step import train_step
+    img = torch.stack([ds[i][0] for i in range(B)]).to(DEV)
+    pk = net.prepare_text([ds[i][1] for i in range(B)]).to(DEV)
+    fac = net.task_factors()
+    for _ in range(2):
+        n0 = _lib.launch_count()
+        train_step(net.engine, img, pk, fac, 3, flat_grad=opt.flat_grad, grad_views=opt.grad_views)
+        opt.step()
+        bare = _lib.launch_count() - n0
+    assert len(per) == 1 and per[0] == bare and bare <= 230, (per, bare)
+    dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
+    foreign = [n for n in dev_events if "anonymous namespace" not in n and "_GLOBAL__N_" not in n and "lpi" not in n.lower() and "StatFin" not in n
+               and "Memcpy" not in n and "Memset" not in n]
+    assert len(dev_events) >= 6 * bare and foreign == [], sorted(set(foreign))
+    monkeypatch.setattr(PL, "_tokenizer", None)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint files
+def test_features_from_a_checkpoint_file_equal_those_from_the_state_dict(tmp_path):
+    """args['clip_state_dict'] = <path>: a TorchScript archive (how OpenAI ships CLIP; torch.jit.load(...).state_dict(), prompt_learner.py:15-17) and a
+    torch.save'd fp16 state dict with the three scalar entries build_model drops — the engine built from either gives the features of the engine built
+    from the in-memory dict, bit for bit; the architecture comes from the tensor shapes."""
+    from lpi_amd.checkpoint import ParamTree
+    from lpi_amd.retrieval.models.slinet import SliNet
+    cfg = synth.TINY
+    sd = {k: torch.as_tensor(np.asarray(v)) for k, v in synth.clip_state_dict(cfg).items()}
+    half = {k: (v.half() if v.is_floating_point() else v) for k, v in sd.items()}
+    half.update(input_resolution=torch.tensor(32), context_length=torch.tensor(77), vocab_size=torch.tensor(49408))
+    p_dict, p_jit = str(tmp_path / "clip_sd.pt"), str(tmp_path / "clip_jit.pt")
+    torch.save(half, p_dict)
+    torch.jit.save(torch.jit.script(ParamTree(half)), p_jit)
+    img = torch.from_numpy(synth.images(4, 32)).to(DEV)
+    ids = torch.from_numpy(synth.token_ids(4))
+    feats = []
+    for src in ({k: v.float() for k, v in half.items() if v.is_floating_point()}, p_dict, p_jit):
+        net = SliNet(tiny_args(clip_state_dict=src, compute_dtype="f16")).to(DEV)
+        set_factors(net)
+        net.numtask = 1
+        net.eval()
+        assert net.clip_cfg.as_clip_args() == cfg.as_clip_args()
+        with torch.no_grad():
+            fi, ft, _, _ = net(img, ids)
+        feats.append((fi.clone(), ft.clone()))
+    for fi, ft in feats[1:]:
+        assert torch.equal(fi, feats[0][0]) and torch.equal(ft, feats[0][1])
+    # fp16 weights are exactly representable in every operand type of the f16 mode: the f32 original of the same weights gives the same features
+    # wherever the engine rounds to fp16 anyway — checked against the widened copy above, not against the unrounded f32 weights
+    with pytest.raises(ValueError):
+        SliNet(tiny_args(clip_state_dict=p_dict, backbonename="tiny14", visual_dim=256))
