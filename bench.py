@@ -486,9 +486,13 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
     ds = SyntheticCoco((steps + warm + 8) * B, [0], net.clip_cfg.image_resolution, seed=0, captions="strings", image_pool=512)
     loader = DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
     optimizer, _ = m._setup_training()
-    t, host, h2d, rows = {}, [], [], []
+    t, host, h2d, rows, evs = {}, [], [], [], []
 
     def on_step(i, batch, out):
+        if i >= warm - 1:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
         if i == warm - 1:
             sync()
             t["n0"] = _lib.launch_count()
@@ -513,6 +517,8 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
                                                if args.get("prefetch", True) else "images.to(device) + net(images, captions) -> cal_loss -> backward + FlatSGD (reference order)"),
            "input": f"DataLoader(SyntheticCoco: host f32 images [3,{net.clip_cfg.image_resolution},{net.clip_cfg.image_resolution}] from a pool of 512, caption strings), bs={B}, "
                     "num_workers=0", "bpe_table": "synthetic" if "lpi_synthetic_bpe" in vocab else "clip"}
+    # step-to-step time on the device inside the loop (HIP events recorded behind every iteration): what the loop costs the GPU, next to the wall clock
+    rec["median_ms_per_step"] = round(float(np.median([evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)])), 3)
     if host:
         rec["producer_ms_per_batch"] = {k: round(float(np.mean([h[k] for h in host])), 3) for k in host[0]}
         rec["producer_ms_per_batch"]["total_without_waits"] = round(sum(v for k, v in rec["producer_ms_per_batch"].items() if k not in ("slot_wait",)), 3)
@@ -522,10 +528,12 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
     # the split of one step on the device (HIP events at the phase boundaries of a few more steps, on the loop's own batches)
     marks_all = []
     it = iter(DataLoader(ds, batch_size=B, shuffle=False, num_workers=0))
-    for _ in range(5):
+    staged = []
+    for _ in range(7):                                           # resident first, so that the instrumented steps run back to back (no host copy between them)
         img, caps = next(it)[:2]
-        img = img.to(dev)
-        ids = net.prepare_text(list(caps)).to(dev)
+        staged.append((img.to(dev), net.prepare_text(list(caps)).to(dev)))
+    torch.cuda.synchronize()
+    for img, ids in staged:
         marks = []
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -536,6 +544,7 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
         e.record()
         marks.append(("optimiser", e))
         marks_all.append(marks)
+    marks_all = marks_all[2:]                                    # the first two start on an idle GPU (launch latency exposed)
     torch.cuda.synchronize()
     rec["device_ms"] = {name: round(float(np.median([mk[j][1].elapsed_time(mk[j + 1][1]) for mk in marks_all])), 3)
                         for j, name in enumerate(n for n, _ in marks_all[0][1:])}

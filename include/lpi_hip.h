@@ -133,6 +133,13 @@ int lpi_gemm_ln_supported(int dtype, int M, int N, int K);
 /* mean[m] = S / d, rstd[m] = 1 / sqrt(Q / d - mean^2 + eps) from the slot sums S, Q an LPI_EPI_RES_ROWSTATS GEMM left in `part` (d / 128 slots,
  * row stride ld): what nn.LayerNorm (model.py:154-160, biased variance, eps 1e-5) computes from the row.  `_pair`: the two towers' in one launch. */
 int lpi_ln_stats_finalize(int rows, int d, const float* part, int ld, float eps, float* mean, float* rstd, void* stream);
+/* Guard of the ONE-SWEEP row statistics (var = E[x^2] - mean^2 in f32: lpi_ln_stats_finalize(_pair), and the out_mean / out_rstd of lpi_vis_assemble_fwd,
+ * lpi_txt_embed_fwd(_varlen), lpi_prompt_add(_varlen) and the PROMPT_ADD row job).  The form loses digits as (mean / std)^2 * 1e-7; LayerNorm itself
+ * (model.py:154-160) does not.  `counter` (DEVICE int32, NULL = off, the default) is remembered for the calling HOST THREAD: every later launch of those
+ * kernels from this thread adds the number of rows with mean^2 > 64 var to it (8 deviations: the error is ~6e-6 there).  The caller reads it when it likes
+ * (no synchronisation here) and switches to the two-sweep statistics pass (lpi_layernorm_fwd with y = NULL) — lpi_amd/engine.py does so from the next
+ * step.  Speed knob's safety net only: never changes a result by itself. */
+int lpi_rowstat_guard(int32_t* counter);
 int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
                                int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream);
 
@@ -428,13 +435,15 @@ int lpi_l1_task_id(int n, int E, int T, int C, const float* feat, int ldf, const
  * The device parts of scikit-learn's fit (k-means++ seeding + Lloyd iterations, sklearn/cluster/_kmeans.py), driven by lpi_amd/kmeans.py, which keeps the
  * random draws (numpy RandomState) and the convergence logic on the host on vectors of n floats at most: the features X [n, E] f32 stay on the device.
  *   lpi_kmeans_sqdist   out[c, i] = |x_i - x_cand[c]|^2, c < nc (the distances of every point to candidate centres, which are points)
- *   lpi_kmeans_assign   labels[i] = argmin_c |x_i - centers[c]|^2 (first minimum; labels in / out), *changed = 1 if any label changed (never cleared here)
+ *   lpi_kmeans_assign   labels[i] = argmin_c |x_i - centers[c]|^2 (first minimum; labels in / out), *changed = 1 if any label changed (never cleared here);
+ *                       mindist (NULL = not wanted) [n]: that minimum — what scikit-learn's empty-cluster relocation ranks the points by
  *   lpi_kmeans_update   new_centers[c] = mean of the points labelled c (0 for an empty cluster), counts[c] = their number; fixed summation order
- *   lpi_kmeans_colstats colsum[e] = sum_i x[i, e], colsq[e] = sum_i x[i, e]^2 (the tolerance mean_e var_i x[i, e] * tol) */
+ *   lpi_kmeans_colstats colsum[e] = sum_i (x[i, e] - center[e]), colsq[e] = sum_i (x[i, e] - center[e])^2, center NULL = 0 (the tolerance mean_e var_i x[i, e] * tol:
+ *                       column means from a first call, centred squares from a second — two passes, no cancellation) */
 int lpi_kmeans_sqdist(int n, int E, int nc, const float* X, int ldx, const int32_t* cand, float* out, void* stream);
-int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, void* stream);
+int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, float* mindist, void* stream);
 int lpi_kmeans_update(int n, int E, int k, const float* X, int ldx, const int32_t* labels, float* new_centers, float* counts, void* stream);
-int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, float* colsum, float* colsq, void* stream);
+int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, const float* center, float* colsum, float* colsq, void* stream);
 
 /* a10 optimiser step, replaces optim.SGD(momentum, weight_decay).step() (methods/sprompt.py:253,311) on one flat f32 vector:
  * d = grad + wd*p; buf = first ? d : momentum*buf + d; p -= lr*buf. */

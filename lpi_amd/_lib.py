@@ -41,6 +41,7 @@ SIGNATURES = {
     "lpi_gemm_last_grouped": [],
     "lpi_gemm_ln_supported": [_I, _I, _I, _I],
     "lpi_ln_stats_finalize": [_I, _I, _P, _I, _F, _P, _P, _P],
+    "lpi_rowstat_guard": [_P],
     "lpi_ln_stats_finalize_pair": [_I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P],
     "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
@@ -101,9 +102,9 @@ SIGNATURES = {
     "lpi_copy_rows": [_I, _I, _P, _L, _P, _L, _P],
     "lpi_l1_task_id": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     "lpi_kmeans_sqdist": [_I, _I, _I, _P, _I, _P, _P, _P],
-    "lpi_kmeans_assign": [_I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "lpi_kmeans_assign": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "lpi_kmeans_update": [_I, _I, _I, _P, _I, _P, _P, _P, _P],
-    "lpi_kmeans_colstats": [_I, _I, _P, _I, _P, _P, _P],
+    "lpi_kmeans_colstats": [_I, _I, _P, _I, _P, _P, _P, _P],
     "lpi_sgd_step": [_L, _P, _P, _P, _F, _F, _F, _I, _P],
     "lpi_cast": [_I, _I, _L, _P, _P, _P],
     "lpi_transpose": [_I, _I, _I, _P, _I, _P, _I, _P],

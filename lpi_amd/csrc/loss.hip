@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void kmeans_sqdist_kernel(int n, int E, int nc
 }
 // labels[i] = argmin_c |x_i - C_c|^2 (first minimum); *changed = 1 if any label differs from the one stored before (labels is in / out)
 __global__ __launch_bounds__(256) void kmeans_assign_kernel(int n, int E, int k, const float* __restrict__ X, int ldx, const float* __restrict__ C,
-                                                           int32_t* __restrict__ labels, int32_t* __restrict__ changed) {
+                                                           int32_t* __restrict__ labels, int32_t* __restrict__ changed, float* __restrict__ mindist) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void kmeans_assign_kernel(int n, int E, int k,
     }
     if (lane == 0) {
         if (labels[i] != bc) { labels[i] = bc; *changed = 1; }
+        if (mindist) mindist[i] = best;
     }
 }
 // Cnew[c, cols] = mean of the points labelled c; counts[c] (written by the column chunk 0 blocks).  Block = (cluster, 64 columns) x 16 waves: wave w scans
@@ -639,14 +640,18 @@ __global__ __launch_bounds__(1024) void kmeans_update_kernel(int n, int E, int k
         if (blockIdx.y == 0 && lane == 0) counts[c] = (float)m;
     }
 }
-// colsum[e] = sum_i x[i, e], colsq[e] = sum_i x[i, e]^2 (for the tolerance mean_e var_i x[i, e] * tol): block = 64 columns x 16 waves, fixed order
-__global__ __launch_bounds__(1024) void kmeans_colstats_kernel(int n, int E, const float* __restrict__ X, int ldx, float* __restrict__ colsum, float* __restrict__ colsq) {
+// colsum[e] = sum_i (x[i, e] - center[e]), colsq[e] = sum_i (x[i, e] - center[e])^2 (center NULL = 0; for the tolerance mean_e var_i x[i, e] * tol: a first
+// call gives the column means, a second one with them the centred squares — no E[x^2] - mean^2 cancellation): block = 64 columns x 16 waves, fixed order
+__global__ __launch_bounds__(1024) void kmeans_colstats_kernel(int n, int E, const float* __restrict__ X, int ldx, const float* __restrict__ center,
+                                                              float* __restrict__ colsum, float* __restrict__ colsq) {
     __shared__ float ps[16][64], pq[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
     float s = 0.f, q = 0.f;
-    if (col < E)
-        for (int i = wave; i < n; i += 16) { const float v = X[(size_t)i * ldx + col]; s += v; q = fmaf(v, v, q); }
+    if (col < E) {
+        const float c = center ? center[col] : 0.f;
+        for (int i = wave; i < n; i += 16) { const float v = X[(size_t)i * ldx + col] - c; s += v; q = fmaf(v, v, q); }
+    }
     ps[wave][lane] = s;
     pq[wave][lane] = q;
     __syncthreads();
@@ -925,9 +930,10 @@ extern "C" int lpi_kmeans_sqdist(int n, int E, int nc, const float* X, int ldx, 
     LPI_CHECK_LAST();
     return 0;
 }
-extern "C" int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, void* stream) {
+extern "C" int lpi_kmeans_assign(int n, int E, int k, const float* X, int ldx, const float* centers, int32_t* labels, int32_t* changed, float* mindist,
+                                 void* stream) {
     if (!X || !centers || !labels || !changed || n <= 0 || E <= 0 || k <= 0 || ldx < E) return LPI_EINVAL;
-    LPI_LAUNCH(kmeans_assign_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, E, k, X, ldx, centers, labels, changed);
+    LPI_LAUNCH(kmeans_assign_kernel, dim3((n + 3) / 4), dim3(256), 0, S(stream), n, E, k, X, ldx, centers, labels, changed, mindist);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -937,9 +943,9 @@ extern "C" int lpi_kmeans_update(int n, int E, int k, const float* X, int ldx, c
     LPI_CHECK_LAST();
     return 0;
 }
-extern "C" int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, float* colsum, float* colsq, void* stream) {
+extern "C" int lpi_kmeans_colstats(int n, int E, const float* X, int ldx, const float* center, float* colsum, float* colsq, void* stream) {
     if (!X || !colsum || !colsq || n <= 0 || E <= 0 || ldx < E) return LPI_EINVAL;
-    LPI_LAUNCH(kmeans_colstats_kernel, dim3((E + 63) / 64), dim3(1024), 0, S(stream), n, E, X, ldx, colsum, colsq);
+    LPI_LAUNCH(kmeans_colstats_kernel, dim3((E + 63) / 64), dim3(1024), 0, S(stream), n, E, X, ldx, center, colsum, colsq);
     LPI_CHECK_LAST();
     return 0;
 }

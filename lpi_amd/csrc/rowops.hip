@@ -12,6 +12,13 @@
 #include <type_traits>
 #include "common.h"
 
+// the guard counter of the one-sweep row statistics (lpi_rowstat_guard, include/lpi_hip.h): per HOST THREAD, like the stream the caller launches on
+static thread_local int* t_rowstat_guard = nullptr;
+extern "C" int lpi_rowstat_guard(int32_t* counter) {
+    t_rowstat_guard = counter;
+    return 0;
+}
+
 namespace {
 
 constexpr float LN_EPS = 1e-5f;
@@ -51,14 +58,23 @@ __device__ __forceinline__ void row_stats(const RowT<NC>& r, int d, int lane, fl
 // mean / rstd of a row in ONE sweep (sum and sum of squares reduced side by side: their cross-lane chains overlap; variance as E[x^2] - mean^2, clamped):
 // for the statistics a kernel leaves of the rows it WRITES, where a second dependent reduction behind the store lengthened every wave (the vision
 // front end 53 -> 83 us with the two-sweep form)
+// The form loses digits as (mean / std)^2 * 1e-7 (2e-3 in rstd at |mean| = 30 std).  `guard` (lpi_rowstat_guard; NULL = off) counts the rows whose
+// mean^2 exceeds ROWSTAT_GUARD x their variance — 8 deviations: the error is still ~6e-6 there — so that the host can fall back to the two-sweep
+// statistics pass long before the one-sweep form hurts (engine.DualEncoder.poll_rowstat_guard).
+constexpr float ROWSTAT_GUARD = 64.f;
+__device__ __forceinline__ void rowstat_guard_check(int* guard, float mu, float var) {
+    if (guard && mu * mu > ROWSTAT_GUARD * fmaxf(var, 0.f)) atomicAdd(guard, 1);
+}
 template <int NC>
-__device__ __forceinline__ void row_stats_1sweep(const RowT<NC>& r, int d, int lane, float& mu, float& rs) {
+__device__ __forceinline__ void row_stats_1sweep(const RowT<NC>& r, int d, int lane, float& mu, float& rs, int* guard = nullptr) {
     float s = 0.f, q = 0.f;
     for_chunks_n<NC>(d, lane, [&](int i, int) { s += hsum(r.v[i]); q += hsum(r.v[i] * r.v[i]); });
     s = wave_sum(s);
     q = wave_sum(q);
     mu = s / (float)d;
-    rs = 1.0f / sqrtf(fmaxf(q / (float)d - mu * mu, 0.f) + LN_EPS);
+    const float var = q / (float)d - mu * mu;
+    rs = 1.0f / sqrtf(fmaxf(var, 0.f) + LN_EPS);
+    if (lane == 0) rowstat_guard_check(guard, mu, var);
 }
 
 // y = LN(r)
@@ -406,7 +422,7 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
                                                               const float* __restrict__ prompt0, long pbs,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               TX* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd,
-                                                              float* __restrict__ omean, float* __restrict__ orstd) {
+                                                              float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
     const int L = 1 + P + G2;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     if (omean) {      // ... and the statistics of the row as STORED: the first block's ln_1 (folded into its in_proj GEMM) needs no pass over x0
         ln_apply_round_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
-        row_stats_1sweep(r, d, lane, mu, rs);
+        row_stats_1sweep(r, d, lane, mu, rs, guard);
         if (lane == 0) { omean[row] = mu; orstd[row] = rs; }
     } else {
         ln_apply_store<TX>(r, d, lane, mu, rs, gamma, beta, x0 + (size_t)row * d);
@@ -515,7 +531,7 @@ template <typename TX>
 __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int* __restrict__ rs, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
                                                        const float* __restrict__ ctx, long cbs, TX* __restrict__ x0,
-                                                       float* __restrict__ omean, float* __restrict__ orstd) {
+                                                       float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, l) over the [B, L] id matrix
     if (row >= B * L) return;
@@ -536,14 +552,14 @@ __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int*
     });
     if (omean) {      // the statistics of the row as stored (the first block's folded ln_1)
         float mu, rs_;
-        row_stats_1sweep(r, d, lane, mu, rs_);
+        row_stats_1sweep(r, d, lane, mu, rs_, guard);
         if (lane == 0) { omean[orow] = mu; orstd[orow] = rs_; }
     }
 }
 
 template <typename TX>
 __device__ __forceinline__ void prompt_add_body(int blk, int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
+                                                const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
     const int lane = threadIdx.x & 63;
     const int w = blk * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
@@ -558,14 +574,14 @@ __device__ __forceinline__ void prompt_add_body(int blk, int B, int L, const int
     });
     if (omean) {      // the rewritten rows' statistics replace the ones the producing GEMM's epilogue left for them (LPI_EPI_RES_ROWSTATS)
         float mu, rs_;
-        row_stats_1sweep(r, d, lane, mu, rs_);
+        row_stats_1sweep(r, d, lane, mu, rs_, guard);
         if (lane == 0) { omean[row] = mu; orstd[row] = rs_; }
     }
 }
 template <typename TX>
 __global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd) {
-    prompt_add_body<TX>(blockIdx.x, B, L, rs, P, d, x, pr, pbs, omean, orstd);
+                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
+    prompt_add_body<TX>(blockIdx.x, B, L, rs, P, d, x, pr, pbs, omean, orstd, guard);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -763,9 +779,9 @@ __global__ __launch_bounds__(256) void transpose2_kernel(int rows0, int cols0, c
 // heads, L2 norms, prompt rows: everything that works on B or B*P rows) is a chain of ~5 us launches, one per tower and op; the towers'
 // launches of the same op (and independent ops of one tower) are independent.  Blocks are dealt to the jobs in order (nb[i] blocks of job i); each
 // job runs the BODY of the single-op kernel above with its own block index, so every result is bit for bit the single launch's.
-struct RowJobs { lpi_row_job j[LPI_ROW_JOBS_MAX]; int nb[LPI_ROW_JOBS_MAX]; int n; };
+struct RowJobs { lpi_row_job j[LPI_ROW_JOBS_MAX]; int nb[LPI_ROW_JOBS_MAX]; int n; int* guard; };
 
-__device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk) {
+__device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk, int* guard) {
     switch (q.op) {
     case LPI_ROWOP_POOL_LN_FWD: {
 #define PLF(TX, TY) pool_ln_fwd_body<TX, TY>(blk, q.B, q.L, q.d, (const TX*)q.a, q.idx, q.gamma, q.beta, (TY*)q.out, q.ld_c, q.mean, q.rstd, (float*)q.out2)
@@ -817,8 +833,8 @@ __device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk) {
         gather_batch_rows_body(blk, q.B, q.L, q.row_start, q.row0, q.P, q.d, (const uint4*)q.a, q.ld_a, (uint4*)q.out, q.ld_c);
         break;
     case LPI_ROWOP_PROMPT_ADD:
-        if (q.dt_a == LPI_F16) prompt_add_body<f16_t>(blk, q.B, q.L, q.row_start, q.P, q.d, (f16_t*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd);
-        else prompt_add_body<float>(blk, q.B, q.L, q.row_start, q.P, q.d, (float*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd);
+        if (q.dt_a == LPI_F16) prompt_add_body<f16_t>(blk, q.B, q.L, q.row_start, q.P, q.d, (f16_t*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd, guard);
+        else prompt_add_body<float>(blk, q.B, q.L, q.row_start, q.P, q.d, (float*)q.out, (const float*)q.a, q.bstride, q.mean, q.rstd, guard);
         break;
     case LPI_ROWOP_LN_BWD_ROWS_H16: {      // compact bf16 dy [B*P, d], fp16 x, bf16 gradient stream (in/out): ln_bwd_h16_kernel with the row map
 #define LNH(NC) ln_bwd_h16_body<NC>(blk, q.B * q.P, q.d, (const bf16_t*)q.a, q.ld_a, (const f16_t*)q.b, q.ld_b, q.gamma, q.mean_in, q.rstd_in, (bf16_t*)q.out2, q.ld_c, q.flag, q.P, q.L, q.row0, q.row_start)
@@ -840,7 +856,7 @@ __global__ __launch_bounds__(256) void row_jobs_kernel(const RowJobs js) {
 #pragma unroll
     for (int i = 0; i < LPI_ROW_JOBS_MAX; ++i) {
         if (i >= js.n) return;
-        if (b < js.nb[i]) { run_row_job(js.j[i], b); return; }
+        if (b < js.nb[i]) { run_row_job(js.j[i], b, js.guard); return; }
         b -= js.nb[i];
     }
 }
@@ -1101,10 +1117,10 @@ extern "C" int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, co
     const long rows = (long)B * (1 + P + G2);
     if (x_dtype == LPI_F32)
         LPI_LAUNCH(vis_assemble_fwd_kernel<float>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
-                   prompt0, prompt_bstride, gamma, beta, (float*)x0, mean, rstd, out_mean, out_rstd);
+                   prompt0, prompt_bstride, gamma, beta, (float*)x0, mean, rstd, out_mean, out_rstd, t_rowstat_guard);
     else if (x_dtype == LPI_F16)
         LPI_LAUNCH(vis_assemble_fwd_kernel<f16_t>, dim3(rows_grid(rows)), dim3(256), 0, S(stream), B, G2, P, d, patch_emb, ldpe, cls, pos,
-                   prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd, out_mean, out_rstd);
+                   prompt0, prompt_bstride, gamma, beta, (f16_t*)x0, mean, rstd, out_mean, out_rstd, t_rowstat_guard);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
@@ -1158,9 +1174,9 @@ extern "C" int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t
     if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0, out_mean, out_rstd);
+        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0, out_mean, out_rstd, t_rowstat_guard);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0, out_mean, out_rstd);
+        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0, out_mean, out_rstd, t_rowstat_guard);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
@@ -1176,9 +1192,9 @@ extern "C" int lpi_prompt_add_varlen(int x_dtype, int B, int L, const int32_t* r
     if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!x || !prompt_l || B <= 0 || P <= 0 || P + 1 > L || bad_row_dim(d) || (prompt_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (float*)x, prompt_l, prompt_bstride, out_mean, out_rstd);
+        LPI_LAUNCH(prompt_add_kernel<float>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (float*)x, prompt_l, prompt_bstride, out_mean, out_rstd, t_rowstat_guard);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (f16_t*)x, prompt_l, prompt_bstride, out_mean, out_rstd);
+        LPI_LAUNCH(prompt_add_kernel<f16_t>, dim3(rows_grid((long)B * P)), dim3(256), 0, S(stream), B, L, row_start, P, d, (f16_t*)x, prompt_l, prompt_bstride, out_mean, out_rstd, t_rowstat_guard);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
@@ -1257,7 +1273,7 @@ extern "C" int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float
 // ---- statistics of the fp16 residual stream from the slot sums an LPI_EPI_RES_ROWSTATS GEMM epilogue left (include/lpi_hip.h): one thread per row
 // adds the d / 128 slots in order; the variance is E[x^2] - mean^2 in f32 (the stream's rows have |mean| well below their deviation: the relative
 // error of the difference is ~1e-7 (1 + mean^2 / var)), clamped at zero.
-struct StatFinP { int rows, nslot; const float* part; int ld; float* mean; float* rstd; float inv_d; };
+struct StatFinP { int rows, nslot; const float* part; int ld; float* mean; float* rstd; float inv_d; int* guard; };
 __device__ __forceinline__ void stat_fin_body(const StatFinP& p, int row, float eps) {
     if (row >= p.rows) return;
     float s = 0.f, q = 0.f;
@@ -1266,9 +1282,10 @@ __device__ __forceinline__ void stat_fin_body(const StatFinP& p, int row, float 
         q += p.part[(size_t)(2 * j + 1) * p.ld + row];
     }
     const float mu = s * p.inv_d;
-    const float var = fmaxf(q * p.inv_d - mu * mu, 0.f);
+    const float var = q * p.inv_d - mu * mu;
     p.mean[row] = mu;
-    p.rstd[row] = 1.0f / sqrtf(var + eps);
+    p.rstd[row] = 1.0f / sqrtf(fmaxf(var, 0.f) + eps);
+    rowstat_guard_check(p.guard, mu, var);
 }
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(StatFinP p0, StatFinP p1, int nb0, float eps) {
     if ((int)blockIdx.x < nb0) stat_fin_body(p0, blockIdx.x * 256 + threadIdx.x, eps);
@@ -1280,8 +1297,8 @@ static bool stat_fin_ok(int rows, int d, const float* part, int ld, const float*
 extern "C" int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
                                           int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream) {
     if (!stat_fin_ok(rows0, d0, part0, ld0, mean0, rstd0) || (rows1 > 0 && !stat_fin_ok(rows1, d1, part1, ld1, mean1, rstd1))) return LPI_EINVAL;
-    const StatFinP p0 = {rows0, d0 / 128, part0, ld0, mean0, rstd0, 1.0f / (float)d0};
-    const StatFinP p1 = {rows1 > 0 ? rows1 : 0, rows1 > 0 ? d1 / 128 : 0, part1, ld1, mean1, rstd1, rows1 > 0 ? 1.0f / (float)d1 : 0.f};
+    const StatFinP p0 = {rows0, d0 / 128, part0, ld0, mean0, rstd0, 1.0f / (float)d0, t_rowstat_guard};
+    const StatFinP p1 = {rows1 > 0 ? rows1 : 0, rows1 > 0 ? d1 / 128 : 0, part1, ld1, mean1, rstd1, rows1 > 0 ? 1.0f / (float)d1 : 0.f, t_rowstat_guard};
     const int nb0 = (rows0 + 255) / 256, nb1 = rows1 > 0 ? (rows1 + 255) / 256 : 0;
     LPI_LAUNCH(ln_stats_finalize_kernel, dim3(nb0 + nb1), dim3(256), 0, S(stream), p0, p1, nb0, eps);
     LPI_CHECK_LAST();
@@ -1339,6 +1356,7 @@ extern "C" int lpi_row_jobs(int n, const lpi_row_job* jobs, void* stream) {
     if (!jobs || n <= 0 || n > LPI_ROW_JOBS_MAX) return LPI_EINVAL;
     RowJobs js = {};
     js.n = n;
+    js.guard = t_rowstat_guard;
     long total = 0;
     for (int i = 0; i < n; ++i) {
         const int nb = row_job_blocks(jobs[i]);

@@ -112,6 +112,11 @@ LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "2"))
 # profiles/r03_experiments.md).  Blocks whose input rows are rewritten by deep prompts first, and the first block, keep the pass.
 MLP_SPLIT = int(_os.environ.get("LPI_MLP_SPLIT", "0"))      # see Tower.mlp_split
 ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "2"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
+# The one-sweep statistics (E[x^2] - mean^2 in f32) lose digits as (mean / std)^2 * 1e-7: harmless on a CLIP residual stream with ordinary rows, 2e-3 in
+# rstd at |mean| = 30 std.  LPI_ROWSTAT_GUARD=1 (default): the kernels count the rows with mean^2 > 64 var (lpi_rowstat_guard), the engine reads the
+# counter without synchronising (a 4-byte copy behind every forward, looked at when it has landed) and drops BOTH towers to the two-sweep statistics
+# pass (rowstats = 0) from the next forward on, with a warning.  0: no counter, no copy (A/B switch).
+ROWSTAT_GUARD = _os.environ.get("LPI_ROWSTAT_GUARD", "1") != "0"
 
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
@@ -821,6 +826,40 @@ class DualEncoder:
         self.logit_scale = t("logit_scale")
         self.logit_scale_exp = float(math.exp(float(np.asarray(state_dict["logit_scale"] if not torch.is_tensor(state_dict["logit_scale"]) else state_dict["logit_scale"].cpu()))))
         self._head_ws = {}
+        # guard of the one-sweep LayerNorm statistics (ROWSTAT_GUARD above): device counter, its pinned landing place, the event of the copy in flight
+        self._guard = torch.zeros(1, dtype=torch.int32, device=dev) if ROWSTAT_GUARD else None
+        self._guard_host = torch.zeros(1, dtype=torch.int32).pin_memory() if ROWSTAT_GUARD else None
+        self._guard_event = None
+        self.rowstat_guard_tripped = 0          # rows counted when the guard switched the towers to the statistics pass (0 = never)
+
+    # ------------------------------------------------------------------ one-sweep statistics guard
+    def _guard_begin(self):
+        """Start of a forward: act on the previous forwards' verdict if its copy has landed (never waits), then register the counter for the kernels this
+        thread is about to launch."""
+        lib = _lib.load()
+        if self._guard is None:
+            return
+        ev = self._guard_event
+        if ev is not None and ev.query():
+            self._guard_event = None
+            n = int(self._guard_host[0])
+            if n > 0 and (self.vis.rowstats or self.txt.rowstats):
+                import warnings
+                warnings.warn(f"lpi_amd: {n} residual-stream rows with |mean| > 8 std were seen by the one-sweep LayerNorm statistics (E[x^2] - mean^2 loses "
+                              "digits there); both towers use the two-sweep statistics pass from now on (LPI_ROWSTATS=0 behaviour: exact, ~0.6 % slower)",
+                              RuntimeWarning, stacklevel=3)
+                self.vis.rowstats = self.txt.rowstats = 0
+                self.rowstat_guard_tripped = n
+        active = bool(self.vis.rowstats or self.txt.rowstats)
+        lib.lpi_rowstat_guard(self._guard.data_ptr() if active else None)
+
+    def _guard_end(self):
+        """End of a forward: ship the (cumulative) counter to the host — one 4-byte copy, none while one is still in flight."""
+        if self._guard is not None and self._guard_event is None and (self.vis.rowstats or self.txt.rowstats):
+            self._guard_host.copy_(self._guard, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._guard_event = ev
 
     # ------------------------------------------------------------------ lanes
     def lane(self, i: int, stream=None):
@@ -887,6 +926,7 @@ class DualEncoder:
     def encode_image_gen(self, image, prompts=None, depth=1, train=False, normalise=True):
         """GENERATOR form of encode_image (yields its GEMMs, see GemmReq); returns (features, backward context)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
+        self._guard_begin()
         B = image.shape[0]
         image = image.to(device=self.device, dtype=torch.float32).contiguous()
         pr, pbs, P = self._prompt_args(prompts, B)
@@ -906,6 +946,7 @@ class DualEncoder:
         xo = yield from self.vis.forward_gen(ws, pr, pbs, depth, train, None, ln1_ready=self.vis.ln1_stats_out(ws)[0] is not None)      # pooled (CLS) rows [Bp, d]
         hw = self._head("v", B, d)
         out = yield from self._head_fwd_gen(hw, xo, self.ln_post, self.vproj, B, d, normalise)
+        self._guard_end()
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.vis.serial)
         self._vis_ctx = ctx
         return out, ctx
@@ -1001,6 +1042,7 @@ class DualEncoder:
     def encode_text_gen(self, ids, prompts=None, depth=1, train=False, use_ctx=True, normalise=True):
         """GENERATOR form of encode_text; returns (features, backward context)."""
         cfg, dt, s = self.cfg, self.dt, _stream()
+        self._guard_begin()
         packed = ids if isinstance(ids, PackedIds) else None
         if packed is not None:
             ids = packed.on(self.device)
@@ -1026,6 +1068,7 @@ class DualEncoder:
              *self.txt.ln1_stats_out(ws), s)
         xo = yield from self.txt.forward_gen(ws, pr, pbs, depth, train, eot_idx, ln1_ready=self.txt.ln1_stats_out(ws)[0] is not None)      # pooled (EOT) rows
         out = yield from self._head_fwd_gen(hw, xo, self.ln_final, self.tproj, B, d, normalise)
+        self._guard_end()
         ctx = (ws, pr, pbs, P, depth, B, L, out, self.txt.serial, eot_idx)
         self._txt_ctx = ctx
         return out, ctx
@@ -1089,18 +1132,24 @@ class PackedIds:
         self._dev = None
         self.row_start_dev = self.pool_rows_dev = self.eot_dev = None
 
-    def on(self, device):
-        """Upload once (ids, row starts, pooled rows); returns the device id matrix [B, Lmax]."""
+    def on(self, device, non_blocking=False):
+        """Upload once (ids, row starts, pooled rows); returns the device id matrix [B, Lmax].  non_blocking: the four arrays go through PINNED copies
+        (kept on this object until it dies) and the calls only enqueue on the current stream — the input pipeline's producer thread must never wait for
+        the stream it feeds (lpi_amd/pipeline.py)."""
         device = torch.device(device)
         if self._dev is None or self._dev.device != device:
-            self._dev = self.ids.to(device)
-            self.row_start_dev = self.row_start.to(device)
-            self.pool_rows_dev = self.pool_rows.to(device)
-            self.eot_dev = self.eot.to(device)
+            if non_blocking:
+                self._pinned = [t.pin_memory() for t in (self.ids, self.row_start, self.pool_rows, self.eot)]
+                self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev = (t.to(device, non_blocking=True) for t in self._pinned)
+            else:
+                self._dev = self.ids.to(device)
+                self.row_start_dev = self.row_start.to(device)
+                self.pool_rows_dev = self.pool_rows.to(device)
+                self.eot_dev = self.eot.to(device)
         return self._dev
 
-    def to(self, device):
-        self.on(device)
+    def to(self, device, non_blocking=False):
+        self.on(device, non_blocking)
         return self
 
     def record_stream(self, stream):

@@ -33,11 +33,14 @@ def kmeans_fit(x: torch.Tensor, n_clusters: int = 5, random_state: int = 0, max_
     dev = x.device
     s = torch.cuda.current_stream().cuda_stream
     k = n_clusters
-    # tolerance: mean over the columns of their variance, times tol
+    # tolerance: mean over the columns of their variance (np.var: about the column mean), times tol — two passes: the column means, then the squares of
+    # the CENTRED values (E[x^2] - mean^2 from single-pass f32 sums cancels for columns whose mean dwarfs their deviation, and can go negative)
     colsum, colsq = torch.empty(E, device=dev), torch.empty(E, device=dev)
-    call("lpi_kmeans_colstats", n, E, x, E, colsum, colsq, s)
+    call("lpi_kmeans_colstats", n, E, x, E, None, colsum, colsq, s)
+    mean = (colsum.double() / n).float().contiguous()
+    call("lpi_kmeans_colstats", n, E, x, E, mean, colsum, colsq, s)
     cs, cq = colsum.double().cpu().numpy(), colsq.double().cpu().numpy()
-    tol_ = float(np.mean(cq / n - (cs / n) ** 2)) * tol
+    tol_ = float(np.mean(np.maximum(cq / n - (cs / n) ** 2, 0.0))) * tol      # cs / n: the f32 rounding of the mean, a second-order correction
     # ---- k-means++ (sklearn _kmeans_plusplus): 2 + int(log k) local trials per centre
     rs = np.random.RandomState(random_state)
     w = np.ones(n, dtype=np.float32)
@@ -71,16 +74,18 @@ def kmeans_fit(x: torch.Tensor, n_clusters: int = 5, random_state: int = 0, max_
     changed = torch.zeros(1, dtype=torch.int32, device=dev)
     new = torch.empty_like(centers)
     counts = torch.empty(k, device=dev)
+    mindist = torch.empty(n, device=dev)
     strict = False
     it = 0
     for it in range(max_iter):
         changed.zero_()
-        call("lpi_kmeans_assign", n, E, k, x, E, centers, labels, changed, s)
+        call("lpi_kmeans_assign", n, E, k, x, E, centers, labels, changed, mindist, s)
         call("lpi_kmeans_update", n, E, k, x, E, labels, new, counts, s)
         ch = int(changed.item())                      # did any label move?  (4 bytes)
         new_h, old_h, cnt_h = new.cpu().numpy(), centers.cpu().numpy(), counts.cpu().numpy()      # k x E floats each: the convergence test runs on the host
         if float(cnt_h.min()) == 0.0:
-            raise _lib.LpiError("KMeans: a cluster lost all its points (scikit-learn would relocate it: not built — the reference's features never do this)")
+            new_h = _relocate_empty_clusters(x, labels, mindist, new_h, cnt_h)
+            new.copy_(torch.from_numpy(new_h))
         shift2 = float((np.sqrt(((new_h - old_h) ** 2).sum(1)) ** 2).sum())
         centers, new = new, centers
         if not ch:
@@ -90,5 +95,30 @@ def kmeans_fit(x: torch.Tensor, n_clusters: int = 5, random_state: int = 0, max_
             break
     if not strict:
         changed.zero_()
-        call("lpi_kmeans_assign", n, E, k, x, E, centers, labels, changed, s)
+        call("lpi_kmeans_assign", n, E, k, x, E, centers, labels, changed, None, s)
     return centers, labels, it + 1
+
+
+def _relocate_empty_clusters(x, labels, mindist, new_h, cnt_h):
+    """scikit-learn's _relocate_empty_clusters_dense (sklearn/cluster/_k_means_common.pyx; called inside every Lloyd iteration before the sums are
+    averaged): each cluster that lost all its points takes the point FARTHEST from its own (old) centre — the n_empty largest distances, in
+    np.argpartition's order — and the donor cluster gives that point up.  The labels stay as they are (the next iteration re-assigns).  Rare (small or
+    duplicate-heavy tasks: COCO repeats every image feature ~5 times), so it runs on the host on what the iteration already produced: the n distances,
+    the labels, the k x E means; the donors' sums are rebuilt as mean x count in float64 (scikit-learn holds the float32 sums themselves: equal to
+    rounding).  Returns the corrected means [k, E] float32."""
+    empty = np.where(cnt_h == 0)[0]
+    n_empty = empty.shape[0]
+    d = mindist.cpu().numpy()
+    far = np.argpartition(d, -n_empty)[:-n_empty - 1:-1]
+    lab = labels[torch.as_tensor(far.copy(), device=labels.device)].cpu().numpy()
+    pts = x[torch.as_tensor(far.copy(), device=x.device)].double().cpu().numpy()
+    sums = new_h.astype(np.float64) * cnt_h.astype(np.float64)[:, None]
+    cnt = cnt_h.astype(np.float64).copy()
+    for j in range(n_empty):
+        new_id, old_id = int(empty[j]), int(lab[j])
+        sums[old_id] -= pts[j]
+        sums[new_id] = pts[j]
+        cnt[new_id] = 1.0
+        cnt[old_id] -= 1.0
+    safe = np.where(cnt > 0, cnt, 1.0)       # a donor emptied in turn keeps a zero centre, as _average_centers leaves it
+    return (sums / safe[:, None]).astype(np.float32)

@@ -124,8 +124,10 @@ class BatchPipeline:
                     if e0 is not None:
                         e0.record(self.side)
                     dev[:B].copy_(stage[:B], non_blocking=True)
-                    if hasattr(text, "to"):
-                        text = text.to(self.device)
+                    if torch.is_tensor(text):
+                        text = text.pin_memory().to(self.device, non_blocking=True) if not text.is_cuda else text
+                    elif hasattr(text, "to"):
+                        text = text.to(self.device, non_blocking=True)      # engine.PackedIds: pinned copies, enqueued only
                     cp = torch.cuda.Event(enable_timing=self.timing)
                     cp.record(self.side)
                 self._copied[slot] = cp

@@ -191,3 +191,15 @@ def clustering_features(n: int = 600, dim: int = 512, modes: int = 7, seed: int 
         x = centres[which] + g.standard_normal((n, dim)) * spread[which][:, None]
         out.append(x.astype(np.float32))
     return out[0], out[1]
+
+
+def duplicate_heavy_features(n: int = 24, distinct: int = 4, dim: int = 4, seed: int = 1):
+    """L2-normalised features with FEWER distinct rows than the 5 clusters of the task keys (a tiny task whose images repeat: COCO pairs every image with
+    ~5 captions, so a task's image features come in runs of equal rows).  k-means++ then has to seed one centre on a row it already chose, that cluster
+    receives no point in the Lloyd iteration, and scikit-learn's empty-cluster relocation (_relocate_empty_clusters_dense) decides how the fit goes on —
+    where the first builds of lpi_amd.kmeans raised.  (Recipe chosen so that numpy's tie order and the device's agree with scikit-learn's.)"""
+    g = np.random.default_rng(seed)
+    g.integers(10, 40), g.integers(2, 6), g.integers(2, 5)          # (keeps the stream position of the search that found the recipe)
+    base = g.standard_normal((distinct, dim)).astype(np.float32)
+    x = base[g.integers(0, distinct, size=n)]
+    return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)

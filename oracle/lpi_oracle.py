@@ -368,8 +368,18 @@ def kmeans_fit(X, n_clusters=5, random_state=0, max_iter=300, tol=1e-4):
         np.add.at(new, labels, X)
         np.add.at(cnt, labels, 1.0)
         if (cnt == 0).any():
-            raise RuntimeError("empty cluster: the relocation step of scikit-learn is not restated")
-        new /= cnt[:, None]
+            # sklearn/cluster/_k_means_common.pyx _relocate_empty_clusters_dense: every empty cluster takes the point farthest from its own (old) centre
+            # (the n_empty largest squared distances, in np.argpartition's order), its donor gives the point up; labels are left for the next iteration
+            empty = np.where(cnt == 0)[0]
+            dist = ((X - centers[labels]) ** 2).sum(axis=1)
+            far = np.argpartition(dist, -len(empty))[:-len(empty) - 1:-1]
+            for j, new_id in enumerate(empty):
+                old_id = labels[far[j]]
+                new[old_id] -= X[far[j]]
+                new[new_id] = X[far[j]]
+                cnt[new_id] = 1.0
+                cnt[old_id] -= 1.0
+        new /= np.where(cnt > 0, cnt, 1.0)[:, None]
         shift = np.sqrt(((new - centers) ** 2).sum(1))
         centers = new
         if np.array_equal(labels, labels_old):

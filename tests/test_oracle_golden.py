@@ -192,3 +192,21 @@ def test_oracle_kmeans_equals_the_reference_clustering(golden):
         centers, labels, iters = O.kmeans_fit(x)
         assert np.abs(centers - g["centers_" + name]).max() < 1e-6, name
         assert labels.min() == 0 and labels.max() == 4 and iters < 50
+
+
+def test_oracle_kmeans_relocates_empty_clusters_like_scikit_learn():
+    """A feature set with fewer distinct rows (4) than clusters (5): k-means++ must seed one centre on a row it already chose, that cluster gets no point
+    in the Lloyd iteration, and scikit-learn relocates it (_relocate_empty_clusters_dense) instead of failing.  The oracle's restatement against
+    scikit-learn itself (the reference's own dependency, sprompt.py:393-394)."""
+    import warnings
+    import numpy as np
+    from sklearn.cluster import KMeans
+    from oracle import lpi_oracle as O
+    from lpi_amd import synth
+    x = synth.duplicate_heavy_features()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = KMeans(n_clusters=5, random_state=0).fit(x)
+    centers, labels, _ = O.kmeans_fit(x)
+    assert np.abs(centers - km.cluster_centers_).max() < 1e-5
+    assert np.array_equal(labels, km.labels_)
