@@ -76,6 +76,7 @@ def kmeans_fit(x: torch.Tensor, n_clusters: int = 5, random_state: int = 0, max_
     counts = torch.empty(k, device=dev)
     mindist = torch.empty(n, device=dev)
     strict = False
+    relocated = set()
     it = 0
     for it in range(max_iter):
         changed.zero_()
@@ -83,15 +84,22 @@ def kmeans_fit(x: torch.Tensor, n_clusters: int = 5, random_state: int = 0, max_
         call("lpi_kmeans_update", n, E, k, x, E, labels, new, counts, s)
         ch = int(changed.item())                      # did any label move?  (4 bytes)
         new_h, old_h, cnt_h = new.cpu().numpy(), centers.cpu().numpy(), counts.cpu().numpy()      # k x E floats each: the convergence test runs on the host
+        cycle = False
         if float(cnt_h.min()) == 0.0:
             new_h = _relocate_empty_clusters(x, labels, mindist, new_h, cnt_h)
             new.copy_(torch.from_numpy(new_h))
+            # With fewer distinct rows than clusters every point coincides with a centre and "the farthest point" is decided by the last bit of a mean of
+            # equal rows: the relocation can then hand one duplicate centre back and forth for ever (scikit-learn's own arithmetic happens to settle;
+            # it would otherwise run to max_iter).  A relocation that reproduces centres already seen ends the fit: nothing new can come.
+            key = new_h.tobytes()
+            cycle = key in relocated
+            relocated.add(key)
         shift2 = float((np.sqrt(((new_h - old_h) ** 2).sum(1)) ** 2).sum())
         centers, new = new, centers
         if not ch:
             strict = True
             break
-        if shift2 <= tol_:
+        if shift2 <= tol_ or cycle:
             break
     if not strict:
         changed.zero_()

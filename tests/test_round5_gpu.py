@@ -259,7 +259,8 @@ def _hostile_weights(cfg):
 def test_one_sweep_statistics_guard_switches_to_the_statistics_pass(monkeypatch):
     """Full ViT-B/16, bf16 mode, weights that put every vision row at |mean| >= 20 std from block 3 on.  The guard counts those rows in the first forward
     (no synchronisation: the verdict is read when its copy has landed), warns, and the next forward runs the two-sweep statistics pass: its features are
-    within the bf16 mode's bar (5e-3, tests/test_fullsize_gpu.py) of the f32 HIP path, which the guard-less engine misses."""
+    exact to f32 round-off where the one-sweep ones were wrong in the fourth digit.  (At the FEATURE level the two are indistinguishable: see the
+    comment at the assertion.)"""
     from lpi_amd import engine as E
     from lpi_amd.engine import DualEncoder, PackedIds
     cfg = synth.CONFIGS["ViT-B/16"]
@@ -280,6 +281,19 @@ def test_one_sweep_statistics_guard_switches_to_the_statistics_pass(monkeypatch)
     ri, rt = feats(enc32)
     del enc32
     err = lambda f: (float((f[0] - ri).abs().max()), float((f[1] - rt).abs().max()))  # noqa: E731
+
+    def rstd_err(enc):
+        """worst relative error of the ln_1 rstd the vision tower USED in blocks 4.., against two-pass f64 statistics of the stored fp16 stream rows"""
+        with torch.no_grad():
+            (_, cv), _ = enc.encode_both(img, PackedIds(ids).to(DEV), vis, txt, 3, train=True)
+        torch.cuda.synchronize()
+        ws, worst, ratio = cv[0], 0.0, 0.0
+        for i in range(4, 11):
+            x = ws["x"][i][:ws["M"]].double()
+            ref = 1.0 / (x.var(1, unbiased=False) + 1e-5).sqrt()
+            worst = max(worst, float((ws["stat"][i][1][:ws["M"]].double() / ref - 1).abs().max()))
+            ratio = max(ratio, float((x.mean(1).abs() / x.std(1, unbiased=False)).max()))
+        return worst, ratio
     enc = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
     assert enc.vis.rowstats == 2 and enc.txt.rowstats == 2
     first = err(feats(enc))                      # one-sweep statistics: the guard counts, nothing has switched yet
@@ -289,13 +303,20 @@ def test_one_sweep_statistics_guard_switches_to_the_statistics_pass(monkeypatch)
     assert enc.rowstat_guard_tripped > 0 and enc.vis.rowstats == 0 and enc.txt.rowstats == 0
     third = err(feats(enc))
     assert third == second                       # stays switched, deterministic
+    guarded_stat, ratio = rstd_err(enc)
     monkeypatch.setattr(E, "ROWSTAT_GUARD", False)
     enc0 = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
     unguarded = [err(feats(enc0)) for _ in range(2)][-1]
+    unguarded_stat, _ = rstd_err(enc0)
     assert enc0.vis.rowstats == 2 and enc0.rowstat_guard_tripped == 0
-    print(f"\n    max |feature - f32 HIP| (image, text): one-sweep {first}, after the switch {second}, guard off {unguarded}")
-    assert max(second) < 5e-3
-    assert unguarded[0] > 2 * second[0] and first[0] > 2 * second[0]
+    print(f"\n    rows at |mean| / std up to {ratio:.0f}: rstd relative error one-sweep {unguarded_stat:.2e}, after the switch {guarded_stat:.2e};"
+          f" max |feature - f32 HIP| (image, text): one-sweep {first}, after the switch {second}, guard off {unguarded}")
+    # the statistics: wrong in the fourth digit without the switch, exact to f32 round-off with it
+    assert ratio >= 30 and unguarded_stat > 1e-4 and guarded_stat < 2e-6
+    # the features: at these rows the fp16 residual stream's own rounding (the reference's activation type, 11 bits on a mean 40 deviations out) is what
+    # separates the mode from the f32 path — measured 5.7e-3 with either statistics (tools/rowstat_guard_probe.py; profiles/r05_rowstat_guard.md: the same up
+    # to |mean| = 1000 std, where the one-sweep rstd is off by 10 %) — so the switch must simply not cost accuracy
+    assert max(second) < 1.15 * max(first) and max(second) < 8e-3 and first == unguarded
     # ordinary weights never trip it (the benchmarked configuration keeps its one-sweep statistics)
     monkeypatch.setattr(E, "ROWSTAT_GUARD", True)
     encn = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
@@ -318,9 +339,16 @@ def test_device_kmeans_relocates_an_empty_cluster_and_its_tolerance_is_two_pass(
         warnings.simplefilter("ignore")
         km = KMeans(n_clusters=5, random_state=0).fit(x)
     centers, labels, iters = kmeans_fit(torch.from_numpy(x).to(DEV), 5, random_state=0)
-    oc, ol, oi = O.kmeans_fit(x)
-    assert np.abs(centers.cpu().numpy() - km.cluster_centers_).max() < 1e-5 and np.array_equal(labels.cpu().numpy(), km.labels_)
-    assert np.abs(centers.cpu().numpy() - oc).max() < 1e-6 and np.array_equal(labels.cpu().numpy(), ol) and iters == oi
+    c, l = centers.cpu().numpy(), labels.cpu().numpy()
+    # every point coincides with a centre here, so "the point farthest from its centre" is a tie among ALL points: which one the relocation takes depends
+    # on the last bits of the distances (scikit-learn centres the data first; the device takes exact differences) — the fits agree in what is determined:
+    # zero inertia, every distinct feature a centre, labels that point at it
+    assert np.isfinite(c).all() and iters <= 6
+    assert float(((x - c[l]) ** 2).sum()) < 1e-10 and float(((x - km.cluster_centers_[km.labels_]) ** 2).sum()) < 1e-10
+    for row in np.unique(x, axis=0):
+        assert np.abs(c - row).sum(1).min() < 1e-6
+    oc, ol, oi = O.kmeans_fit(x)                     # the oracle restates scikit-learn's host arithmetic: equal to it on this recipe (CPU test)
+    assert float(((x - oc[ol]) ** 2).sum()) < 1e-10
     # tolerance: features riding on a large common offset (|mean| = 1000 x deviation)
     f = synth.clustering_features(600, 64)[0] * 1e-3 + 1.0
     ref = KMeans(n_clusters=5, random_state=0).fit(f)
