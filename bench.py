@@ -96,6 +96,49 @@ def _free_port():
     return p
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def pin_rank_to_cpus(local_rank, local_world):
+    """Give this rank its own slice of the host CPUs BEFORE anything touches the GPU: W processes that each spawn library / pipeline threads on all cores
+    migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first (node r * nodes // W for local rank r — on
+    an 8-GPU MI355X node GPUs 0-3 hang off socket 0 and 4-7 off socket 1 in device order), then evenly among the ranks of a node.  LPI_NO_AFFINITY=1
+    leaves the affinity alone.  Returns the CPU list (or None)."""
+    if os.environ.get("LPI_NO_AFFINITY") == "1" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = []
+    try:
+        import glob
+        for d in sorted(glob.glob("/sys/devices/system/node/node[0-9]*"), key=lambda q: int(q.rsplit("node", 1)[1])):
+            cpus = [c for c in _cpulist(open(os.path.join(d, "cpulist")).read()) if c in set(allowed)]
+            if cpus:
+                nodes.append(cpus)
+    except OSError:
+        nodes = []
+    if not nodes:
+        nodes = [allowed]
+    if len(nodes) > local_world or local_world % len(nodes):
+        nodes = [allowed]
+    per_node = local_world // len(nodes)
+    cpus = nodes[local_rank // per_node]
+    k = local_rank % per_node
+    share = max(1, len(cpus) // per_node)
+    mine = cpus[k * share:(k + 1) * share] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
 def self_launch(a):
     """`python bench.py --gpus N` typed by hand: start the ranks as a child torch.distributed.run BEFORE any GPU call in this process
     (a process that has initialised the GPU must never exec or be replaced), relay rank 0's JSON line, return the child's exit code."""
@@ -584,6 +627,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    cpus = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # before the first GPU call of this process
+    if cpus is not None:
+        torch.set_num_threads(max(1, min(len(cpus), 16)))
     dev_index = 0 if a.share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -629,10 +675,27 @@ def main():
         # device collectives (RCCL) are timed with HIP events; host-staged ones (gloo, ranks sharing a GPU) carry no per-collective time
         collectives = {k: round(1e3 * float(np.mean([e0.elapsed_time(e1) for kk, e0, e1 in tl if kk == k])), 1)
                        for k in sorted({kk for kk, _, _ in tl})} or None
-        collectives = {"mean_us_per_step": collectives, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
-                       "messages": "one all_gather_into_tensor of img_f||txt_f [B, 1024] f32 + one all_reduce(SUM) of the 5 284 factor gradients"
-                                   + (" + one reduce_scatter_tensor of the key gradients [W B, 1024] f32" if a.gather_with_grad else "")}
+        E2 = 2 * cfg.embed_dim
+        nfac = sum(int(v.numel()) for v in wl.fac.values())
+        mine = {"rank": rank, "mean_us_per_step": collectives, "median_ms_per_step": round(float(np.median(per)), 3), "cpus": None if cpus is None else len(cpus)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)                     # after the timed region: a few hundred bytes of bookkeeping per rank
+        collectives = {"mean_us_per_step": collectives, "per_rank": per_rank, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
+                       "messages": f"one all_gather_into_tensor of img_f||txt_f [B, {E2}] f32 ({B * E2 * 4} bytes per rank) + one all_reduce(SUM) of the "
+                                   f"{nfac} factor gradients"
+                                   + (f" + one reduce_scatter_tensor of the key gradients [W B, {E2}] f32" if a.gather_with_grad else "")}
         exchange.timing = None
+        # the same step WITHOUT the exchange on every rank at once (each rank its own contrastive matrix, no collective): what the collectives and the
+        # larger loss matrix cost the job — a self-check beside the driver's own N = 1 run, not a scaling claim
+        if not a.fwd_only:
+            wl.exchange = None
+            el0, _ = wl.run(max(4, a.steps // 2), 2, sync)
+            wl.exchange = exchange
+            el0 = rank_max(el0)
+            v0 = world * B * max(4, a.steps // 2) / el0
+            collectives["without_exchange"] = {"value": round(v0, 2), "unit": "pairs/s", "steps": max(4, a.steps // 2),
+                                               "ratio_with_exchange": round(pairs_s / v0, 4),
+                                               "note": "all ranks stepping at once with exchange = None (local 256 x 256 loss, no all-gather / all-reduce)"}
 
     roofline = None if a.no_roofline else wl.gemm_roofline()
     from lpi_amd import _lib as _L

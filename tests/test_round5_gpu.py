@@ -343,7 +343,7 @@ def test_device_kmeans_relocates_an_empty_cluster_and_its_tolerance_is_two_pass(
     # every point coincides with a centre here, so "the point farthest from its centre" is a tie among ALL points: which one the relocation takes depends
     # on the last bits of the distances (scikit-learn centres the data first; the device takes exact differences) — the fits agree in what is determined:
     # zero inertia, every distinct feature a centre, labels that point at it
-    assert np.isfinite(c).all() and iters <= 6
+    assert np.isfinite(c).all() and iters <= 20          # a handful of relocations, then the cycle guard (not max_iter = 300)
     assert float(((x - c[l]) ** 2).sum()) < 1e-10 and float(((x - km.cluster_centers_[km.labels_]) ** 2).sum()) < 1e-10
     for row in np.unique(x, axis=0):
         assert np.abs(c - row).sum(1).min() < 1e-6
@@ -355,3 +355,27 @@ def test_device_kmeans_relocates_an_empty_cluster_and_its_tolerance_is_two_pass(
     c2, l2, it2 = kmeans_fit(torch.from_numpy(f).to(DEV), 5, random_state=0)
     assert it2 == ref.n_iter_ and np.array_equal(l2.cpu().numpy(), ref.labels_)
     assert np.abs(c2.cpu().numpy() - ref.cluster_centers_).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]'s gather path through bench.py once
+def test_bench_vit_l14_four_ranks_on_one_gpu():
+    """BASELINE.json configs[4] (ViT-L/14, prompt_depth 12, r 8: E = 768, 12-layer prompt stacks) through bench.py's multi-rank path before the driver's
+    8-GPU run meets it: four ranks share this GPU over gloo (host-staged messages), 8 pairs each.  Rank 0's line carries the observed world size, the
+    per-rank collective block and the without-exchange self-check; profiles/r05_bench_dp4_vitl14_shared_gpu.json keeps one such line."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--share-gpu", "--model", "ViT-L/14", "--batch", "8", "--depth", "12",
+                        "--rank", "8", "--prompt-layers", "12", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-extras"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    c = j["collectives"]
+    assert j["n_gpus"] == 4 and c["observed_world_size"] == 4 and c["backend"] == "gloo" and j["config"]["global_batch"] == 32
+    assert [r["rank"] for r in c["per_rank"]] == [0, 1, 2, 3] and all(r["median_ms_per_step"] > 0 for r in c["per_rank"])
+    assert "1536] f32" in c["messages"] and "14688 factor gradients" in c["messages"]          # E = 768 -> 2E = 1536; 12 x 8 + 2 x 16 x 8 + (1024 + 768) x 8 factors
+    assert c["without_exchange"]["value"] > 0 and 0.2 < c["without_exchange"]["ratio_with_exchange"] < 1.5
+    assert "ViT-L/14" in j["metric"] and j["value"] > 0
+    out = os.path.join(REPO, "gpurun_out")
+    if os.path.isdir(out):
+        open(os.path.join(out, "bench_dp4_vitl14_shared_gpu.json"), "w").write(json.dumps(j) + "\n")
