@@ -31,6 +31,9 @@ The JSON line carries, besides the driver's contract keys:
   eval_path    : (N = 1) the reference's evaluation path per batch (task-id pass, L1 task selection, per-sample prompted forward), images/s and
                  captions/s, and the score matrix + ranks at COCO 5k-test size;
   f16_mode     : (N = 1) the same step with fp16 MFMA operands in the forward (the reference's arithmetic type): 4x lower logit error;
+  parity       : (N = 1) what the headline's arithmetic is worth, measured in this very run: the f32 HIP step against the fixture captured from the imported
+                 reference (tests/golden/vitb16_d3_patched.npz: ViT-B/16, 8 pairs, depth 3 — a fixture is data, not the oracle) and the bf16 / f16 steps
+                 against the f32 HIP step on the benchmarked batch (256 pairs); the 1e-4 bar belongs to the first, the throughput modes are held to the second;
   plugin_step  : (N = 1) the reference's real caller loop — SPrompts.train_epoch (methods/sprompt.py:290-334) built from configs/lpi/coco_lpi.json, fed by a
                  DataLoader over a synthetic Coco that yields HOST f32 images and caption STRINGS: H2D copy, tokenisation, forward, losses, backward, SGD
                  step; pairs/s from the wall clock around K loop iterations, its ratio to the bare step (`value`) and the split of a step;
@@ -502,6 +505,62 @@ def run_record(a, dev, proc_rank, sync, dtype, fwd_only, steps, warm, roofline=T
     return rec
 
 
+def parity_block(a, dev):
+    """Parity on the same line as the headline.  No oracle here: the reference's own outputs come from the committed fixture."""
+    import gc
+    import numpy as np
+    import torch
+    from lpi_amd import synth
+    from lpi_amd.engine import DualEncoder
+    from lpi_amd.step import train_step
+    cfg = synth.CONFIGS["ViT-B/16"]
+    gpath = os.path.join(REPO, "tests", "golden", "vitb16_d3_patched.npz")
+    out = {}
+
+    def run(enc, img, ids, depth):
+        fac = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+        o = train_step(enc, img, ids, fac, depth)
+        torch.cuda.synchronize()
+        return o, fac
+    mx = lambda x, y: float(np.abs(np.asarray(x, dtype=np.float64) - np.asarray(y, dtype=np.float64)).max())  # noqa: E731
+    sd = synth.clip_state_dict(cfg)
+    enc32 = DualEncoder(cfg, sd, dtype="f32", device=dev)
+    if os.path.isfile(gpath):
+        g = dict(np.load(gpath, allow_pickle=False))
+        img = torch.from_numpy(synth.images(8, cfg.image_resolution)).to(dev)
+        o, fac = run(enc32, img, torch.from_numpy(g["token_ids"]).to(dev), 3)
+        lg = (enc32.logit_scale_exp * o["img_f"] @ o["txt_f"].t()).cpu().numpy()
+        out["f32_vs_reference_fixture"] = {
+            "fixture": "tests/golden/vitb16_d3_patched.npz (imported reference, deep-prompt guard patched: SURVEY F1; ViT-B/16, 8 pairs, depth 3, r 4)",
+            "max_abs_logit_err": mx(lg, g["logits"]), "max_abs_feature_err": max(mx(o["img_f"].cpu().numpy(), g["img_f"]), mx(o["txt_f"].cpu().numpy(), g["txt_f"])),
+            "base_loss_err": abs(float(o["base_loss"]) - float(g["base_loss"])),
+            "max_rel_factor_grad_err": max(mx(fac[k].grad.cpu().numpy(), g["grad." + k]) / float(np.abs(g["grad." + k]).max()) for k in synth.PROMPT_NAMES),
+            "bar": "1e-4 (logits, losses), 1e-3 relative (factor gradients): tests/test_model_gpu.py"}
+    B = a.batch
+    img = torch.from_numpy(synth.images(B, cfg.image_resolution)).to(dev)
+    ids = torch.from_numpy(synth.token_ids(B)).to(dev)
+    o32, f32 = run(enc32, img, ids, a.depth)
+    o32 = {k: v.clone() for k, v in o32.items()}
+    g32 = {k: f32[k].grad.double().cpu() for k in synth.PROMPT_NAMES}
+    del enc32
+    gc.collect()
+    torch.cuda.empty_cache()
+    for mode in ("bf16", "f16"):
+        enc = DualEncoder(cfg, sd, dtype=mode, device=dev)
+        ob, fb = run(enc, img, ids, a.depth)
+        cos = min(float((fb[k].grad.double().cpu() * g32[k]).sum() / (fb[k].grad.double().cpu().norm() * g32[k].norm())) for k in synth.PROMPT_NAMES)
+        l32 = enc.logit_scale_exp * o32["img_f"] @ o32["txt_f"].t()
+        lb = enc.logit_scale_exp * ob["img_f"] @ ob["txt_f"].t()
+        out[f"{mode}_vs_f32_hip_bs{B}"] = {"max_abs_feature_err": max(float((ob["img_f"] - o32["img_f"]).abs().max()), float((ob["txt_f"] - o32["txt_f"]).abs().max())),
+                                           "max_abs_logit_err": float((lb - l32).abs().max()), "base_loss_rel_err": abs(float(ob["base_loss"]) - float(o32["base_loss"])) / abs(float(o32["base_loss"])),
+                                           "min_factor_grad_cosine": cos, "top1_agreement": float((lb.argmax(1) == l32.argmax(1)).float().mean()),
+                                           "bar": "features 5e-3 (bf16) / 1.5e-3 (f16), gradient cosine 0.9995: tests/test_fullsize_gpu.py"}
+        del enc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def plugin_step(a, dev, sync, steps=60, warm=10, **over):
     """The plugin's hot loop as the reference's caller runs it (methods/sprompt.py:290-334: DataLoader batch -> images.cuda() -> SliNet.forward on caption
     strings -> cal_loss -> backward -> optimizer.step), timed like every other record: wall clock around exactly `steps` iterations of SPrompts.train_epoch,
@@ -732,6 +791,8 @@ def main():
             extras["plugin_step"] = plugin_step(a, dev, sync)
             extras["plugin_step"]["vs_bare_step"] = round(extras["plugin_step"]["value"] / pairs_s, 4)
             extras["plugin_step_reference_order"] = plugin_step(a, dev, sync, steps=15, warm=4, prefetch=False, fused_step=False)
+        if a.model == "ViT-B/16":
+            extras["parity"] = parity_block(a, dev)
         extras["eval_path"] = eval_path(a, dev, rank, sync)
         extras["packed_ids_host_us_per_batch"] = packed_ids_host_cost(B, dev)
 
