@@ -45,6 +45,10 @@ constexpr int EPI_PLAIN16 = 100;
 // groups' c1 / c2 and its eight rows' mean / rstd are loaded once per tile (plain loads: 24 per lane) — and staged in the output type.  The same
 // expression on the same values as gemm_epilogue_store: bit for bit the generic epilogue (tests/test_round4_gpu.py).
 constexpr int EPI_LN16 = 101;
+// Weight slices (round 5, see launchp_impl) are compiled into every instantiation but the plain QuickGELU + aux one (c_fc WITHOUT the LayerNorm fold:
+// LPI_LN_FOLD < 2, an A/B path): its register allocation sits on the edge, and the two compares of the slice fold-back made it spill 56 bytes per lane
+// (tests/test_no_spills.py) — a scratch reload there drains the LDS-DMA queue every tile.
+template <int EPI, bool SAVE_U> constexpr bool slices_ok() { return !(EPI == LPI_EPI_QUICKGELU && SAVE_U); }
 #ifndef LPI_EPI_DB
 #define LPI_EPI_DB false     /* -DLPI_EPI_DB=true: eight double-buffered passes of 32 rows for the store-only epilogues with arithmetic — measured SLOWER on the whole
                                 step (22.66-22.71 ms with the four single-buffer passes against 22.78-22.82: twice the barriers for half the work per pass) */
@@ -59,7 +63,10 @@ struct PProb {
     int N, K, lda, ldb, ldc, ldr, ldaux, tiles_m, tiles_n;
     int vb0;        // first virtual workgroup id
     int bias_off;   // offset (floats) of its bias vector in the LDS copy (SIDE16 epilogues)
-    int group_m;    // order of its tiles inside an XCD's share: group_m row panels at a time, rows fastest (1 = columns fastest)
+    int group_m;    // order of its tiles inside an XCD's share: low 16 bits = group_m row panels at a time, rows fastest (1 = columns fastest); high 16 bits
+                    // (round 5, weight SLICES, see launchp_impl): 0, or the REAL number of row panels while tiles_m / tiles_n describe the virtual problem
+                    // "S slices of tiles_n column tiles stacked below each other" (tiles_m = S x real): a tile whose virtual row panel lies in slice g is the
+                    // tile (row panel - g x real, column + g x tiles_n) of the real problem
 };
 struct PGroup {
     PProb p[2];
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     typedef typename AuxT<T>::type TA;
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     constexpr bool LNE = EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU;
+    constexpr bool SLICES = slices_ok<EPI, SAVE_U>();
     constexpr bool P16 = EPI == EPI_PLAIN16, L16 = EPI == EPI_LN16;
     constexpr int EPIX = P16 ? LPI_EPI_NONE : (L16 ? LPI_EPI_LN : EPI);      // the epilogue kind the half-tile body sees
     // the CURRENT problem's operands and geometry (wave-uniform; re-bound by bind() when the workgroup moves on to the next problem)
@@ -119,12 +127,22 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     auto coords = [&](int vb, int& m0, int& n0) {
         const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        const int group = t / (group_m * tiles_n);
-        const int first_m = group * group_m;
-        const int gsz = min(tiles_m - first_m, group_m);
-        const int in_group = t - group * group_m * tiles_n;
+        const int gm = SLICES ? (group_m & 0xffff) : group_m;
+        const int group = t / (gm * tiles_n);
+        const int first_m = group * gm;
+        const int gsz = min(tiles_m - first_m, gm);
+        const int in_group = t - group * gm * tiles_n;
         m0 = (first_m + in_group % gsz) * T256;
         n0 = (in_group / gsz) * T256;
+        // weight slices (at most three): the virtual row panel folds back into the real one, the column moves on by a slice — two compares, no division
+        // (a third integer division at this point made the QuickGELU + aux instantiations spill)
+        if constexpr (SLICES) {
+            const int wrap = (group_m >> 16) * T256;
+            if (wrap) {
+                if (m0 >= wrap) { m0 -= wrap; n0 += tiles_n * T256; }
+                if (m0 >= wrap) { m0 -= wrap; n0 += tiles_n * T256; }
+            }
+        }
     };
 
     // ---- staging: a half tile = 128 rows x 128 B = 2 LDS-DMA instructions of 512 lanes x 16 B (as gemm256_tile.h), but addressed as
@@ -730,6 +748,25 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
         // (ViT-B/16: 1.2-4.7 MB; whole step 24.16 -> 24.05 ms against 8).  Larger weights (ViT-L/14: 6-8 MB) would be re-read every round:
         // there 8 row panels at a time, rows fastest, is better (99.7 against 100.7 ms per step).  Tuning key 4 > 0 overrides.
         P.group_m = g_lpi_tuning[4] > 0 ? g_lpi_tuning[4] : ((size_t)h.N * h.K * sizeof(T) <= ((size_t)5 << 20) ? 1 : 8);
+        // Round 5 — weight SLICES.  With columns fastest every round of an XCD (32 tiles = 2.7 row panels x all N-tiles) touches the WHOLE weight matrix,
+        // and a 3.5-4.7 MB matrix does not survive a round in a 4 MB L2 next to the A panels and the C stream: rocprofv3 FETCH_SIZE showed the wide-N
+        // GEMMs fetching 3.8x (in_proj) / 5.5x (c_fc) / 1.9x (d c_proj) their algorithmic bytes = the weights re-read by 8 XCDs x 7-10 rounds
+        // (profiles/r03_gemm_shapes_pmc.json).  Ordering the tiles slice-major — the N-tiles cut into S slices whose weights (<= ~2.4 MB) DO stay resident,
+        // every XCD walking one slice after the other down the row panels — trades that for reading the A panels once per slice (S x 84 MB instead of
+        // 80 x 4.7 MB).  The chip is power-limited under these kernels (1 371 W of a 1 400 W cap over the whole step, tools/power_poll.py) and bytes from
+        // beyond L2 are the first thing that costs clock (cdna_hip_programming.md rule 28).  Tuning key 15: 0 = automatic (weights above 3 MB: the fewest
+        // equal slices, 2 or 3, of at most 2.5 MB), 2 / 3 = that many slices where N divides, -1 = off.  Same tiles, same bits: only the order changes.
+        if (slices_ok<EPI, SAVE_U>() && P.group_m == 1 && g_lpi_tuning[15] >= 0 && P.tiles_m < 32768) {
+            int S = 0;
+            const size_t wbytes = (size_t)h.N * h.K * sizeof(T);
+            if (g_lpi_tuning[15] > 0) S = g_lpi_tuning[15];
+            else if (wbytes > ((size_t)3 << 20)) S = (P.tiles_n % 2 == 0 && wbytes / 2 <= ((size_t)5 << 19)) ? 2 : 3;
+            if ((S == 2 || S == 3) && P.tiles_n % S == 0 && P.tiles_n / S >= 2) {
+                P.group_m |= P.tiles_m << 16;      // the real row-panel count
+                P.tiles_n /= S;
+                P.tiles_m *= S;
+            }
+        }
         nsum += h.N;
     }
     if (SIDE16 && nsum > 8192) return LPI_ENOSYS;       // the bias vectors must fit behind the ring (the caller falls back to the one-tile kernel)

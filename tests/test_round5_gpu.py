@@ -379,3 +379,41 @@ def test_bench_vit_l14_four_ranks_on_one_gpu():
     out = os.path.join(REPO, "gpurun_out")
     if os.path.isdir(out):
         open(os.path.join(out, "bench_dp4_vitl14_shared_gpu.json"), "w").write(json.dumps(j) + "\n")
+
+
+# ------------------------------------------------------------------------------------------------ persistent GEMM: weight slices (tuning key 15)
+@pytest.mark.parametrize("tm,N,K,key", [(43, 3072, 768, 0), (43, 2304, 768, 0), (213, 3072, 768, 0), (20, 3072, 768, 3), (37, 2048, 1024, 2)])
+def test_gemm_weight_slices_change_the_order_not_the_bits(tm, N, K, key):
+    """Tuning key 15 (round 5): the tiles of a GEMM whose weight does not fit an XCD's L2 run slice-major (2 or 3 slices of the N-tiles, each XCD walking one
+    slice after the other down the row panels).  Same tiles, same arithmetic: bit for bit the columns-fastest order (key 15 = -1) — alone, with a bias and
+    the derivative epilogue, grouped with a second problem, on shapes with a hybrid half-tile round — and equal to f64 within bf16 rounding."""
+    from lpi_amd import engine as E
+    from lpi_amd._lib import BF16, call
+    M = tm * 256
+    g = torch.Generator().manual_seed(tm + N)
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    b = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    aux = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    a2 = torch.randn(2560, 512, generator=g).bfloat16().to(DEV)
+    b2 = (torch.randn(1536, 512, generator=g) * 0.05).bfloat16().to(DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for k15 in (-1, key):
+            call("lpi_set_tuning", 15, k15)
+            c0 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            E.gemm(BF16, a, b, c0, M, N, K, bias=bias)
+            c1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            E.gemm(BF16, a, b, c1, M, N, K, epi=E.EPI_DQUICKGELU, aux=aux)
+            c2, c3 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV), torch.zeros(2560, 1536, dtype=torch.bfloat16, device=DEV)
+            _lib.gemm_grouped(BF16, BF16, E.EPI_NONE, 1.0, [dict(M=M, N=N, K=K, a=a, b=b, c=c2), dict(M=2560, N=1536, K=512, a=a2, b=b2, c=c3)], s)
+            torch.cuda.synchronize()
+            outs.append((c0, c1, c2, c3))
+    finally:
+        call("lpi_set_tuning", 15, 0)
+    for x, y in zip(*outs):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    assert not torch.isnan(outs[1][0].float()).any()
+    ref = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+    assert float((outs[1][0].double().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
