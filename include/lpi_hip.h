@@ -138,11 +138,13 @@ int lpi_gemm_ln_supported(int dtype, int M, int N, int K);
 int lpi_ln_stats_finalize(int rows, int d, const float* part, int ld, float eps, float* mean, float* rstd, void* stream);
 /* Guard of the ONE-SWEEP row statistics (var = E[x^2] - mean^2 in f32: lpi_ln_stats_finalize(_pair), and the out_mean / out_rstd of lpi_vis_assemble_fwd,
  * lpi_txt_embed_fwd(_varlen), lpi_prompt_add(_varlen) and the PROMPT_ADD row job).  The form loses digits as (mean / std)^2 * 1e-7; LayerNorm itself
- * (model.py:154-160) does not.  `counter` (DEVICE int32, NULL = off, the default) is remembered for the calling HOST THREAD: every later launch of those
- * kernels from this thread adds the number of rows with mean^2 > 64 var to it (8 deviations: the error is ~6e-6 there).  The caller reads it when it likes
- * (no synchronisation here) and switches to the two-sweep statistics pass (lpi_layernorm_fwd with y = NULL) — lpi_amd/engine.py does so from the next
- * step.  Speed knob's safety net only: never changes a result by itself. */
-int lpi_rowstat_guard(int32_t* counter);
+ * (model.py:154-160) does not.  `counter` (DEVICE int32; NULL = off, the default) and `flag` are remembered for the calling HOST THREAD: every later launch
+ * of those kernels from this thread adds the number of rows with mean^2 > 64 var (8 deviations: the error is ~6e-6 there) to *counter, and the row that
+ * takes it from 0 to 1 also stores 1 to *flag.  `flag` (optional) may be a word of PINNED HOST memory (hipHostMalloc / torch pin_memory: the library
+ * resolves its device alias with hipPointerGetAttributes and returns LPI_EINVAL for memory the device cannot write): the host then reads its own word
+ * whenever it likes — no copy, no event, no synchronisation — and switches to the two-sweep statistics pass (lpi_layernorm_fwd with y = NULL);
+ * lpi_amd/engine.py does so from the next forward.  A speed knob's safety net: never changes a result by itself. */
+int lpi_rowstat_guard(int32_t* counter, int32_t* flag);
 int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
                                int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream);
 

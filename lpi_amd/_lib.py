@@ -41,7 +41,7 @@ SIGNATURES = {
     "lpi_gemm_last_grouped": [],
     "lpi_gemm_ln_supported": [_I, _I, _I, _I],
     "lpi_ln_stats_finalize": [_I, _I, _P, _I, _F, _P, _P, _P],
-    "lpi_rowstat_guard": [_P],
+    "lpi_rowstat_guard": [_P, _P],
     "lpi_ln_stats_finalize_pair": [_I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P],
     "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
     "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],

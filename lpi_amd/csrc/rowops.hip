@@ -12,10 +12,23 @@
 #include <type_traits>
 #include "common.h"
 
-// the guard counter of the one-sweep row statistics (lpi_rowstat_guard, include/lpi_hip.h): per HOST THREAD, like the stream the caller launches on
-static thread_local int* t_rowstat_guard = nullptr;
-extern "C" int lpi_rowstat_guard(int32_t* counter) {
-    t_rowstat_guard = counter;
+// the guard of the one-sweep row statistics (lpi_rowstat_guard, include/lpi_hip.h): per HOST THREAD, like the stream the caller launches on.
+// counter: device memory; flag: the DEVICE alias of a word of pinned host memory (or of device memory), written once, by the row that takes the
+// counter from 0 to 1 — the host reads its own word whenever it likes: no copy, no event, no kernel
+struct RowstatGuard { int* counter; int* flag; };
+static thread_local RowstatGuard t_rowstat_guard = {nullptr, nullptr};
+extern "C" int lpi_rowstat_guard(int32_t* counter, int32_t* flag) {
+    int* dflag = nullptr;
+    if (flag) {
+        if (!counter) return LPI_EINVAL;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, flag) != hipSuccess || !at.devicePointer) {      // not memory the device can write: refuse, never fault
+            (void)hipGetLastError();
+            return LPI_EINVAL;
+        }
+        dflag = static_cast<int*>(at.devicePointer);
+    }
+    t_rowstat_guard = {counter, dflag};
     return 0;
 }
 
@@ -62,11 +75,13 @@ __device__ __forceinline__ void row_stats(const RowT<NC>& r, int d, int lane, fl
 // mean^2 exceeds ROWSTAT_GUARD x their variance — 8 deviations: the error is still ~6e-6 there — so that the host can fall back to the two-sweep
 // statistics pass long before the one-sweep form hurts (engine.DualEncoder.poll_rowstat_guard).
 constexpr float ROWSTAT_GUARD = 64.f;
-__device__ __forceinline__ void rowstat_guard_check(int* guard, float mu, float var) {
-    if (guard && mu * mu > ROWSTAT_GUARD * fmaxf(var, 0.f)) atomicAdd(guard, 1);
+__device__ __forceinline__ void rowstat_guard_check(RowstatGuard guard, float mu, float var) {
+    if (guard.counter && mu * mu > ROWSTAT_GUARD * fmaxf(var, 0.f)) {
+        if (atomicAdd(guard.counter, 1) == 0 && guard.flag) *reinterpret_cast<volatile int*>(guard.flag) = 1;      // one write towards the host per reset
+    }
 }
 template <int NC>
-__device__ __forceinline__ void row_stats_1sweep(const RowT<NC>& r, int d, int lane, float& mu, float& rs, int* guard = nullptr) {
+__device__ __forceinline__ void row_stats_1sweep(const RowT<NC>& r, int d, int lane, float& mu, float& rs, RowstatGuard guard = RowstatGuard{nullptr, nullptr}) {
     float s = 0.f, q = 0.f;
     for_chunks_n<NC>(d, lane, [&](int i, int) { s += hsum(r.v[i]); q += hsum(r.v[i] * r.v[i]); });
     s = wave_sum(s);
@@ -422,7 +437,7 @@ __global__ __launch_bounds__(256) void vis_assemble_fwd_kernel(int B, int G2, in
                                                               const float* __restrict__ prompt0, long pbs,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               TX* __restrict__ x0, float* __restrict__ mean, float* __restrict__ rstd,
-                                                              float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
+                                                              float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard) {
     const int L = 1 + P + G2;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -531,7 +546,7 @@ template <typename TX>
 __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int* __restrict__ rs, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
                                                        const float* __restrict__ ctx, long cbs, TX* __restrict__ x0,
-                                                       float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
+                                                       float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, l) over the [B, L] id matrix
     if (row >= B * L) return;
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int*
 
 template <typename TX>
 __device__ __forceinline__ void prompt_add_body(int blk, int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
+                                                const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard) {
     const int lane = threadIdx.x & 63;
     const int w = blk * 4 + (threadIdx.x >> 6);
     if (w >= B * P) return;
@@ -580,7 +595,7 @@ __device__ __forceinline__ void prompt_add_body(int blk, int B, int L, const int
 }
 template <typename TX>
 __global__ __launch_bounds__(256) void prompt_add_kernel(int B, int L, const int* __restrict__ rs, int P, int d, TX* __restrict__ x,
-                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, int* guard) {
+                                                        const float* __restrict__ pr, long pbs, float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard) {
     prompt_add_body<TX>(blockIdx.x, B, L, rs, P, d, x, pr, pbs, omean, orstd, guard);
 }
 
@@ -779,9 +794,9 @@ __global__ __launch_bounds__(256) void transpose2_kernel(int rows0, int cols0, c
 // heads, L2 norms, prompt rows: everything that works on B or B*P rows) is a chain of ~5 us launches, one per tower and op; the towers'
 // launches of the same op (and independent ops of one tower) are independent.  Blocks are dealt to the jobs in order (nb[i] blocks of job i); each
 // job runs the BODY of the single-op kernel above with its own block index, so every result is bit for bit the single launch's.
-struct RowJobs { lpi_row_job j[LPI_ROW_JOBS_MAX]; int nb[LPI_ROW_JOBS_MAX]; int n; int* guard; };
+struct RowJobs { lpi_row_job j[LPI_ROW_JOBS_MAX]; int nb[LPI_ROW_JOBS_MAX]; int n; RowstatGuard guard; };
 
-__device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk, int* guard) {
+__device__ __forceinline__ void run_row_job(const lpi_row_job& q, int blk, RowstatGuard guard) {
     switch (q.op) {
     case LPI_ROWOP_POOL_LN_FWD: {
 #define PLF(TX, TY) pool_ln_fwd_body<TX, TY>(blk, q.B, q.L, q.d, (const TX*)q.a, q.idx, q.gamma, q.beta, (TY*)q.out, q.ld_c, q.mean, q.rstd, (float*)q.out2)
@@ -1273,7 +1288,7 @@ extern "C" int lpi_l2norm_bwd(int B, int E, const float* y, int ldy, const float
 // ---- statistics of the fp16 residual stream from the slot sums an LPI_EPI_RES_ROWSTATS GEMM epilogue left (include/lpi_hip.h): one thread per row
 // adds the d / 128 slots in order; the variance is E[x^2] - mean^2 in f32 (the stream's rows have |mean| well below their deviation: the relative
 // error of the difference is ~1e-7 (1 + mean^2 / var)), clamped at zero.
-struct StatFinP { int rows, nslot; const float* part; int ld; float* mean; float* rstd; float inv_d; int* guard; };
+struct StatFinP { int rows, nslot; const float* part; int ld; float* mean; float* rstd; float inv_d; RowstatGuard guard; };
 __device__ __forceinline__ void stat_fin_body(const StatFinP& p, int row, float eps) {
     if (row >= p.rows) return;
     float s = 0.f, q = 0.f;

@@ -114,8 +114,8 @@ MLP_SPLIT = int(_os.environ.get("LPI_MLP_SPLIT", "0"))      # see Tower.mlp_spli
 ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "2"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
 # The one-sweep statistics (E[x^2] - mean^2 in f32) lose digits as (mean / std)^2 * 1e-7: harmless on a CLIP residual stream with ordinary rows, 2e-3 in
 # rstd at |mean| = 30 std.  LPI_ROWSTAT_GUARD=1 (default): the kernels count the rows with mean^2 > 64 var (lpi_rowstat_guard), the engine reads the
-# counter without synchronising (a 4-byte copy behind every forward, looked at when it has landed) and drops BOTH towers to the two-sweep statistics
-# pass (rowstats = 0) from the next forward on, with a warning.  0: no counter, no copy (A/B switch).
+# count without synchronising (the first flagged row stores 1 to a word of pinned host memory; the host looks at its own word before every forward) and
+# drops BOTH towers to the two-sweep statistics pass (rowstats = 0) from the next forward on, with a warning.  0: no counter (A/B switch).
 ROWSTAT_GUARD = _os.environ.get("LPI_ROWSTAT_GUARD", "1") != "0"
 
 
@@ -826,40 +826,33 @@ class DualEncoder:
         self.logit_scale = t("logit_scale")
         self.logit_scale_exp = float(math.exp(float(np.asarray(state_dict["logit_scale"] if not torch.is_tensor(state_dict["logit_scale"]) else state_dict["logit_scale"].cpu()))))
         self._head_ws = {}
-        # guard of the one-sweep LayerNorm statistics (ROWSTAT_GUARD above): device counter, its pinned landing place, the event of the copy in flight
+        # guard of the one-sweep LayerNorm statistics (ROWSTAT_GUARD above): a device counter, and a word of PINNED host memory the kernels flag
         self._guard = torch.zeros(1, dtype=torch.int32, device=dev) if ROWSTAT_GUARD else None
-        self._guard_host = torch.zeros(1, dtype=torch.int32).pin_memory() if ROWSTAT_GUARD else None
-        self._guard_event = None
+        self._guard_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if ROWSTAT_GUARD else None
         self.rowstat_guard_tripped = 0          # rows counted when the guard switched the towers to the statistics pass (0 = never)
 
     # ------------------------------------------------------------------ one-sweep statistics guard
     def _guard_begin(self):
-        """Start of a forward: act on the previous forwards' verdict if its copy has landed (never waits), then register the counter for the kernels this
-        thread is about to launch."""
+        """Start of a forward: if an earlier forward's kernels have flagged the host word (a plain read of this process's own memory: no copy, no event,
+        no wait), drop both towers to the two-sweep statistics pass; then register counter and flag for the kernels this thread is about to launch."""
         lib = _lib.load()
         if self._guard is None:
             return
-        ev = self._guard_event
-        if ev is not None and ev.query():
-            self._guard_event = None
-            n = int(self._guard_host[0])
-            if n > 0 and (self.vis.rowstats or self.txt.rowstats):
-                import warnings
-                warnings.warn(f"lpi_amd: {n} residual-stream rows with |mean| > 8 std were seen by the one-sweep LayerNorm statistics (E[x^2] - mean^2 loses "
-                              "digits there); both towers use the two-sweep statistics pass from now on (LPI_ROWSTATS=0 behaviour: exact, ~0.6 % slower)",
-                              RuntimeWarning, stacklevel=3)
-                self.vis.rowstats = self.txt.rowstats = 0
-                self.rowstat_guard_tripped = n
+        if int(self._guard_flag[0]) != 0 and (self.vis.rowstats or self.txt.rowstats):
+            n = int(self._guard.item())          # the one synchronisation, once, on the way out of the fast path
+            import warnings
+            warnings.warn(f"lpi_amd: {n} residual-stream rows with |mean| > 8 std were seen by the one-sweep LayerNorm statistics (E[x^2] - mean^2 loses "
+                          "digits there); both towers use the two-sweep statistics pass from now on (LPI_ROWSTATS=0 behaviour: exact, ~0.6 % slower)",
+                          RuntimeWarning, stacklevel=3)
+            self.vis.rowstats = self.txt.rowstats = 0
+            self.rowstat_guard_tripped = max(n, 1)
         active = bool(self.vis.rowstats or self.txt.rowstats)
-        lib.lpi_rowstat_guard(self._guard.data_ptr() if active else None)
+        rc = lib.lpi_rowstat_guard(self._guard.data_ptr() if active else None, self._guard_flag.data_ptr() if active else None)
+        if rc != 0:
+            raise _lib.LpiError(f"lpi_rowstat_guard failed with code {rc} (the pinned flag word is not device-accessible)")
 
     def _guard_end(self):
-        """End of a forward: ship the (cumulative) counter to the host — one 4-byte copy, none while one is still in flight."""
-        if self._guard is not None and self._guard_event is None and (self.vis.rowstats or self.txt.rowstats):
-            self._guard_host.copy_(self._guard, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._guard_event = ev
+        pass
 
     # ------------------------------------------------------------------ lanes
     def lane(self, i: int, stream=None):
