@@ -15,7 +15,7 @@ from lpi_amd._lib import BF16, call  # noqa: E402
 REPS = 8
 TD = torch.bfloat16
 dev = "cuda:0"
-Mv, Mt = 54528, 10880          # vision rows (256 x 213) and packed text rows (256 x 42.1 -> whole 128-row tiles)
+Mv, Mt = 54528, 10752          # vision rows (256 x 213) and packed text rows (256 x 42 -> whole 256-row tiles: the LN-fold epilogues live in the 256x256 kernel)
 shapes = [  # (name, M, N, K, c dtype, epi, residual)
     ("v.qkv", Mv, 2304, 768, TD, 0, False), ("v.out+res", Mv, 768, 768, torch.float16, 0, True), ("v.fc+gelu", Mv, 3072, 768, TD, 1, False),
     ("v.proj+res", Mv, 768, 3072, torch.float16, 0, True), ("v.dproj*dgelu", Mv, 3072, 768, TD, 2, False), ("v.dfc", Mv, 768, 3072, TD, 0, False),
@@ -38,7 +38,10 @@ for name, M, N, K, cdt, epi, res in shapes:
         blk = torch.zeros(3 * M + N, device=dev)
         blk[M:2 * M] = 1.0
         for _ in range(REPS):
-            E.gemm(E.F16, a, b, c, M, N, K, bias=bias, residual=blk, ldr=M, epi=(E.EPI_LN_QUICKGELU if epi else E.EPI_LN), aux=aux)
+            try:
+                E.gemm(E.F16, a, b, c, M, N, K, bias=bias, residual=blk, ldr=M, epi=(E.EPI_LN_QUICKGELU if epi else E.EPI_LN), aux=aux)
+            except Exception as e:
+                raise RuntimeError(f"{name}: M {M} N {N} K {K} c {c.dtype} aux {None if aux is None else aux.dtype}: {e}")
     for _ in range(0 if fold else REPS):
         E.gemm(BF16, a, b, c, M, N, K, bias=bias, residual=r, epi=epi, aux=aux)
     torch.cuda.synchronize()
