@@ -84,8 +84,8 @@ uint64_t lpi_launch_count(void);
  *   key 14     1: the generic epilogue of the persistent GEMM everywhere (no half-width staging for store-only 2-byte outputs); 3: also the opt-in
  *              half-width LayerNorm-fold epilogue (A/B switches, same bits).
  *   key 15     tile order of the persistent 256x256 GEMM for weights that do not fit an XCD's L2 next to the activation stream (round 5): 0 (default) = the
- *              N-tiles of a weight above 3 MB are cut into two SLICES and the tiles run slice-major, so that each XCD keeps one slice resident instead of
- *              re-reading the whole weight every round; > 0: that many column tiles per slice; -1: off (columns fastest over the whole N).  Same bits.
+ *              N-tiles (an even number) of a weight above 3 MB are cut into two SLICES and the tiles run slice-major, so that each XCD keeps one slice
+ *              resident instead of re-reading the whole weight every round; 2 / 3: that many slices wherever N divides; -1: off.  Same bits.
  *   keys 9, 10 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */

@@ -753,14 +753,16 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
         // GEMMs fetching 3.8x (in_proj) / 5.5x (c_fc) / 1.9x (d c_proj) their algorithmic bytes = the weights re-read by 8 XCDs x 7-10 rounds
         // (profiles/r03_gemm_shapes_pmc.json).  Ordering the tiles slice-major — the N-tiles cut into S slices whose weights (<= ~2.4 MB) DO stay resident,
         // every XCD walking one slice after the other down the row panels — trades that for reading the A panels once per slice (S x 84 MB instead of
-        // 80 x 4.7 MB).  The chip is power-limited under these kernels (1 371 W of a 1 400 W cap over the whole step, tools/power_poll.py) and bytes from
-        // beyond L2 are the first thing that costs clock (cdna_hip_programming.md rule 28).  Tuning key 15: 0 = automatic (weights above 3 MB: the fewest
-        // equal slices, 2 or 3, of at most 2.5 MB), 2 / 3 = that many slices where N divides, -1 = off.  Same tiles, same bits: only the order changes.
+        // 80 x 4.7 MB).  Measured (tools/shape_pmc_r05.sh, bytes fetched from beyond L2 per launch): c_fc 489 -> 362 MB, d c_proj 817 -> 719 MB, in_proj
+        // with three slices 331 -> 341 MB (hence two slices only); -1.0 % / -0.4 % on the two GEMMs alone (tools/slice_ab.py), nothing measurable on the
+        // whole step (22.75 ms either way, four interleaved pairs).  The chip is power-limited under these kernels (1 371 W of a 1 400 W cap over the whole step, tools/power_poll.py) and bytes from
+        // beyond L2 are the first thing that costs clock (cdna_hip_programming.md rule 28).  Tuning key 15: 0 = automatic (weights above 3 MB with
+        // an even number of N-tiles: two slices), 2 / 3 = that many slices where N divides, -1 = off.  Same tiles, same bits: only the order changes.
         if (slices_ok<EPI, SAVE_U>() && P.group_m == 1 && g_lpi_tuning[15] >= 0 && P.tiles_m < 32768) {
             int S = 0;
             const size_t wbytes = (size_t)h.N * h.K * sizeof(T);
             if (g_lpi_tuning[15] > 0) S = g_lpi_tuning[15];
-            else if (wbytes > ((size_t)3 << 20)) S = (P.tiles_n % 2 == 0 && wbytes / 2 <= ((size_t)5 << 19)) ? 2 : 3;
+            else if (wbytes > ((size_t)3 << 20) && P.tiles_n % 2 == 0) S = 2;      // three slices (in_proj: 9 N-tiles) measured no fewer fetched bytes
             if ((S == 2 || S == 3) && P.tiles_n % S == 0 && P.tiles_n / S >= 2) {
                 P.group_m |= P.tiles_m << 16;      // the real row-panel count
                 P.tiles_n /= S;
