@@ -382,7 +382,7 @@ def test_bench_vit_l14_four_ranks_on_one_gpu():
 
 
 # ------------------------------------------------------------------------------------------------ persistent GEMM: weight slices (tuning key 15)
-@pytest.mark.parametrize("tm,N,K,key", [(43, 3072, 768, 0), (43, 2304, 768, 0), (213, 3072, 768, 0), (20, 3072, 768, 3), (37, 2048, 1024, 2)])
+@pytest.mark.parametrize("tm,N,K,key", [(43, 3072, 768, 0), (43, 2304, 768, 3), (213, 3072, 768, 0), (20, 3072, 768, 3), (37, 2048, 1024, 2)])
 def test_gemm_weight_slices_change_the_order_not_the_bits(tm, N, K, key):
     """Tuning key 15 (round 5): the tiles of a GEMM whose weight does not fit an XCD's L2 run slice-major (2 or 3 slices of the N-tiles, each XCD walking one
     slice after the other down the row panels).  Same tiles, same arithmetic: bit for bit the columns-fastest order (key 15 = -1) — alone, with a bias and
