@@ -31,7 +31,7 @@ def _free_port():
 
 def _args(dev):
     args = json.load(open(os.path.join(RET, "configs", "lpi", "coco_lpi.json")))
-    args.update(backbonename="tiny", visual_dim=128, textual_dim=128, device=[dev], compute_dtype="f32", batch_size=B, epochs=EPOCHS, num_workers=0)
+    args.update(backbonename="tiny", visual_dim=128, textual_dim=128, device=[dev], compute_dtype="f32", batch_size=B, epochs=EPOCHS, num_workers=0)      # (batch_size is not read: the loaders are lists)
     return args
 
 
@@ -51,12 +51,12 @@ def _run(rank, world):
             getattr(net.prompts[t], k).data = torch.from_numpy(v.copy()).to(dev)
     net.numtask = 2
     img, ids = _data()
-    per = B * world                                   # global batch; rank r takes rows [r B, (r + 1) B) of it
-    nb = img.shape[0] // (W * B) * (W // world)
+    G = W * B                                         # the GLOBAL batch, the same for every world size; a rank takes its contiguous share of it
+    share = G // world
     loader = []
-    for b in range(nb):
-        lo = b * per + rank * B
-        loader.append((img[lo:lo + B] if world > 1 else img[b * per:(b + 1) * per], ids[lo:lo + B] if world > 1 else ids[b * per:(b + 1) * per], 0, 1))
+    for b in range(img.shape[0] // G):
+        lo = b * G + rank * share
+        loader.append((img[lo:lo + share], ids[lo:lo + share], 0, 1))
     opt, sched = m._setup_training()
     log = LossLog()
     for ep in range(EPOCHS):
