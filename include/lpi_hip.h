@@ -317,6 +317,11 @@ int lpi_prompt_cp_bwd2(int Lyr, int P, int Dv, int Dt, int r, const float* d1, c
  *      LayerNorm needs (model.py:172: ln_1 of the block that reads the stream) without a pass over it; lpi_prompt_add overwrites the entries of the
  *      rows it rewrites, which a GEMM epilogue (LPI_EPI_RES_ROWSTATS) had filled from their old contents. */
 int lpi_patchify(int dtype, int B, int R, int ps, const float* image, void* cols, int ldcols, void* stream);
+/* The same im2col from UINT8 pixels [B,3,R,R] (what the decoder produces: PIL -> HWC bytes -> CHW) with the loader's ToTensor + Normalize
+ * (utils/data.py:201-204: x / 255, (x - mean) / std) folded in through `lut` (f32 [3][256], DEVICE: lut[c][v] = the f32 value the host pipeline gives byte v
+ * in channel c — filled by the caller with those very operations, so the columns equal lpi_patchify's on the normalised f32 image bit for bit).  A quarter
+ * of the host-to-device bytes of the f32 batch (38.5 MB instead of 154 MB per 256 images).  ps and R multiples of 4, image 4-byte aligned. */
+int lpi_patchify_u8(int dtype, int B, int R, int ps, const uint8_t* image, const float* lut, void* cols, int ldcols, void* stream);
 int lpi_vis_assemble_fwd(int x_dtype, int B, int G2, int P, int d, const float* patch_emb, int ldpe, const float* cls,
                          const float* pos, const float* prompt0, long prompt_bstride,
                          const float* gamma, const float* beta, void* x0, float* mean, float* rstd, float* out_mean, float* out_rstd, void* stream);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "lpi_align_loss_fwd_bwd": [_I, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "lpi_nt_bxent_fwd_bwd": [_I, _I, _I, _P, _P, _F, _F, _P, _P, _I, _P, _P],
     "lpi_patchify": [_I, _I, _I, _I, _P, _P, _I, _P],
+    "lpi_patchify_u8": [_I, _I, _I, _I, _P, _P, _P, _I, _P],
     "lpi_vis_assemble_fwd": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P],
     "lpi_vis_assemble_bwd": [_I, _I, _I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
     "lpi_txt_embed_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P],

@@ -412,6 +412,32 @@ __global__ __launch_bounds__(256) void patchify_kernel(int B, int R, int ps, int
     Elem<T>::st4(cols + (size_t)patch * ldcols + k4, v);
 }
 
+// The same im2col from UINT8 pixels [B, 3, R, R] with ToTensor + Normalize folded in (utils/data.py:201-204: x / 255, then (x - mean) / std per channel):
+// lut[c][v] holds that f32 value for channel c and byte v, computed by the HOST with the very torch operations the f32 pipeline applies, so the columns are
+// bit for bit those of patchify_kernel on the normalised f32 image — at a quarter of the host-to-device bytes.  ps and R multiples of 4.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_u8_kernel(int B, int R, int ps, int G, int Kp, const uint8_t* __restrict__ img, const float* __restrict__ lut,
+                                                         T* __restrict__ cols, int ldcols) {
+    __shared__ float s_lut[3 * 256];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) s_lut[i] = lut[i];
+    __syncthreads();
+    const int K = 3 * ps * ps;
+    const long total = (long)B * G * G * (Kp >> 2);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int k4 = (int)(t % (Kp >> 2)) << 2;
+    const long patch = t / (Kp >> 2);
+    const int b = (int)(patch / (G * G)), gy = (int)(patch % (G * G)) / G, gx = (int)(patch % G);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+        const int c = k4 / (ps * ps), rem = k4 % (ps * ps), dy = rem / ps, dx = rem % ps;
+        const uint32_t px = *reinterpret_cast<const uint32_t*>(img + (((size_t)b * 3 + c) * R + gy * ps + dy) * R + gx * ps + dx);
+        const float* l = s_lut + c * 256;
+        v = f32x4{l[px & 255u], l[(px >> 8) & 255u], l[(px >> 16) & 255u], l[px >> 24]};
+    }
+    Elem<T>::st4(cols + (size_t)patch * ldcols + k4, v);
+}
+
 __device__ __forceinline__ void vis_pre_row(Row& r, int b, int l, int G2, int P, int d, int lane, const float* patch_emb,
                                             int ldpe, const float* cls, const float* pos, const float* prompt0, long pbs) {
     if (l == 0) {
@@ -1118,6 +1144,23 @@ extern "C" int lpi_patchify(int dtype, int B, int R, int ps, const float* image,
     else if (dtype == LPI_F16) PATCHIFY(f16_t);
     else return LPI_EINVAL;
 #undef PATCHIFY
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_patchify_u8(int dtype, int B, int R, int ps, const uint8_t* image, const float* lut, void* cols, int ldcols, void* stream) {
+    if (!image || !lut || !cols || B <= 0 || ps <= 0 || R % ps || (ps & 3) || (R & 3) || ((uintptr_t)image & 3)) return LPI_EINVAL;
+    const int G = R / ps, K = 3 * ps * ps;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    const int bk = 128 / esz;
+    const int Kp = (K + bk - 1) / bk * bk;
+    if (ldcols < Kp || (ldcols & 3)) return LPI_EINVAL;
+    const long total = (long)B * G * G * (Kp >> 2);
+    dim3 g((unsigned)((total + 255) / 256)), b(256);
+    if (dtype == LPI_F32) LPI_LAUNCH(patchify_u8_kernel<float>, g, b, 0, S(stream), B, R, ps, G, Kp, image, lut, (float*)cols, ldcols);
+    else if (dtype == LPI_BF16) LPI_LAUNCH(patchify_u8_kernel<bf16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, lut, (bf16_t*)cols, ldcols);
+    else if (dtype == LPI_F16) LPI_LAUNCH(patchify_u8_kernel<f16_t>, g, b, 0, S(stream), B, R, ps, G, Kp, image, lut, (f16_t*)cols, ldcols);
+    else return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
 }

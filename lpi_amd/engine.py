@@ -831,6 +831,17 @@ class DualEncoder:
         self._guard_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if ROWSTAT_GUARD else None
         self.rowstat_guard_tripped = 0          # rows counted when the guard switched the towers to the statistics pass (0 = never)
 
+    # ------------------------------------------------------------------ uint8 pixels
+    def pixel_lut(self, mean=None, std=None):
+        """f32 [3, 256] on the device: lut[c][v] = ((v / 255) - mean[c]) / std[c], evaluated with the torch operations of the loader's ToTensor +
+        Normalize (utils/data.py:201-204 -> lpi_amd.retrieval.utils.data._to_normalised_tensor: .float().div_(255.0), then (a - mean) / std in f32), so
+        that lpi_patchify_u8 reproduces the f32 pipeline bit for bit.  Default statistics: ImageNet's, as the reference's transforms use."""
+        key = (tuple(mean) if mean is not None else None, tuple(std) if std is not None else None)
+        lut = self.__dict__.setdefault("_pixel_luts", {}).get(key)
+        if lut is None:
+            lut = self._pixel_luts[key] = make_pixel_lut(mean, std).to(self.device)
+        return lut
+
     # ------------------------------------------------------------------ one-sweep statistics guard
     def _guard_begin(self):
         """Start of a forward: if an earlier forward's kernels have flagged the host word (a plain read of this process's own memory: no copy, no event,
@@ -921,7 +932,8 @@ class DualEncoder:
         cfg, dt, s = self.cfg, self.dt, _stream()
         self._guard_begin()
         B = image.shape[0]
-        image = image.to(device=self.device, dtype=torch.float32).contiguous()
+        u8 = image.dtype == torch.uint8      # decoded pixels: ToTensor + Normalize happen inside the im2col kernel (pixel_lut)
+        image = image.to(device=self.device).contiguous() if u8 else image.to(device=self.device, dtype=torch.float32).contiguous()
         pr, pbs, P = self._prompt_args(prompts, B)
         G2, d = cfg.n_patches, cfg.vision_width
         L = 1 + P + G2
@@ -932,7 +944,10 @@ class DualEncoder:
             fe = {"cols": torch.zeros(rows, self.kp, dtype=_TORCH_DT[dt], device=self.device),
                   "pe": torch.zeros(rows, d, device=self.device), "stat": torch.zeros(2, ws["Mp"], device=self.device)}
             ws["front"] = fe
-        call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
+        if u8:
+            call("lpi_patchify_u8", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, self.pixel_lut(), fe["cols"], self.kp, s)
+        else:
+            call("lpi_patchify", dt, B, cfg.image_resolution, cfg.vision_patch_size, image, fe["cols"], self.kp, s)
         yield GemmReq(None, dt, fe["cols"], self.conv.w, fe["pe"], fe["cols"].shape[0], d, self.kp, m_real=B * G2)
         call("lpi_vis_assemble_fwd", self.vis.xdt, B, G2, P, d, fe["pe"], d, self.cls, self.vpos, pr, pbs, self.ln_pre[0], self.ln_pre[1],
              ws["x"][0], fe["stat"][0], fe["stat"][1], *self.vis.ln1_stats_out(ws), s)
@@ -1097,6 +1112,14 @@ class DualEncoder:
     def encode_both_backward(self, dimg, dtxt, vis_ctx, txt_ctx):
         """The two backward passes in lock step -> (dL/d vis prompts, dL/d txt prompts)."""
         return run_lockstep(self.encode_image_backward_gen(dimg, vis_ctx), self.encode_text_backward_gen(dtxt, txt_ctx))
+
+
+def make_pixel_lut(mean=None, std=None) -> torch.Tensor:
+    """[3, 256] f32 on the host: lut[c][v] = ToTensor + Normalize of byte v in channel c, in the loader's own torch operations (see DualEncoder.pixel_lut)."""
+    m = torch.tensor(mean if mean is not None else (0.485, 0.456, 0.406)).view(3, 1)
+    sd = torch.tensor(std if std is not None else (0.229, 0.224, 0.225)).view(3, 1)
+    a = torch.arange(256, dtype=torch.uint8).view(1, 256).expand(3, 256).float().div_(255.0)
+    return ((a - m) / sd).contiguous()
 
 
 class PackedIds:

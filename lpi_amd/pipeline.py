@@ -11,7 +11,8 @@ step.  At 22 ms per step on an MI355X both would sit on the critical path (a pag
 
 and the training loop only makes its stream wait for that event (no host synchronisation anywhere).  A device slot is reused once the step that read it
 has been enqueued and its completion event recorded; a staging slot once its copy has finished.  ``images`` stay f32 as the reference's loader
-delivers them (bit-identical input to the f32 patchify kernel).
+delivers them (bit-identical input to the f32 patchify kernel) — or uint8 when the dataset hands over decoded pixels (``pixel_format='u8'``: the
+loader's ToTensor + Normalize run inside lpi_patchify_u8, bit for bit, and the copy moves a quarter of the bytes).
 
 Python threads are enough: every heavy part (memcpy, BPE, hipMemcpyAsync) runs in native code with the GIL released; the main thread needs ~4 ms of
 host time per step to enqueue it (profiles/r04: tools/host_ahead.py).
@@ -29,7 +30,7 @@ from . import _lib
 
 
 class DeviceBatch:
-    """One training batch on the device: ``images`` f32 [B,3,R,R] (a view of a ring slot — valid until the NEXT batch is requested), ``text`` whatever
+    """One training batch on the device: ``images`` f32 (or uint8) [B,3,R,R] (a view of a ring slot — valid until the NEXT batch is requested), ``text`` whatever
     ``prepare_text`` returned (device-resident), ``rest`` the loader's remaining fields, ``host_ms`` the producer's per-phase host times."""
     __slots__ = ("images", "text", "rest", "ready", "slot", "host_ms", "h2d", "index")
 
@@ -63,22 +64,23 @@ class BatchPipeline:
         _lib.load()
 
     # ------------------------------------------------------------------ producer
-    def _slot_buffers(self, slot, shape):
+    def _slot_buffers(self, slot, shape, dtype):
         st = self._stage[slot]
-        if st is None or tuple(st.shape[1:]) != tuple(shape[1:]) or st.shape[0] < shape[0]:
-            st = self._stage[slot] = torch.empty(shape, dtype=torch.float32, pin_memory=True)
-            self._dev[slot] = torch.empty(shape, dtype=torch.float32, device=self.device)
+        if st is None or st.dtype != dtype or tuple(st.shape[1:]) != tuple(shape[1:]) or st.shape[0] < shape[0]:
+            st = self._stage[slot] = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self._dev[slot] = torch.empty(shape, dtype=dtype, device=self.device)
         return st, self._dev[slot]
 
     def _gather(self, images, stage):
-        """images (list of [3,R,R] f32 tensors, or one [B,3,R,R] tensor) -> stage[:B] on self.threads host threads."""
+        """images (list of [3,R,R] tensors, or one [B,3,R,R] tensor; f32, or uint8 pixels for the in-kernel normalisation) -> stage[:B] on
+        self.threads host threads."""
+        keep = stage.dtype
         if torch.is_tensor(images):
+            images = images if images.dtype == keep else images.to(keep)
             rows = [images[i] for i in range(images.shape[0])] if images.is_contiguous() else [t.contiguous() for t in images]
         else:
-            rows = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous() for t in images]
-        if rows and rows[0].dtype != torch.float32:
-            rows = [t.float() for t in rows]
-        n, each = len(rows), rows[0].numel() * 4
+            rows = [t if (t.dtype == keep and t.is_contiguous()) else t.to(keep).contiguous() for t in images]
+        n, each = len(rows), rows[0].numel() * rows[0].element_size()
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in rows])
         rc = _lib.load().lpi_host_gather(stage.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), n, each, self.threads)
         if rc != 0:
@@ -108,7 +110,7 @@ class BatchPipeline:
                 shape = (B,) + tuple(one.shape)
                 if self._copied[slot] is not None:
                     self._copied[slot].synchronize()          # the staging slot's previous copy has left the host buffer
-                stage, dev = self._slot_buffers(slot, shape)
+                stage, dev = self._slot_buffers(slot, shape, torch.uint8 if one.dtype == torch.uint8 else torch.float32)
                 t2 = time.perf_counter()
                 self._gather(images, stage)
                 t3 = time.perf_counter()

@@ -116,9 +116,12 @@ class SPrompts(BaseLearner):
             impl = "coco" if os.path.isdir(str(self.args.get("image_root", ""))) else "synthetic"
         if impl == "coco":          # sprompt.py:163-170
             from lpi_amd.retrieval.utils.data import Coco, CocoEval
-            return (Coco(image_root=self.args['image_root'], ann_file=self.args['annotation_train_root'], tasks=[i]),
+            # pixel_format = 'u8': the datasets hand over the decoded uint8 pixels and ToTensor + Normalize run inside the im2col kernel (lpi_patchify_u8:
+            # bit for bit the f32 pipeline, a quarter of the host-to-device bytes)
+            pf = self.args.get('pixel_format', 'f32')
+            return (Coco(image_root=self.args['image_root'], ann_file=self.args['annotation_train_root'], tasks=[i], pixel_format=pf),
                     CocoEval(image_root=self.args['image_root'], ann_file=self.args['annotation_val_root'], tasks=np.arange(0, i + 1),
-                             eval_transform=self.args.get('eval_transform', 'center')))
+                             eval_transform=self.args.get('eval_transform', 'center'), pixel_format=pf))
         if impl != "synthetic":
             raise ValueError(f"unknown dataset_impl {impl!r} (coco | synthetic)")
         res = self._network.clip_cfg.image_resolution
@@ -127,7 +130,7 @@ class SPrompts(BaseLearner):
         # synthetic_captions = 'strings': items carry caption STRINGS like the reference's Coco (needs a BPE merge table: lpi_amd.synth_bpe.ensure_vocab
         # supplies a synthetic one where CLIP's is absent); synthetic_image_pool = K: K distinct images, generated once (items are views)
         return (SyntheticCoco(n_train, [i], res, seed=i, captions=self.args.get("synthetic_captions", "ids"),
-                              image_pool=int(self.args.get("synthetic_image_pool", 0))),
+                              image_pool=int(self.args.get("synthetic_image_pool", 0)), pixel_format=self.args.get("pixel_format", "f32")),
                 SyntheticCocoEval(n_eval, np.arange(0, i + 1), 2, res, seed=i))
 
     def incremental_train(self):

@@ -36,12 +36,16 @@ class SyntheticCoco(Dataset):
     captions = 'ids' (default): a caption is its row of ready token ids [77] (no tokenizer, no merge table needed); 'strings': a caption is a STRING of
     COCO-like words (lpi_amd.synth_bpe.captions) — the item then has exactly the reference's structure (utils/data.py:376-382: f32 image, str, 0, task) and
     the step tokenises it like PromptLearner.forward does.
+    pixel_format = 'u8': items carry uint8 CHW pixels (uniform bytes) and ToTensor + Normalize run on the GPU (lpi_patchify_u8).
     image_pool = K > 0: the K distinct images are generated once and item i returns pool image i % K (a VIEW: the collate / pipeline copies it) — an
     item costs nothing, so that a throughput measurement of the training loop times the loop and not numpy's generator (150 k normals per image)."""
 
-    def __init__(self, n, tasks, resolution=224, seed=0, captions="ids", image_pool=0):
+    def __init__(self, n, tasks, resolution=224, seed=0, captions="ids", image_pool=0, pixel_format="f32"):
         if captions not in ("ids", "strings"):
             raise ValueError(f"captions must be 'ids' or 'strings', not {captions!r}")
+        if pixel_format not in ("f32", "u8"):
+            raise ValueError(f"pixel_format must be 'f32' or 'u8', not {pixel_format!r}")
+        self.pixel_format = pixel_format
         self.n, self.tasks, self.res = n, list(tasks), resolution
         self.seed = seed
         if captions == "ids":
@@ -51,7 +55,11 @@ class SyntheticCoco(Dataset):
             from lpi_amd.synth_bpe import captions as make
             self.ids, self.captions = None, make(n, seed=synth.TOKEN_SEED + 17 * seed)
         k = min(int(image_pool), n) if image_pool else 0
-        self.pool = None if k <= 0 else torch.from_numpy(synth.normal(synth.IMAGE_SEED + seed, f"pool{k}", (k, 3, resolution, resolution)))
+        if pixel_format == "u8":          # uniform bytes: "decoded pixels"; pixel_format='f32' of the same dataset = their ToTensor + Normalize
+            k = k or n
+            self.pool = torch.from_numpy(synth._rng(synth.IMAGE_SEED + seed, f"u8pool{k}").integers(0, 256, (k, 3, resolution, resolution), dtype=np.uint8))
+        else:
+            self.pool = None if k <= 0 else torch.from_numpy(synth.normal(synth.IMAGE_SEED + seed, f"pool{k}", (k, 3, resolution, resolution)))
 
     def __len__(self):
         return self.n
@@ -122,6 +130,18 @@ def _pil():
     return Image
 
 
+def _to_u8_chw(img):
+    """The decoded pixels as the GPU takes them (pixel_format='u8'): HWC uint8 -> CHW uint8; ToTensor + Normalize then run inside lpi_patchify_u8."""
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).contiguous()
+
+
+def normalise_u8(u8):
+    """ToTensor + Normalize on a CHW (or BCHW) uint8 tensor, in the operations of _to_normalised_tensor — the f32 image the 'f32' pixel format delivers."""
+    a = u8.float().div_(255.0)
+    shape = (3, 1, 1)
+    return (a - torch.tensor(IMAGENET_MEAN).view(shape)) / torch.tensor(IMAGENET_STD).view(shape)
+
+
 def _to_normalised_tensor(img):
     """ToTensor + Normalize(ImageNet) (utils/data.py:201-204): HWC uint8 -> CHW f32 in [0,1], then (x - mean) / std."""
     a = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
@@ -130,7 +150,7 @@ def _to_normalised_tensor(img):
     return (a - mean) / std
 
 
-def train_transform(img, size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+def train_transform(img, size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), pixel_format="f32"):
     """RandomResizedCrop(size) + RandomHorizontalFlip + ToTensor + Normalize (utils/data.py:193-204), torch RNG: a crop of random area
     (scale x image area) and log-uniform aspect ratio, ten attempts, else the largest centred crop inside the ratio bounds; bilinear."""
     Image = _pil()
@@ -160,10 +180,10 @@ def train_transform(img, size=224, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.
     img = img.crop(box).resize((size, size), Image.BILINEAR)
     if float(torch.rand(1)) < 0.5:
         img = img.transpose(Image.FLIP_LEFT_RIGHT)
-    return _to_normalised_tensor(img)
+    return _to_u8_chw(img) if pixel_format == "u8" else _to_normalised_tensor(img)
 
 
-def test_transform(img, resize=256, size=224):
+def test_transform(img, resize=256, size=224, pixel_format="f32"):
     """Resize(256) (shorter side, bilinear) + CenterCrop(224) + ToTensor + Normalize (utils/data.py:197-204)."""
     Image = _pil()
     w, h = img.size
@@ -173,7 +193,8 @@ def test_transform(img, resize=256, size=224):
         nw, nh = int(resize * w / h), resize
     img = img.resize((nw, nh), Image.BILINEAR)
     left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
-    return _to_normalised_tensor(img.crop((left, top, left + size, top + size)))
+    img = img.crop((left, top, left + size, top + size))
+    return _to_u8_chw(img) if pixel_format == "u8" else _to_normalised_tensor(img)
 
 
 def _load(image_root, name, transform):
@@ -185,8 +206,12 @@ def _load(image_root, name, transform):
 class Coco(Dataset):
     """Training pairs of the given tasks (utils/data.py:308-382): item = (image, prompt + pre_caption(caption), 0, task)."""
 
-    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, prompt='', tasks=(0,), replay_list=()):
+    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, prompt='', tasks=(0,), replay_list=(), pixel_format="f32"):
         _pil()
+        if pixel_format not in ("f32", "u8"):
+            raise ValueError(f"pixel_format must be 'f32' or 'u8', not {pixel_format!r}")
+        if transform is None and pixel_format == "u8":
+            transform = lambda im: train_transform(im, pixel_format="u8")  # noqa: E731
         with open(ann_file, 'r') as f:
             records = json.load(f)
         cats = {TASK_CATEGORIES[int(t)] for t in tasks}
@@ -213,8 +238,13 @@ class CocoEval(Dataset):
     """Evaluation images of tasks 0..t with every caption of every image in the lookup tables the scoring loop reads
     (utils/data.py:186-306; sprompt.py:433-548): text, text_cat, image, txt2img, img2txt; item = (image, image index, task)."""
 
-    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, tasks=(0,), eval_transform='center'):
+    def __init__(self, transform=None, image_root=None, ann_file=None, max_words=30, tasks=(0,), eval_transform='center', pixel_format="f32"):
         _pil()
+        if pixel_format not in ("f32", "u8"):
+            raise ValueError(f"pixel_format must be 'f32' or 'u8', not {pixel_format!r}")
+        if transform is None and pixel_format == "u8":
+            base = test_transform if eval_transform == 'center' else train_transform
+            transform = lambda im: base(im, pixel_format="u8")  # noqa: E731
         with open(ann_file, 'r') as f:
             records = json.load(f)
         cats = {TASK_CATEGORIES[int(t)] for t in tasks}

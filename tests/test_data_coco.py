@@ -105,3 +105,32 @@ def test_sprompts_selects_the_coco_datasets(coco, monkeypatch):
     m.args["dataset_impl"] = "nope"
     with pytest.raises(ValueError):
         S.SPrompts._datasets(m, 0)
+
+
+def test_uint8_pixel_format_is_the_f32_pipeline_before_totensor_and_normalize(tmp_path):
+    """pixel_format='u8' (round 5): the datasets hand over the decoded CHW bytes and the GPU applies ToTensor + Normalize through a 3 x 256 table
+    (lpi_patchify_u8).  On the host: the table equals the loader's own arithmetic for every byte and channel, bit for bit, and a u8 item normalised with
+    it IS the f32 item."""
+    import numpy as np
+    import torch
+    from lpi_amd.engine import make_pixel_lut
+    from lpi_amd.retrieval.utils import data as D
+    lut = make_pixel_lut()
+    for c in range(3):
+        ramp = torch.arange(256, dtype=torch.uint8).view(1, 16, 16).expand(3, 16, 16).contiguous()
+        ref = D.normalise_u8(ramp)[c].reshape(-1)
+        assert torch.equal(lut[c], ref)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.default_rng(0)
+    img = Image.fromarray(rng.integers(0, 256, (300, 260, 3), dtype=np.uint8))
+    u8 = D.test_transform(img, pixel_format="u8")
+    f32 = D.test_transform(img)
+    assert u8.dtype == torch.uint8 and u8.shape == (3, 224, 224) and f32.dtype == torch.float32
+    assert torch.equal(D.normalise_u8(u8), f32)
+    gathered = torch.stack([lut[c][u8[c].long()] for c in range(3)])          # what the kernel computes
+    assert torch.equal(gathered, f32)
+    ds = D.SyntheticCoco(5, [0], 32, pixel_format="u8", image_pool=3)
+    assert ds[4][0].dtype == torch.uint8 and ds[4][0].data_ptr() == ds[1][0].data_ptr()

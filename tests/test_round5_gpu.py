@@ -417,3 +417,62 @@ def test_gemm_weight_slices_change_the_order_not_the_bits(tm, N, K, key):
     assert not torch.isnan(outs[1][0].float()).any()
     ref = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
     assert float((outs[1][0].double().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ uint8 pixels
+def test_uint8_pixels_give_the_f32_pipelines_features_bit_for_bit():
+    """lpi_patchify_u8 (ToTensor + Normalize folded into the im2col through the 3 x 256 table): the im2col columns of uint8 pixels equal lpi_patchify's on
+    the host-normalised f32 image bit for bit, in every operand type; so do the image features; and the plugin loop on a u8 dataset (pipeline staging in
+    uint8: a quarter of the bytes) trains to the same parameters as on the f32 dataset of the same pixels."""
+    from lpi_amd.engine import DualEncoder
+    from lpi_amd.retrieval.utils.data import normalise_u8
+    from lpi_amd._lib import BF16, F16, F32, call
+    g = torch.Generator().manual_seed(5)
+    for R, ps, dts in ((32, 16, (F32, BF16, F16)), (224, 16, (BF16,)), (28, 14, (F32,))):
+        if ps % 4:
+            continue
+        B = 3
+        u8 = torch.randint(0, 256, (B, 3, R, R), generator=g, dtype=torch.uint8)
+        f32 = normalise_u8(u8)
+        G, K = R // ps, 3 * ps * ps
+        for dt in dts:
+            esz = 4 if dt == F32 else 2
+            kp = (K + 128 // esz - 1) // (128 // esz) * (128 // esz)
+            td = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+            c0 = torch.zeros(B * G * G, kp, dtype=td, device=DEV)
+            c1 = torch.full((B * G * G, kp), 7.0, dtype=td, device=DEV)
+            s = torch.cuda.current_stream().cuda_stream
+            from lpi_amd.engine import make_pixel_lut
+            call("lpi_patchify", dt, B, R, ps, f32.to(DEV), c0, kp, s)
+            call("lpi_patchify_u8", dt, B, R, ps, u8.to(DEV), make_pixel_lut().to(DEV), c1, kp, s)
+            torch.cuda.synchronize()
+            assert torch.equal(c0.view(torch.int32 if esz == 4 else torch.int16), c1.view(torch.int32 if esz == 4 else torch.int16)), (R, ps, dt)
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f32", device=DEV)
+    u8 = torch.randint(0, 256, (5, 3, 32, 32), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        fa = enc.encode_image(u8.to(DEV)).clone()
+        fb = enc.encode_image(normalise_u8(u8).to(DEV)).clone()
+    assert torch.equal(fa, fb)
+    # the plugin loop on the two pixel formats of the same pixels
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    ids = torch.from_numpy(synth.token_ids(8, seed=5))
+    px = torch.randint(0, 256, (8, 3, 32, 32), generator=g, dtype=torch.uint8)
+    got = []
+    for fmt in ("u8", "f32"):
+        im = px if fmt == "u8" else normalise_u8(px)
+        loader = [(im[:4], ids[:4], 0, 0), ([im[j] for j in range(4, 8)], ids[4:], 0, 0)]
+        m = SPrompts(tiny_args(epochs=2))
+        net = m._network.to(DEV)
+        set_factors(net)
+        net.numtask = 1
+        opt, sch = m._setup_training()
+        for ep in range(2):
+            m.train_epoch(loader, opt, ep)
+            sch.step()
+        torch.cuda.synchronize()
+        got.append({k: getattr(net.prompts[0], k).detach().clone() for k in synth.PROMPT_NAMES})
+        if fmt == "u8":
+            assert m._pipeline._stage[0].dtype == torch.uint8 and m._pipeline._dev[0].dtype == torch.uint8
+    for k in synth.PROMPT_NAMES:
+        assert torch.equal(got[0][k], got[1][k]), k
