@@ -585,7 +585,8 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
     m = SPrompts(args)
     net = m._network
     net.update_fc(0)                                            # task 0 (numtask = 1), as incremental_train does
-    ds = SyntheticCoco((steps + warm + 8) * B, [0], net.clip_cfg.image_resolution, seed=0, captions="strings", image_pool=512)
+    pf = args.get("pixel_format", "f32")
+    ds = SyntheticCoco((steps + warm + 8) * B, [0], net.clip_cfg.image_resolution, seed=0, captions="strings", image_pool=512, pixel_format=pf)
     loader = DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
     optimizer, _ = m._setup_training()
     t, host, h2d, rows, evs = {}, [], [], [], []
@@ -617,7 +618,7 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
            "launches_per_step": (t["n1"] - t["n0"]) // steps,
            "loop": "SPrompts.train_epoch: " + ("BatchPipeline (pinned staging, side-stream H2D, tokenise ahead) + fused SliNet.train_step + FlatSGD"
                                                if args.get("prefetch", True) else "images.to(device) + net(images, captions) -> cal_loss -> backward + FlatSGD (reference order)"),
-           "input": f"DataLoader(SyntheticCoco: host f32 images [3,{net.clip_cfg.image_resolution},{net.clip_cfg.image_resolution}] from a pool of 512, caption strings), bs={B}, "
+           "input": f"DataLoader(SyntheticCoco: host {pf} images [3,{net.clip_cfg.image_resolution},{net.clip_cfg.image_resolution}] from a pool of 512, caption strings), bs={B}, "
                     "num_workers=0", "bpe_table": "synthetic" if "lpi_synthetic_bpe" in vocab else "clip"}
     # step-to-step time on the device inside the loop (HIP events recorded behind every iteration): what the loop costs the GPU, next to the wall clock
     rec["median_ms_per_step"] = round(float(np.median([evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)])), 3)
@@ -625,7 +626,7 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
         rec["producer_ms_per_batch"] = {k: round(float(np.mean([h[k] for h in host])), 3) for k in host[0]}
         rec["producer_ms_per_batch"]["total_without_waits"] = round(sum(v for k, v in rec["producer_ms_per_batch"].items() if k not in ("slot_wait",)), 3)
         rec["h2d_ms_per_batch"] = round(float(np.mean([e0.elapsed_time(e1) for e0, e1 in h2d if e0 is not None])), 3)
-        rec["h2d_bytes_per_batch"] = B * 3 * net.clip_cfg.image_resolution ** 2 * 4
+        rec["h2d_bytes_per_batch"] = B * 3 * net.clip_cfg.image_resolution ** 2 * (1 if pf == "u8" else 4)
         rec["text_rows_computed"] = round(float(np.mean(rows)) / B, 2)
     # the split of one step on the device (HIP events at the phase boundaries of a few more steps, on the loop's own batches)
     marks_all = []
@@ -791,6 +792,9 @@ def main():
             extras["plugin_step"] = plugin_step(a, dev, sync)
             extras["plugin_step"]["vs_bare_step"] = round(extras["plugin_step"]["value"] / pairs_s, 4)
             extras["plugin_step_reference_order"] = plugin_step(a, dev, sync, steps=15, warm=4, prefetch=False, fused_step=False)
+            # ... and with the dataset handing over decoded uint8 pixels (ToTensor + Normalize inside lpi_patchify_u8, bit for bit: a quarter of the H2D bytes)
+            extras["plugin_step_u8"] = plugin_step(a, dev, sync, steps=40, warm=8, pixel_format="u8")
+            extras["plugin_step_u8"]["vs_bare_step"] = round(extras["plugin_step_u8"]["value"] / pairs_s, 4)
         if a.model == "ViT-B/16":
             extras["parity"] = parity_block(a, dev)
         extras["eval_path"] = eval_path(a, dev, rank, sync)
