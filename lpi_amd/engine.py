@@ -195,7 +195,20 @@ def _ln_fold_ok(Mp, d):
     return ok
 
 
-class GemmReq:
+class Req:
+    """Base of everything a tower generator yields to its driver (run_alone / run_lockstep).  `tag` names the op — requests with EQUAL tags of the two
+    towers are issued as one pair; `optional` says that a tower emits this request CONDITIONALLY (its partner may have nothing at that point): run_lockstep
+    then issues it alone without advancing the partner, so the towers re-align instead of running shifted — and ungrouped — for the rest of the pass.  Every
+    request class states it (a class default or a per-instance value); LOCKSTEP_STATS['shifted'] counts the issues that found no partner although neither side
+    was optional (a request class that forgot the flag): 0 in every tested configuration."""
+    __slots__ = ()
+    optional = False
+
+
+LOCKSTEP_STATS = {"paired": 0, "alone_optional": 0, "shifted": 0}
+
+
+class GemmReq(Req):
     """A GEMM a tower wants issued: the towers' forward / backward are generators that YIELD their GEMMs instead of launching them, so
     that a driver (run_lockstep) can launch the vision and the text tower's GEMM of the same layer op as ONE grouped launch
     (lpi_gemm_nt_grouped).  `tag` names the op ("3.qkv", "last.kv", ...): only requests with equal tags are paired; None = never."""
@@ -209,7 +222,7 @@ class GemmReq:
         gemm(self.dt, self.a, self.b, self.c, self.M, self.N, self.K, **self.kw)
 
 
-class AttnFwdReq:
+class AttnFwdReq(Req):
     """An attention forward a tower wants issued (args of lpi_attn_fwd_varlen after the dtype): the two towers' go out as one launch."""
     __slots__ = ("tag", "dt", "args")
 
@@ -220,7 +233,7 @@ class AttnFwdReq:
         call("lpi_attn_fwd_varlen", self.dt, *self.args, _stream())
 
 
-class LnReq:
+class LnReq(Req):
     """A LayerNorm a tower wants issued (forward: kind "fwd", args of lpi_layernorm_fwd after the two dtypes; backward: "bwd", args of
     lpi_layernorm_bwd after the three dtypes).  Yielded like a GemmReq so that the two towers' LayerNorms of the same layer go out as
     ONE launch (lpi_layernorm_fwd_pair / _bwd_pair): the text tower's alone is a few-microsecond kernel that is mostly launch ramp."""
@@ -235,7 +248,7 @@ class LnReq:
         call("lpi_layernorm_fwd" if self.kind == "fwd" else "lpi_layernorm_bwd", *self.dts, *self.args, _stream())
 
 
-class StatFinReq:
+class StatFinReq(Req):
     """The row statistics of a residual-stream GEMM output from the slot sums its epilogue left (LPI_EPI_RES_ROWSTATS -> lpi_ln_stats_finalize):
     args = (rows, d, part, ld, mean, rstd).  The two towers' go out as one launch."""
     __slots__ = ("tag", "args")
@@ -249,7 +262,7 @@ class StatFinReq:
         call("lpi_ln_stats_finalize", rows, d, part, ld, 1e-5, mean, rstd, _stream())
 
 
-class RowReq:
+class RowReq(Req):
     """Small row kernels a tower wants issued (a list of _lib.RowJob of ONE dependency level: lpi_row_jobs).  Yielded like a GemmReq so that the two
     towers' jobs of the same op go out as ONE launch — each alone is a ~5 us launch on B or B*P rows, and the tail of a step is a chain of them."""
     __slots__ = ("tag", "jobs", "optional")
@@ -261,7 +274,7 @@ class RowReq:
         _lib.row_jobs(self.jobs, _stream())
 
 
-class RowsSumReq:
+class RowsSumReq(Req):
     """A batch sum of prompt rows (args of lpi_rows_sum_over_batch_varlen after the dtype, before the stream); the towers' pair = one launch."""
     __slots__ = ("tag", "dt", "args")
     optional = True      # emitted by the layers below the prompt depth only: a tower with fewer such layers must not be shifted (run_lockstep)
@@ -273,7 +286,7 @@ class RowsSumReq:
         call("lpi_rows_sum_over_batch_varlen", self.dt, *self.args, _stream())
 
 
-class PoolAttnReq:
+class PoolAttnReq(Req):
     """The pooled-row attention of the last block (forward or backward): `desc` = the lpi_attn_pooled_desc fields of this tower."""
     __slots__ = ("tag", "dt", "bwd", "desc")
 
@@ -424,15 +437,18 @@ def run_lockstep(g0, g1):
             continue
         if cur[0].tag == cur[1].tag:
             _issue_pair(cur[0], cur[1])
+            LOCKSTEP_STATS["paired"] += 1
         else:
-            o0, o1 = bool(getattr(cur[0], "optional", False)), bool(getattr(cur[1], "optional", False))
+            o0, o1 = bool(cur[0].optional), bool(cur[1].optional)
             if o0 != o1:
                 i = 0 if o0 else 1
                 cur[i].issue()
+                LOCKSTEP_STATS["alone_optional"] += 1
                 adv(i)
                 continue
             cur[0].issue()
             cur[1].issue()
+            LOCKSTEP_STATS["shifted"] += 1
         adv(0)
         adv(1)
     return ret[0], ret[1]
