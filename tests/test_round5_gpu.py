@@ -203,7 +203,10 @@ def test_plugin_loop_on_strings_issues_the_bare_steps_launches_and_no_other_kern
         bare = _lib.launch_count() - n0
     assert len(per) == 1 and per[0] == bare and bare <= 230, (per, bare)
     from lpi_amd import engine as E
-    assert E.LOCKSTEP_STATS["paired"] > 0 and E.LOCKSTEP_STATS["shifted"] == 0, E.LOCKSTEP_STATS      # no request without its partner
+    # no request without its partner in this configuration (towers of equal depth): counted over the bare steps above
+    stats0 = dict(E.LOCKSTEP_STATS)
+    train_step(net.engine, img, pk, fac, 3, flat_grad=opt.flat_grad, grad_views=opt.grad_views)
+    assert E.LOCKSTEP_STATS["paired"] > stats0["paired"] and E.LOCKSTEP_STATS["shifted"] == stats0["shifted"], (stats0, E.LOCKSTEP_STATS)
     dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
     foreign = [n for n in dev_events if "anonymous namespace" not in n and "_GLOBAL__N_" not in n and "lpi" not in n.lower() and "StatFin" not in n
                and "Memcpy" not in n and "Memset" not in n]
