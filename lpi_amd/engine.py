@@ -200,7 +200,8 @@ class Req:
     towers are issued as one pair; `optional` says that a tower emits this request CONDITIONALLY (its partner may have nothing at that point): run_lockstep
     then issues it alone without advancing the partner, so the towers re-align instead of running shifted — and ungrouped — for the rest of the pass.  Every
     request class states it (a class default or a per-instance value); LOCKSTEP_STATS['shifted'] counts the issues that found no partner although neither side
-    was optional (a request class that forgot the flag): 0 in every tested configuration."""
+    was optional: expected where the towers differ in depth (ViT-L/14: 24 vision blocks against 12 text blocks), 0 for towers of equal depth — asserted for
+    the benchmarked configuration (tests/test_round5_gpu.py), where a request class that forgot the flag would show up."""
     __slots__ = ()
     optional = False
 
