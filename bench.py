@@ -355,6 +355,8 @@ class Workload:
             # separate rocprofv3 --pmc passes of THIS workload (model / batch / depth), dtype, tuning and library build, summarised by tools/pmc_summary.py;
             # a summary of another workload (or of an older build) is never attached: null instead
             pj = json.load(open(pmc))
+            if not isinstance(pj, dict):
+                continue
             if (pj.get("workload") == wl and pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(lib.lpi_version())):
                 names = {"k256": ("gemm256_kernel", "gemm256_tail_kernel", "gemm256p_kernel"), "k128": ("gemm_nt_kernel",), "k256x128": ("gemm256x128_kernel",),
                          "few_rows": ("gemm_nt_splitk_kernel", "gemm_nt_splitk_pair_kernel")}[dom]
