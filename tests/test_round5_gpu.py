@@ -481,3 +481,47 @@ def test_uint8_pixels_give_the_f32_pipelines_features_bit_for_bit():
             assert m._pipeline._stage[0].dtype == torch.uint8 and m._pipeline._dev[0].dtype == torch.uint8
     for k in synth.PROMPT_NAMES:
         assert torch.equal(got[0][k], got[1][k]), k
+
+
+# ------------------------------------------------------------------------------------------------ the loop's edges
+def test_plugin_loop_edges_long_caption_worker_processes_ragged_last_batch(tmp_path, monkeypatch):
+    """(a) a caption that does not fit the 77-token context raises RuntimeError like clip.tokenize (clip.py:213-218) — raised in the pipeline's producer
+    thread, delivered to the training loop; (b) a DataLoader with WORKER PROCESSES (the reference's num_workers = 8, sprompt.py:166-167: batches arrive stacked in
+    shared memory, the pipeline's gather is their pinning copy) and a ragged last batch train to the same parameters as the single-process loader."""
+    from torch.utils.data import DataLoader
+    from lpi_amd import synth_bpe
+    from lpi_amd.retrieval.methods.sprompt import SPrompts
+    from lpi_amd.retrieval.models.clip import prompt_learner as PL
+    from lpi_amd.retrieval.utils.data import SyntheticCoco, collate_keep_images
+    monkeypatch.setenv("LPI_BPE_VOCAB", synth_bpe.write_table(tmp_path / "bpe.txt.gz", seed=2))
+    monkeypatch.setattr(PL, "_tokenizer", None)
+    m = SPrompts(tiny_args(epochs=1))
+    net = m._network.to(DEV)
+    set_factors(net)
+    net.numtask = 1
+    opt, _ = m._setup_training()
+    img = torch.from_numpy(synth.images(4, 32))
+    bad = [(img, ["a dog", "x " * 80, "a cat", "a bus"], 0, 0)]
+    with pytest.raises(RuntimeError, match="too long for context length"):
+        m.train_epoch(bad, opt, 0)
+    # (b) 10 pairs in batches of 4 (the last one holds 2), caption strings
+    ds = SyntheticCoco(10, [0], 32, captions="strings", image_pool=10)
+    got = []
+    for workers in (0, 2):
+        mm = SPrompts(tiny_args(epochs=2))
+        nn_ = mm._network.to(DEV)
+        set_factors(nn_)
+        nn_.numtask = 1
+        o, sch = mm._setup_training()
+        loader = DataLoader(ds, batch_size=4, shuffle=False, num_workers=workers, collate_fn=collate_keep_images if workers == 0 else None)
+        seen = []
+        for ep in range(2):
+            mm.train_epoch(loader, o, ep, None, lambda i, b, out: seen.append(b.images.shape[0]) and False)
+            sch.step()
+        torch.cuda.synchronize()
+        assert seen == [4, 4, 2, 4, 4, 2]
+        got.append({k: getattr(nn_.prompts[0], k).detach().clone() for k in synth.PROMPT_NAMES})
+        del loader
+    for k in synth.PROMPT_NAMES:
+        assert torch.equal(got[0][k], got[1][k]), k
+    monkeypatch.setattr(PL, "_tokenizer", None)
