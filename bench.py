@@ -711,6 +711,10 @@ def main():
         exchange = Exchange(timing=True, local_loss=a.local_loss, gather_with_grad=a.gather_with_grad)
     if os.environ.get("LPI_MAIN_STREAM") == "side":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # A/B: the step on a side stream instead of the (blocking) null stream
+    elif os.environ.get("LPI_MAIN_STREAM") == "high":
+        # A/B (round 5): the main stream (with --overlap: the vision tower) at HIGH priority, so that the text tower's lane only fills the CUs the
+        # vision tower's kernels leave idle (their partial last rounds)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
 
     def sync():
         if exchange is not None:
