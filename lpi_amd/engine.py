@@ -878,9 +878,16 @@ class DualEncoder:
         rc = lib.lpi_rowstat_guard(self._guard.data_ptr() if active else None, self._guard_flag.data_ptr() if active else None)
         if rc != 0:
             raise _lib.LpiError(f"lpi_rowstat_guard failed with code {rc} (the pinned flag word is not device-accessible)")
+        self._guard_depth = self.__dict__.get("_guard_depth", 0) + 1
 
     def _guard_end(self):
-        pass
+        """End of a forward (the second one's, when the towers run in lock step): take the registration back, so that no later launch of this thread —
+        another engine's, a test's direct call — writes to a counter whose engine may be gone."""
+        if self._guard is None:
+            return
+        self._guard_depth = max(0, self.__dict__.get("_guard_depth", 1) - 1)
+        if self._guard_depth == 0:
+            _lib.load().lpi_rowstat_guard(None, None)
 
     # ------------------------------------------------------------------ lanes
     def lane(self, i: int, stream=None):

@@ -57,6 +57,7 @@ class BatchPipeline:
         self._dev = [None] * self.depth         # device slots
         self._copied = [None] * self.depth      # event: H2D of the staging slot finished (recorded on the side stream)
         self._done = [None] * self.depth        # event: the step that read the device slot is complete (recorded on the consumer's stream)
+        self._retired = []                      # slot buffers replaced by larger ones
         self._free = threading.Semaphore(self.depth)
         self._q = queue.Queue()
         self._stop = threading.Event()
@@ -67,6 +68,8 @@ class BatchPipeline:
     def _slot_buffers(self, slot, shape, dtype):
         st = self._stage[slot]
         if st is None or st.dtype != dtype or tuple(st.shape[1:]) != tuple(shape[1:]) or st.shape[0] < shape[0]:
+            if st is not None:      # a step in flight may still read the old device slot: the old pair lives until the pipeline is dropped
+                self._retired.append((st, self._dev[slot]))
             st = self._stage[slot] = torch.empty(shape, dtype=dtype, pin_memory=True)
             self._dev[slot] = torch.empty(shape, dtype=dtype, device=self.device)
         return st, self._dev[slot]
