@@ -276,6 +276,14 @@ class SliNet(nn.Module):
         new._modules["clip_model"] = clip
         return new
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """nn.Module.load_state_dict; when the state carries backbone tensors (clip_model.*) the engine's operand copies (bf16 / fp16 / transposed) are stale:
+        the engine is dropped and rebuilt from the new masters at the next use."""
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        if any(k.startswith("clip_model.") for k in state_dict):
+            self.engine, self._task_term = None, None
+        return out
+
     def trainable_state_dict(self):
         """The state a checkpoint of a continual run needs besides the frozen backbone: the 12 x 5 prompt factors (+ numtask)."""
         sd = {k: v.detach().clone() for k, v in self.state_dict().items() if k.startswith("prompts.")}

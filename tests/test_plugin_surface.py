@@ -86,6 +86,24 @@ def test_copy_shares_engine_and_freeze():
     assert c.clip_model is net.clip_model and "clip_model" in dict(net.named_children())
 
 
+def test_full_state_dict_round_trip_drops_the_stale_engine():
+    """SliNet.state_dict() holds what the reference network's does — backbone, prompts, the PromptLearners' ctx — and loads into a fresh network; operand
+    copies built from the old backbone are dropped."""
+    from lpi_amd.retrieval.models.slinet import SliNet
+    a = SliNet(load_args(backbonename="tiny", visual_dim=128, textual_dim=128))
+    b = SliNet(load_args(backbonename="tiny", visual_dim=128, textual_dim=128))
+    sd = a.state_dict()
+    assert {k.split(".")[0] for k in sd} == {"prompts", "classifier_pool", "clip_model"}
+    b.engine = object()
+    b.load_state_dict(sd)
+    assert b.engine is None
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+    b.engine = object()
+    b.load_state_dict({k: v for k, v in sd.items() if k.startswith("prompts.")}, strict=False)      # prompts only: the engine stays
+    assert b.engine is not None
+
+
 def test_learner_state_round_trip():
     """the state a continual run carries besides the frozen backbone — 12 x 5 prompt factors, numtask, the KMeans task keys of both
     modalities — through SPrompts.state_dict / load_state_dict (and torch.save / torch.load of it)."""
