@@ -13,7 +13,9 @@ for p in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(p)):
         ker.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 for p in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(p)):
+    rd = csv.DictReader(open(p))
+    print("memory-copy columns:", rd.fieldnames)
+    for r in rd:
         cp.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Direction", r.get("Name", "")), int(float(r.get("Bytes", r.get("Size", 0)) or 0))))
 ker.sort()
 cp.sort()
