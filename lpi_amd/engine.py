@@ -1178,7 +1178,10 @@ class PackedIds:
         the stream it feeds (lpi_amd/pipeline.py)."""
         device = torch.device(device)
         if self._dev is None or self._dev.device != device:
-            if non_blocking:
+            if non_blocking and _os.environ.get("LPI_PACKED_ONECOPY", "1") == "0":      # A/B: four pinned copies
+                self._pinned = [t.pin_memory() for t in (self.ids, self.row_start, self.pool_rows, self.eot)]
+                self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev = (t.to(device, non_blocking=True) for t in self._pinned)
+            elif non_blocking:
                 # ONE pinned buffer, ONE copy (a small host-to-device copy is a blit kernel on this runtime: four arrays were four of them per batch):
                 # [ids int64 | row_start int32 | pool_rows int32 | eot int32], every part 16-byte aligned
                 parts = (self.ids.reshape(-1), self.row_start, self.pool_rows, self.eot)

@@ -25,6 +25,20 @@ m._network.update_fc(0)
 ds = SyntheticCoco((n + 2) * 256, [0], 224, captions="strings", image_pool=256, pixel_format=pf)
 loader = DataLoader(ds, batch_size=256, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
 opt, _ = m._setup_training()
-m.train_epoch(loader, opt, 0, None, lambda i, b, o: i == n - 1)
-torch.cuda.synchronize()
-print("done", n, "iterations")
+import time  # noqa: E402
+t = {}
+
+
+def on_step(i, b, o):
+    if i == 7:
+        torch.cuda.synchronize()
+        t[0] = time.perf_counter()
+    if i == n - 1:
+        torch.cuda.synchronize()
+        t[1] = time.perf_counter()
+        return True
+    return False
+
+
+m.train_epoch(loader, opt, 0, None, on_step)
+print("done", n, "iterations;", round(1e3 * (t[1] - t[0]) / (n - 8), 3), "ms per iteration after 8 warm-up iterations")
