@@ -29,7 +29,12 @@ import time  # noqa: E402
 t = {}
 
 
+hm = []
+
+
 def on_step(i, b, o):
+    if i > 7 and hasattr(b, "host_ms"):
+        hm.append(b.host_ms)
     if i == 7:
         torch.cuda.synchronize()
         t[0] = time.perf_counter()
@@ -41,4 +46,6 @@ def on_step(i, b, o):
 
 
 m.train_epoch(loader, opt, 0, None, on_step)
+if hm:
+    print("producer ms per batch:", {k: round(sum(h[k] for h in hm) / len(hm), 3) for k in hm[0]})
 print("done", n, "iterations;", round(1e3 * (t[1] - t[0]) / (n - 8), 3), "ms per iteration after 8 warm-up iterations")
