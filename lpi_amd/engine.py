@@ -1178,26 +1178,12 @@ class PackedIds:
         the stream it feeds (lpi_amd/pipeline.py)."""
         device = torch.device(device)
         if self._dev is None or self._dev.device != device:
-            if non_blocking and _os.environ.get("LPI_PACKED_ONECOPY", "1") == "0":      # A/B: four pinned copies
+            if non_blocking:
+                # four small pinned copies (each is a blit kernel of a few microseconds on the copy's stream).  Packing the four arrays into ONE pinned buffer
+                # and one copy was tried in round 5 and made the training loop 1.7x SLOWER (38.5 against 22.1 ms per iteration, tools/plugin_loop.py): the
+                # producer then spent 17 ms in the upload and 18 ms in the image gather — the byte-view upload did not stay asynchronous
                 self._pinned = [t.pin_memory() for t in (self.ids, self.row_start, self.pool_rows, self.eot)]
                 self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev = (t.to(device, non_blocking=True) for t in self._pinned)
-            elif non_blocking:
-                # ONE pinned buffer, ONE copy (a small host-to-device copy is a blit kernel on this runtime: four arrays were four of them per batch):
-                # [ids int64 | row_start int32 | pool_rows int32 | eot int32], every part 16-byte aligned
-                parts = (self.ids.reshape(-1), self.row_start, self.pool_rows, self.eot)
-                offs, total = [], 0
-                for t in parts:
-                    offs.append(total)
-                    total += (t.numel() * t.element_size() + 15) // 16 * 16
-                host = torch.empty(total, dtype=torch.uint8).pin_memory()
-                for t, o in zip(parts, offs):
-                    host[o:o + t.numel() * t.element_size()].copy_(t.contiguous().view(torch.uint8).reshape(-1))
-                self._pinned = host
-                dev = host.to(device, non_blocking=True)
-                self._packed_dev = dev
-                view = lambda t, o: dev[o:o + t.numel() * t.element_size()].view(t.dtype)  # noqa: E731
-                self._dev = view(parts[0], offs[0]).view(self.ids.shape)
-                self.row_start_dev, self.pool_rows_dev, self.eot_dev = view(parts[1], offs[1]), view(parts[2], offs[2]), view(parts[3], offs[3])
             else:
                 self._dev = self.ids.to(device)
                 self.row_start_dev = self.row_start.to(device)
@@ -1211,7 +1197,7 @@ class PackedIds:
 
     def record_stream(self, stream):
         """The device arrays were allocated on the stream that uploaded them (lpi_amd.pipeline: a side stream); tell the allocator who else reads them."""
-        for t in (getattr(self, "_packed_dev", None), self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev):
+        for t in (self._dev, self.row_start_dev, self.pool_rows_dev, self.eot_dev):
             if t is not None:
                 t.record_stream(stream)
 
