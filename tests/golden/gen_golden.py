@@ -12,6 +12,10 @@ exactly the shim list of SURVEY.md section 8(c):
                  models.slinet.load_clip_to_cpu -> CLIP(...).float().eval() with synthetic weights
                  (skips the download and the fp16 convert_weights: F3), cwd = retrieval/ (./MID/...)
 
+A third family (round 5), ``*_fp16``: the reference in ITS OWN arithmetic type — ``build_model``'s ``convert_weights`` (model.py:394-415, 522) applied, so
+``SliNet.dtype`` is fp16 and images / prompts are cast to it (slinet.py:30, 117-128), run by torch's CPU fp16 kernels.  It pins the ``compute_dtype='f16'``
+mode of the build to the reference's fp16 behaviour (within fp16 rounding: accumulation orders differ), next to the f32 families that pin the parity mode.
+
 Two golden families (F1):
   * ``*_d1``          true oracle: the shipped code, whose deep-prompt guard is dead => depth 1.
   * ``*_d3_patched``  patched oracle: ResidualAttentionBlock.forward re-stated in this harness with the
@@ -89,13 +93,18 @@ def ref_args(cfg: synth.ClipConfig):
     return args
 
 
-def build_slinet(cfg: synth.ClipConfig):
+def build_slinet(cfg: synth.ClipConfig, fp16: bool = False):
     import models.slinet as slinet
-    from models.clip.model import CLIP
+    from models.clip.model import CLIP, convert_weights
 
     def load_clip_to_cpu(_args):
-        model = CLIP(*cfg.as_clip_args()).float().eval()
         sd = {k: torch.from_numpy(v) for k, v in synth.clip_state_dict(cfg).items()}
+        if fp16:      # build_model's own sequence (model.py:516-523): CLIP(...), convert_weights, load_state_dict, eval
+            model = CLIP(*cfg.as_clip_args())
+            convert_weights(model)
+            model.load_state_dict(sd)
+            return model.eval()
+        model = CLIP(*cfg.as_clip_args()).float().eval()
         model.load_state_dict(sd)
         return model
 
@@ -171,16 +180,16 @@ def train_step(net, cfg, batch, numtask):
             " ".join(["X"] * 16) + " " + c + ".") for c in caps])
     res = {
         "token_ids": ids.numpy(),
-        "img_f": img_f.detach().numpy(), "txt_f": txt_f.detach().numpy(),
-        "logits": logits.numpy(),
-        "vis_prompt": vp[0].detach().numpy(), "txt_prompt": tp[0].detach().numpy(),
+        "img_f": img_f.detach().float().numpy(), "txt_f": txt_f.detach().float().numpy(),      # (.float(): the fp16 family stores what fp16 held, widened)
+        "logits": logits.float().numpy(),
+        "vis_prompt": vp[0].detach().float().numpy(), "txt_prompt": tp[0].detach().float().numpy(),
         "trainable": np.array(names),
     }
     for k, v in out["loss"].items():
         res[k] = np.float32(v.item())
     for name, p in net.named_parameters():
         if p.requires_grad:
-            res["grad." + name.split(".")[-1]] = p.grad.detach().numpy().copy()
+            res["grad." + name.split(".")[-1]] = p.grad.detach().float().numpy().copy()
     # per-row top-5 with margins (F8): index parity is only asserted where the margin is large
     for tag, S in (("i2t", logits), ("t2i", logits.t())):
         srt, idx = torch.sort(S, dim=1, descending=True, stable=True)
@@ -473,6 +482,17 @@ def main():
             r[k] = r[k][:3]
         save("vitb16_d3_patched", r, meta)
         undo()
+
+    if a.only in (None, "fp16"):
+        # the reference in its own fp16 (convert_weights), torch CPU: tiny and ViT-B/16 (8 pairs), depth 1 = the shipped code
+        for name, cfg, batch in (("tiny_fp16", synth.TINY, 4), ("vitb16_fp16", synth.VIT_B16, 8)):
+            net = build_slinet(cfg, fp16=True)
+            assert net.dtype == torch.float16
+            r = train_step(net, cfg, batch, 1)
+            for k in ("vis_prompt", "txt_prompt"):
+                r[k] = r[k][:1]
+            r["reference_dtype"] = np.array("float16 (convert_weights), torch CPU")
+            save(name, r, meta)
 
     if a.only in (None, "vitb16", "vitb16_eval"):
         cfg = synth.VIT_B16

@@ -210,3 +210,20 @@ def test_oracle_kmeans_relocates_empty_clusters_like_scikit_learn():
     centers, labels, _ = O.kmeans_fit(x)
     assert np.abs(centers - km.cluster_centers_).max() < 1e-5
     assert np.array_equal(labels, km.labels_)
+
+
+@pytest.mark.parametrize("fp16,f32", [("tiny_fp16", "tiny_d1"), ("vitb16_fp16", "vitb16_d1")])
+def test_fp16_family_is_the_reference_in_its_own_type(golden, fp16, f32):
+    """tests/golden/*_fp16.npz: the imported reference run the way it ships — build_model's convert_weights (model.py:394-415, 522), SliNet.dtype fp16
+    (slinet.py:30) — on torch's CPU fp16 kernels, same weights / inputs / captions as the f32 family.  Sanity of the fixture: it is the f32 family within
+    fp16 rounding (and NOT equal to it), so it can pin the build's compute_dtype='f16' mode (tests/test_round5_gpu.py)."""
+    a, b = golden(fp16), golden(f32)
+    assert (a["token_ids"] == b["token_ids"]).all() and str(a["reference_dtype"]).startswith("float16")
+    for k, bar in (("img_f", 1e-3), ("txt_f", 1e-3), ("logits", 1e-2)):
+        e = float(np.abs(a[k] - b[k]).max())
+        assert 0 < e < bar, (k, e)
+    for k in ("base_loss", "alignment_loss"):
+        assert abs(float(a[k]) - float(b[k])) < 2e-3 * max(1.0, abs(float(b[k])))
+    for k in [k for k in a if k.startswith("grad.")]:
+        cos = float((a[k] * b[k]).sum() / np.sqrt((a[k] ** 2).sum() * (b[k] ** 2).sum()))
+        assert cos > 0.999, (k, cos)

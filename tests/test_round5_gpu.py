@@ -525,3 +525,34 @@ def test_plugin_loop_edges_long_caption_worker_processes_ragged_last_batch(tmp_p
     for k in synth.PROMPT_NAMES:
         assert torch.equal(got[0][k], got[1][k]), k
     monkeypatch.setattr(PL, "_tokenizer", None)
+
+
+# ------------------------------------------------------------------------------------------------ the f16 mode against the reference in its own fp16
+@pytest.mark.parametrize("fx,f32fx,cfgname,batch", [("tiny_fp16", "tiny_d1", "tiny", 4), ("vitb16_fp16", "vitb16_d1", "ViT-B/16", 8)])
+def test_f16_mode_against_the_reference_run_in_its_own_fp16(golden, fx, f32fx, cfgname, batch):
+    """compute_dtype='f16' is "the reference's own arithmetic type" (model.py:394-415): here it is held against the reference actually RUN in that type
+    (tests/golden/*_fp16.npz: convert_weights applied, torch CPU fp16 kernels).  Two fp16 evaluations of the same network differ by their accumulation
+    orders, so the bar is fp16 rounding — and the HIP f16 step must be at least as close to the f32 reference as the reference's own fp16 run is (f32
+    accumulation, f32 LayerNorm statistics and softmax here)."""
+    from lpi_amd.engine import DualEncoder
+    from lpi_amd.step import train_step
+    cfg = synth.CONFIGS[cfgname]
+    g16, g32 = golden(fx), golden(f32fx)
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="f16", device=DEV)
+    fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+    img = torch.from_numpy(synth.images(batch, cfg.image_resolution)).to(DEV)
+    out = train_step(enc, img, torch.from_numpy(g16["token_ids"]).to(DEV), fac, 1)
+    torch.cuda.synchronize()
+    mx = lambda a, b: float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())  # noqa: E731
+    hip = {"img_f": out["img_f"].cpu().numpy(), "txt_f": out["txt_f"].cpu().numpy(),
+           "logits": (enc.logit_scale_exp * out["img_f"] @ out["txt_f"].t()).cpu().numpy()}
+    d = {k: (mx(hip[k], g16[k]), mx(hip[k], g32[k]), mx(g16[k], g32[k])) for k in hip}
+    print(f"\\n    {cfgname}: max |HIP f16 - ref fp16|, |HIP f16 - ref f32|, |ref fp16 - ref f32|: " + ", ".join(f"{k} {a:.2e} {b:.2e} {c:.2e}" for k, (a, b, c) in d.items()))
+    for k, bar in (("img_f", 1e-3), ("txt_f", 1e-3), ("logits", 1e-2)):
+        assert d[k][0] < bar, (k, d[k])
+        assert d[k][1] < 2.0 * d[k][2] + 1e-4, (k, d[k])          # as close to the f32 reference as the reference's own fp16 run (within 2x)
+    assert abs(float(out["base_loss"]) - float(g16["base_loss"])) < 3e-3 * max(1.0, abs(float(g16["base_loss"])))
+    for k in synth.PROMPT_NAMES:
+        a, r16, r32 = fac[k].grad.cpu().numpy().astype(np.float64), g16["grad." + k].astype(np.float64), g32["grad." + k].astype(np.float64)
+        cos = lambda x, y: float((x * y).sum() / np.sqrt((x * x).sum() * (y * y).sum()))  # noqa: E731
+        assert cos(a, r16) > 0.998 and cos(a, r32) > 0.998, (k, cos(a, r16), cos(a, r32))
