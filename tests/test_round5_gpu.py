@@ -547,7 +547,7 @@ def test_f16_mode_against_the_reference_run_in_its_own_fp16(golden, fx, f32fx, c
     hip = {"img_f": out["img_f"].cpu().numpy(), "txt_f": out["txt_f"].cpu().numpy(),
            "logits": (enc.logit_scale_exp * out["img_f"] @ out["txt_f"].t()).cpu().numpy()}
     d = {k: (mx(hip[k], g16[k]), mx(hip[k], g32[k]), mx(g16[k], g32[k])) for k in hip}
-    print(f"\\n    {cfgname}: max |HIP f16 - ref fp16|, |HIP f16 - ref f32|, |ref fp16 - ref f32|: " + ", ".join(f"{k} {a:.2e} {b:.2e} {c:.2e}" for k, (a, b, c) in d.items()))
+    print(f"\n    {cfgname}: max |HIP f16 - ref fp16|, |HIP f16 - ref f32|, |ref fp16 - ref f32|: " + ", ".join(f"{k} {a:.2e} {b:.2e} {c:.2e}" for k, (a, b, c) in d.items()))
     for k, bar in (("img_f", 1e-3), ("txt_f", 1e-3), ("logits", 1e-2)):
         assert d[k][0] < bar, (k, d[k])
         assert d[k][1] < 2.0 * d[k][2] + 1e-4, (k, d[k])          # as close to the f32 reference as the reference's own fp16 run (within 2x)
