@@ -111,8 +111,8 @@ def _cpulist(text):
 
 def pin_rank_to_cpus(local_rank, local_world):
     """Give this rank its own slice of the host CPUs BEFORE anything touches the GPU: W processes that each spawn library / pipeline threads on all cores
-    migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first (node r * nodes // W for local rank r — on
-    an 8-GPU MI355X node GPUs 0-3 hang off socket 0 and 4-7 off socket 1 in device order), then evenly among the ranks of a node.  LPI_NO_AFFINITY=1
+    migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first (local rank r uses GPU r, which hangs off node
+    r * nodes // n_gpus — on an 8-GPU MI355X node GPUs 0-3 are on socket 0 and 4-7 on socket 1 in device order), then evenly among the ranks of a node.  LPI_NO_AFFINITY=1
     leaves the affinity alone.  Returns the CPU list (or None)."""
     if os.environ.get("LPI_NO_AFFINITY") == "1" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
@@ -128,12 +128,18 @@ def pin_rank_to_cpus(local_rank, local_world):
         nodes = []
     if not nodes:
         nodes = [allowed]
-    if len(nodes) > local_world or local_world % len(nodes):
-        nodes = [allowed]
-    per_node = local_world // len(nodes)
-    cpus = nodes[local_rank // per_node]
-    k = local_rank % per_node
-    share = max(1, len(cpus) // per_node)
+    # which NUMA node a local rank's GPU hangs off: GPU g of the host's n GPUs -> node g * nodes / n (device order follows the sockets on the MI355X
+    # platforms); rank r uses GPU r.  The ranks that share a node split its CPUs evenly.
+    try:
+        import torch
+        ngpu = max(int(torch.cuda.device_count()), local_world)      # does not initialise the GPU on this image
+    except Exception:      # noqa: BLE001
+        ngpu = local_world
+    node_of = [min(len(nodes) - 1, r * len(nodes) // ngpu) for r in range(local_world)]
+    mates = [r for r in range(local_world) if node_of[r] == node_of[local_rank]]
+    cpus = nodes[node_of[local_rank]]
+    k = mates.index(local_rank)
+    share = max(1, len(cpus) // len(mates))
     mine = cpus[k * share:(k + 1) * share] or cpus
     try:
         os.sched_setaffinity(0, mine)

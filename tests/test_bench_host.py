@@ -13,7 +13,8 @@ sys.path.insert(0, {REPO!r})
 import bench
 before = sorted(os.sched_getaffinity(0))
 mine = bench.pin_rank_to_cpus(int(sys.argv[1]), int(sys.argv[2]))
-print(json.dumps({{"before": before, "mine": mine, "now": sorted(os.sched_getaffinity(0)), "torch": "torch" in sys.modules}}))
+import torch
+print(json.dumps({{"before": before, "mine": mine, "now": sorted(os.sched_getaffinity(0)), "gpu_initialised": bool(torch.cuda.is_initialized())}}))
 """
     import json
     allowed = sorted(os.sched_getaffinity(0))
@@ -24,7 +25,7 @@ print(json.dumps({{"before": before, "mine": mine, "now": sorted(os.sched_getaff
         out = subprocess.run([sys.executable, "-c", code, str(r), "2"], capture_output=True, text=True, check=True)
         got.append(json.loads(out.stdout.strip().splitlines()[-1]))
     a, b = got
-    assert a["mine"] == a["now"] and b["mine"] == b["now"] and not a["torch"]          # set without importing torch, let alone touching the GPU
+    assert a["mine"] == a["now"] and b["mine"] == b["now"] and not a["gpu_initialised"]          # set before anything initialises the GPU
     assert set(a["mine"]) and set(b["mine"]) and not (set(a["mine"]) & set(b["mine"]))
     assert set(a["mine"]) | set(b["mine"]) <= set(allowed)
     one = subprocess.run([sys.executable, "-c", code, "0", "1"], capture_output=True, text=True, check=True)
