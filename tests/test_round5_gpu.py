@@ -556,3 +556,39 @@ def test_f16_mode_against_the_reference_run_in_its_own_fp16(golden, fx, f32fx, c
         a, r16, r32 = fac[k].grad.cpu().numpy().astype(np.float64), g16["grad." + k].astype(np.float64), g32["grad." + k].astype(np.float64)
         cos = lambda x, y: float((x * y).sum() / np.sqrt((x * x).sum() * (y * y).sum()))  # noqa: E731
         assert cos(a, r16) > 0.998 and cos(a, r32) > 0.998, (k, cos(a, r16), cos(a, r32))
+
+
+def test_fused_plugin_step_at_vitb16_size_matches_the_reference_fixture(golden):
+    """BASELINE.json configs[0]'s shape through the PLUGIN's fused step: SliNet(configs/lpi/coco_lpi.json, ViT-B/16, f32).train_step on 8 pairs against the
+    imported reference's outputs (tests/golden/vitb16_d1.npz: the shipped code, effective prompt depth 1) — features and logits to 1e-4, losses to 1e-4,
+    factor gradients to 1e-3 relative — and the top-5 retrieval indices wherever the reference's recorded margin exceeds 10x the measured logit error."""
+    from lpi_amd.retrieval.models.slinet import SliNet
+    g = golden("vitb16_d1")
+    args = json.load(open(os.path.join(RET, "configs", "lpi", "coco_lpi.json")))
+    args.update(device=[DEV], compute_dtype="f32")
+    net = SliNet(args).to(DEV)
+    cfg = net.clip_cfg
+    for t in range(len(net.prompts)):
+        for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width, task=t).items():
+            getattr(net.prompts[t], k).data = torch.from_numpy(v.copy()).to(DEV)
+    net.numtask = 1
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad_("prompts.0." in n)
+    img = torch.from_numpy(synth.images(8, cfg.image_resolution)).to(DEV)
+    out = net.train_step(img, torch.from_numpy(g["token_ids"]))
+    torch.cuda.synchronize()
+    fi, ft = out["image_features"], out["text_features"]
+    assert float((fi.cpu() - torch.from_numpy(g["img_f"])).abs().max()) < 1e-4 and float((ft.cpu() - torch.from_numpy(g["txt_f"])).abs().max()) < 1e-4
+    logits = (net.engine.logit_scale_exp * fi @ ft.t()).cpu().numpy()
+    err = float(np.abs(logits - g["logits"]).max())
+    assert err < 1e-4
+    for k in ("base_loss", "alignment_loss"):
+        assert abs(float(out["loss"][k]) - float(g[k])) < 1e-4
+    for k in synth.PROMPT_NAMES:
+        got, ref = getattr(net.prompts[0], k).grad.cpu().numpy(), g["grad." + k]
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, k
+    for tag, S in (("i2t", logits), ("t2i", logits.T)):
+        idx = np.argsort(-S, axis=1, kind="stable")[:, : g[f"top5_{tag}"].shape[1]]
+        safe = g[f"top5_margin_{tag}"] > 10 * err
+        assert safe.mean() > 0.5 and (idx[safe] == g[f"top5_{tag}"][safe]).all()
