@@ -78,6 +78,9 @@ def parse_args():
                     help="run the towers one after the other instead of in lock step with grouped GEMM launches (A/B switch; same bits)")
     ap.add_argument("--no-text-pack", action="store_true",
                     help="cut the text batch at the LONGEST caption only instead of packing every caption at its own length (A/B switch)")
+    ap.add_argument("--no-text-shared", action="store_true",
+                    help="store SOT and the 16 context slots per sample instead of ONCE for the batch (engine.PackedIds(shared=17): the prompts are broadcast, so "
+                         "under the causal mask those 17 positions hold the same rows for every sample in every block; A/B switch, bf16 / f16 modes)")
     ap.add_argument("--no-text-trim", action="store_true", help="compute all 77 text positions, also those behind every caption's EOT (A/B switch)")
     ap.add_argument("--vision-lanes", type=int, default=1, help="micro-batches of the vision tower on separate streams (measured null on MI355X)")
     ap.add_argument("--text-lanes", type=int, default=1)
@@ -261,9 +264,12 @@ class Workload:
             ids_host = np.ascontiguousarray(trim_token_ids(ids_host))
         self.ids = torch.from_numpy(ids_host).to(dev)
         self.text_rows = float(self.ids.shape[1])
+        self.text_shared = 0
         if not (a.no_text_trim or a.no_text_pack):
             # ... and so are the rows behind every caption's OWN EOT (engine.PackedIds: the text batch packed, one row per live token)
-            self.ids = PackedIds(ids_host).to(dev)
+            # ... and the 17 positions every caption has in common (SOT + the broadcast context slots) are stored and computed once (bf16 / f16 kernels)
+            self.text_shared = 0 if (a.no_text_shared or dtype == "f32") else 17
+            self.ids = PackedIds(ids_host, self.text_shared).to(dev)
             self.text_rows = self.ids.rows / B
         self.fac = {k: torch.from_numpy(v).to(dev).requires_grad_(not fwd_only)
                     for k, v in synth.prompt_factors(max(a.prompt_layers, a.depth), 16, cfg.vision_width, cfg.transformer_width, r=a.rank).items()}
@@ -466,7 +472,7 @@ def eval_path(a, dev, rank, sync, tasks=3, centres=5, n_img=5000, n_txt=25000):
                         "per-sample prompt stacks (depth as the train step); then the f32 score matrix and ground-truth ranks at COCO 5k-test size"}
 
 
-def attention_gflop(cfg, B, P, text_rows, fwd_only):
+def attention_gflop(cfg, B, P, text_rows, fwd_only, text_shared=0):
     """Matrix FLOPs the attention kernels execute per step (2 x MACs, dense L x L per head over the rows actually computed; the causal text
     tower's masked tiles count half): forward 4 L^2 d per sample and layer, backward 8 L^2 d (the recomputed scores are not counted: the
     model-FLOP convention of SURVEY 8(d)); the last block attends from the pooled row only (attn_pooled.hip), the first block's backward covers
@@ -475,6 +481,8 @@ def attention_gflop(cfg, B, P, text_rows, fwd_only):
     Lt, dt, nt = text_rows, cfg.transformer_width, cfg.transformer_layers
     fv = 4.0 * Lv * Lv * dv * B * (nv - 1)
     ft = 0.5 * 4.0 * Lt * Lt * dt * B * (nt - 1)
+    if text_shared:      # shared prefix: a sample's Lt own rows attend to the shared keys (all of them) and causally to each other; the shared sequence once
+        ft = 4.0 * (Lt * (text_shared + 0.5 * Lt) * B + 0.5 * text_shared * text_shared) * dt * (nt - 1)
     if fwd_only:
         return (fv + ft) / 1e9
     return (fv + ft + 2.0 * (fv + ft) * (max(nv - 2, 0) / max(nv - 1, 1))) / 1e9
@@ -507,7 +515,7 @@ def run_record(a, dev, proc_rank, sync, dtype, fwd_only, steps, warm, roofline=T
            "peak_tflops": PEAK_TF[dtype]}
     if roofline and not fwd_only:
         rec["roofline"] = wl.gemm_roofline()
-        hw = wl.gemm_gflop_all + attention_gflop(wl.cfg, B, 16, wl.text_rows, fwd_only)
+        hw = wl.gemm_gflop_all + attention_gflop(wl.cfg, B, 16, wl.text_rows, fwd_only, wl.text_shared)
         rec["hw_flop_frac"] = round(hw * 1e9 / (1e-3 * float(np.median(per))) / (PEAK_TF[dtype] * 1e12), 4)
         rec["executed_gflop_per_step"] = round(hw, 1)
     del wl
@@ -781,7 +789,7 @@ def main():
 
     hw_gflop = None
     if roofline is not None and not a.fwd_only:
-        hw_gflop = wl.gemm_gflop_all + attention_gflop(cfg, B, 16, wl.text_rows, False)
+        hw_gflop = wl.gemm_gflop_all + attention_gflop(cfg, B, 16, wl.text_rows, False, wl.text_shared)
     extras = {}
     if world == 1 and not a.no_extras and not a.fwd_only and a.dtype == "bf16":
         del wl.opt
@@ -796,6 +804,10 @@ def main():
         extras["f16_mode"]["note"] = ("compute_dtype='f16': v_mfma_f32_16x16x32_f16 forward, bf16 gradient stream; on the ViT-B/16 fixture 4.6x lower "
                                       "feature error and 4x lower logit error than the bf16 line (tests/test_model_gpu.py); the fp16 MFMA runs "
                                       "5-9 % slower than the bf16 one on the same GEMM shapes (power-limited clock), hence not the default")
+        # ... and the headline workload with the 17 common text positions stored per sample (the layout of rounds 3-4), for the A/B on this box
+        if not a.no_text_shared:
+            extras["without_shared_text_prefix"] = run_record(a, dev, rank, sync, "bf16", False, 20, 3, roofline=False, no_text_shared=True)
+            extras["without_shared_text_prefix"]["note"] = "engine.PackedIds without shared=17 (bench.py --no-text-shared): every caption carries its own SOT + 16 context rows"
         # ... and BASELINE.json configs[4]'s per-GPU workload: ViT-L/14, 512 pairs, prompt_depth 12, r 8, bf16
         if a.model == "ViT-B/16":
             extras["vit_l14"] = run_record(a, dev, rank, sync, "bf16", False, 8, 2, model="ViT-L/14", batch=512, depth=12, rank=8, prompt_layers=12)
@@ -832,7 +844,7 @@ def main():
                        # rows per caption actually computed: the rows behind a caption's EOT are dead under the causal mask and skipped, exactly
                        # (packed: every caption cut at its OWN EOT; --no-text-pack: at the longest one; --no-text-trim: all 77)
                        "text_rows_computed": round(wl.text_rows, 2),
-                       "text_layout": "77 columns" if a.no_text_trim else ("cut at the longest caption" if a.no_text_pack else "packed (engine.PackedIds)"),
+                       "text_layout": "77 columns" if a.no_text_trim else ("cut at the longest caption" if a.no_text_pack else ("packed (engine.PackedIds)" + (", SOT + 16 broadcast context slots stored once for the batch (shared=17)" if wl.text_shared else ""))),
                        "towers": "one after the other" if (a.no_lockstep or a.overlap) else "lock step, GEMMs of one layer op grouped in one launch",
                        "parallelism": f"dp{world}" + (" (ranks share one GPU, gloo, host-staged messages)" if a.share_gpu and world > 1 else ""),
                        "dp_mode": None if world == 1 and exchange is None else

@@ -245,6 +245,7 @@ typedef struct lpi_attn_fwd_desc {
     void* ctx; int ldctx;
     float* lse;
     int causal;
+    int shared_rows;       /* 0, or the shared prefix of lpi_attn_fwd_shared (2-byte operand types, causal, row_start given) */
 } lpi_attn_fwd_desc;
 int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 /* The same backward when only the FIRST `rows_needed` token rows of dqkv are wanted (the first block: nothing upstream of the prompt slots
@@ -273,9 +274,36 @@ typedef struct lpi_attn_pooled_desc {
     void* dq; int lddq;
     void* dqkv; int lddqkv;
     int causal;
+    int shared_rows;       /* 0, or the shared prefix (below): idx[b] stays the query's POSITION in sample b's sequence, L the longest sequence */
+    float* shared_dkv;     /* bwd with shared_rows > 0: f32 scratch [B, shared_rows, 2 H 64] */
 } lpi_attn_pooled_desc;
 int lpi_attn_pooled_fwd_pair(int dtype, const lpi_attn_pooled_desc* d /* [2] */, void* stream);
 int lpi_attn_pooled_bwd_pair(int dtype, const lpi_attn_pooled_desc* d /* [2] */, void* stream);
+/* ONE problem in descriptor form (the only single-problem form that takes the shared-prefix fields). */
+int lpi_attn_pooled_fwd_desc(int dtype, const lpi_attn_pooled_desc* d, void* stream);
+int lpi_attn_pooled_bwd_desc(int dtype, const lpi_attn_pooled_desc* d, void* stream);
+
+/* ---- SHARED PREFIX of the text tower (round 5).  replaces nothing new: the same model.py:179-193, 347-353 and prompt_learner.py:155-163 arithmetic
+ * on fewer rows.  In training every caption is [SOT][n_ctx context slots][caption tokens][EOT] and the context / deep prompts are broadcast over the
+ * batch (slinet.py:119-130), so positions 0 .. n_ctx of ALL samples hold the same rows in every block: under the causal mask they attend only to each
+ * other.  Layout: global rows [0, shared_rows) = those positions, stored ONCE; sample b owns rows row_start[b] .. row_start[b+1]-1 = its positions
+ * shared_rows, shared_rows + 1, ... (row_start[0] = shared_rows); L = the longest sequence INCLUDING the shared positions; lse / delta hold
+ * (B + 1) x H x L floats, sample index B being the shared sequence, indexed by OWN row.  Every row-wise op (LayerNorm, GEMMs) just sees fewer rows;
+ * attention reads keys [shared rows | own rows].  The gradient that reaches the shared rows is the batch SUM (what lpi_rows_sum_over_batch produces
+ * in the plain layout): dK / dV of the shared keys are summed over the samples in f32 in a fixed order (bitwise reproducible), so the prompt
+ * gradients differ from the plain layout's only by the rounding of intermediate bf16 stores.  bf16 / f16 operand types only. */
+int lpi_txt_embed_fwd_shared(int x_dtype, int B, int L, const int32_t* row_start, int shared_rows /* = 1 + P */, int P, int d, const int64_t* ids,
+                             const float* tok_emb, const float* pos, const float* ctx /* [P, d], broadcast */, void* x0, float* out_mean,
+                             float* out_rstd, void* stream);
+int lpi_attn_fwd_shared(int dtype, int B, int L, const int32_t* row_start, int shared_rows, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                        float* lse, void* stream);
+/* rows_needed counts POSITIONS (>= shared_rows); shared_dkv: f32 scratch [B, shared_rows, 2 H 64].  Runs the fused backward, then
+ * lpi_shared_kv_reduce(accumulate = 1). */
+int lpi_attn_bwd_shared(int dtype, int B, int L, const int32_t* row_start, int shared_rows, int rows_needed, int H, const void* qkv, int ldqkv,
+                        const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
+                        float* shared_dkv, void* stream);
+/* dqkv[key][H 64 .. 3 H 64) (+)= sum_b partial[b][key][0 .. 2 H 64) for key < shared_rows (the K and V columns of the shared rows). */
+int lpi_shared_kv_reduce(int dtype, int B, int shared_rows, int H, const float* partial, void* dqkv, int lddqkv, int accumulate, void* stream);
 int lpi_layernorm_bwd_rows_varlen(int dy_dtype, int cast_dtype, int x_dtype, int B, int L, const int32_t* row_start, int row0, int P, int d,
                                   const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean, const float* rstd,
                                   float* dx, int lddx, void* dx_cast, int ldcast, int accumulate, void* stream);

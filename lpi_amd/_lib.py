@@ -97,6 +97,12 @@ SIGNATURES = {
     "lpi_rows_sum_over_batch_pair": [_I, _P, _P],
     "lpi_attn_pooled_fwd_pair": [_I, _P, _P],
     "lpi_attn_pooled_bwd_pair": [_I, _P, _P],
+    "lpi_attn_pooled_fwd_desc": [_I, _P, _P],
+    "lpi_attn_pooled_bwd_desc": [_I, _P, _P],
+    "lpi_txt_embed_fwd_shared": [_I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "lpi_attn_fwd_shared": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _P],
+    "lpi_attn_bwd_shared": [_I, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+    "lpi_shared_kv_reduce": [_I, _I, _I, _I, _P, _P, _I, _I, _P],
     "lpi_ce_rows_fwd_bwd": [_I, _I, _P, _I, _I, _F, _P, _P, _I, _P],
     "lpi_sum_scaled": [_I, _P, _P, _F, _P, _P],
     "lpi_zero": [_P, _L, _P],
@@ -126,7 +132,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 500
+EXPECTED_ABI = 501
 VARIANT_OFFSET = 1000000      # lpi_version() of a tools/build_variant.sh build = EXPECTED_ABI + this
 
 _lib = None
@@ -201,15 +207,16 @@ class LnBwdDesc(ctypes.Structure):
 class AttnFwdDesc(ctypes.Structure):
     """``lpi_attn_fwd_desc``"""
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("row_start", c_void_p), ("qkv", c_void_p), ("ldqkv", c_int), ("ctx", c_void_p),
-                ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int)]
+                ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int), ("shared_rows", c_int)]
 
 
 def attn_fwd_pair(dt, a, b, stream):
-    """Two argument tuples (B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal) of lpi_attn_fwd_varlen in one launch."""
+    """Two argument tuples (B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal[, shared_rows]) of lpi_attn_fwd_varlen / _shared in one launch."""
     arr = (AttnFwdDesc * 2)()
     for q, t in zip(arr, (a, b)):
         q.B, q.L, q.row_start, q.H, q.qkv, q.ldqkv, q.ctx, q.ldctx, q.lse, q.causal = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), t[7],
                                                                                      _ptr(t[8]), t[9])
+        q.shared_rows = t[10] if len(t) > 10 else 0
     rc = load().lpi_attn_fwd_pair(dt, ctypes.cast(arr, c_void_p), stream)
     if rc != 0:
         raise LpiError(f"lpi_attn_fwd_pair failed with code {rc}")
@@ -334,13 +341,27 @@ class AttnPooledDesc(ctypes.Structure):
     """``lpi_attn_pooled_desc``"""
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("row_start", c_void_p), ("q", c_void_p), ("ldq", c_int), ("qkv", c_void_p), ("ldqkv", c_int),
                 ("idx", c_void_p), ("ctx", c_void_p), ("ldctx", c_int), ("lse", c_void_p), ("dctx", c_void_p), ("lddctx", c_int), ("dq", c_void_p),
-                ("lddq", c_int), ("dqkv", c_void_p), ("lddqkv", c_int), ("causal", c_int)]
+                ("lddq", c_int), ("dqkv", c_void_p), ("lddqkv", c_int), ("causal", c_int), ("shared_rows", c_int), ("shared_dkv", c_void_p)]
+
+
+_POOLED_PTRS = {"row_start", "q", "qkv", "idx", "ctx", "lse", "dctx", "dq", "dqkv", "shared_dkv"}
+
+
+def attn_pooled_one(dt, a, stream, backward=False):
+    """One dict of lpi_attn_pooled_desc fields -> lpi_attn_pooled_fwd_desc / _bwd_desc."""
+    q = AttnPooledDesc()
+    for k, v in a.items():
+        setattr(q, k, (_ptr(v) if k in _POOLED_PTRS else v))
+    fn = load().lpi_attn_pooled_bwd_desc if backward else load().lpi_attn_pooled_fwd_desc
+    rc = fn(dt, ctypes.cast(ctypes.pointer(q), c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_attn_pooled_{'bwd' if backward else 'fwd'}_desc failed with code {rc}")
 
 
 def attn_pooled_pair(dt, a, b, stream, backward=False):
     """Two dicts of lpi_attn_pooled_desc fields (tensors or ints) -> lpi_attn_pooled_fwd_pair / _bwd_pair."""
     arr = (AttnPooledDesc * 2)()
-    ptrs = {"row_start", "q", "qkv", "idx", "ctx", "lse", "dctx", "dq", "dqkv"}
+    ptrs = _POOLED_PTRS
     for q, t in zip(arr, (a, b)):
         for k, v in t.items():
             setattr(q, k, (_ptr(v) if k in ptrs else v))

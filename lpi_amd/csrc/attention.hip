@@ -57,8 +57,10 @@ template <> struct AT<bf16_t> {
 // SW: the images have UNPADDED 128-byte rows (2-byte types) with the 16-byte chunk index XOR-ed with (row & 6) — conflict-free for the row-fragment and
 // the transposing reads alike (tools/lds_swizzle_check.py; the layout of attention4.hip's images) — instead of rows padded to 160 bytes: a head of
 // 257 .. 288 tokens (ViT-L/14: 273) then takes 72 KiB instead of 90, so that TWO workgroups fit a CU's 160 KiB like they do at L = 213
+// pre / seg (shared-prefix ragged batches, see attn_fwd_body): image rows [0, pre) come from global rows [0, pre) of g0 / g1, image rows >= pre from global
+// rows r + seg (g0 / g1 then point at global row 0); pre = 0, seg = 0: image row r = global row r of the sample's own base pointer
 template <typename T, bool CV0 = false, bool CV1 = false, bool SW = false>
-__device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1, const T* g1, int ld0, int ld1, int L, int Lp) {
+__device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1, const T* g1, int ld0, int ld1, int L, int Lp, int pre = 0, long seg = 0) {
     constexpr int NCH = HD * (int)sizeof(T) / 16;
     const int n = Lp * NCH, nt = blockDim.x;
     for (int base = threadIdx.x; base < n; base += 4 * nt) {
@@ -73,8 +75,9 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
 #else
             if (i < n && row < L) {
 #endif
-                v0[j] = *reinterpret_cast<const uint4*>(g0 + (size_t)row * ld0 + c * Elem<T>::EPC);
-                v1[j] = *reinterpret_cast<const uint4*>(g1 + (size_t)row * ld1 + c * Elem<T>::EPC);
+                const size_t srow = (size_t)(row < pre ? (long)row : (long)row + seg);
+                v0[j] = *reinterpret_cast<const uint4*>(g0 + srow * ld0 + c * Elem<T>::EPC);
+                v1[j] = *reinterpret_cast<const uint4*>(g1 + srow * ld1 + c * Elem<T>::EPC);
             }
         }
 #pragma unroll
@@ -233,19 +236,31 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// SHARED PREFIX (round 5; causal, ragged batches only: pre > 0).  In training the text tower's first `pre` positions of every caption — SOT and the context
+// slots — are the same rows for all samples (the prompts are broadcast, slinet.py:119-130) and, under the causal mask (model.py:347-353), stay the same
+// through every block.  They are then stored ONCE, as global rows [0, pre); sample b owns rows rs[b] .. rs[b+1]-1 = its positions pre, pre + 1, ...; its keys
+// and values are [shared rows | own rows], its queries the own rows (position = pre + own index).  Workgroups of sample index `bshared` (= B, one past the
+// tail samples) compute the shared sequence itself: rows [0, pre), plain causal attention among themselves.
 template <typename T, bool CAUSAL, bool SW = false>
 __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
-                                              T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
+                                              T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre = 0, int bshared = -1) {
     const int b = bh / H, h = bh % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
-    int L = Lmax, Lp = Lpmax;
+    int L = Lmax, Lp = Lpmax;         // L: the sample's OWN rows (its queries); Lk below: its keys
     size_t row0 = (size_t)b * Lmax;
-    if (rs) {
+    int pb = 0;                       // shared positions in front of this sample's own rows
+    if (CAUSAL && pre > 0 && b == bshared) {
+        row0 = 0;
+        L = pre;
+        Lp = (L + 31) / 32 * 32;
+    } else if (rs) {
         const int r = rs[b];
         row0 = (size_t)r;
         L = rs[b + 1] - r;
-        Lp = (L + 31) / 32 * 32;
+        if (CAUSAL && pre > 0) pb = pre;
+        Lp = (pb + L + 31) / 32 * 32;
     }
+    const int Lk = pb + L;
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
     const int dm = H * HD;
     const T* qg = qkv + row0 * ldqkv + h * HD;
@@ -262,7 +277,8 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         const int qr = (wave * NB + j) * 16 + (lane & 15);
         load_row_chunks<T>(q[j], qg, qr, ldqkv, g, qr < L);
     }
-    stage_rows2<T, false, false, SW>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    if (pb) stage_rows2<T, false, false, SW>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
+    else stage_rows2<T, false, false, SW>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const float c = SCALE * LOG2E;
@@ -277,9 +293,9 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         for (int dt = 0; dt < 4; ++dt) to[dt] = rr * 128 + (((2 * dt + (pq >> 1)) ^ (rr & 6)) << 4) + (pq & 1) * 8;
     }
     for (int q0 = wave * 16 * NB; q0 < L; q0 += nw * 16 * NB) {
-        int qrow[NB];
+        int qrow[NB], qpos[NB];       // own row index (loads / stores), position in the sequence (masks)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) qrow[j] = q0 + 16 * j + (lane & 15);
+        for (int j = 0; j < NB; ++j) { qrow[j] = q0 + 16 * j + (lane & 15); qpos[j] = qrow[j] + pb; }
         if (q0 != wave * 16 * NB) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) load_row_chunks<T>(q[j], qg, qrow[j], ldqkv, g, qrow[j] < L);
@@ -301,20 +317,20 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
                 const char* kb_ = k_lds + kb * 128;
                 mma_lds_rows_sw<T>(s0, kb_, ro, q);
                 mma_lds_rows_sw<T>(s1, kb_ + 16 * 128, ro, q);
-                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
+                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, Lk, qpos, c);
                 mma_transposed_sw<T>(o, v_lds + kb * 128, to, s0, s1);
             } else {
                 const char* kp = kp0 + kb * AT<T>::RS;
                 mma_lds_rows<T>(s0, kp, q);
                 mma_lds_rows<T>(s1, kp + 16 * AT<T>::RS, q);
-                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, L, qrow, c);
+                attn_softmax_tile<NB, MASKED, CAUSAL>(s0, s1, m, lsum, o, kb, g, Lk, qpos, c);
                 mma_transposed<T>(o, vt0 + kb * AT<T>::RS, s0, s1);
             }
         };
-        const int qlast = q0 + 16 * NB - 1;
+        const int qlast = q0 + pb + 16 * NB - 1;      // positions
         const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
-        // unmasked tiles: every key < L and (causal) every key <= the smallest query of the blocks
-        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        // unmasked tiles: every key < Lk and (causal) every key <= the smallest query position of the blocks
+        const int kfull = CAUSAL ? min((Lk / 32) * 32, ((q0 + pb) / 32) * 32) : (Lk / 32) * 32;
         int kb = 0;
 #ifdef LPI_ABL_ATTN_NOCOMPUTE      /* ablation build: loads, staging and stores only */
         kb = kend - 32;
@@ -344,9 +360,9 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
 
 template <typename T, bool CAUSAL, bool SW = false>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
-                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse) {
+                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre, int bshared) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_fwd_body<T, CAUSAL, SW>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse);
+    attn_fwd_body<T, CAUSAL, SW>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse, pre, bshared);
 }
 // TWO attention forwards in one launch (the vision tower's and the text tower's of the same layer): workgroups [0, nb0) run problem 0, the
 // rest problem 1.  The text tower's forward alone is a 15 us kernel — a chain of dependent HBM round trips with the chip nearly idle; here its
@@ -355,12 +371,13 @@ template <typename T>
 struct AttnFwdP {
     int L, Lp, H, ldqkv, ldctx;
     const int* rs; const T* qkv; T* ctx; float* lse;
+    int pre, bshared;      // shared prefix (attn_fwd_body): 0, -1 = none
 };
 template <typename T, bool C0, bool C1, bool SW0 = false>
 __global__ __launch_bounds__(512) void attn_fwd_pair_kernel(AttnFwdP<T> p0, AttnFwdP<T> p1, int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0, SW0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse);
-    else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse);
+    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0, SW0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse, p0.pre, p0.bshared);
+    else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse, p1.pre, p1.bshared);
 }
 
 // ------------------------------------------------------------------------------------------------ backward A
@@ -595,19 +612,29 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int lddqkv, int rows_hi) {
+                                                            T* __restrict__ dqkv, int lddqkv, int rows_hi, int pre, int bshared, float* __restrict__ shared_dkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
-    int L = Lmax, Lp = Lpmax;
+    // shared prefix (pre > 0, causal ragged batches; see attn_fwd_body): the sample's keys are [shared rows | own rows], its queries the own rows;
+    // dK / dV of the SHARED keys go, as f32 partials, to shared_dkv[b][key][dK (H 64) | dV (H 64)] — lpi_shared_kv_reduce adds them over the samples
+    // onto the shared rows of dqkv, which the workgroups of sample `bshared` (the shared sequence itself) write
+    int L = Lmax, Lp = Lpmax;         // L: the sample's OWN rows (queries); Lk: its keys
     size_t row0 = (size_t)b * Lmax;
-    if (rs) {
+    int pb = 0;
+    if (CAUSAL && pre > 0 && b == bshared) {
+        row0 = 0;
+        L = pre;
+        Lp = (L + 31) / 32 * 32;
+    } else if (rs) {
         const int r = rs[b];
         row0 = (size_t)r;
         L = rs[b + 1] - r;
-        Lp = (L + 31) / 32 * 32;
+        if (CAUSAL && pre > 0) pb = pre;
+        Lp = (pb + L + 31) / 32 * 32;
     }
-    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
+    const int Lk = pb + L;
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
     const int dm = H * HD;
     const T* qg = qkv + row0 * ldqkv + h * HD;
     const int img = Lp * AT<T>::RS;
@@ -617,9 +644,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
     char* do_lds = smem + 3 * img;
     float* lse_lds = reinterpret_cast<float*>(smem + 4 * img);
     float* dl_lds = lse_lds + Lp;
-    stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    if (pb) stage_rows2<T, SV16, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
+    else stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
-    for (int i = threadIdx.x; i < Lp; i += blockDim.x) lse_lds[i] = i < L ? lse[lse0 + i] * LOG2E : INFINITY;
+    for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
+        lse_lds[i] = i < L ? lse[lse0 + i] * LOG2E : INFINITY;
+        if (pb) dl_lds[i] = 0.f;      // phase A covers the OWN rows' 32-row spans only; the image is as long as the KEYS
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -683,18 +714,18 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
                     float e1 = fast_exp2(fmaf(s1[j][r], c, -lq[j]));
                     if constexpr (MASKED) {
                         const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) e0 = 0.f;
-                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) e1 = 0.f;
+                        if (!(k0 < Lk && (!CAUSAL || k0 <= qrow[j] + pb))) e0 = 0.f;
+                        if (!(k1 < Lk && (!CAUSAL || k1 <= qrow[j] + pb))) e1 = 0.f;
                     }
                     s0[j][r] = e0 * fmaf(p0[j][r], SCALE, -dls[j]);
                     s1[j][r] = e1 * fmaf(p1[j][r], SCALE, -dls[j]);
                 }
             mma_transposed<T>(dq, kt0 + kb * AT<T>::RS, s0, s1);
         };
-        if (q0 >= rows_hi) continue;      // rows_hi: only dQ / dK / dV of token rows < rows_hi are wanted (delta above is needed for every row)
-        const int qlast = q0 + 16 * NB - 1;
+        if (q0 + pb >= rows_hi) continue;      // rows_hi: only dQ / dK / dV of token POSITIONS < rows_hi are wanted (delta above is needed for every row)
+        const int qlast = q0 + pb + 16 * NB - 1;
         const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
-        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        const int kfull = CAUSAL ? min((Lk / 32) * 32, ((q0 + pb) / 32) * 32) : (Lk / 32) * 32;
         int kb = 0;
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
@@ -712,7 +743,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
     __syncthreads();   // every row < Lp of dl_lds was written: the waves' 32-row spans tile [0, Lp)
 
     // ---- phase B: a wave owns NB x 16 keys -> dK, dV
-    for (int k0 = wave * 16 * NB; k0 < min(L, rows_hi); k0 += nw * 16 * NB) {
+    for (int k0 = wave * 16 * NB; k0 < min(Lk, rows_hi); k0 += nw * 16 * NB) {
         int krow[NB];
         Chunk kk[NB][AT<T>::KS], vv[NB][AT<T>::KS];
         f32x4 dk[NB][4], dv[NB][4];
@@ -742,7 +773,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
                     e0[j][r] = fast_exp2(fmaf(s0[j][r], c, -l0[r]));
                     e1[j][r] = fast_exp2(fmaf(s1[j][r], c, -l1[r]));
                     if constexpr (MASKED) {
-                        const int qa = qb + 4 * g + r, qc = qa + 16;
+                        const int qa = qb + pb + 4 * g + r, qc = qa + 16;      // query positions
                         if (krow[j] > qa) e0[j][r] = 0.f;
                         if (krow[j] > qc) e1[j][r] = 0.f;
                     }
@@ -752,20 +783,32 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
             mma_transposed<T>(dv, dt0 + qb * AT<T>::RS, e0, e1);
             mma_transposed<T>(dk, qt0 + qb * AT<T>::RS, s0, s1);
         };
-        int qb = CAUSAL ? (k0 / 32) * 32 : 0;
+        // query tiles by OWN index; a key at position k is seen by the own queries i with i + pb >= k
+        const int kq = k0 - pb;
+        int qb = CAUSAL ? (kq > 0 ? (kq / 32) * 32 : 0) : 0;
         if constexpr (CAUSAL) {
-            const int qdiag = min(Lp, ((k0 + 16 * NB - 1) / 32 + 1) * 32);
+            const int qdiag = (kq + 16 * NB - 1 >= 0) ? min(Lp, ((kq + 16 * NB - 1) / 32 + 1) * 32) : 0;
             for (; qb < qdiag; qb += 32) tile(qb, std::true_type{});
         }
         for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
+            if (pb && krow[j] < pb) {      // a SHARED key: this sample's f32 partial (summed over the samples by lpi_shared_kv_reduce)
+                float* dst = shared_dkv + ((size_t)b * pb + krow[j]) * 2 * dm + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<f32x4*>(dst + dt * 16) = dk[j][dt];
+                    *reinterpret_cast<f32x4*>(dst + dm + dt * 16) = dv[j][dt];
+                }
+                continue;
+            }
+            const size_t orow = row0 + (krow[j] - pb);      // own key
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (row0 + krow[j]) * lddqkv + h * HD;
-                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
-                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
-            } else if (krow[j] < L) {
-                T* dst = dqkv + (row0 + krow[j]) * lddqkv + h * HD + 4 * g;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + h * HD;
+                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < Lk);
+                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < Lk);
+            } else if (krow[j] < Lk) {
+                T* dst = dqkv + orow * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
@@ -810,7 +853,9 @@ int set_lds(const void* kern, size_t bytes) {
 static bool fwd_swizzled(int Lp) { return g_lpi_tuning[13] != 1 && (size_t)2 * 2 * Lp * 160 > (size_t)160 * 1024 && (size_t)2 * 2 * Lp * 128 <= (size_t)160 * 1024; }
 
 template <typename T, bool CAUSAL>
-int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr) {
+int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr, int pre = 0) {
+    // pre > 0 (causal ragged batches): B tail samples + the shared sequence as sample B (attn_fwd_body)
+    const int nbh = (B + (pre > 0 ? 1 : 0)) * H, bsh = pre > 0 ? B : -1;
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)2 * Lp * AT<T>::RS;
     const int thr = 64 * pick_waves(L);
@@ -818,21 +863,22 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
         if (fwd_swizzled(Lp) && !rs) {      // 257 .. 288 tokens: unpadded swizzled images, two workgroups per CU (stage_rows2)
             const size_t lsw = (size_t)2 * Lp * 128;
             if (int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL, true>, lsw)) return e;
-            LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL, true>), dim3(B * H), dim3(thr), lsw, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+            LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL, true>), dim3(nbh), dim3(thr), lsw, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh);
             LPI_CHECK_LAST();
             return 0;
         }
     }
     int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL>, lds);
     if (e) return e;
-    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(B * H), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse);
+    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(nbh), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh);
     LPI_CHECK_LAST();
     return 0;
 }
 
 template <typename T, bool CAUSAL, bool SV16 = false>
 int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr, int rows_hi = 1 << 30) {
+               const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr, int rows_hi = 1 << 30, int pre = 0,
+               float* shared_dkv = nullptr) {
     const int Lp = (L + 31) / 32 * 32;
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
@@ -843,11 +889,12 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     if (sizeof(T) == 2 && ldsF <= 160 * 1024 && g_lpi_tuning[3] == 0) {
         int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL, SV16>, ldsF);
         if (ef) return ef;
-        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsF, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-                   (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi);
+        LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3((B + (pre > 0 ? 1 : 0)) * H), dim3(thr), ldsF, s, L, Lp, rs, H, (const T*)qkv, ldqkv,
+                   (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, pre, pre > 0 ? B : -1, shared_dkv);
         LPI_CHECK_LAST();
         return 0;
     }
+    if (pre > 0) return LPI_ENOSYS;      // the shared prefix lives in the fused kernel only
     int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL, SV16>, ldsA);
     if (e) return e;
     e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL, SV16>, ldsB);
@@ -904,11 +951,13 @@ static int fwd_pair_launch(const lpi_attn_fwd_desc* d, hipStream_t s) {
     int thr = 0;
     for (int i = 0; i < 2; ++i) {
         const int Lp = (d[i].L + 31) / 32 * 32;
-        p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse};
+        const int pre = d[i].shared_rows;
+        if (pre < 0 || (pre > 0 && (!d[i].causal || !d[i].row_start || pre >= d[i].L))) return LPI_EINVAL;
+        p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse, pre, pre > 0 ? d[i].B : -1};
         lds = std::max(lds, (size_t)2 * Lp * AT<T>::RS);
         thr = std::max(thr, 64 * pick_waves(d[i].L));
     }
-    const int nb0 = d[0].B * d[0].H, nb1 = d[1].B * d[1].H;
+    const int nb0 = (d[0].B + (d[0].shared_rows > 0)) * d[0].H, nb1 = (d[1].B + (d[1].shared_rows > 0)) * d[1].H;
     if (!d[0].causal && d[1].causal && !d[0].row_start && fwd_swizzled(p[0].Lp)) {      // a long vision sequence beside the text tower: problem 0 on the swizzled images
         const size_t lsw = std::max((size_t)2 * p[0].Lp * 128, (size_t)2 * p[1].Lp * AT<T>::RS);
         if (int e = set_lds((const void*)attn_fwd_pair_kernel<T, false, true, true>, lsw)) return e;
@@ -939,10 +988,79 @@ extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* st
     }
     if (dtype == LPI_BF16) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
     if (dtype == LPI_F16) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        if (d[i].shared_rows) return LPI_ENOSYS;      // f32: no shared prefix
         if (int e = lpi_attn_fwd_varlen(dtype, d[i].B, d[i].L, d[i].row_start, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, d[i].causal, stream))
             return e;
+    }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ shared prefix (see attn_fwd_body)
+namespace {
+// dqkv[key][K | V columns] (+)= sum over the B samples of their f32 partials part[b][key][dK (dm) | dV (dm)], in the fixed order b = 0 .. B-1
+template <typename T>
+__global__ __launch_bounds__(256) void shared_kv_reduce_kernel(int B, int pre, int dm, const float* __restrict__ part, T* __restrict__ dqkv, int ld, int accumulate) {
+    const int per_row = 2 * dm / 4;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= pre * per_row) return;
+    const int key = t / per_row, c = (t % per_row) * 4;
+    const float* p = part + (size_t)key * 2 * dm + c;
+    const size_t bstride = (size_t)pre * 2 * dm;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {      // four independent chains: the loads of a sample do not wait for the previous sample's add
+        a0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
+        a1 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 1) * bstride);
+        a2 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 2) * bstride);
+        a3 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 3) * bstride);
+    }
+    for (; b < B; ++b) a0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
+    f32x4 v = (a0 + a1) + (a2 + a3);
+    T* o = dqkv + (size_t)key * ld + dm + c;      // K columns at dm .., V columns at 2 dm .. : column dm + c for c in [0, 2 dm)
+    if (accumulate) v += Elem<T>::ld4(o);
+    Elem<T>::st4(o, v);
+}
+}  // namespace
+
+extern "C" int lpi_shared_kv_reduce(int dtype, int B, int shared_rows, int H, const float* partial, void* dqkv, int lddqkv, int accumulate, void* stream) {
+    if (!partial || !dqkv || B <= 0 || shared_rows <= 0 || H <= 0 || lddqkv < 3 * H * HD || (lddqkv & 3) || ((uintptr_t)partial & 15) || ((uintptr_t)dqkv & 7)) return LPI_EINVAL;
+    const int dm = H * HD, n = shared_rows * (2 * dm / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_BF16 || dtype == LPI_F16)      // F16: "saved activations fp16, gradients bf16" (lpi_attn_bwd_prefix)
+        LPI_LAUNCH((shared_kv_reduce_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, s, B, shared_rows, dm, partial, (bf16_t*)dqkv, lddqkv, accumulate);
+    else
+        return LPI_ENOSYS;
+    LPI_CHECK_LAST();
+    return 0;
+}
+
+extern "C" int lpi_attn_fwd_shared(int dtype, int B, int L, const int32_t* row_start, int shared_rows, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
+                                   float* lse, void* stream) {
+    if (!qkv || !ctx || !lse || !row_start || shared_rows <= 0 || shared_rows >= L || bad_attn(dtype, B, L, H, ldqkv) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
+    if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F16) return fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, row_start, shared_rows);
+    if (dtype == LPI_BF16) return fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, row_start, shared_rows);
+    return LPI_ENOSYS;
+}
+
+extern "C" int lpi_attn_bwd_shared(int dtype, int B, int L, const int32_t* row_start, int shared_rows, int rows_needed, int H, const void* qkv, int ldqkv,
+                                   const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv,
+                                   float* shared_dkv, void* stream) {
+    if (!row_start || !shared_dkv || shared_rows <= 0 || shared_rows >= L || rows_needed < shared_rows) return LPI_EINVAL;
+    const int rows_hi = rows_needed >= L ? (1 << 30) : rows_needed;
+    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv) || bad_attn(dtype, B, L, H, lddqkv)) return LPI_EINVAL;
+    if (ldctx < H * HD || lddctx < H * HD || (ldctx * 2) % 16 || (lddctx * 2) % 16) return LPI_EINVAL;
+    if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv | (uintptr_t)shared_dkv) & 15) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int e;
+    if (dtype == LPI_F16) e = bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
+    else if (dtype == LPI_BF16) e = bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
+    else return LPI_ENOSYS;
+    if (e) return e;
+    // the shared sequence's own workgroups wrote dK / dV of the shared rows; the tail samples' partial sums are added on top
+    return lpi_shared_kv_reduce(dtype, B, shared_rows, H, shared_dkv, dqkv, lddqkv, 1, stream);
 }
 
 extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,

@@ -572,13 +572,21 @@ template <typename TX>
 __global__ __launch_bounds__(256) void txt_embed_kernel(int B, int L, const int* __restrict__ rs, int P, int d, const int64_t* __restrict__ ids,
                                                        const float* __restrict__ tok, const float* __restrict__ pos,
                                                        const float* __restrict__ ctx, long cbs, TX* __restrict__ x0,
-                                                       float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard) {
+                                                       float* __restrict__ omean, float* __restrict__ orstd, RowstatGuard guard, int pre) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // (b, l) over the [B, L] id matrix
     if (row >= B * L) return;
     const int b = row / L, l = row % L;
     size_t orow = row;
-    if (rs) {                                                  // ragged batch: sample b owns rows rs[b] .. rs[b+1]-1; tokens behind them are not embedded
+    if (rs && pre > 0) {                                       // shared prefix (attention.hip: attn_fwd_body): positions < pre are stored once, as rows 0 .. pre-1
+        if (l < pre) {
+            if (b != 0) return;
+            orow = (size_t)l;
+        } else {
+            if (l - pre >= rs[b + 1] - rs[b]) return;
+            orow = (size_t)rs[b] + (l - pre);
+        }
+    } else if (rs) {                                           // ragged batch: sample b owns rows rs[b] .. rs[b+1]-1; tokens behind them are not embedded
         if (l >= rs[b + 1] - rs[b]) return;
         orow = (size_t)rs[b] + l;
     }
@@ -1227,18 +1235,30 @@ extern "C" int lpi_vis_assemble_bwd(int dtype, int B, int G2, int P, int d, void
     return lpi_rows_sum_over_batch(dtype, B, L, 1, P, d, dx0, dprompt, 0, stream);
 }
 
-extern "C" int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
-                                        const float* pos, const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {
+static int txt_embed_launch(int x_dtype, int B, int L, const int32_t* row_start, int pre, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
+                            const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream);
+extern "C" int lpi_txt_embed_fwd_shared(int x_dtype, int B, int L, const int32_t* row_start, int shared_rows, int P, int d, const int64_t* ids, const float* tok_emb,
+                                        const float* pos, const float* ctx, void* x0, float* out_mean, float* out_rstd, void* stream) {
+    // the shared rows hold SOT and the P context slots: they are the same for every sample only if the context is broadcast (ctx_bstride = 0) and spliced in
+    if (!row_start || !ctx || shared_rows != 1 + P || shared_rows >= L) return LPI_EINVAL;
+    return txt_embed_launch(x_dtype, B, L, row_start, shared_rows, P, d, ids, tok_emb, pos, ctx, 0, x0, out_mean, out_rstd, stream);
+}
+static int txt_embed_launch(int x_dtype, int B, int L, const int32_t* row_start, int pre, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos,
+                            const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {
     if ((out_mean != nullptr) != (out_rstd != nullptr)) return LPI_EINVAL;
     if (!ids || !tok_emb || !pos || !x0 || B <= 0 || L <= 0 || P < 0 || P + 1 > L || bad_row_dim(d) || (ctx_bstride & 3)) return LPI_EINVAL;
     if (x_dtype == LPI_F32)
-        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0, out_mean, out_rstd, t_rowstat_guard);
+        LPI_LAUNCH(txt_embed_kernel<float>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (float*)x0, out_mean, out_rstd, t_rowstat_guard, pre);
     else if (x_dtype == LPI_F16)
-        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0, out_mean, out_rstd, t_rowstat_guard);
+        LPI_LAUNCH(txt_embed_kernel<f16_t>, dim3(rows_grid((long)B * L)), dim3(256), 0, S(stream), B, L, row_start, P, d, ids, tok_emb, pos, ctx, ctx_bstride, (f16_t*)x0, out_mean, out_rstd, t_rowstat_guard, pre);
     else
         return LPI_EINVAL;
     LPI_CHECK_LAST();
     return 0;
+}
+extern "C" int lpi_txt_embed_fwd_varlen(int x_dtype, int B, int L, const int32_t* row_start, int P, int d, const int64_t* ids, const float* tok_emb,
+                                        const float* pos, const float* ctx, long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {
+    return txt_embed_launch(x_dtype, B, L, row_start, 0, P, d, ids, tok_emb, pos, ctx, ctx_bstride, x0, out_mean, out_rstd, stream);
 }
 extern "C" int lpi_txt_embed_fwd(int x_dtype, int B, int L, int P, int d, const int64_t* ids, const float* tok_emb, const float* pos, const float* ctx,
                                  long ctx_bstride, void* x0, float* out_mean, float* out_rstd, void* stream) {

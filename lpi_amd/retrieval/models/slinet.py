@@ -141,14 +141,22 @@ class SliNet(nn.Module):
     def feature_dim(self):
         return self.clip_cfg.embed_dim
 
-    def _ids(self, text, pool_idx):
+    def _shared_rows(self):
+        """Rows of the text tower's SHARED PREFIX in the training forward (engine.PackedIds(shared=...)): SOT and the n_ctx context slots, which hold the
+        same rows for every sample because the prompts are broadcast over the batch (slinet.py:119-130) — 0 in the f32 parity mode (the layout exists
+        for the bf16 / f16 kernels) or with args['share_text_prefix'] = False."""
+        if self.compute_dtype == "f32" or not self.args.get("share_text_prefix", True):
+            return 0
+        return 1 + self.cfg.NCTX
+
+    def _ids(self, text, pool_idx, shared=0):
         ids = self.classifier_pool[pool_idx](text)
         if not ids.is_cuda and self.args.get("trim_text", True):
             # rows behind a caption's EOT are dead under the causal mask: exact, and free here because the tokenizer ran on the host.
             # pack_text (default): every caption cut at its OWN end, the batch packed (engine.PackedIds); else cut at the longest one
             from lpi_amd.engine import PackedIds, trim_token_ids
             if self.args.get("pack_text", True):
-                return PackedIds(ids).to(self.engine.device)
+                return PackedIds(ids, shared).to(self.engine.device)
             ids = trim_token_ids(ids).contiguous()
         return ids.to(self.engine.device)
 
@@ -167,7 +175,7 @@ class SliNet(nn.Module):
         eng = self._ensure_engine()
         visual_prompt, textual_prompt = self.prompts[self.numtask - 1]()
         bs = image.shape[0]
-        ids = self._ids(text, self.numtask - 1)
+        ids = self._ids(text, self.numtask - 1, self._shared_rows())
         # the two towers in lock step (one autograd node): their GEMMs of the same layer op go out as one grouped launch
         image_features, text_features = EncodeBothFn.apply(eng, image, ids, visual_prompt, textual_prompt, self.depth)
         return image_features, text_features, visual_prompt.expand(bs, -1, -1, -1), textual_prompt.expand(bs, -1, -1, -1)
@@ -179,7 +187,7 @@ class SliNet(nn.Module):
         ids = self.classifier_pool[self.numtask - 1](text)
         if not ids.is_cuda and self.args.get("trim_text", True):
             from lpi_amd.engine import PackedIds, trim_token_ids
-            return PackedIds(ids) if self.args.get("pack_text", True) else trim_token_ids(ids).contiguous()
+            return PackedIds(ids, self._shared_rows()) if self.args.get("pack_text", True) else trim_token_ids(ids).contiguous()
         return ids
 
     def task_factors(self):
@@ -194,7 +202,7 @@ class SliNet(nn.Module):
         from lpi_amd.engine import PackedIds
         from lpi_amd.step import train_step
         eng = self._ensure_engine()
-        ids = text if isinstance(text, PackedIds) or (torch.is_tensor(text) and text.is_cuda) else self._ids(text, self.numtask - 1)
+        ids = text if isinstance(text, PackedIds) or (torch.is_tensor(text) and text.is_cuda) else self._ids(text, self.numtask - 1, self._shared_rows())
         if isinstance(ids, PackedIds):
             ids.to(eng.device)
         term = None
