@@ -998,28 +998,40 @@ extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* st
 
 // ------------------------------------------------------------------------------------------------ shared prefix (see attn_fwd_body)
 namespace {
-// dqkv[key][K | V columns] (+)= sum over the B samples of their f32 partials part[b][key][dK (dm) | dV (dm)], in the fixed order b = 0 .. B-1
+// dqkv[key][K | V columns] (+)= sum over the B samples of their f32 partials part[b][key][dK (dm) | dV (dm)].  A workgroup owns 16 consecutive float4 outputs;
+// its 16 x 16 threads each add up every 16th sample (b = slice, slice + 16, ...) and the 16 slice sums are added in slice order through LDS: a FIXED
+// summation tree (bitwise reproducible), 272 workgroups at H = 8 instead of the 17 a thread-per-output kernel fills (measured 23.8 us -> see profiles/)
 template <typename T>
 __global__ __launch_bounds__(256) void shared_kv_reduce_kernel(int B, int pre, int dm, const float* __restrict__ part, T* __restrict__ dqkv, int ld, int accumulate) {
-    const int per_row = 2 * dm / 4;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= pre * per_row) return;
-    const int key = t / per_row, c = (t % per_row) * 4;
-    const float* p = part + (size_t)key * 2 * dm + c;
-    const size_t bstride = (size_t)pre * 2 * dm;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-    int b = 0;
-    for (; b + 4 <= B; b += 4) {      // four independent chains: the loads of a sample do not wait for the previous sample's add
-        a0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
-        a1 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 1) * bstride);
-        a2 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 2) * bstride);
-        a3 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 3) * bstride);
+    __shared__ f32x4 red[16][16];
+    const int per_row = 2 * dm / 4, n = pre * per_row;
+    const int o = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + o;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (t < n) {
+        const int key = t / per_row, c = (t % per_row) * 4;
+        const float* p = part + (size_t)key * 2 * dm + c;
+        const size_t bstride = (size_t)pre * 2 * dm;
+        f32x4 a1 = a;
+        int b = slice;
+        for (; b + 16 < B; b += 32) {      // two independent chains per thread
+            a += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
+            a1 += *reinterpret_cast<const f32x4*>(p + (size_t)(b + 16) * bstride);
+        }
+        if (b < B) a += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
+        a += a1;
     }
-    for (; b < B; ++b) a0 += *reinterpret_cast<const f32x4*>(p + (size_t)b * bstride);
-    f32x4 v = (a0 + a1) + (a2 + a3);
-    T* o = dqkv + (size_t)key * ld + dm + c;      // K columns at dm .., V columns at 2 dm .. : column dm + c for c in [0, 2 dm)
-    if (accumulate) v += Elem<T>::ld4(o);
-    Elem<T>::st4(o, v);
+    red[slice][o] = a;
+    __syncthreads();
+    if (slice == 0 && t < n) {
+        f32x4 v = red[0][o];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) v += red[i][o];
+        const int key = t / per_row, c = (t % per_row) * 4;
+        T* out = dqkv + (size_t)key * ld + dm + c;      // K columns at dm .., V columns at 2 dm .. : column dm + c for c in [0, 2 dm)
+        if (accumulate) v += Elem<T>::ld4(out);
+        Elem<T>::st4(out, v);
+    }
 }
 }  // namespace
 
@@ -1028,7 +1040,7 @@ extern "C" int lpi_shared_kv_reduce(int dtype, int B, int shared_rows, int H, co
     const int dm = H * HD, n = shared_rows * (2 * dm / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_BF16 || dtype == LPI_F16)      // F16: "saved activations fp16, gradients bf16" (lpi_attn_bwd_prefix)
-        LPI_LAUNCH((shared_kv_reduce_kernel<bf16_t>), dim3((n + 255) / 256), dim3(256), 0, s, B, shared_rows, dm, partial, (bf16_t*)dqkv, lddqkv, accumulate);
+        LPI_LAUNCH((shared_kv_reduce_kernel<bf16_t>), dim3((n + 15) / 16), dim3(256), 0, s, B, shared_rows, dm, partial, (bf16_t*)dqkv, lddqkv, accumulate);
     else
         return LPI_ENOSYS;
     LPI_CHECK_LAST();
