@@ -413,6 +413,9 @@ def eval_path(a, dev, rank, sync, tasks=3, centres=5, n_img=5000, n_txt=25000):
     from lpi_amd import _lib
     from lpi_amd.engine import score_matrix
     from lpi_amd.functional import DecomposedPromptFn
+    import copy
+    a = copy.copy(a)
+    a.no_text_shared = True      # inference: un-prompted rows and per-sample prompt stacks — no positions in common, the plain packed layout
     wl = Workload(a, dev, rank, "bf16", True, None)
     enc, B, E = wl.enc, a.batch, wl.cfg.embed_dim
     names = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")
@@ -608,8 +611,21 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
     loader = DataLoader(ds, batch_size=B, shuffle=False, num_workers=0, collate_fn=collate_keep_images)
     optimizer, _ = m._setup_training()
     t, host, h2d, rows, evs = {}, [], [], [], []
+    # the MAIN thread's side of an iteration: how long it takes to enqueue a step (Python generators + ctypes: no device wait in it) and how long it sits
+    # between two steps (hand-over of the next batch, the loss log) — against the device's step time this says how far ahead of the GPU the host runs
+    enq, stamps = [], []
+    if args.get("fused_step", True):
+        inner = net.train_step
+
+        def timed_step(*aa, **kw):
+            t0 = time.perf_counter()
+            r = inner(*aa, **kw)
+            enq.append((t0, time.perf_counter()))
+            return r
+        net.train_step = timed_step
 
     def on_step(i, batch, out):
+        stamps.append(time.perf_counter())
         if i >= warm - 1:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -639,7 +655,14 @@ def plugin_step(a, dev, sync, steps=60, warm=10, **over):
            "input": f"DataLoader(SyntheticCoco: host {pf} images [3,{net.clip_cfg.image_resolution},{net.clip_cfg.image_resolution}] from a pool of 512, caption strings), bs={B}, "
                     "num_workers=0", "bpe_table": "synthetic" if "lpi_synthetic_bpe" in vocab else "clip"}
     # step-to-step time on the device inside the loop (HIP events recorded behind every iteration): what the loop costs the GPU, next to the wall clock
-    rec["median_ms_per_step"] = round(float(np.median([evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)])), 3)
+    per = [evs[j].elapsed_time(evs[j + 1]) for j in range(len(evs) - 1)]
+    rec["median_ms_per_step"] = round(float(np.median(per)), 3)
+    rec["ms_per_step_p10_p90"] = [round(float(np.percentile(per, 10)), 3), round(float(np.percentile(per, 90)), 3)]
+    if len(enq) > warm + 2:
+        d = np.array([1e3 * (b - a_) for a_, b in enq[warm:]])
+        gap = np.array([1e3 * (enq[j + 1][0] - enq[j][1]) for j in range(warm, len(enq) - 1)])
+        rec["main_thread_ms_per_iteration"] = {"enqueue_step_median": round(float(np.median(d)), 3), "enqueue_step_p90": round(float(np.percentile(d, 90)), 3),
+                                               "between_steps_median": round(float(np.median(gap)), 3), "between_steps_p90": round(float(np.percentile(gap, 90)), 3)}
     if host:
         rec["producer_ms_per_batch"] = {k: round(float(np.mean([h[k] for h in host])), 3) for k in host[0]}
         rec["producer_ms_per_batch"]["total_without_waits"] = round(sum(v for k, v in rec["producer_ms_per_batch"].items() if k not in ("slot_wait",)), 3)
