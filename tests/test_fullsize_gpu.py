@@ -317,6 +317,42 @@ def test_packed_text_batch_at_the_benchmarked_configuration(data):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("mode,ftol", [("bf16", 5e-3), ("f16", 1.5e-3)])
+def test_shared_prefix_text_layout_at_the_benchmarked_configuration(enc32, data, mode, ftol):
+    """bench.py's text layout since round 5 — packed AND the 17 positions every caption has in common (SOT + the broadcast context slots) stored once
+    (engine.PackedIds(shared=17)) — at B = 256, depth 3: text features bit-identical to the plain packed layout; factor gradients inside the bars the
+    throughput modes are held to against the f32 step (which the fixtures pin to the reference), and not further from it than the plain layout's."""
+    from lpi_amd.engine import PackedIds
+    img, ids = data
+    ids_h = synth.token_ids(B)
+    f32 = factors()
+    o32 = train_step(enc32, img, ids, f32, 3)
+    o32 = {k: v.clone() for k, v in o32.items()}
+    g32 = {k: f32[k].grad.double().cpu() for k in synth.PROMPT_NAMES}
+    enc = DualEncoder(CFG, synth.clip_state_dict(CFG), dtype=mode, device=DEV)
+    res = {}
+    for tag, shared in (("plain", 0), ("shared", 17)):
+        fac = factors()
+        pk = PackedIds(ids_h, shared).to(DEV)
+        out = train_step(enc, img, pk, fac, 3)
+        torch.cuda.synchronize()
+        res[tag] = ({k: v.clone() for k, v in out.items()}, {k: fac[k].grad.double().cpu() for k in synth.PROMPT_NAMES}, pk.rows)
+    assert res["shared"][2] < 0.65 * res["plain"][2]
+    assert torch.equal(res["plain"][0]["img_f"], res["shared"][0]["img_f"]) and torch.equal(res["plain"][0]["txt_f"], res["shared"][0]["txt_f"])
+    assert float((res["shared"][0]["txt_f"] - o32["txt_f"]).abs().max()) < ftol
+    cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm()))  # noqa: E731
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())  # noqa: E731
+    report = {k: (cos(res["plain"][1][k], g32[k]), cos(res["shared"][1][k], g32[k]), rel(res["plain"][1][k], g32[k]), rel(res["shared"][1][k], g32[k]))
+              for k in synth.PROMPT_NAMES}
+    print(f"{mode} factor gradients vs the f32 step (cosine plain, shared; max rel err plain, shared):", {k: tuple(round(x, 5) for x in v) for k, v in report.items()})
+    for k, (cp, cs, rp, rs_) in report.items():
+        assert cs >= 0.9995 and rs_ <= 0.03, (k, cs, rs_)
+        assert rs_ <= 1.25 * rp + 2e-3, (k, rp, rs_)
+        assert cos(res["shared"][1][k], res["plain"][1][k]) > 0.99995, k
+    del enc
+    torch.cuda.empty_cache()
+
+
 def test_eval_shard_at_vitb16_size_matches_reference(golden):
     """north_star: 'R@1 indices bit-identical to reference on a fixed synthetic shard'.  The reference's whole evaluation
     (sprompt.py:433-646: task ids by L1 distance to keys, per-sample prompted features, N_img x N_txt score matrix, per-row rank of the
