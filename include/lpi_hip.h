@@ -86,7 +86,9 @@ uint64_t lpi_launch_count(void);
  *   key 15     tile order of the persistent 256x256 GEMM for weights that do not fit an XCD's L2 next to the activation stream (round 5): 0 (default) = the
  *              N-tiles (an even number) of a weight above 3 MB are cut into two SLICES and the tiles run slice-major, so that each XCD keeps one slice
  *              resident instead of re-reading the whole weight every round; 2 / 3: that many slices wherever N divides; -1: off.  Same bits.
- *   keys 9, 10 reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
+ *   key 9      > 0: minimum number of waves (<= 8) of a workgroup of the one-head attention kernels on RAGGED batches (the text tower: thousands of
+ *              workgroups of a few dozen rows, bound by the latency of their staging loads; the waves beyond the row blocks only help to stage).  Same bits.
+ *   key 10     reserved (0).  Returns LPI_EINVAL for a key outside 0..15. */
 int lpi_set_tuning(int key, int value);
 int lpi_get_tuning(int key);   /* current value of a knob (>= 0), LPI_EINVAL for a key outside 0..15 */
 

@@ -94,6 +94,50 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
     }
 }
 
+// FOUR images in one sweep (the fused backward: K, V with La valid rows and the pre / seg row map, Q, dO with Lb valid rows): all of a thread's loads are
+// in flight before the first LDS write — one HBM round trip where two stage_rows2 calls in a row take two (the text tower's backward is a chain of such
+// round trips: 2 056 workgroups of a few dozen rows).  CVA: K, V, Q are fp16 and become bf16 on the way (f16 mode); dO never is.
+template <typename T, bool CVA>
+__device__ __forceinline__ void stage_rows4(char* lds_k, const T* gk, char* lds_v, const T* gv, int ldkv, int La, int pre, long seg,
+                                            char* lds_q, const T* gq, int ldq, char* lds_do, const T* gdo, int lddo, int Lb, int Lp) {
+    constexpr int NCH = HD * (int)sizeof(T) / 16;
+    const int n = Lp * NCH, nt = blockDim.x;
+    for (int base = threadIdx.x; base < n; base += 4 * nt) {
+        uint4 vk[4], vv[4], vq[4], vd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * nt, row = i / NCH, c = i % NCH;
+            vk[j] = vv[j] = vq[j] = vd[j] = make_uint4(0, 0, 0, 0);
+            if (i < n && row < La) {
+                const size_t srow = (size_t)(row < pre ? (long)row : (long)row + seg);
+                vk[j] = *reinterpret_cast<const uint4*>(gk + srow * ldkv + c * Elem<T>::EPC);
+                vv[j] = *reinterpret_cast<const uint4*>(gv + srow * ldkv + c * Elem<T>::EPC);
+            }
+            if (i < n && row < Lb) {
+                vq[j] = *reinterpret_cast<const uint4*>(gq + (size_t)row * ldq + c * Elem<T>::EPC);
+                vd[j] = *reinterpret_cast<const uint4*>(gdo + (size_t)row * lddo + c * Elem<T>::EPC);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * nt, row = i / NCH, c = i % NCH;
+            if (i < n) {
+                if constexpr (CVA) {
+                    Chunk t;
+                    t.u = vk[j]; chunk_f16_to_bf16(t); vk[j] = t.u;
+                    t.u = vv[j]; chunk_f16_to_bf16(t); vv[j] = t.u;
+                    t.u = vq[j]; chunk_f16_to_bf16(t); vq[j] = t.u;
+                }
+                const int lo = row * AT<T>::RS + c * 16;
+                *reinterpret_cast<uint4*>(lds_k + lo) = vk[j];
+                *reinterpret_cast<uint4*>(lds_v + lo) = vv[j];
+                *reinterpret_cast<uint4*>(lds_q + lo) = vq[j];
+                *reinterpret_cast<uint4*>(lds_do + lo) = vd[j];
+            }
+        }
+    }
+}
+
 // this lane's KS row chunks of LDS row `row` (rows >= L were zero filled by the staging)
 template <typename T>
 __device__ __forceinline__ void lds_row_chunks(Chunk (&q)[AT<T>::KS], const char* lds, int row, int grp) {
@@ -644,17 +688,26 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
     char* do_lds = smem + 3 * img;
     float* lse_lds = reinterpret_cast<float*>(smem + 4 * img);
     float* dl_lds = lse_lds + Lp;
-    if (pb) stage_rows2<T, SV16, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
-    else stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
-    stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int g = lane >> 4;
+    // everything the workgroup reads from HBM is requested before anything waits: this thread's lse value, the context rows of the wave's first query
+    // blocks (delta), then the four images in one sweep
+    const int li = threadIdx.x;
+    const float lse_first = (li < L) ? lse[lse0 + li] : 0.f;
+    Chunk oc0[NB][AT<T>::KS];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int qr = (wave * NB + j) * 16 + (lane & 15);
+        load_row_chunks<T>(oc0[j], ctx + h * HD, row0 + qr, ldctx, g, qr < L);
+    }
+    stage_rows4<T, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, Lk, pb ? pb : 0, pb ? (long)row0 - pb : (long)row0, q_lds, qg, ldqkv, do_lds,
+                         dctx + row0 * lddctx + h * HD, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
-        lse_lds[i] = i < L ? lse[lse0 + i] * LOG2E : INFINITY;
+        lse_lds[i] = i < L ? (i == li ? lse_first : lse[lse0 + i]) * LOG2E : INFINITY;
         if (pb) dl_lds[i] = 0.f;      // phase A covers the OWN rows' 32-row spans only; the image is as long as the KEYS
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int g = lane >> 4;
     const float c = SCALE * LOG2E;
     const char* const qp0 = q_lds + row_ptr_off<T>(lane);
     const char* const kp0 = k_lds + row_ptr_off<T>(lane);
@@ -677,7 +730,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
             lds_row_chunks<T>(q[j], q_lds, qrow[j], g);
             lds_row_chunks<T>(dO[j], do_lds, qrow[j], g);
             Chunk oc[AT<T>::KS];
-            load_row_chunks<T>(oc, ctx + h * HD, row0 + qrow[j], ldctx, g, valid);
+            if (q0 == wave * 16 * NB) {      // fetched ahead of the staging
+#pragma unroll
+                for (int ks = 0; ks < AT<T>::KS; ++ks) oc[ks] = oc0[j][ks];
+            } else {
+                load_row_chunks<T>(oc, ctx + h * HD, row0 + qrow[j], ldctx, g, valid);
+            }
             float dl = 0.f;
 #pragma unroll
             for (int ks = 0; ks < AT<T>::KS; ++ks) {
@@ -825,6 +883,12 @@ inline int pick_waves(int L) {
     const int rounds = (nqb + 7) / 8;
     return (nqb + rounds - 1) / rounds;
 }
+// ragged batches (the text tower: 2 000 workgroups of a few dozen rows, latency-bound): tuning key 9 = minimum number of waves per workgroup — the waves
+// beyond the row blocks take part in the staging only (more loads in flight per workgroup)
+inline int pick_waves_ragged(int L) {
+    const int w = pick_waves(L), lo = g_lpi_tuning[9];
+    return lo > w ? (lo < 8 ? lo : 8) : w;
+}
 
 // allow the full 160 KiB of a CU's LDS for a kernel: once per (kernel function, device), safe from any host thread
 int set_lds(const void* kern, size_t bytes) {
@@ -858,7 +922,7 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
     const int nbh = (B + (pre > 0 ? 1 : 0)) * H, bsh = pre > 0 ? B : -1;
     const int Lp = (L + 31) / 32 * 32;
     const size_t lds = (size_t)2 * Lp * AT<T>::RS;
-    const int thr = 64 * pick_waves(L);
+    const int thr = 64 * (rs ? pick_waves_ragged(L) : pick_waves(L));
     if constexpr (sizeof(T) == 2 && !CAUSAL) {
         if (fwd_swizzled(Lp) && !rs) {      // 257 .. 288 tokens: unpadded swizzled images, two workgroups per CU (stage_rows2)
             const size_t lsw = (size_t)2 * Lp * 128;
@@ -882,7 +946,7 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     const int Lp = (L + 31) / 32 * 32;
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
-    const int thr = 64 * pick_waves(L);
+    const int thr = 64 * (rs ? pick_waves_ragged(L) : pick_waves(L));
     const size_t ldsF = (size_t)4 * Lp * AT<T>::RS + (size_t)2 * Lp * sizeof(float);
     // fused single pass for 2-byte operands (HBM bound: -7 % at L = 213, -23 % at L = 77); f32 is compute bound and faster with the
     // two-pass kernels at two workgroups per CU.  Tuning key 3 != 0 forces the two-pass kernels.
@@ -955,7 +1019,7 @@ static int fwd_pair_launch(const lpi_attn_fwd_desc* d, hipStream_t s) {
         if (pre < 0 || (pre > 0 && (!d[i].causal || !d[i].row_start || pre >= d[i].L))) return LPI_EINVAL;
         p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse, pre, pre > 0 ? d[i].B : -1};
         lds = std::max(lds, (size_t)2 * Lp * AT<T>::RS);
-        thr = std::max(thr, 64 * pick_waves(d[i].L));
+        thr = std::max(thr, 64 * (d[i].row_start ? pick_waves_ragged(d[i].L) : pick_waves(d[i].L)));
     }
     const int nb0 = (d[0].B + (d[0].shared_rows > 0)) * d[0].H, nb1 = (d[1].B + (d[1].shared_rows > 0)) * d[1].H;
     if (!d[0].causal && d[1].causal && !d[0].row_start && fwd_swizzled(p[0].Lp)) {      // a long vision sequence beside the text tower: problem 0 on the swizzled images

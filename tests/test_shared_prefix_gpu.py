@@ -269,6 +269,24 @@ def test_vitb16_fixture_in_both_layouts(golden, dtype):
         assert _cos(shared[k], plain[k]) > 0.9995, k
 
 
+def test_towers_one_after_the_other_equal_the_lock_stepped_towers_on_the_shared_layout():
+    """run_alone issues lpi_attn_fwd_shared / lpi_attn_pooled_*_desc / single launches where run_lockstep issues the pair forms: the same kernel bodies,
+    the same bits (ViT-B/16 widths at 8 pairs, so that the paired launches really pair)."""
+    cfg = synth.VIT_B16
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
+    ids = synth.token_ids(8)
+    img = torch.from_numpy(synth.images(8, cfg.image_resolution)).to(DEV)
+    res = {}
+    for lock in (True, False):
+        fac = _factors(cfg)
+        out = train_step(enc, img, PackedIds(ids, PRE).to(DEV), fac, 3, lockstep=lock)
+        torch.cuda.synchronize()
+        res[lock] = (out["txt_f"].clone(), out["img_f"].clone(), {k: fac[k].grad.clone() for k in synth.PROMPT_NAMES})
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in synth.PROMPT_NAMES:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
 def _ids_with_lengths(lengths, seed=3):
     """[B, 77] token ids: SOT, 16 placeholder slots, caption tokens, EOT at position lengths[b] - 1."""
     g = np.random.default_rng(seed)
