@@ -49,3 +49,5 @@ m.train_epoch(loader, opt, 0, None, on_step)
 if hm:
     print("producer ms per batch:", {k: round(sum(h[k] for h in hm) / len(hm), 3) for k in hm[0]})
 print("done", n, "iterations;", round(1e3 * (t[1] - t[0]) / (n - 8), 3), "ms per iteration after 8 warm-up iterations")
+print("device memory: allocated", round(torch.cuda.memory_allocated() / 2**30, 2), "GiB, peak", round(torch.cuda.max_memory_allocated() / 2**30, 2), "GiB, reserved",
+      round(torch.cuda.memory_reserved() / 2**30, 2), "GiB;  text layout shared rows:", m._network._shared_rows())
