@@ -287,6 +287,27 @@ def test_towers_one_after_the_other_equal_the_lock_stepped_towers_on_the_shared_
         assert torch.equal(res[True][2][k], res[False][2][k]), k
 
 
+def test_text_micro_batches_on_stream_lanes_keep_the_shared_layout():
+    """overlap_towers with two text lanes: PackedIds[lo:hi] keeps shared = 17 (each micro-batch stores its own copy of the common rows) and the step agrees
+    with the lock-stepped one (other row counts pick other GEMM kernels: bf16 round-off, not bits)."""
+    cfg = synth.TINY
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
+    ids = synth.token_ids(8)
+    img = torch.from_numpy(synth.images(8, cfg.image_resolution)).to(DEV)
+    pk = PackedIds(ids, PRE)
+    assert pk[0:4].shared == PRE and pk[4:8].rows == PRE + int((pk.lengths[4:8] - PRE).sum())
+    res = {}
+    for tag, kw in (("lock", {}), ("lanes", dict(overlap_towers=True, text_lanes=2))):
+        fac = _factors(cfg)
+        out = train_step(enc, img, PackedIds(ids, PRE).to(DEV) if tag == "lock" else PackedIds(ids, PRE), fac, 2, **kw)
+        torch.cuda.synchronize()
+        res[tag] = (out["txt_f"].float().cpu(), {k: fac[k].grad.cpu() for k in synth.PROMPT_NAMES})
+    assert float((res["lock"][0] - res["lanes"][0]).abs().max()) < 4e-3
+    for k in synth.PROMPT_NAMES:
+        a, b = res["lock"][1][k], res["lanes"][1][k]
+        assert float((a - b).abs().max()) <= 3e-2 * float(a.abs().max()) + 1e-6, k
+
+
 def _ids_with_lengths(lengths, seed=3):
     """[B, 77] token ids: SOT, 16 placeholder slots, caption tokens, EOT at position lengths[b] - 1."""
     g = np.random.default_rng(seed)
