@@ -852,6 +852,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (pb && krow[j] < pb) {      // a SHARED key: this sample's f32 partial (summed over the samples by lpi_shared_kv_reduce)
+#ifdef LPI_ABL_SHARED_NOPARTIAL       /* ablation build: what the partial stores cost the kernel (results are wrong) */
+                if (b != 0) continue;
+#endif
                 float* dst = shared_dkv + ((size_t)b * pb + krow[j]) * 2 * dm + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
