@@ -187,10 +187,16 @@ def test_plugin_loop_on_strings_issues_the_bare_steps_launches_and_no_other_kern
         return i == 5
     m.train_epoch(loader, opt, 0, None, on_step)            # warm-up pass: arenas, pinned slots, tokenizer tables
     torch.cuda.synchronize()
-    counts.clear()
     state["profile"] = True
-    m.train_epoch(loader, opt, 0, None, on_step)
-    torch.cuda.synchronize()
+    dev_events = []
+    for attempt in range(3):      # the tracer now and then hands back a fraction of a window's records (17 of 237 seen once): profile another pass then
+        counts.clear()
+        prof = profile(activities=[ProfilerActivity.CUDA])
+        m.train_epoch(loader, opt, 0, None, on_step)
+        torch.cuda.synchronize()
+        dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
+        if len(dev_events) >= 200:
+            break
     per = sorted({b - a for a, b in zip(counts, counts[1:])})
     print(f"\n    library launches per iteration of the plugin loop: {per}")
     # the bare step on resident tensors of the same batch
@@ -210,7 +216,6 @@ def test_plugin_loop_on_strings_issues_the_bare_steps_launches_and_no_other_kern
     stats0 = dict(E.LOCKSTEP_STATS)
     train_step(net.engine, img, pk, fac, 3, flat_grad=opt.flat_grad, grad_views=opt.grad_views)
     assert E.LOCKSTEP_STATS["paired"] > stats0["paired"] and E.LOCKSTEP_STATS["shifted"] == stats0["shifted"], (stats0, E.LOCKSTEP_STATS)
-    dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
     foreign = [n for n in dev_events if "anonymous namespace" not in n and "_GLOBAL__N_" not in n and "lpi" not in n.lower() and "StatFin" not in n
                and "Memcpy" not in n and "Memset" not in n]
     assert len(dev_events) >= bare and foreign == [], (len(dev_events), sorted(set(foreign)))
