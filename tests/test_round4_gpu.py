@@ -348,10 +348,14 @@ def test_steady_state_launch_count_and_no_foreign_kernel_in_the_step(full):
     assert n1 - n0 == n2 - n1
     assert n1 - n0 <= LAUNCHES_PER_STEP_MAX, n1 - n0
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        step()
-        torch.cuda.synchronize()
-    dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
+    dev_events = []
+    for attempt in range(3):      # the tracer now and then hands back a fraction of a window's records (seen once in round 5): profile another step then
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        dev_events = [e.name for e in prof.events() if e.device_type.name != "CPU"]
+        if len(dev_events) >= n1 - n0:
+            break
     foreign = [n for n in dev_events if "anonymous namespace" not in n and "_GLOBAL__N_" not in n and "lpi" not in n.lower() and "StatFin" not in n
                and "Memcpy" not in n and "Memset" not in n]
     assert len(dev_events) >= n1 - n0 and foreign == [], foreign
