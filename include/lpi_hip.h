@@ -247,7 +247,7 @@ typedef struct lpi_attn_fwd_desc {
     void* ctx; int ldctx;
     float* lse;
     int causal;
-    int shared_rows;       /* 0, or the shared prefix of lpi_attn_fwd_shared (2-byte operand types, causal, row_start given) */
+    int shared_rows;       /* 0, or the shared prefix of lpi_attn_fwd_shared (causal, row_start given) */
 } lpi_attn_fwd_desc;
 int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 /* The same backward when only the FIRST `rows_needed` token rows of dqkv are wanted (the first block: nothing upstream of the prompt slots
@@ -293,7 +293,8 @@ int lpi_attn_pooled_bwd_desc(int dtype, const lpi_attn_pooled_desc* d, void* str
  * (B + 1) x H x L floats, sample index B being the shared sequence, indexed by OWN row.  Every row-wise op (LayerNorm, GEMMs) just sees fewer rows;
  * attention reads keys [shared rows | own rows].  The gradient that reaches the shared rows is the batch SUM (what lpi_rows_sum_over_batch produces
  * in the plain layout): dK / dV of the shared keys are summed over the samples in f32 in a fixed order (bitwise reproducible), so the prompt
- * gradients differ from the plain layout's only by the rounding of intermediate bf16 stores.  bf16 / f16 operand types only. */
+ * gradients differ from the plain layout's only by the rounding of intermediate bf16 stores (f32: by the order of f32 sums).  All three operand types; f32
+ * runs the two-pass backward kernels and ignores rows_needed. */
 int lpi_txt_embed_fwd_shared(int x_dtype, int B, int L, const int32_t* row_start, int shared_rows /* = 1 + P */, int P, int d, const int64_t* ids,
                              const float* tok_emb, const float* pos, const float* ctx /* [P, d], broadcast */, void* x0, float* out_mean,
                              float* out_rstd, void* stream);

@@ -429,24 +429,33 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                          const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                          const float* __restrict__ lse, float* __restrict__ delta,
-                                                         T* __restrict__ dqkv, int lddqkv) {
+                                                         T* __restrict__ dqkv, int lddqkv, int pre, int bshared) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    // shared prefix (pre > 0): as in attn_bwd_fused_kernel — keys [shared rows | own rows], queries the own rows, masks on positions
     int L = Lmax, Lp = Lpmax;
     size_t row0 = (size_t)b * Lmax;
-    if (rs) {
+    int pb = 0;
+    if (CAUSAL && pre > 0 && b == bshared) {
+        row0 = 0;
+        L = pre;
+        Lp = (L + 31) / 32 * 32;
+    } else if (rs) {
         const int r = rs[b];
         row0 = (size_t)r;
         L = rs[b + 1] - r;
-        Lp = (L + 31) / 32 * 32;
+        if (CAUSAL && pre > 0) pb = pre;
+        Lp = (pb + L + 31) / 32 * 32;
     }
-    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
+    const int Lk = pb + L;
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
     const int dm = H * HD;
     const T* qg = qkv + row0 * ldqkv + h * HD;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
-    stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    if (pb) stage_rows2<T, SV16, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
+    else stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -504,17 +513,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, c
                     float e1 = fast_exp2(fmaf(s1[j][r], c, -lq[j]));
                     if constexpr (MASKED) {
                         const int k0 = kb + 4 * g + r, k1 = k0 + 16;
-                        if (!(k0 < L && (!CAUSAL || k0 <= qrow[j]))) e0 = 0.f;
-                        if (!(k1 < L && (!CAUSAL || k1 <= qrow[j]))) e1 = 0.f;
+                        if (!(k0 < Lk && (!CAUSAL || k0 <= qrow[j] + pb))) e0 = 0.f;
+                        if (!(k1 < Lk && (!CAUSAL || k1 <= qrow[j] + pb))) e1 = 0.f;
                     }
                     s0[j][r] = e0 * fmaf(p0[j][r], SCALE, -dls[j]);       // P * (dP - delta) * scale
                     s1[j][r] = e1 * fmaf(p1[j][r], SCALE, -dls[j]);
                 }
             mma_transposed<T>(dq, kt0 + kb * AT<T>::RS, s0, s1);
         };
-        const int qlast = q0 + 16 * NB - 1;
+        const int qlast = q0 + pb + 16 * NB - 1;      // positions
         const int kend = CAUSAL ? min(Lp, (qlast / 32 + 1) * 32) : Lp;
-        const int kfull = CAUSAL ? min((L / 32) * 32, (q0 / 32) * 32) : (L / 32) * 32;
+        const int kfull = CAUSAL ? min((Lk / 32) * 32, ((q0 + pb) / 32) * 32) : (Lk / 32) * 32;
         int kb = 0;
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
@@ -535,21 +544,32 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, c
 template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ dctx, int lddctx, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv) {
+                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv, int pre, int bshared,
+                                                          float* __restrict__ shared_dkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
+    // shared prefix (pre > 0): as in attn_bwd_fused_kernel's phase B — a tail sample's dK / dV of the shared keys leave as f32 partials
     int L = Lmax, Lp = Lpmax;
     size_t row0 = (size_t)b * Lmax;
-    if (rs) {
+    int pb = 0;
+    if (CAUSAL && pre > 0 && b == bshared) {
+        row0 = 0;
+        L = pre;
+        Lp = (L + 31) / 32 * 32;
+    } else if (rs) {
         const int r = rs[b];
         row0 = (size_t)r;
         L = rs[b + 1] - r;
-        Lp = (L + 31) / 32 * 32;
+        if (CAUSAL && pre > 0) pb = pre;
+        Lp = (pb + L + 31) / 32 * 32;
     }
-    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
+    const int Lk = pb + L;
+    const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
     const int dm = H * HD;
     const T* qg = qkv + row0 * ldqkv + h * HD;
+    const T* kg = qkv + h * HD + dm;                      // keys / values by GLOBAL row (key position p -> row p, or row0 + p - pb behind the shared ones)
+    auto krow_global = [&](int p) -> size_t { return (size_t)(p < pb ? (long)p : (long)row0 + p - pb); };
     char* q_lds = smem;
     char* do_lds = smem + Lp * AT<T>::RS;
     float* lse_lds = reinterpret_cast<float*>(smem + 2 * Lp * AT<T>::RS);
@@ -560,8 +580,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
 #pragma unroll
     for (int j = 0; j < NB; ++j) {          // first key blocks: fetched ahead of the staging
         const int kr = (wave * NB + j) * 16 + (lane & 15);
-        load_row_chunks<T, SV16>(kk[j], qg + dm, kr, ldqkv, g, kr < L);
-        load_row_chunks<T, SV16>(vv[j], qg + 2 * dm, kr, ldqkv, g, kr < L);
+        load_row_chunks<T, SV16>(kk[j], kg, krow_global(kr), ldqkv, g, kr < Lk);
+        load_row_chunks<T, SV16>(vv[j], kg + dm, krow_global(kr), ldqkv, g, kr < Lk);
     }
     stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
@@ -575,15 +595,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
     const char* const dp0 = do_lds + row_ptr_off<T>(lane);
     const char* const qt0 = q_lds + tr_ptr_off<T>(lane);
     const char* const dt0 = do_lds + tr_ptr_off<T>(lane);
-    for (int k0 = wave * 16 * NB; k0 < L; k0 += nw * 16 * NB) {
+    for (int k0 = wave * 16 * NB; k0 < Lk; k0 += nw * 16 * NB) {
         int krow[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) krow[j] = k0 + 16 * j + (lane & 15);
         if (k0 != wave * 16 * NB) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                load_row_chunks<T, SV16>(kk[j], qg + dm, krow[j], ldqkv, g, krow[j] < L);
-                load_row_chunks<T, SV16>(vv[j], qg + 2 * dm, krow[j], ldqkv, g, krow[j] < L);
+                load_row_chunks<T, SV16>(kk[j], kg, krow_global(krow[j]), ldqkv, g, krow[j] < Lk);
+                load_row_chunks<T, SV16>(vv[j], kg + dm, krow_global(krow[j]), ldqkv, g, krow[j] < Lk);
             }
         }
         f32x4 dk[NB][4], dv[NB][4];
@@ -613,7 +633,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
                     e0[j][r] = fast_exp2(fmaf(s0[j][r], c, -l0[r]));
                     e1[j][r] = fast_exp2(fmaf(s1[j][r], c, -l1[r]));
                     if constexpr (MASKED) {
-                        const int qa = qb + 4 * g + r, qc = qa + 16;
+                        const int qa = qb + pb + 4 * g + r, qc = qa + 16;      // query positions
                         if (krow[j] > qa) e0[j][r] = 0.f;
                         if (krow[j] > qc) e1[j][r] = 0.f;
                     }
@@ -623,20 +643,32 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
             mma_transposed<T>(dv, dt0 + qb * AT<T>::RS, e0, e1);
             mma_transposed<T>(dk, qt0 + qb * AT<T>::RS, s0, s1);
         };
-        int qb = CAUSAL ? (k0 / 32) * 32 : 0;
+        // query tiles by OWN index; a key at position k is seen by the own queries i with i + pb >= k
+        const int kq = k0 - pb;
+        int qb = CAUSAL ? (kq > 0 ? (kq / 32) * 32 : 0) : 0;
         if constexpr (CAUSAL) {
-            const int qdiag = min(Lp, ((k0 + 16 * NB - 1) / 32 + 1) * 32);      // tiles that can hold q < key
+            const int qdiag = (kq + 16 * NB - 1 >= 0) ? min(Lp, ((kq + 16 * NB - 1) / 32 + 1) * 32) : 0;      // tiles that can hold q < key
             for (; qb < qdiag; qb += 32) tile(qb, std::true_type{});
         }
         for (; qb < Lp; qb += 32) tile(qb, std::false_type{});
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
+            if (pb && krow[j] < pb) {      // a SHARED key: this sample's f32 partial (summed over the samples by lpi_shared_kv_reduce)
+                float* dst = shared_dkv + ((size_t)b * pb + krow[j]) * 2 * dm + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *reinterpret_cast<f32x4*>(dst + dt * 16) = dk[j][dt];
+                    *reinterpret_cast<f32x4*>(dst + dm + dt * 16) = dv[j][dt];
+                }
+                continue;
+            }
+            const size_t orow = row0 + (krow[j] - pb);      // own key
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + (row0 + krow[j]) * lddqkv + h * HD;
-                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < L);
-                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < L);
-            } else if (krow[j] < L) {
-                T* dst = dqkv + (row0 + krow[j]) * lddqkv + h * HD + 4 * g;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + h * HD;
+                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < Lk);
+                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < Lk);
+            } else if (krow[j] < Lk) {
+                T* dst = dqkv + orow * lddqkv + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
@@ -961,16 +993,16 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
         LPI_CHECK_LAST();
         return 0;
     }
-    if (pre > 0) return LPI_ENOSYS;      // the shared prefix lives in the fused kernel only
     int e = set_lds((const void*)attn_bwd_dq_kernel<T, CAUSAL, SV16>, ldsA);
     if (e) return e;
     e = set_lds((const void*)attn_bwd_dkv_kernel<T, CAUSAL, SV16>, ldsB);
     if (e) return e;
-    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsA, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-               (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv);
+    const int nbh = (B + (pre > 0 ? 1 : 0)) * H, bsh = pre > 0 ? B : -1;
+    LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(nbh), dim3(thr), ldsA, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
+               (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, pre, bsh);
     LPI_CHECK_LAST();
-    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(B * H), dim3(thr), ldsB, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
-               lse, delta, (T*)dqkv, lddqkv);
+    LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(nbh), dim3(thr), ldsB, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
+               lse, delta, (T*)dqkv, lddqkv, pre, bsh, shared_dkv);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -1056,7 +1088,10 @@ extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* st
     if (dtype == LPI_BF16) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
     if (dtype == LPI_F16) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
     for (int i = 0; i < 2; ++i) {
-        if (d[i].shared_rows) return LPI_ENOSYS;      // f32: no shared prefix
+        if (d[i].shared_rows) {
+            if (int e = lpi_attn_fwd_shared(dtype, d[i].B, d[i].L, d[i].row_start, d[i].shared_rows, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, stream)) return e;
+            continue;
+        }
         if (int e = lpi_attn_fwd_varlen(dtype, d[i].B, d[i].L, d[i].row_start, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, d[i].causal, stream))
             return e;
     }
@@ -1103,11 +1138,13 @@ __global__ __launch_bounds__(256) void shared_kv_reduce_kernel(int B, int pre, i
 }  // namespace
 
 extern "C" int lpi_shared_kv_reduce(int dtype, int B, int shared_rows, int H, const float* partial, void* dqkv, int lddqkv, int accumulate, void* stream) {
-    if (!partial || !dqkv || B <= 0 || shared_rows <= 0 || H <= 0 || lddqkv < 3 * H * HD || (lddqkv & 3) || ((uintptr_t)partial & 15) || ((uintptr_t)dqkv & 7)) return LPI_EINVAL;
+    if (!partial || !dqkv || B <= 0 || shared_rows <= 0 || H <= 0 || lddqkv < 3 * H * HD || (lddqkv & 3) || ((uintptr_t)partial & 15) || ((uintptr_t)dqkv & (dtype == LPI_F32 ? 15 : 7))) return LPI_EINVAL;
     const int dm = H * HD, n = shared_rows * (2 * dm / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_BF16 || dtype == LPI_F16)      // F16: "saved activations fp16, gradients bf16" (lpi_attn_bwd_prefix)
         LPI_LAUNCH((shared_kv_reduce_kernel<bf16_t>), dim3((n + 15) / 16), dim3(256), 0, s, B, shared_rows, dm, partial, (bf16_t*)dqkv, lddqkv, accumulate);
+    else if (dtype == LPI_F32)
+        LPI_LAUNCH((shared_kv_reduce_kernel<float>), dim3((n + 15) / 16), dim3(256), 0, s, B, shared_rows, dm, partial, (float*)dqkv, lddqkv, accumulate);
     else
         return LPI_ENOSYS;
     LPI_CHECK_LAST();
@@ -1121,6 +1158,7 @@ extern "C" int lpi_attn_fwd_shared(int dtype, int B, int L, const int32_t* row_s
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LPI_F16) return fwd_launch<f16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, row_start, shared_rows);
     if (dtype == LPI_BF16) return fwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, row_start, shared_rows);
+    if (dtype == LPI_F32) return fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, row_start, shared_rows);
     return LPI_ENOSYS;
 }
 
@@ -1130,11 +1168,14 @@ extern "C" int lpi_attn_bwd_shared(int dtype, int B, int L, const int32_t* row_s
     if (!row_start || !shared_dkv || shared_rows <= 0 || shared_rows >= L || rows_needed < shared_rows) return LPI_EINVAL;
     const int rows_hi = rows_needed >= L ? (1 << 30) : rows_needed;
     if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv) || bad_attn(dtype, B, L, H, lddqkv)) return LPI_EINVAL;
-    if (ldctx < H * HD || lddctx < H * HD || (ldctx * 2) % 16 || (lddctx * 2) % 16) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if (ldctx < H * HD || lddctx < H * HD || (ldctx * esz) % 16 || (lddctx * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv | (uintptr_t)shared_dkv) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int e;
-    if (dtype == LPI_F16) e = bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
+    if (dtype == LPI_F32)      // the two-pass kernels (f32 is compute-bound); rows_needed is not used: everything is computed
+        e = bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
+    else if (dtype == LPI_F16) e = bwd_launch<bf16_t, true, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
     else if (dtype == LPI_BF16) e = bwd_launch<bf16_t, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, row_start, rows_hi, shared_rows, shared_dkv);
     else return LPI_ENOSYS;
     if (e) return e;

@@ -287,7 +287,7 @@ extern "C" int lpi_attn_pooled_fwd_pair(int dtype, const lpi_attn_pooled_desc* d
         if (((uintptr_t)q.q | (uintptr_t)q.qkv) & 15) return LPI_EINVAL;
         const int Lp = (q.L + 63) / 64 * 64;
         lds = std::max(lds, (size_t)(2 * Lp + WPB * DH) * sizeof(float));
-        if (q.shared_rows < 0 || (q.shared_rows > 0 && (!q.causal || !q.row_start || !q.idx || q.shared_rows >= q.L || dtype == LPI_F32))) return LPI_EINVAL;
+        if (q.shared_rows < 0 || (q.shared_rows > 0 && (!q.causal || !q.row_start || !q.idx || q.shared_rows >= q.L))) return LPI_EINVAL;
         p[i] = PoolFwdP{q.B, q.L, q.H, Lp, q.ldq, q.ldqkv, q.ldctx, q.causal, q.row_start, q.q, q.qkv, q.idx, q.ctx, q.lse, q.shared_rows};
     }
     if (lds > 64 * 1024) return LPI_EINVAL;
@@ -315,7 +315,7 @@ extern "C" int lpi_attn_pooled_bwd_pair(int dtype, const lpi_attn_pooled_desc* d
         if (((uintptr_t)q.q | (uintptr_t)q.qkv | (uintptr_t)q.dctx) & 15) return LPI_EINVAL;
         const int Lp = (q.L + 63) / 64 * 64;
         lds = std::max(lds, (size_t)(3 * Lp + WPB * DH) * sizeof(float));
-        if (q.shared_rows < 0 || (q.shared_rows > 0 && (!q.causal || !q.row_start || !q.idx || q.shared_rows >= q.L || !q.shared_dkv || dtype == LPI_F32))) return LPI_EINVAL;
+        if (q.shared_rows < 0 || (q.shared_rows > 0 && (!q.causal || !q.row_start || !q.idx || q.shared_rows >= q.L || !q.shared_dkv))) return LPI_EINVAL;
         p[i] = PoolBwdP{q.B, q.L, q.H, Lp, q.ldq, q.ldqkv, q.lddctx, q.lddq, q.lddqkv, q.causal, q.row_start, q.q, q.qkv, q.idx, q.dctx, q.lse, q.dq, q.dqkv, q.shared_rows,
                         q.shared_dkv};
     }
@@ -342,14 +342,18 @@ extern "C" int lpi_attn_pooled_fwd_desc(int dtype, const lpi_attn_pooled_desc* d
         return lpi_attn_pooled_fwd_varlen(dtype, d->B, d->L, d->row_start, d->H, d->q, d->ldq, d->qkv, d->ldqkv, d->idx, d->ctx, d->ldctx, d->lse, d->causal, stream);
     if (!d->q || !d->qkv || !d->ctx || !d->lse || !d->row_start || !d->idx || !d->causal || d->B <= 0 || d->L <= 0 || d->H <= 0 || d->shared_rows < 0 || d->shared_rows >= d->L)
         return LPI_EINVAL;
-    if (d->ldqkv < 3 * d->H * DH || d->ldq < d->H * DH || d->ldctx < d->H * DH || (d->ldqkv * 2) % 16 || (d->ldq * 2) % 16) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if (d->ldqkv < 3 * d->H * DH || d->ldq < d->H * DH || d->ldctx < d->H * DH || (d->ldqkv * esz) % 16 || (d->ldq * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)d->q | (uintptr_t)d->qkv) & 15) return LPI_EINVAL;
     const int Lp = (d->L + 63) / 64 * 64;
     const size_t lds = (size_t)(2 * Lp + WPB * DH) * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(d->B * d->H), block(WAVE * WPB);
-    if (dtype == LPI_BF16)
+    if (dtype == LPI_F32)
+        LPI_LAUNCH((attn_pooled_fwd_kernel<float>), grid, block, lds, s, d->B, d->L, d->row_start, d->H, Lp, (const float*)d->q, d->ldq, (const float*)d->qkv, d->ldqkv, d->idx,
+                   (float*)d->ctx, d->ldctx, d->lse, 1, d->shared_rows);
+    else if (dtype == LPI_BF16)
         LPI_LAUNCH((attn_pooled_fwd_kernel<bf16_t>), grid, block, lds, s, d->B, d->L, d->row_start, d->H, Lp, (const bf16_t*)d->q, d->ldq, (const bf16_t*)d->qkv, d->ldqkv, d->idx,
                    (bf16_t*)d->ctx, d->ldctx, d->lse, 1, d->shared_rows);
     else if (dtype == LPI_F16)
@@ -370,14 +374,18 @@ extern "C" int lpi_attn_pooled_bwd_desc(int dtype, const lpi_attn_pooled_desc* d
         d->shared_rows < 0 || d->shared_rows >= d->L)
         return LPI_EINVAL;
     if (d->ldqkv < 3 * d->H * DH || d->lddqkv < 3 * d->H * DH || d->ldq < d->H * DH || d->lddctx < d->H * DH || d->lddq < d->H * DH) return LPI_EINVAL;
-    if ((d->ldqkv * 2) % 16 || (d->ldq * 2) % 16 || (d->lddctx * 2) % 16) return LPI_EINVAL;
+    const int esz = dtype == LPI_F32 ? 4 : 2;
+    if ((d->ldqkv * esz) % 16 || (d->ldq * esz) % 16 || (d->lddctx * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)d->q | (uintptr_t)d->qkv | (uintptr_t)d->dctx) & 15) return LPI_EINVAL;
     const int Lp = (d->L + 63) / 64 * 64;
     const size_t lds = (size_t)(3 * Lp + WPB * DH) * sizeof(float);
     if (lds > 64 * 1024) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(d->B * d->H), block(WAVE * WPB);
-    if (dtype == LPI_BF16)
+    if (dtype == LPI_F32)
+        LPI_LAUNCH((attn_pooled_bwd_kernel<float>), grid, block, lds, s, d->B, d->L, d->row_start, d->H, Lp, (const float*)d->q, d->ldq, (const float*)d->qkv, d->ldqkv, d->idx,
+                   (const float*)d->dctx, d->lddctx, d->lse, (float*)d->dq, d->lddq, (float*)d->dqkv, d->lddqkv, 1, d->shared_rows, d->shared_dkv);
+    else if (dtype == LPI_BF16)
         LPI_LAUNCH((attn_pooled_bwd_kernel<bf16_t>), grid, block, lds, s, d->B, d->L, d->row_start, d->H, Lp, (const bf16_t*)d->q, d->ldq, (const bf16_t*)d->qkv, d->ldqkv, d->idx,
                    (const bf16_t*)d->dctx, d->lddctx, d->lse, (bf16_t*)d->dq, d->lddq, (bf16_t*)d->dqkv, d->lddqkv, 1, d->shared_rows, d->shared_dkv);
     else if (dtype == LPI_F16)

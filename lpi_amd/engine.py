@@ -1116,8 +1116,6 @@ class DualEncoder:
             # per-sample prompts (slinet.py:215: inference) and extract_vector (use_ctx=False) need the plain packed layout
             if pr is None or pbs != 0 or not use_ctx or pre != 1 + self.n_ctx:
                 raise ValueError("PackedIds(shared=1 + n_ctx) needs broadcast prompts spliced into the caption (the training forward)")
-            if dt == F32:
-                raise ValueError("the shared-prefix layout exists for the bf16 / f16 modes only")
         ws = self.txt.workspace(B, L, train, cap=cfg.context_length, packed=packed)
         hw = self._head("t", B, d)
         if packed is not None:       # the EOT positions came with the packed layout (host side): no argmax kernel

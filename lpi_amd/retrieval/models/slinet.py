@@ -143,9 +143,9 @@ class SliNet(nn.Module):
 
     def _shared_rows(self):
         """Rows of the text tower's SHARED PREFIX in the training forward (engine.PackedIds(shared=...)): SOT and the n_ctx context slots, which hold the
-        same rows for every sample because the prompts are broadcast over the batch (slinet.py:119-130) — 0 in the f32 parity mode (the layout exists
-        for the bf16 / f16 kernels) or with args['share_text_prefix'] = False."""
-        if self.compute_dtype == "f32" or not self.args.get("share_text_prefix", True):
+        same rows for every sample because the prompts are broadcast over the batch (slinet.py:119-130) — 0 with args['share_text_prefix'] = False.  Exact in
+        every operand mode: the f32 parity mode meets the reference fixtures' 1e-4 bar on this layout (tests/test_shared_prefix_gpu.py)."""
+        if not self.args.get("share_text_prefix", True):
             return 0
         return 1 + self.cfg.NCTX
 
