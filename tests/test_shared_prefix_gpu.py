@@ -195,6 +195,29 @@ def test_text_embedding_on_the_shared_layout():
     assert bad(rs=None) == -22 and bad(pre=16) == -22 and bad(ctx=None) == -22
 
 
+@pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("B,H", [(1, 1), (5, 2), (16, 8), (33, 12), (256, 8)])
+def test_shared_kv_reduce_against_a_float64_sum(dt, B, H):
+    """dqkv[key][K | V columns] (+)= sum over the samples of the f32 partials: against the f64 sum (f32 output: a few ulps of the fixed summation tree; bf16
+    output: one rounding on top), the Q columns and the rows behind the shared ones untouched, twice the same bits."""
+    d = H * 64
+    part = rnd(B, PRE, 2 * d, seed=7 * B + H).to(DEV)
+    base = rnd(64, 3 * d, seed=11).to(TDX[dt])
+    ref = part.double().sum(0).cpu()
+    for acc in (0, 1):
+        outs = []
+        for _ in range(2):
+            dq = base.clone().to(DEV)
+            call("lpi_shared_kv_reduce", dt, B, PRE, H, part, dq, 3 * d, acc, stream())
+            torch.cuda.synchronize()
+            outs.append(dq.cpu())
+        assert torch.equal(outs[0], outs[1])
+        want = ref + (base[:PRE, d:].double() if acc else 0.0)
+        err = (outs[0][:PRE, d:].double() - want).abs().max() / want.abs().max()
+        assert float(err) < (2e-6 if dt == F32 else 6e-3), (acc, float(err))
+        assert torch.equal(outs[0][:PRE, :d], base[:PRE, :d]) and torch.equal(outs[0][PRE:], base[PRE:])
+
+
 def test_shared_entry_points_refuse_what_they_cannot_do():
     lib = _lib.load()
     B, L, H, d = 2, 40, 1, 64
