@@ -27,8 +27,12 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     if world == 1:
         return t
-    on_dev = dist.get_backend(group) == "nccl" or not t.is_cuda
-    w = t if on_dev else t.cpu()
+    # the staging device follows the BACKEND, not the tensor: RCCL moves device memory only (a host tensor — the scikit-learn clustering keeps its features on
+    # the host — goes through the current device), gloo moves host memory only.  The result comes back where `t` lives.
+    if dist.get_backend(group) == "nccl":
+        w = t if t.is_cuda else t.to(torch.device("cuda", torch.cuda.current_device()))
+    else:
+        w = t.cpu() if t.is_cuda else t
     counts = torch.zeros(world, dtype=torch.int64, device=w.device)
     mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=w.device)
     dist.all_gather_into_tensor(counts, mine, group=group)

@@ -157,6 +157,7 @@ class BatchPipeline:
         self._thread = threading.Thread(target=self._produce, name="lpi-batch-pipeline", daemon=True)
         self._thread.start()
         q, free = self._q, self._free
+        out = None      # the batch handed out and not yet returned
         try:
             while True:
                 b = q.get()
@@ -168,13 +169,21 @@ class BatchPipeline:
                 cur.wait_event(b.ready)                       # stream-ordered: the host does not wait
                 if hasattr(b.text, "record_stream"):
                     b.text.record_stream(cur)                 # allocated on the side stream, read on this one
+                out = b
                 yield b
                 # the consumer has enqueued the step that read this slot (it is back for the next batch): mark its end, free the slot
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self._done[b.slot] = ev
+                out = None
                 free.release()
         finally:
+            if out is not None:
+                # the pass ends with a batch still out (the caller broke out of its loop, or its step raised): whatever it enqueued on this slot ends
+                # before the event below, so the next pass — slot indices restart at 0 — cannot overwrite a ring slot a step in flight still reads
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self._done[out.slot] = ev
             self.close()
 
     def close(self):

@@ -125,14 +125,25 @@ class SliNet(nn.Module):
     def _ensure_engine(self, device=None):
         if self.engine is None:
             from lpi_amd.engine import DualEncoder
-            dev = torch.device(device) if device is not None else next(self.parameters()).device
+            dev = torch.device(device) if device is not None else self.prompts[0].dim_1_share.device
             self.engine = DualEncoder(self.clip_cfg, self.clip_model.state_dict(), dtype=self.compute_dtype, device=dev, n_ctx=self.cfg.NCTX)
             self.logit_scale = self.engine.logit_scale
         return self.engine
 
+    def _apply(self, fn, recurse=True):
+        """.to() / .cuda() / .float() move the TRAINABLE state; the frozen f32 masters (clip_model: 0.6 GB for ViT-B/16, 1.7 GB for ViT-L/14) stay where the
+        checkpoint put them — the host.  The engine holds its own operand copies on the device and never reads the masters after it is built, so a device
+        copy of them would be HBM that nothing uses; state_dict() / named_parameters() / count_parameters still see all 149.78 M of them."""
+        clip = self._modules.pop("clip_model", None)
+        try:
+            return super()._apply(fn, recurse)
+        finally:
+            if clip is not None:
+                self._modules["clip_model"] = clip
+
     def to(self, *a, **k):
         out = super().to(*a, **k)
-        dev = next(self.parameters()).device
+        dev = self.prompts[0].dim_1_share.device
         if dev.type == "cuda":
             self._ensure_engine(dev)
         return out
@@ -269,6 +280,7 @@ class SliNet(nn.Module):
     # ------------------------------------------------------------------ slinet.py:223-234
     def update_fc(self, nb_classes):
         self.numtask += 1
+        self._task_term = None      # caches the finished tasks' stacks for ONE numtask
 
     def copy(self):
         """Deep copy of the trainable state; the frozen engine (operand weights + workspace arena) and the frozen f32 masters (clip_model) are shared, not
@@ -289,7 +301,9 @@ class SliNet(nn.Module):
         the engine is dropped and rebuilt from the new masters at the next use."""
         out = super().load_state_dict(state_dict, *args, **kwargs)
         if any(k.startswith("clip_model.") for k in state_dict):
-            self.engine, self._task_term = None, None
+            self.engine = None
+        if any(k.startswith(("clip_model.", "prompts.")) for k in state_dict):
+            self._task_term = None      # it caches the reconstructed stacks of the finished tasks: stale once any factor is replaced
         return out
 
     def trainable_state_dict(self):
@@ -308,6 +322,7 @@ class SliNet(nn.Module):
         with torch.no_grad():
             for k, v in sd.items():
                 own[k].copy_(v)          # in place: FlatSGD's seating and the parameters' device stay as they are
+        self._task_term = None           # the fused task term caches the finished tasks' stacks (rows 0..t-1): rebuilt from the restored factors
         return self
 
     def freeze(self):

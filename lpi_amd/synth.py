@@ -145,6 +145,21 @@ def prompt_factors(layer_num: int, prompt_num: int, vis_dim: int, txt_dim: int, 
     return {k: normal(seed, f"prompts.{task}.{k}", s, 0.5) for k, s in shapes.items()}
 
 
+def task_family_factors(family: str, task: int, vis_dim: int, txt_dim: int, r: int = 4, layer_num: int = 9, prompt_num: int = 16) -> dict:
+    """The factors of task `task` in a 12-task session of the task-loss fixtures (tests/golden/task_loss_wide.npz): 'random' = independent draws at the
+    reference's init scale (prompt_factors(task=t)); 'drift' = a common ancestor (task 0's draw) plus a step of 2 % of the scale per task in an independent
+    direction — neighbouring tasks stay nearly parallel (cosine of the flattened stacks close to one)."""
+    base = prompt_factors(layer_num, prompt_num, vis_dim, txt_dim, r=r, task=task)
+    if family == "mixed":      # tasks 0-3 drift around the ancestor, the later ones are independent: saturated and live pairs in one matrix
+        family = "drift" if task < 4 else "random"
+    if family == "random":
+        return base
+    if family != "drift":
+        raise ValueError(family)
+    anc = prompt_factors(layer_num, prompt_num, vis_dim, txt_dim, r=r, task=0)
+    return {k: (anc[k] + np.float32(0.02 * task) * base[k]).astype(np.float32) for k in anc}
+
+
 def images(batch: int, resolution: int, seed: int = IMAGE_SEED) -> np.ndarray:
     """N(0,1) stand-in for ImageNet-normalised pixels (``utils/data.py:310-313``)."""
     return normal(seed, "images", (batch, 3, resolution, resolution))

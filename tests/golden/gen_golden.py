@@ -199,6 +199,92 @@ def train_step(net, cfg, batch, numtask):
     return res
 
 
+def train_step_ids(net, cfg, batch, numtask, ids):
+    """The same step as `train_step`, on TOKEN IDS given by the caller (round 6: bench.py's own batch, `synth.token_ids(256)`, whose random ids are not the
+    BPE of any string).  `clip.tokenize` as PromptLearner.forward reaches it (prompt_learner.py:131: one call per prompt) is replaced by a function that
+    hands out the next prepared row; everything else — embedding look-up, ctx insertion, both towers, cal_loss, backward — is the imported reference.
+    Tokenisation itself is pinned separately (tokenizer.npz / tokenizer_wide.npz)."""
+    import models.clip.prompt_learner as PL
+    rows = [torch.from_numpy(ids[i:i + 1].copy()) for i in range(batch)]
+    it = iter(rows)
+    real = PL.clip.tokenize
+    PL.clip.tokenize = lambda *_a, **_k: next(it)
+    try:
+        net.numtask = numtask
+        net.train()
+        names = []
+        for name, p in net.named_parameters():
+            p.requires_grad_(False)
+            if "prompts." + str(numtask - 1) + "." in name:  # sprompt.py:235
+                p.requires_grad_(True)
+                names.append(name)
+                p.grad = None
+        img = torch.from_numpy(synth.images(batch, cfg.image_resolution))
+        img_f, txt_f, vp, tp = net(img, [f"caption {i}" for i in range(batch)])
+        out = net.cal_loss(img_f, txt_f, vp, tp)
+        loss = sum(v for v in out["loss"].values())
+        loss.backward()
+    finally:
+        PL.clip.tokenize = real
+    with torch.no_grad():
+        logits = net.logit_scale.exp() * img_f @ txt_f.t()
+    res = {"token_ids_crc32": np.uint32(__import__("zlib").crc32(np.ascontiguousarray(ids).tobytes())),      # the ids are regenerated from the seed by the tests
+           "img_f": img_f.detach().numpy(), "txt_f": txt_f.detach().numpy(), "logits": logits.numpy(), "trainable": np.array(names)}
+    for k, v in out["loss"].items():
+        res[k] = np.float32(v.item())
+    for name, p in net.named_parameters():
+        if p.requires_grad:
+            res["grad." + name.split(".")[-1]] = p.grad.detach().numpy().copy()
+    for tag, S in (("i2t", logits), ("t2i", logits.t())):
+        srt, idx = torch.sort(S, dim=1, descending=True, stable=True)
+        res[f"top5_{tag}"] = idx[:, :5].numpy().astype(np.int32)
+        res[f"top5_margin_{tag}"] = (srt[:, :5] - srt[:, 1:6]).numpy()
+    return res
+
+
+def task_loss_case(cfg=None):
+    """`SliNet.cal_task_loss` (slinet.py:167-183) -> `nt_bxent_loss` (loss/loss.py:6-33) at the sizes the reference runs it: the stacked, flattened prompts of
+    tasks 0..t are [t+1, 9*16*768 = 110 592] and [t+1, 73 728], temperature 0.001, for numtask in {2, 7, 12}.  The imported method is called unbound on a
+    stand-in that holds only what it reads (`self.prompts`: the imported DecomposedPrompt modules) — no backbone is involved.  Two families of factors:
+    'random' = the reference's own initialiser scale (synth.prompt_factors(task=t): pairwise cosines of a few 1e-3, i.e. cos / 0.001 of order one — the
+    regime where the double sigmoid decides the loss), 'drift' = every task a small step away from a common ancestor (what a continual session that
+    initialises from similar solutions looks like: cosines near one, the inner sigmoid saturated and the gradient exactly zero), 'mixed' = tasks 0-3 drifting,
+    the later ones independent.  Stored: the loss and the gradient w.r.t. the CURRENT
+    task's five factors (sprompt.py:235: the only trainable ones)."""
+    import models.slinet as slinet
+    from models.prompts.prompts import DecomposedPrompt
+    cfg = cfg or synth.VIT_B16
+    res = {"widths": np.array([cfg.vision_width, cfg.transformer_width]), "numtasks": np.array([2, 7, 12])}
+    for fam in ("random", "drift", "mixed"):
+        mods = []
+        for t in range(12):
+            m = DecomposedPrompt(9, 16, cfg.vision_width, cfg.transformer_width)
+            fac = synth.task_family_factors(fam, t, cfg.vision_width, cfg.transformer_width)
+            for k, v in fac.items():
+                getattr(m, k).data = torch.from_numpy(v.copy())
+            mods.append(m)
+        ns = types.SimpleNamespace(prompts=mods)
+        for numtask in (2, 7, 12):
+            for m in mods:
+                for p_ in m.parameters():
+                    p_.requires_grad_(False)
+                    p_.grad = None
+            for p_ in mods[numtask - 1].parameters():
+                p_.requires_grad_(True)
+            dummy = torch.zeros(1)
+            loss = slinet.SliNet.cal_task_loss(ns, numtask - 1, dummy, dummy)
+            loss.backward()
+            res[f"{fam}.{numtask}.loss"] = np.float32(loss.item())
+            for k in synth.PROMPT_NAMES:
+                res[f"{fam}.{numtask}.grad.{k}"] = getattr(mods[numtask - 1], k).grad.numpy().copy()
+            with torch.no_grad():      # the cosines themselves, for the record of which regime a case is in
+                for tag, j in (("v", 0), ("t", 1)):
+                    X = torch.stack([mods[i]()[j].view(-1) for i in range(numtask)])
+                    Xn = X / X.norm(dim=-1, keepdim=True)
+                    res[f"{fam}.{numtask}.cos_{tag}"] = (Xn @ Xn.t()).numpy()
+    return res
+
+
 def eval_case(net, cfg, batch):
     """Eval interfaces (slinet.py:85-107, 185-220) + task-id selection and itm_eval (sprompt.py:336-368, 550-646)."""
     from methods.sprompt import SPrompts
@@ -483,6 +569,17 @@ def main():
         save("vitb16_d3_patched", r, meta)
         undo()
 
+
+    if a.only in (None, "task_loss"):      # round 6: a9 at its operating size (12 tasks, real widths, temperature 0.001)
+        save("task_loss_wide", task_loss_case(), meta)
+    if a.only in (None, "vitb16", "vitb16_task12"):      # the whole step of the LAST task of a 12-task session (task term included), ViT-B/16, 8 pairs
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        r = train_step(net, cfg, 8, 12)
+        for k in ("vis_prompt", "txt_prompt"):
+            r[k] = r[k][:1]
+        save("vitb16_task12", r, meta)
+
     if a.only in (None, "fp16"):
         # the reference in its own fp16 (convert_weights), torch CPU: tiny and ViT-B/16 (8 pairs), depth 1 = the shipped code
         for name, cfg, batch in (("tiny_fp16", synth.TINY, 4), ("vitb16_fp16", synth.VIT_B16, 8)):
@@ -493,6 +590,20 @@ def main():
                 r[k] = r[k][:1]
             r["reference_dtype"] = np.array("float16 (convert_weights), torch CPU")
             save(name, r, meta)
+
+
+    # round 6: the BENCHMARKED configuration at its own size (BASELINE.json configs[2]: ViT-B/16, 256 pairs; sprompt.py:297-311) on bench.py's own
+    # synthetic batch (synth.images(256), synth.token_ids(256)): ~35 GB of autograd state, a few minutes of CPU each; not part of the default run.
+    if a.only in ("bs256", "bs256_d3"):
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        undo = patch_depth(3)
+        save("vitb16_bs256_d3_patched", train_step_ids(net, cfg, 256, 1, synth.token_ids(256)), meta)
+        undo()
+    if a.only in ("bs256", "bs256_d1"):
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        save("vitb16_bs256_d1", train_step_ids(net, cfg, 256, 1, synth.token_ids(256)), meta)
 
     if a.only in (None, "vitb16", "vitb16_eval"):
         cfg = synth.VIT_B16

@@ -89,3 +89,35 @@ def test_w_rank_step_equals_global_batch(W):
     for k in res[0][2]:
         for r in range(1, W):
             assert np.array_equal(res[0][2][k], res[r][2][k])
+
+
+def _rows_worker(rank, port, q, W):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from lpi_amd.dp import all_gather_rows
+    n = 5 + 3 * rank                                     # ragged shards (the last shard of a sampler without drop_last)
+    t = torch.arange(n * 4, dtype=torch.float32).view(n, 4) + 1000 * rank
+    out = all_gather_rows(t)
+    q.put((rank, out.numpy().copy(), str(out.device)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_rows_of_host_tensors_with_ragged_shards():
+    """dp.all_gather_rows on HOST tensors (the scikit-learn clustering keeps its features on the host: ADVICE round 5) with a different row count per rank:
+    every rank receives the concatenation in rank order, on the device the input lives on."""
+    W = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, port, q, W)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(W)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.arange((5 + 3 * r) * 4, dtype=np.float32).reshape(-1, 4) + 1000 * r for r in range(W)])
+    for rank, got, dev in res:
+        assert dev == "cpu" and np.array_equal(got, want), rank

@@ -128,3 +128,35 @@ def test_rccl_branch_of_the_exchange_every_gather_mode():
                 assert np.abs(g - r).max() <= 1e-3 * np.abs(r).max() + 1e-6, (ll, gwg, k)
     # the partial-gradient mode really is a different gradient (the mode flag reaches the loss kernels)
     assert not np.array_equal(res[(True, False, "rccl")][2], res[(False, False, "rccl")][2])
+
+
+def test_all_gather_rows_stages_host_tensors_on_the_device_under_rccl(monkeypatch):
+    """with kmeans_impl='sklearn' the clustering features live on the HOST; RCCL moves device memory only, so dp.all_gather_rows must stage
+    them through the current device (it handed host tensors to all_gather_into_tensor and raised).  Two ranks cannot share a GPU under RCCL, so the
+    collective itself is a stand-in that refuses host tensors exactly as RCCL does and plays rank 1's part; the staging logic under test is dp's own."""
+    import torch.distributed as dist
+    from lpi_amd import dp
+
+    calls = []
+
+    def fake_all_gather_into_tensor(out, inp, group=None):
+        assert out.is_cuda and inp.is_cuda, "RCCL cannot move host memory"
+        calls.append(tuple(inp.shape))
+        n = inp.shape[0]
+        out[:n].copy_(inp)
+        if inp.dtype == torch.int64:
+            out[n:] = 3                       # rank 1 holds 3 rows
+        else:
+            out[n:].fill_(7.0)
+
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather_into_tensor)
+    torch.cuda.set_device(0)
+    t = torch.arange(20, dtype=torch.float32).view(5, 4)            # a HOST tensor, 5 rows on this rank
+    out = dp.all_gather_rows(t)
+    assert out.device.type == "cpu" and out.shape == (8, 4)
+    assert torch.equal(out[:5], t) and bool((out[5:] == 7.0).all())
+    assert calls == [(1,), (5, 4)]
+    d = dp.all_gather_rows(t.cuda())                                # device input: stays on the device
+    assert d.is_cuda and torch.equal(d.cpu(), out)

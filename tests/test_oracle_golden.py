@@ -227,3 +227,63 @@ def test_fp16_family_is_the_reference_in_its_own_type(golden, fp16, f32):
     for k in [k for k in a if k.startswith("grad.")]:
         cos = float((a[k] * b[k]).sum() / np.sqrt((a[k] ** 2).sum() * (b[k] ** 2).sum()))
         assert cos > 0.999, (k, cos)
+
+
+# ----------------------------------------------------------------------------------------------- round 6: the fixtures at operating size
+@pytest.mark.parametrize("fam", ["random", "drift", "mixed"])
+@pytest.mark.parametrize("numtask", [2, 7, 12])
+def test_task_loss_at_operating_size(golden, fam, numtask):
+    """a9 where the reference runs it (slinet.py:167-183 -> loss.py:6-33): stacks of [t+1, 110 592] / [t+1, 73 728] for up to 12 tasks at temperature 0.001 —
+    the imported `SliNet.cal_task_loss` on three families of factors (cosines of a few 1e-3: cos / 0.001 decides the loss; cosines near one: saturated,
+    the gradient exactly zero; both in one matrix).  Loss and the gradient of the current task's five factors."""
+    g = golden("task_loss_wide")
+    cfg = synth.VIT_B16
+    allf = [{k: torch.from_numpy(v) for k, v in synth.task_family_factors(fam, t, cfg.vision_width, cfg.transformer_width).items()} for t in range(numtask)]
+    for v in allf[numtask - 1].values():
+        v.requires_grad_(True)
+    loss = O.task_loss(numtask - 1, allf, TASK_SIM)
+    loss.backward()
+    ref = float(g[f"{fam}.{numtask}.loss"])
+    assert abs(float(loss.detach()) - ref) <= 2e-5 * max(1.0, abs(ref)), (float(loss.detach()), ref)
+    for k in synth.PROMPT_NAMES:
+        r = g[f"{fam}.{numtask}.grad.{k}"]
+        got = allf[numtask - 1][k].grad.numpy()
+        if np.abs(r).max() == 0.0:
+            assert np.abs(got).max() == 0.0, k          # saturated: the reference's gradient is exactly zero
+        else:
+            assert rel_err(got, r) <= 2e-3, (k, rel_err(got, r))
+
+
+def test_vitb16_last_task_of_a_twelve_task_session(golden):
+    """The whole step of task 12 (numtask = 12: base + alignment + task loss over twelve stacks), ViT-B/16, 8 pairs, as the imported reference computes it."""
+    cfg = synth.VIT_B16
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
+    g = golden("vitb16_task12")
+    allf = [factors(cfg, t) for t in range(12)]
+    res = O.train_step(orc, synth.images(8, 224), g["token_ids"], allf[11], depth=1, numtask=12, all_factors_np=allf, task_sim=TASK_SIM)
+    check_step(res, g, tol=5e-5, gtol=2e-3)
+    assert abs(res["task_loss"] - g["task_loss"]) <= 2e-5 * max(1.0, abs(g["task_loss"]))
+
+
+@pytest.mark.parametrize("name,depth", [("vitb16_bs256_d1", 1), ("vitb16_bs256_d3_patched", 3)])
+def test_oracle_against_the_256_pair_fixture_on_a_slice_of_the_batch(golden, name, depth):
+    """The benchmarked batch (synth.images(256), synth.token_ids(256)) went through the imported reference once (gen_golden.py --only bs256).  A sample's
+    features do not depend on its batch (broadcast prompts, slinet.py:116-128), so the oracle on samples [96, 104) must reproduce the fixture's rows
+    96..103, and the logits block between them; the full 256-pair step (35 GB of autograd state) is what the GPU tests hold the HIP path to."""
+    g = golden(name)
+    cfg = synth.VIT_B16
+    ids = synth.token_ids(256)
+    import zlib
+    assert zlib.crc32(np.ascontiguousarray(ids).tobytes()) == int(g["token_ids_crc32"])
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg))
+    sl = slice(96, 104)
+    fac = {k: torch.from_numpy(v) for k, v in factors(cfg).items()}
+    with torch.no_grad():
+        img_f, txt_f, _, _ = orc.forward(torch.from_numpy(synth.images(256, 224)[sl]), torch.from_numpy(ids[sl]), fac, depth)
+    assert np.abs(img_f.numpy() - g["img_f"][sl]).max() <= 2e-5
+    assert np.abs(txt_f.numpy() - g["txt_f"][sl]).max() <= 2e-5
+    lg = (orc.W["logit_scale"].exp() * img_f @ txt_f.t()).numpy()
+    assert np.abs(lg - g["logits"][sl, sl]).max() <= 1e-4
+    # the stored losses follow from the stored logits (ClipLoss, loss.py:75-87)
+    L = torch.from_numpy(g["logits"]).double()
+    assert abs(float(O.clip_loss(L)) - float(g["base_loss"])) <= 2e-5 * float(g["base_loss"])

@@ -141,8 +141,12 @@ def test_pipeline_passes_loader_errors_on_and_stops_on_early_exit():
     many = [(torch.zeros(2, 3, 8, 8), torch.zeros(2, 77, dtype=torch.long)) for _ in range(50)]
     pipe = BatchPipeline(many, DEV, None, depth=2)
     it = iter(pipe)
-    next(it)
+    b0 = next(it)
+    assert pipe._done[b0.slot] is None
     it.close()                                     # the consumer leaves after one batch
+    # the batch that was out when the pass ended has its end-of-use event, so the next pass (slot indices restart at 0) cannot copy into
+    # a ring slot that a step in flight still reads
+    assert pipe._done[b0.slot] is not None
     pipe._thread.join(timeout=5.0)
     assert not pipe._thread.is_alive()
     assert not [t for t in threading.enumerate() if t.name == "lpi-batch-pipeline" and t.is_alive()]
