@@ -105,8 +105,34 @@ def _block(sd, seed, prefix, width, layers):
             sd[p + nm] = normal(seed, p + nm, shape, std, mean)
 
 
-def clip_state_dict(cfg: ClipConfig, seed: int = WEIGHT_SEED) -> dict:
-    """Synthetic state dict with the reference's key names / shapes (``model.py:418-441``)."""
+def clip_state_dict(cfg: ClipConfig, seed: int = WEIGHT_SEED, outliers: str | None = None) -> dict:
+    """Synthetic state dict with the reference's key names / shapes (``model.py:418-441``).
+
+    outliers (round 6; the statistics real CLIP checkpoints show and N(0, sigma) weights do not): ``'channels'`` — "massive activation" channels: the first
+    block's ``c_proj`` bias drives two residual channels of each tower to +150 / -90 (100-300x the stream's typical magnitude of 0.5-1, carried by the
+    residual connection through every later block) and one ``ln_pre`` / first ``ln_1`` gain is 40; ``'offset'`` — every row of the stream gets a common offset
+    of about 12 standard deviations (``ln_pre`` bias, text positional embedding), the case where one-sweep variance E[x^2] - mean^2 loses digits and the
+    engine's guard (mean^2 > 64 var) must switch to two-sweep statistics."""
+    sd = _clip_state_dict(cfg, seed)
+    if outliers is None:
+        return sd
+    vw, tw = cfg.vision_width, cfg.transformer_width
+    if outliers == "channels":
+        for pre, w in (("visual.transformer.", vw), ("transformer.", tw)):
+            b = sd[pre + "resblocks.0.mlp.c_proj.bias"]
+            b[37 % w] += np.float32(150.0)
+            b[(w * 5) // 8 + 3] -= np.float32(90.0)
+        sd["visual.ln_pre.weight"][11] = np.float32(40.0)
+        sd["transformer.resblocks.0.ln_1.weight"][11] = np.float32(40.0)
+    elif outliers == "offset":
+        sd["visual.ln_pre.bias"] += np.float32(12.0)
+        sd["positional_embedding"] += np.float32(6.0)        # the text stream has a standard deviation of 0.2-0.9 behind the first block
+    else:
+        raise ValueError(outliers)
+    return sd
+
+
+def _clip_state_dict(cfg: ClipConfig, seed: int) -> dict:
     sd = {}
     vw, tw = cfg.vision_width, cfg.transformer_width
     ps = cfg.vision_patch_size

@@ -285,6 +285,88 @@ def task_loss_case(cfg=None):
     return res
 
 
+def tokenizer_wide_texts(n=1200, seed=606):
+    """>= 1000 strings for the tokenizer fixture (round 6): COCO-like captions from templates, and the things captions in the wild carry — HTML entities
+    (html.unescape runs twice in basic_clean, simple_tokenizer.py:50-53), runs of whitespace / tabs / newlines (whitespace_clean), mixed case, digits and
+    decimals, contractions (the pattern's 's|'t|'re|'ve|'m|'ll|'d alternatives), hyphens and punctuation runs, Latin-1 / Greek / Cyrillic / Hebrew / Arabic /
+    CJK / Hangul / Thai text, emoji incl. ZWJ sequences and skin tones, the special-token strings, very long words, and > 77-token overflows."""
+    import random
+    rng = random.Random(seed)
+    subj = ["a man", "a woman", "two dogs", "a group of people", "three children", "an old bus", "the black cat", "a young girl", "several giraffes",
+            "a baseball player", "a red double decker bus", "the chef", "a flock of birds", "someone", "a surfer", "two zebras", "an elderly couple"]
+    verb = ["riding", "holding", "standing next to", "looking at", "sitting on", "eating", "walking past", "flying", "parked near", "jumping over",
+            "playing with", "waiting for", "leaning against", "cutting", "pointing at"]
+    obj = ["a wave", "an umbrella", "a wooden table", "a plate of broccoli and rice", "the train station", "a laptop keyboard", "a colorful kite",
+           "a fire hydrant", "a stop sign", "a frisbee", "some tall trees", "a pizza", "the city street", "a tennis racket", "a pile of luggage"]
+    tail = ["", " in the park", " at night", " on a sunny day", " near the beach", " in black and white", " while it rains", " with a blue sky behind",
+            " during the 2014 world cup", " at 5:30 pm", " for $3.50", " (blurry)", " -- taken in 1998", " #nofilter", ", isn't it?", "!!!", "..."]
+    contr = ["don't", "it's", "we're", "I've", "I'm", "they'll", "he'd", "can't", "won't", "'tis", "o'clock", "dog's", "dogs'", "y'all'd've", "'s", "'T"]
+    ent = ["&amp;", "&lt;b&gt;", "&quot;quoted&quot;", "&#39;", "&amp;amp;", "&nbsp;", "&eacute;", "&copy; 2014", "&lt;|endoftext|&gt;", "&#x1F600;"]
+    ws = ["  ", "   ", "\t", "\n", " \n ", "\r\n", "\u00a0", "\u2003"]
+    scripts = ["caf\u00e9 na\u00efve r\u00e9sum\u00e9 \u00fcber stra\u00dfe", "\u03b1\u03b2\u03b3 \u0394\u03b5\u03bb\u03c4\u03b1", "\u0416\u0434\u0451\u043c \u043f\u043e\u0435\u0437\u0434",
+               "\u05e9\u05dc\u05d5\u05dd \u05e2\u05d5\u05dc\u05dd", "\u0645\u0631\u062d\u0628\u0627 \u0628\u0627\u0644\u0639\u0627\u0644\u0645", "\u4f60\u597d\uff0c\u4e16\u754c\uff01", "\u3053\u3093\u306b\u3061\u306f \u4e16\u754c",
+               "\ud55c\uad6d\uc5b4 \ud14c\uc2a4\ud2b8", "\u0e2a\u0e27\u0e31\u0e2a\u0e14\u0e35", "\u0967\u0968\u0969 \u0664\u0665\u0666 \uff11\uff12\uff13 \u2163 \u00bd \u00b2", "\u00bfqu\u00e9? \u00a1s\u00ed! \u20ac5 \u00a33 \u00a5100 \u00b0C \u00b15%"]
+    emoji = ["\U0001F600", "\U0001F389\U0001F389", "\U0001F44D\U0001F3FD", "\u2708\ufe0f", "\U0001F468\u200d\U0001F469\u200d\U0001F467", "\u2764\ufe0f\u200d\U0001F525", "\U0001F1EF\U0001F1F5", "\u263a"]
+    special = ["<|startoftext|>", "<|endoftext|>", "hello<|endoftext|>world", "<|startoftext|> a cat <|endoftext|>", "<|STARTOFTEXT|>", "<|endoftext|"]
+    out = []
+
+    def cap():
+        return f"{rng.choice(subj)} {rng.choice(verb)} {rng.choice(obj)}{rng.choice(tail)}"
+
+    def mixcase(t):
+        return "".join(c.upper() if rng.random() < 0.4 else c for c in t)
+    for i in range(n):
+        k = i % 12
+        if k == 0:
+            t = cap()
+        elif k == 1:
+            t = mixcase(cap())
+        elif k == 2:
+            t = cap().replace(" ", rng.choice(ws), rng.randint(1, 4)) + rng.choice(ws)
+        elif k == 3:
+            t = f"{cap()} {rng.choice(ent)} {rng.choice(ent)}{rng.choice(obj)}"
+        elif k == 4:
+            t = f"{rng.choice(contr)} {cap()} {rng.choice(contr)} {rng.choice(contr)}"
+        elif k == 5:
+            t = f"{rng.randint(0, 99999)} {rng.random() * 1000:.3f} {rng.randint(0, 9)}x{rng.randint(0, 9)} {cap()} no.{i} 1,000,000 3rd 0x{i:04X}"
+        elif k == 6:
+            t = f"{rng.choice(scripts)} {cap()} {rng.choice(scripts)}"
+        elif k == 7:
+            t = f"{cap()} {rng.choice(emoji)}{rng.choice(emoji)} {rng.choice(emoji)}"
+        elif k == 8:
+            t = f"{rng.choice(special)} {cap()}" if rng.random() < 0.5 else rng.choice(special)
+        elif k == 9:
+            t = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(20, 60))) + " " + "-".join(rng.choice(obj).split()) + "_" * rng.randint(1, 5) + "/\\|~^`"
+        elif k == 10:
+            t = " ".join(cap() for _ in range(rng.randint(4, 9)))          # > 77 tokens: overflow
+        else:
+            t = rng.choice(["", " ", ".", "a", "A.", "?!", "''", "' '", "\t\n", "x" * rng.randint(1, 90), "X X X X X X X X X X X X X X X X " + cap() + "."])
+        out.append(t)
+    return out
+
+
+def tokenizer_wide_case():
+    """`SimpleTokenizer.encode` (simple_tokenizer.py:121-127) and `clip.tokenize` (clip.py:185-221) of the imported reference on tokenizer_wide_texts():
+    the ragged ids of every string (encode), the padded [n, 77] rows of those that fit, and which ones raise the too-long RuntimeError (clip.py:213-218).
+    (`ftfy.fix_text` is the identity in this harness — ftfy is not installed — and in this repo's tokenizer alike.)"""
+    from models.clip.clip import tokenize
+    from models.clip.clip import _tokenizer as tk
+    texts = tokenizer_wide_texts()
+    enc = [tk.encode(t) for t in texts]
+    offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.int64)
+    flat = np.array([i for e in enc for i in e], dtype=np.int32)
+    too_long = np.zeros(len(texts), dtype=bool)
+    rows = np.zeros((len(texts), 77), dtype=np.int32)
+    for i, t in enumerate(texts):
+        try:
+            rows[i] = tokenize(t)[0].numpy()
+        except RuntimeError:
+            too_long[i] = True
+            rows[i] = tokenize(t, truncate=True)[0].numpy()
+    assert too_long.sum() >= 50 and (~too_long).sum() >= 1000
+    return {"texts": np.array(texts), "encode_flat": flat, "encode_offsets": offs, "too_long": too_long, "rows": rows}
+
+
 def eval_case(net, cfg, batch):
     """Eval interfaces (slinet.py:85-107, 185-220) + task-id selection and itm_eval (sprompt.py:336-368, 550-646)."""
     from methods.sprompt import SPrompts
@@ -539,6 +621,9 @@ def main():
                  " ".join(["X"] * 16) + " a man riding a wave on top of a surfboard."]
         save("tokenizer", {"texts": np.array(texts), "ids": tokenize(texts).numpy()}, meta)
 
+    if a.only in (None, "tokenizer", "tokenizer_wide"):
+        save("tokenizer_wide", tokenizer_wide_case(), meta)
+
     if a.only in (None, "tiny"):
         cfg = synth.TINY
         net = build_slinet(cfg)
@@ -609,6 +694,15 @@ def main():
         cfg = synth.VIT_B16
         net = build_slinet(cfg)
         save("vitb16_eval", eval_shard(net, cfg, 32, 2, 3), meta)   # north_star: R@1 indices on a fixed synthetic shard at full size
+
+    if a.only in ("vitb16_eval12",):      # round 6: 256 images x 1 280 captions x 12 tasks (minutes of CPU: not part of the default run)
+        cfg = synth.VIT_B16
+        net = build_slinet(cfg)
+        r = eval_shard(net, cfg, 256, 5, 12)
+        for k in ("extract_textual_vector", "text_feats"):      # 2 x 2.6 MB that the score matrix (image_feats x text_feats) and the L1 distances already pin
+            r.pop(k)
+        r["token_ids"] = r["token_ids"].astype(np.int32)
+        save("vitb16_eval12", r, meta)
 
     with open(meta_path, "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -108,3 +108,25 @@ def test_native_tokenizer_matches_python_on_a_synthetic_merge_table(tmp_path):
     with pytest.raises(RuntimeError):
         T.tokenize(tk, ["word " * 100])
     assert T.tokenize(tk, ["word " * 100], truncate=True)[0, -1] == 49407
+
+
+@needs_vocab
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_wide_fixture_of_reference_ids(golden, impl):
+    """Round 6: 1 200 strings through the imported reference's `SimpleTokenizer.encode` and `clip.tokenize` (tests/golden/gen_golden.py
+    tokenizer_wide_case: COCO-like captions, HTML entities, whitespace runs, mixed case, digits, contractions, non-Latin scripts, emoji, special-token
+    strings, long words, > 77-token overflows).  Both of this repo's BPEs — the C++ one the plugin uses and the Python one — must give the reference's ids
+    for every string, the same padded rows, and raise on exactly the strings the reference raises on (clip.py:213-218)."""
+    g = golden("tokenizer_wide")
+    tk = T.SimpleTokenizer(VOCAB) if impl == "python" else T.NativeTokenizer(VOCAB)
+    texts = [str(t) for t in g["texts"]]
+    assert len(texts) >= 1000
+    offs, flat = g["encode_offsets"], g["encode_flat"]
+    for i, t in enumerate(texts):
+        assert tk.encode(t) == flat[offs[i]:offs[i + 1]].tolist(), (i, repr(t))
+    fit = [t for t, long_ in zip(texts, g["too_long"]) if not long_]
+    assert (T.tokenize(tk, fit).numpy() == g["rows"][~g["too_long"]]).all()
+    for i in np.nonzero(g["too_long"])[0]:
+        with pytest.raises(RuntimeError):
+            T.tokenize(tk, [texts[i]])
+        assert (T.tokenize(tk, [texts[i]], truncate=True).numpy()[0] == g["rows"][i]).all()
