@@ -111,7 +111,7 @@ def clip_state_dict(cfg: ClipConfig, seed: int = WEIGHT_SEED, outliers: str | No
     outliers (round 6; the statistics real CLIP checkpoints show and N(0, sigma) weights do not): ``'channels'`` — "massive activation" channels: the first
     block's ``c_proj`` bias drives two residual channels of each tower to +150 / -90 (100-300x the stream's typical magnitude of 0.5-1, carried by the
     residual connection through every later block) and one ``ln_pre`` / first ``ln_1`` gain is 40; ``'offset'`` — every row of the stream gets a common offset
-    of about 12 standard deviations (``ln_pre`` bias, text positional embedding), the case where one-sweep variance E[x^2] - mean^2 loses digits and the
+    of about 12 standard deviations (``ln_pre`` bias; the text tower's first ``c_proj`` bias), the case where one-sweep variance E[x^2] - mean^2 loses digits and the
     engine's guard (mean^2 > 64 var) must switch to two-sweep statistics."""
     sd = _clip_state_dict(cfg, seed)
     if outliers is None:
@@ -126,7 +126,9 @@ def clip_state_dict(cfg: ClipConfig, seed: int = WEIGHT_SEED, outliers: str | No
         sd["transformer.resblocks.0.ln_1.weight"][11] = np.float32(40.0)
     elif outliers == "offset":
         sd["visual.ln_pre.bias"] += np.float32(12.0)
-        sd["positional_embedding"] += np.float32(6.0)        # the text stream has a standard deviation of 0.2-0.9 behind the first block
+        # the text stream starts at a deviation of 0.02 and has 0.2-0.9 behind the first block: the offset enters there (an offset of 6 on the embeddings
+        # themselves would put them below fp16's resolution — in the reference's fp16 as much as in any other)
+        sd["transformer.resblocks.0.mlp.c_proj.bias"] += np.float32(6.0)
     else:
         raise ValueError(outliers)
     return sd

@@ -264,6 +264,25 @@ def test_outlier_statistics_through_the_folded_layernorms(cfgname, B, depth, out
     assert r32["logit"] <= 2e-4 and r32["feature"] <= 2e-5 and r32["rel"] <= 2e-3
     del enc
     bars = {"bf16": dict(feature=2e-2, logit=0.3, cos=0.99), "f16": dict(feature=6e-3, logit=0.1, cos=0.995)}
+    if outliers == "offset":
+        # a stream whose rows sit 12 sigma off zero costs ANY fp16 storage of it digits (ulp 2^-7 at 8..16 against a deviation of 1): the reference, which
+        # runs fp16 end to end (model.py:394-415), pays that too.  The oracle's emulation of the reference's arithmetic type (fp16 operands, fp16 stream, f32
+        # sums) on these weights says how much; the HIP modes must not be worse than twice that (different rounding order), nor than their usual bars.
+        from oracle import lpi_oracle as O
+        orc = O.Oracle(cfg, sd)
+        fac_t = {k: torch.from_numpy(v) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+        try:
+            O.OPERAND_DTYPE, O.STREAM_DTYPE = torch.float16, torch.float16
+            with torch.no_grad():
+                fi, ft, _, _ = orc.forward(torch.from_numpy(synth.images(B, cfg.image_resolution)), torch.from_numpy(ids), fac_t, depth=depth)
+        finally:
+            O.OPERAND_DTYPE = O.STREAM_DTYPE = None
+        e_feat = max(float(np.abs(fi.numpy() - ref["img_f"]).max()), float(np.abs(ft.numpy() - ref["txt_f"]).max()))
+        e_logit = float(np.abs((orc.W["logit_scale"].exp() * fi @ ft.t()).numpy() - ref["logits"]).max())
+        print(f"{cfgname}, outliers=offset: the reference's own arithmetic type (oracle emulation: fp16 operands + stream) is {e_feat:.2e} (features) / {e_logit:.2e} (logits) "
+              f"from the exact f32 result")
+        for m in bars:
+            bars[m] = dict(feature=max(bars[m]["feature"], 2 * e_feat), logit=max(bars[m]["logit"], 2 * e_logit), cos=0.99)
     for mode in ("bf16", "f16"):
         enc = DualEncoder(cfg, sd, dtype=mode, device=DEV)
         first = run(enc)
@@ -277,7 +296,10 @@ def test_outlier_statistics_through_the_folded_layernorms(cfgname, B, depth, out
         assert smax < 6.0e4
         held = all(first[k] <= bars[mode][k] for k in ("feature", "logit")) and first["cos"] >= bars[mode]["cos"]
         assert held or tripped, "the one-sweep statistics lost accuracy and the guard did not notice"
-        if outliers == "offset":
+        # the one-sweep statistics exist only where the persistent GEMM takes the folded LayerNorms (the tiny towers at 4 pairs are below its row count:
+        # their LayerNorm is the two-pass kernel, and there is nothing to guard)
+        one_sweep = any(E._ln_fold_ok(ws["Mp"], t.spec.width) for t in (enc.vis, enc.txt) for ws in t._ws.values())
+        if outliers == "offset" and one_sweep:
             assert tripped, "rows 12 sigma off zero must trip the guard (mean^2 > 64 var)"
             assert enc.vis.rowstats == 0 and enc.txt.rowstats == 0
         else:
