@@ -112,10 +112,52 @@ def _cpulist(text):
     return out
 
 
-def pin_rank_to_cpus(local_rank, local_world):
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in HIP's device order, read from sysfs WITHOUT touching the GPU: the KFD topology lists the nodes in the order ROCr enumerates
+    them (CPU nodes have simd_count 0), a GPU node's `drm_render_minor` names its DRM render node, and /sys/class/drm/renderD<minor>/device/numa_node is the
+    PCI device's NUMA node (-1 where the platform does not say).  Fallback: the amdgpu cards of /sys/class/drm in PCI bus order.  HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES given as index lists are applied.  -> list of ints (-1 = unknown), or None when sysfs has nothing to say."""
+    import glob
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    nodes = []
+    kfd = sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/[0-9]*")), key=lambda q: int(os.path.basename(q)))
+    for d in kfd:
+        props = dict(ln.split(None, 1) for ln in (read(os.path.join(d, "properties")) or "").splitlines() if " " in ln)
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue
+        minor = props.get("drm_render_minor")
+        nn = read(os.path.join(sysfs, f"class/drm/renderD{minor}/device/numa_node")) if minor else None
+        nodes.append(int(nn) if nn not in (None, "") else -1)
+    if not nodes:
+        cards = []
+        for c in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*")):
+            if not os.path.basename(c)[4:].isdigit() or read(os.path.join(c, "device/vendor")) != "0x1002":
+                continue
+            nn = read(os.path.join(c, "device/numa_node"))
+            cards.append((os.path.basename(os.path.realpath(os.path.join(c, "device"))), int(nn) if nn not in (None, "") else -1))
+        nodes = [n for _, n in sorted(cards)]
+    if not nodes:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):      # ROCr filters first, HIP filters what is left
+        v = os.environ.get(var)
+        if v and all(t.strip().isdigit() for t in v.split(",")):
+            idx = [int(t) for t in v.split(",")]
+            if all(i < len(nodes) for i in idx):
+                nodes = [nodes[i] for i in idx]
+    return nodes
+
+
+def pin_rank_to_cpus(local_rank, local_world, share_gpu=False):
     """Give this rank its own slice of the host CPUs BEFORE anything touches the GPU: W processes that each spawn library / pipeline threads on all cores
-    migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first (local rank r uses GPU r, which hangs off node
-    r * nodes // n_gpus — on an 8-GPU MI355X node GPUs 0-3 are on socket 0 and 4-7 on socket 1 in device order), then evenly among the ranks of a node.  LPI_NO_AFFINITY=1
+    migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first — local rank r uses GPU r, whose node comes
+    from sysfs (gpu_numa_nodes: KFD topology -> DRM render node -> PCI numa_node; round 6: this replaced the guess that device order follows the sockets,
+    which stays the fallback where the platform reports no node) — then evenly among the ranks that share a node.  LPI_NO_AFFINITY=1
     leaves the affinity alone.  Returns the CPU list (or None)."""
     if os.environ.get("LPI_NO_AFFINITY") == "1" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
@@ -138,7 +180,19 @@ def pin_rank_to_cpus(local_rank, local_world):
         ngpu = max(int(torch.cuda.device_count()), local_world)      # does not initialise the GPU on this image
     except Exception:      # noqa: BLE001
         ngpu = local_world
-    node_of = [min(len(nodes) - 1, r * len(nodes) // ngpu) for r in range(local_world)]
+    node_of = [min(len(nodes) - 1, r * len(nodes) // ngpu) for r in range(local_world)]      # fallback: device order follows the sockets
+    node_ids = []
+    try:
+        import glob as _g
+        node_ids = sorted(int(q.rsplit("node", 1)[1]) for q in _g.glob("/sys/devices/system/node/node[0-9]*")
+                          if any(c in set(allowed) for c in _cpulist(open(os.path.join(q, "cpulist")).read())))
+    except (OSError, ValueError):
+        node_ids = []
+    gn = gpu_numa_nodes()
+    gpu_of = (lambda r: 0) if share_gpu else (lambda r: r)      # --share-gpu: every rank runs on GPU 0
+    if gn is not None and len(gn) > max(gpu_of(r) for r in range(local_world)) and len(node_ids) == len(nodes) \
+            and all(gn[gpu_of(r)] in node_ids for r in range(local_world)):
+        node_of = [node_ids.index(gn[gpu_of(r)]) for r in range(local_world)]
     mates = [r for r in range(local_world) if node_of[r] == node_of[local_rank]]
     cpus = nodes[node_of[local_rank]]
     k = mates.index(local_rank)
@@ -763,7 +817,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    cpus = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))      # before the first GPU call of this process
+    cpus = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), a.share_gpu)      # before the first GPU call of this process
     if cpus is not None:
         torch.set_num_threads(max(1, min(len(cpus), 16)))
     dev_index = 0 if a.share_gpu else local_rank
@@ -820,7 +874,11 @@ def main():
         mine = {"rank": rank, "mean_us_per_step": collectives, "median_ms_per_step": round(float(np.median(per)), 3), "cpus": None if cpus is None else len(cpus)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)                     # after the timed region: a few hundred bytes of bookkeeping per rank
+        meds = [r["median_ms_per_step"] for r in per_rank if r is not None]
         collectives = {"mean_us_per_step": collectives, "per_rank": per_rank, "backend": dist.get_backend(), "observed_world_size": dist.get_world_size(),
+                       # round 6, first-contact diagnostics: the spread of the ranks' own median step (a straggler GPU or a starved host shows here) ...
+                       "per_rank_median_ms": {"min": min(meds), "max": max(meds), "spread_pct": round(100.0 * (max(meds) - min(meds)) / min(meds), 2)},
+                       "gpu_numa_nodes": gpu_numa_nodes(),
                        "messages": f"one all_gather_into_tensor of img_f||txt_f [B, {E2}] f32 ({B * E2 * 4} bytes per rank) + one all_reduce(SUM) of the "
                                    f"{nfac} factor gradients"
                                    + (f" + one reduce_scatter_tensor of the key gradients [W B, {E2}] f32" if a.gather_with_grad else "")}
@@ -830,12 +888,26 @@ def main():
         if not a.fwd_only:
             wl.exchange = None
             el0, _ = wl.run(max(4, a.steps // 2), 2, sync)
-            wl.exchange = exchange
             el0 = rank_max(el0)
             v0 = world * B * max(4, a.steps // 2) / el0
             collectives["without_exchange"] = {"value": round(v0, 2), "unit": "pairs/s", "steps": max(4, a.steps // 2),
                                                "ratio_with_exchange": round(pairs_s / v0, 4),
                                                "note": "all ranks stepping at once with exchange = None (local 256 x 256 loss, no all-gather / all-reduce)"}
+            # ... and ONE rank stepping alone while the others wait at a barrier: the N = 1 value of THIS run on THIS node.  It should match the driver's
+            # single-GPU line within box noise (5 %); `without_exchange` / W below it = what W busy GPUs cost each other (host, power, fabric), and
+            # `value` below `without_exchange` = what the exchange and the W x larger loss matrix cost.
+            n_solo = max(4, a.steps // 2)
+            el1 = None
+            if rank == 0:
+                el1, per1 = wl.run(n_solo, 2, lambda: torch.cuda.synchronize())
+            dist.barrier()
+            wl.exchange = exchange
+            if rank == 0:
+                v1 = B * n_solo / el1
+                collectives["single_rank_alone"] = {"value": round(v1, 2), "unit": "pairs/s", "steps": n_solo, "median_ms_per_step": round(float(np.median(per1)), 3),
+                                                    "all_ranks_without_exchange_per_gpu_ratio": round(v0 / world / v1, 4),
+                                                    "job_per_gpu_ratio": round(pairs_s / world / v1, 4),
+                                                    "note": "rank 0 stepping alone (exchange = None), the other ranks idle at a barrier: compare with the N = 1 line"}
 
     roofline = None if a.no_roofline else wl.gemm_roofline()
     from lpi_amd import _lib as _L

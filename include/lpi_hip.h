@@ -248,6 +248,11 @@ typedef struct lpi_attn_fwd_desc {
     float* lse;
     int causal;
     int shared_rows;       /* 0, or the shared prefix of lpi_attn_fwd_shared (causal, row_start given) */
+    /* LAYOUT (round 6; all 0 = the interleaved default above).  Element (row, head h, which in {q, k, v}, c) of qkv sits at row * ldqkv + h * qkv_hs +
+     * which * qkv_vs + c, element (row, h, c) of ctx at row * ldctx + h * ctx_hs + c (elements; multiples of 8).  Head-BLOCKED planes [3 H][rows][64] /
+     * [H][rows][64] — what the GEMMs write and read with a plane stride (lpi_gemm_nt_planes): ldqkv = ldctx = 64, qkv_hs = ctx_hs = rows * 64, qkv_vs =
+     * H * rows * 64: a (sample, head) slice is one contiguous run.  2-byte types, uniform sequences (row_start = NULL, shared_rows = 0) only. */
+    int qkv_hs, qkv_vs, ctx_hs;
 } lpi_attn_fwd_desc;
 int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 /* The same backward when only the FIRST `rows_needed` token rows of dqkv are wanted (the first block: nothing upstream of the prompt slots
@@ -256,6 +261,10 @@ int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,
                         int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal,
                         void* stream);
+/* The backward of lpi_attn_fwd_pair's explicit LAYOUT (lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs} (elements, multiples
+ * of 8); 2-byte types, non-causal, uniform sequences the streamed single-pass kernel takes (L <= 288).  delta: [B, H, L] f32 scratch as above. */
+int lpi_attn_bwd_layout(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+                        const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* lay /* HOST, 6 ints */, void* stream);
 /* idx[b] stays the token index WITHIN sample b (the causal limit) */
 int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
                                const int32_t* idx, void* ctx, int ldctx, float* lse, int causal, void* stream);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "lpi_attn_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_fwd_pair": [_I, _P, _P],
+    "lpi_attn_bwd_layout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
     "lpi_attn_bwd_prefix": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
@@ -207,7 +208,7 @@ class LnBwdDesc(ctypes.Structure):
 class AttnFwdDesc(ctypes.Structure):
     """``lpi_attn_fwd_desc``"""
     _fields_ = [("B", c_int), ("L", c_int), ("H", c_int), ("row_start", c_void_p), ("qkv", c_void_p), ("ldqkv", c_int), ("ctx", c_void_p),
-                ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int), ("shared_rows", c_int)]
+                ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int), ("shared_rows", c_int), ("qkv_hs", c_int), ("qkv_vs", c_int), ("ctx_hs", c_int)]
 
 
 def attn_fwd_pair(dt, a, b, stream):
@@ -217,6 +218,7 @@ def attn_fwd_pair(dt, a, b, stream):
         q.B, q.L, q.row_start, q.H, q.qkv, q.ldqkv, q.ctx, q.ldctx, q.lse, q.causal = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), t[7],
                                                                                      _ptr(t[8]), t[9])
         q.shared_rows = t[10] if len(t) > 10 else 0
+        q.qkv_hs, q.qkv_vs, q.ctx_hs = t[11] if len(t) > 11 else (0, 0, 0)      # layout strides (include/lpi_hip.h): 0 = interleaved
     rc = load().lpi_attn_fwd_pair(dt, ctypes.cast(arr, c_void_p), stream)
     if rc != 0:
         raise LpiError(f"lpi_attn_fwd_pair failed with code {rc}")

@@ -287,7 +287,12 @@ __device__ __forceinline__ float group_sum(float v) {
 // tail samples) compute the shared sequence itself: rows [0, pre), plain causal attention among themselves.
 template <typename T, bool CAUSAL, bool SW = false>
 __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
-                                              T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre = 0, int bshared = -1) {
+                                              T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre = 0, int bshared = -1,
+                                              int qkv_hs = 0, int qkv_vs = 0, int ctx_hs = 0) {
+    // LAYOUT of q / k / v and ctx (round 6; include/lpi_hip.h, lpi_attn_fwd_desc): element (row, head h, which in {q, k, v}, c) of qkv sits at
+    // row ldqkv + h hs + which vs + c.  0 = the interleaved default [B L, 3 H 64]: hs = 64, vs = H 64.  Head-BLOCKED planes [3 H][rows][64]: ldqkv = 64,
+    // hs = rows 64, vs = H rows 64 — a (sample, head) slice is then one contiguous run of L x 128 bytes instead of L pieces at a stride of 6 H 64 bytes.
+    const int hs = qkv_hs ? qkv_hs : HD, chs = ctx_hs ? ctx_hs : HD;
     const int b = bh / H, h = bh % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
     int L = Lmax, Lp = Lpmax;         // L: the sample's OWN rows (its queries); Lk below: its keys
@@ -306,8 +311,8 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
     }
     const int Lk = pb + L;
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B, H, Lmax]
-    const int dm = H * HD;
-    const T* qg = qkv + row0 * ldqkv + h * HD;
+    const int dm = qkv_vs ? qkv_vs : H * HD;
+    const T* qg = qkv + row0 * ldqkv + (size_t)h * hs;
     constexpr int RSX = SW ? 128 : AT<T>::RS;      // image row stride (SW: see stage_rows2)
     static_assert(!SW || sizeof(T) == 2, "the swizzled images are for the 2-byte operand types");
     char* k_lds = smem;
@@ -321,8 +326,8 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         const int qr = (wave * NB + j) * 16 + (lane & 15);
         load_row_chunks<T>(q[j], qg, qr, ldqkv, g, qr < L);
     }
-    if (pb) stage_rows2<T, false, false, SW>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
-    else stage_rows2<T, false, false, SW>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    if (pb) stage_rows2<T, false, false, SW>(k_lds, qkv + (size_t)h * hs + dm, v_lds, qkv + (size_t)h * hs + 2 * (size_t)dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
+    else stage_rows2<T, false, false, SW>(k_lds, qg + dm, v_lds, qg + 2 * (size_t)dm, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const float c = SCALE * LOG2E;
@@ -390,10 +395,10 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
                 f32x4 os[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) os[dt] = o[j][dt] * inv;
-                store_row16_t<T>(ctx + (row0 + qrow[j]) * ldctx + h * HD, os, g, qrow[j] < L);
+                store_row16_t<T>(ctx + (row0 + qrow[j]) * ldctx + (size_t)h * chs, os, g, qrow[j] < L);
                 if (qrow[j] < L && g == 0) lse[lse0 + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
             } else if (qrow[j] < L) {
-                T* dst = ctx + (row0 + qrow[j]) * ldctx + h * HD + 4 * g;
+                T* dst = ctx + (row0 + qrow[j]) * ldctx + (size_t)h * chs + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, o[j][dt] * inv);
                 if (g == 0) lse[lse0 + qrow[j]] = (m[j] + log2f(ltot)) * LN2;
@@ -416,12 +421,13 @@ struct AttnFwdP {
     int L, Lp, H, ldqkv, ldctx;
     const int* rs; const T* qkv; T* ctx; float* lse;
     int pre, bshared;      // shared prefix (attn_fwd_body): 0, -1 = none
+    int hs, vs, chs;       // layout strides (attn_fwd_body): 0 = the interleaved default
 };
 template <typename T, bool C0, bool C1, bool SW0 = false>
 __global__ __launch_bounds__(512) void attn_fwd_pair_kernel(AttnFwdP<T> p0, AttnFwdP<T> p1, int nb0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0, SW0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse, p0.pre, p0.bshared);
-    else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse, p1.pre, p1.bshared);
+    if ((int)blockIdx.x < nb0) attn_fwd_body<T, C0, SW0>(blockIdx.x, smem, p0.L, p0.Lp, p0.rs, p0.H, p0.qkv, p0.ldqkv, p0.ctx, p0.ldctx, p0.lse, p0.pre, p0.bshared, p0.hs, p0.vs, p0.chs);
+    else attn_fwd_body<T, C1>(blockIdx.x - nb0, smem, p1.L, p1.Lp, p1.rs, p1.H, p1.qkv, p1.ldqkv, p1.ctx, p1.ldctx, p1.lse, p1.pre, p1.bshared, p1.hs, p1.vs, p1.chs);
 }
 
 // ------------------------------------------------------------------------------------------------ backward A
@@ -1018,7 +1024,7 @@ inline bool bad_attn(int dtype, int B, int L, int H, int ld) {
 // the default for L > 160 (tuning key 7 = 0), forced at every L it takes by key 7 = 5, never with key 7 = 1
 bool lpi_attn4_bwd_ok(int L, int causal);
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
-                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi);
+                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi, const int* lay = nullptr);
 extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                                    float* lse, int causal, void* stream) {
     const int* rs = row_start;      // ragged batch: the one-head-per-workgroup kernels take a per-sample length
@@ -1052,7 +1058,8 @@ static int fwd_pair_launch(const lpi_attn_fwd_desc* d, hipStream_t s) {
         const int Lp = (d[i].L + 31) / 32 * 32;
         const int pre = d[i].shared_rows;
         if (pre < 0 || (pre > 0 && (!d[i].causal || !d[i].row_start || pre >= d[i].L))) return LPI_EINVAL;
-        p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse, pre, pre > 0 ? d[i].B : -1};
+        p[i] = AttnFwdP<T>{d[i].L, Lp, d[i].H, d[i].ldqkv, d[i].ldctx, d[i].row_start, (const T*)d[i].qkv, (T*)d[i].ctx, d[i].lse, pre, pre > 0 ? d[i].B : -1,
+                           d[i].qkv_hs, d[i].qkv_vs, d[i].ctx_hs};
         lds = std::max(lds, (size_t)2 * Lp * AT<T>::RS);
         thr = std::max(thr, 64 * (d[i].row_start ? pick_waves_ragged(d[i].L) : pick_waves(d[i].L)));
     }
@@ -1082,7 +1089,11 @@ extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_s
 extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream) {
     if (!d) return LPI_EINVAL;
     for (int i = 0; i < 2; ++i) {
-        if (!d[i].qkv || !d[i].ctx || !d[i].lse || bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv) || d[i].ldctx < d[i].H * HD || (d[i].ldctx & 7)) return LPI_EINVAL;
+        const bool lay = d[i].qkv_hs || d[i].qkv_vs || d[i].ctx_hs;      // an explicit layout: the strides are the caller's statement, only their alignment is checked
+        if (lay && (dtype == LPI_F32 || d[i].row_start || d[i].shared_rows || !d[i].qkv_hs || !d[i].qkv_vs || !d[i].ctx_hs ||
+                    ((d[i].qkv_hs | d[i].qkv_vs | d[i].ctx_hs | d[i].ldqkv | d[i].ldctx) & 7) || d[i].ldqkv < HD || d[i].ldctx < HD)) return LPI_EINVAL;
+        if (!d[i].qkv || !d[i].ctx || !d[i].lse || (!lay && (bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv) || d[i].ldctx < d[i].H * HD)) || (d[i].ldctx & 7)) return LPI_EINVAL;
+        if (lay && (d[i].B <= 0 || d[i].H <= 0 || d[i].L <= 0 || d[i].L > 288)) return LPI_EINVAL;
         if (((uintptr_t)d[i].qkv | (uintptr_t)d[i].ctx) & 15) return LPI_EINVAL;
     }
     if (dtype == LPI_BF16) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
@@ -1224,4 +1235,18 @@ extern "C" int lpi_attn_bwd_varlen(int dtype, int B, int L, const int32_t* row_s
 extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx,
                             int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal, void* stream) {
     return lpi_attn_bwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, stream);
+}
+
+// The streamed backward (attention4.hip) on an explicit LAYOUT (round 6; see lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs},
+// element strides, multiples of 8.  2-byte operand types, non-causal, uniform sequences of at most 288 tokens the streamed kernel takes (lpi_attn4_bwd_ok).
+extern "C" int lpi_attn_bwd_layout(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+                                   const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* lay, void* stream) {
+    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || !lay || B <= 0 || H <= 0 || L <= 0) return LPI_EINVAL;
+    if (dtype != LPI_BF16 && dtype != LPI_F16) return LPI_EINVAL;
+    if (!lpi_attn4_bwd_ok(L, 0)) return LPI_EINVAL;
+    int bits = ldqkv | ldctx | lddctx | lddqkv;
+    for (int i = 0; i < 6; ++i) { if (lay[i] <= 0) return LPI_EINVAL; bits |= lay[i]; }
+    if ((bits & 7) || ldqkv < HD || ldctx < HD || lddctx < HD || lddqkv < HD) return LPI_EINVAL;
+    if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) return LPI_EINVAL;
+    return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, (hipStream_t)stream, dtype == LPI_F16 ? 1 : 0, L, lay);
 }

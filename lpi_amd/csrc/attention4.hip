@@ -131,6 +131,9 @@ struct Args4 {
     // (Lp = L rounded up to 32 = 32 x the query slices).  A sequence longer than 224 tokens (ViT-L/14: 273) runs as two launches — keys 0 .. 223 on
     // the Lp = 224 configuration, the rest (<= 64 keys) on the generic one with acc_dq: its dQ is ADDED to what the first launch stored.
     int kw0, Lk, Lkp, acc_dq;
+    // LAYOUT (round 6, lpi_attn_bwd_layout): head stride and q -> k -> v stride (elements) of qkv and of dqkv, head stride of ctx and of dctx; the interleaved
+    // default is hs = 64, vs = H 64; head-blocked planes [.][rows][64]: row stride 64, hs = rows 64, vs = H rows 64
+    int q_hs, q_vs, dq_hs, dq_vs, c_hs, dc_hs;
 };
 
 // LDS map (byte offsets from the dynamic region; Lp <= 224: 161 792 B):
@@ -163,7 +166,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const T* const dctx = A.dctx; const int lddctx = A.lddctx;
     float* const delta = A.delta;
     T* const dqkv = A.dqkv; const int lddqkv = A.lddqkv;
-    const int dm = H * HD;
+    const int dm = A.q_vs;            // q -> k -> v stride of qkv (H * HD in the interleaved layout)
     const float c = SCALE * LOG2E;
     const int nheads = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // heads of this workgroup
     const int nslices = nheads * NSL;
@@ -263,8 +266,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int nblk = (Lk + 7) >> 3;
     const int kv_parts = (2 * nblk + 15) >> 4;
     // scalar base of a head's rows in a [B L, ld] matrix (+ a column offset)
-    auto head_base = [&](const T* m, int ld, const Head& x, int col) {
-        return (const T*)scalar_ptr(m + ((size_t)x.b * L * ld + x.h * HD + col));
+    auto head_base = [&](const T* m, int ld, int hs, const Head& x, int col) {
+        return (const T*)scalar_ptr(m + ((size_t)x.b * L * ld + (size_t)x.h * hs + col));
     };
     const T* kv_base = nullptr;           // K columns of the head whose K / V are being fetched
     auto issue_kv_part = [&](int part) {
@@ -303,6 +306,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const bool mv_dq = WIN == 2 && wave >= 4 && wave < 6;      // WIN == 2: waves 4, 5 move the stored dQ rows of every slice (piece 3 of the slot)
     const T* const sl_m0 = wave < 4 ? qkv : (mv_dq ? (const T*)dqkv : A.ctx);             // this wave's first source matrix and row stride
     const int sl_ld0 = wave < 4 ? ldqkv : (mv_dq ? lddqkv : A.ldctx);
+    const int sl_hs0 = wave < 4 ? A.q_hs : (mv_dq ? A.dq_hs : A.c_hs);
     const int sl_blk0 = wave < 4 ? wave : ((wave & 1) << 1);
     const unsigned sl_dst = lds0 + o_ring + (wave < 4 ? 0 : (mv_dq ? 3 : 2)) * 32 * RB + sl_blk0 * 1024;
     const int sl_rl = sl_blk0 * 8 + (lane >> 3);
@@ -312,8 +316,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const T* sl_b1 = nullptr;
     auto slice_bases = [&](const Head& x) {
         if (!sl_mine) return;
-        sl_b0 = head_base(sl_m0, sl_ld0, x, 0);
-        if (wave < 4) sl_b1 = head_base(dctx, lddctx, x, 0);
+        sl_b0 = head_base(sl_m0, sl_ld0, sl_hs0, x, 0);
+        if (wave < 4) sl_b1 = head_base(dctx, lddctx, A.dc_hs, x, 0);
     };
     auto issue_slice = [&](int t, int slot) {
         if (abl_dma && sl_mine) {
@@ -513,7 +517,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 
     // ---- launch prologue: first head's K, V, lse and the first AHEAD slices
     Head cur{(int)blockIdx.x / H, (int)blockIdx.x % H};
-    kv_base = head_base(qkv, ldqkv, cur, dm);
+    kv_base = head_base(qkv, ldqkv, A.q_hs, cur, dm);
     for (int part = 0; part < kv_parts; ++part) issue_kv_part(part);
     issue_lse(cur, 0);
     issue_dlt(cur, 0);
@@ -529,7 +533,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         LPI4_STAMP();
         Head nxt = cur;
         next_head(nxt);
-        T* const dqh = dqkv + (size_t)cur.b * L * lddqkv + cur.h * HD;
+        T* const dqh = dqkv + (size_t)cur.b * L * lddqkv + (size_t)cur.h * A.dq_hs;
         if constexpr (WIN == 1) dlt_g = delta + (size_t)(cur.b * H + cur.h) * L;
         // own K, V rows and the K^T fragments out of the images (landed a head ago)
 #pragma unroll
@@ -561,7 +565,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
         LPI4_BARRIER();           // delta of slice 0 and the scaled lse complete; every wave has its K, V rows: the images are free
         const bool spread_kv = NSL >= 6 && kv_parts <= NSL - 2 && !(A.flags & 1);      // parts 0 .. over iterations 0 ..: landed well before the head ends
         if (it + 1 < nheads) {
-            kv_base = head_base(qkv, ldqkv, nxt, dm);
+            kv_base = head_base(qkv, ldqkv, A.q_hs, nxt, dm);
             issue_lse(nxt, lbuf ^ 1);
             issue_dlt(nxt, lbuf ^ 1);
             if (!spread_kv)
@@ -660,8 +664,8 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
             for (int u = 0; u < NUW; ++u) {
                 if (kw0 + (ub + u) * 16 >= rows_hi) continue;
                 T* dst = dqh + (unsigned)((kw0 + (ub + u) * 16) * lddqkv);
-                store_tile(dst + dm, dk[u], (ub + u) * 16);
-                store_tile(dst + 2 * dm, dv[u], (ub + u) * 16);
+                store_tile(dst + A.dq_vs, dk[u], (ub + u) * 16);
+                store_tile(dst + 2 * (size_t)A.dq_vs, dv[u], (ub + u) * 16);
             }
         }
         cur = nxt;
@@ -728,7 +732,9 @@ bool lpi_attn4_bwd_ok(int L, int causal) {
 }
 
 int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
-                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi) {
+                  float* delta, void* dqkv, int lddqkv, hipStream_t s, int saved_f16, int rows_hi, const int* lay) {
+    // lay: NULL = the interleaved layout, else {q_hs, q_vs, dq_hs, dq_vs, c_hs, dc_hs} (Args4)
+    const int l_qh = lay ? lay[0] : HD, l_qv = lay ? lay[1] : H * HD, l_dh = lay ? lay[2] : HD, l_dv = lay ? lay[3] : H * HD, l_ch = lay ? lay[4] : HD, l_dch = lay ? lay[5] : HD;
     const int Lp = (L + 31) / 32 * 32;
     const int total = B * H;
     int grid = std::min(total, cu_count4());
@@ -746,9 +752,9 @@ int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
     } while (0)
         const int Lk1 = L - WIN0, Lkp1 = (Lk1 + 31) / 32 * 32;
         const Args4 A0{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
-                       0, WIN0, WIN0, 0};
+                       0, WIN0, WIN0, 0, l_qh, l_qv, l_dh, l_dv, l_ch, l_dch};
         const Args4 A1{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
-                       WIN0, Lk1, Lkp1, 1};
+                       WIN0, Lk1, Lkp1, 1, l_qh, l_qv, l_dh, l_dv, l_ch, l_dch};
         if (saved_f16) { BWD4W(true, 7, 1, w0, A0, lds_bytes4(WIN0, Lp)); BWD4W(true, 0, 2, w1, A1, lds_bytes4(Lkp1, Lp, 2)); }
         else { BWD4W(false, 7, 1, w2, A0, lds_bytes4(WIN0, Lp)); BWD4W(false, 0, 2, w3, A1, lds_bytes4(Lkp1, Lp, 2)); }
 #undef BWD4W
@@ -757,7 +763,7 @@ int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
     }
     const size_t lds = lds_bytes4(Lp, Lp);
     const Args4 A{L, Lp, H, total, (const T*)qkv, ldqkv, (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, g_lpi_tuning[12],
-                  0, L, Lp, 0};
+                  0, L, Lp, 0, l_qh, l_qv, l_dh, l_dv, l_ch, l_dch};
 #define BWD4(S, K, O)                                                                               \
     do {                                                                                            \
         if (int e = lpi_ensure_lds(O, (const void*)attn_bwd4_kernel<S, K>, 160 * 1024)) return e;   \
