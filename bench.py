@@ -89,6 +89,9 @@ def parse_args():
                          "blocks only, labels offset by rank * B")
     ap.add_argument("--gather-with-grad", action="store_true",
                     help="N > 1: gradients through the gathered features (sprompt.py:67-69): the key gradients are reduce-scattered to their owners")
+    ap.add_argument("--no-affinity", action="store_true", help="N > 1: leave the ranks' CPU affinity alone (default: every rank gets its own slice of its GPU's NUMA node)")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: run the step through a one-rank RCCL process group (the code path an 8-GPU run takes)")
+    ap.add_argument("--cpu-baseline-bs256", action="store_true", help="also time ONE bs=256 oracle step on the host (~70 s; needs 200 GiB of host memory and 32 CPUs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU with a gloo group (messages staged through the host): exercises the multi-rank path on a 1-GPU box")
     return ap.parse_args()
@@ -153,13 +156,13 @@ def gpu_numa_nodes(sysfs="/sys"):
     return nodes
 
 
-def pin_rank_to_cpus(local_rank, local_world, share_gpu=False):
+def pin_rank_to_cpus(local_rank, local_world, share_gpu=False, enabled=True):
     """Give this rank its own slice of the host CPUs BEFORE anything touches the GPU: W processes that each spawn library / pipeline threads on all cores
     migrate across sockets and stall each other's launch loops.  The allowed CPUs are split by NUMA node first — local rank r uses GPU r, whose node comes
     from sysfs (gpu_numa_nodes: KFD topology -> DRM render node -> PCI numa_node; round 6: this replaced the guess that device order follows the sockets,
-    which stays the fallback where the platform reports no node) — then evenly among the ranks that share a node.  LPI_NO_AFFINITY=1
-    leaves the affinity alone.  Returns the CPU list (or None)."""
-    if os.environ.get("LPI_NO_AFFINITY") == "1" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+    which stays the fallback where the platform reports no node) — then evenly among the ranks that share a node.  enabled = False
+    (bench.py --no-affinity) leaves the affinity alone.  Returns the CPU list (or None)."""
+    if not enabled or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
     nodes = []
@@ -231,7 +234,7 @@ def self_launch(a):
     return 0
 
 
-def cpu_baseline(cfg, depth, seconds_budget=30.0):
+def cpu_baseline(cfg, depth, seconds_budget=30.0, bs256=False):
     """Oracle fwd+loss+bwd at bs=8 (BASELINE.json configs[0] shape) on the host cores.  torch's default (all logical CPUs) oversubscribes
     a bs=8 step, so the thread count is swept first (one step each, after a warm-up) and the best one is timed: >= 3 warm-up steps, then
     >= 10 timed steps, the MEDIAN step time is reported (the mean beside it).  When the host has the memory (the oracle keeps
@@ -281,7 +284,7 @@ def cpu_baseline(cfg, depth, seconds_budget=30.0):
     except Exception:
         avail = 0.0
     # opt-in since round 5 (LPI_CPU_BASELINE_BS256=1): the one un-warmed bs=256 step takes 70 s of host time — beyond the 10-30 s a bounded sample should cost
-    if avail >= 200.0 and ncpu >= 32 and os.environ.get("LPI_CPU_BASELINE_BS256", "0") == "1":
+    if avail >= 200.0 and ncpu >= 32 and bs256:
         Bl, tl = 256, min(64, ncpu)
         torch.set_num_threads(tl)
         imgl, idsl = synth.images(Bl, cfg.image_resolution), synth.token_ids(Bl)
@@ -293,8 +296,8 @@ def cpu_baseline(cfg, depth, seconds_budget=30.0):
         del imgl, idsl
     else:
         out["bs256_sample"] = None
-        out["bs256_skipped"] = ("opt-in (LPI_CPU_BASELINE_BS256=1): one bs=256 step costs ~70 s of host time; round 4 measured 3.5 pairs/s at 64 threads"
-                                if os.environ.get("LPI_CPU_BASELINE_BS256", "0") != "1" else f"host memory available {avail:.0f} GiB (< 200) or {ncpu} cpus (< 32)")
+        out["bs256_skipped"] = ("opt-in (bench.py --cpu-baseline-bs256): one bs=256 step costs ~70 s of host time; round 4 measured 3.5 pairs/s at 64 threads"
+                                if not bs256 else f"host memory available {avail:.0f} GiB (< 200) or {ncpu} cpus (< 32)")
     torch.set_num_threads(default_threads)
     return out
 
@@ -817,14 +820,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    cpus = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), a.share_gpu)      # before the first GPU call of this process
+    cpus = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), a.share_gpu, not a.no_affinity)      # before the first GPU call of this process
     if cpus is not None:
         torch.set_num_threads(max(1, min(len(cpus), 16)))
     dev_index = 0 if a.share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     exchange = None
-    if world > 1 or os.environ.get("LPI_FORCE_DIST") == "1":       # LPI_FORCE_DIST: exercise the RCCL path on a 1-GPU box
+    if world > 1 or a.force_dist:       # --force-dist: exercise the RCCL path on a 1-GPU box
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -835,13 +838,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         from lpi_amd.dp import Exchange
         exchange = Exchange(timing=True, local_loss=a.local_loss, gather_with_grad=a.gather_with_grad)
-    if os.environ.get("LPI_MAIN_STREAM") == "side":
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # A/B: the step on a side stream instead of the (blocking) null stream
-    elif os.environ.get("LPI_MAIN_STREAM") == "high":
-        # A/B (round 5): the main stream (with --overlap: the vision tower) at HIGH priority, so that the text tower's lane only fills the CUs the
-        # vision tower's kernels leave idle (their partial last rounds)
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
-
     def sync():
         if exchange is not None:
             dist.barrier()
@@ -995,7 +991,7 @@ def main():
         out.update(extras)
         if collectives is not None:
             out["collectives"] = collectives
-        out["cpu_baseline"] = cpu_baseline(cfg, a.depth) if (world == 1 and not a.no_cpu_baseline) else None
+        out["cpu_baseline"] = cpu_baseline(cfg, a.depth, bs256=a.cpu_baseline_bs256) if (world == 1 and not a.no_cpu_baseline) else None
     line = json.dumps(out) if rank == 0 else None
     try:
         if exchange is not None:

@@ -261,10 +261,13 @@ int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_start, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx,
                         int ldctx, const void* dctx, int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, int causal,
                         void* stream);
-/* The backward of lpi_attn_fwd_pair's explicit LAYOUT (lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs} (elements, multiples
- * of 8); 2-byte types, non-causal, uniform sequences the streamed single-pass kernel takes (L <= 288).  delta: [B, H, L] f32 scratch as above. */
-int lpi_attn_bwd_layout(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
+/* The backward of an explicit LAYOUT (lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs} (elements, multiples of 8); 2-byte
+ * types, non-causal, uniform sequences; rows_needed as lpi_attn_bwd_prefix (<= 0 or >= L: all rows).  Where the one-head-per-workgroup kernels run (short
+ * sequences, tuning keys 3 / 7) ctx_hs and dctx_hs must be 64.  delta: [B, H, L] f32 scratch as above. */
+int lpi_attn_bwd_layout(int dtype, int B, int L, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                         const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* lay /* HOST, 6 ints */, void* stream);
+/* ONE forward in descriptor form: the single-problem call that takes the layout strides (all zero: lpi_attn_fwd_varlen / _shared) */
+int lpi_attn_fwd_one(int dtype, const lpi_attn_fwd_desc* d, void* stream);
 /* idx[b] stays the token index WITHIN sample b (the causal limit) */
 int lpi_attn_pooled_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* q, int ldq, const void* qkv, int ldqkv,
                                const int32_t* idx, void* ctx, int ldctx, float* lse, int causal, void* stream);

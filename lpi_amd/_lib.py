@@ -59,7 +59,8 @@ SIGNATURES = {
     "lpi_attn_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_fwd_pair": [_I, _P, _P],
-    "lpi_attn_bwd_layout": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+    "lpi_attn_bwd_layout": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+    "lpi_attn_fwd_one": [_I, _P, _P],
     "lpi_attn_bwd_prefix": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
@@ -133,7 +134,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 501
+EXPECTED_ABI = 600
 VARIANT_OFFSET = 1000000      # lpi_version() of a tools/build_variant.sh build = EXPECTED_ABI + this
 
 _lib = None
@@ -211,14 +212,26 @@ class AttnFwdDesc(ctypes.Structure):
                 ("ldctx", c_int), ("lse", c_void_p), ("causal", c_int), ("shared_rows", c_int), ("qkv_hs", c_int), ("qkv_vs", c_int), ("ctx_hs", c_int)]
 
 
+def _fill_attn_fwd(q, t):
+    q.B, q.L, q.row_start, q.H, q.qkv, q.ldqkv, q.ctx, q.ldctx, q.lse, q.causal = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), t[7], _ptr(t[8]), t[9])
+    q.shared_rows = t[10] if len(t) > 10 else 0
+    q.qkv_hs, q.qkv_vs, q.ctx_hs = t[11] if len(t) > 11 and t[11] is not None else (0, 0, 0)      # layout strides (include/lpi_hip.h): 0 = interleaved
+
+
+def attn_fwd_one(dt, a, stream):
+    """One argument tuple of attn_fwd_pair through lpi_attn_fwd_one (the single-problem call that takes the layout strides)."""
+    q = AttnFwdDesc()
+    _fill_attn_fwd(q, a)
+    rc = load().lpi_attn_fwd_one(dt, ctypes.cast(ctypes.pointer(q), c_void_p), stream)
+    if rc != 0:
+        raise LpiError(f"lpi_attn_fwd_one failed with code {rc}")
+
+
 def attn_fwd_pair(dt, a, b, stream):
     """Two argument tuples (B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal[, shared_rows]) of lpi_attn_fwd_varlen / _shared in one launch."""
     arr = (AttnFwdDesc * 2)()
     for q, t in zip(arr, (a, b)):
-        q.B, q.L, q.row_start, q.H, q.qkv, q.ldqkv, q.ctx, q.ldctx, q.lse, q.causal = (t[0], t[1], _ptr(t[2]), t[3], _ptr(t[4]), t[5], _ptr(t[6]), t[7],
-                                                                                     _ptr(t[8]), t[9])
-        q.shared_rows = t[10] if len(t) > 10 else 0
-        q.qkv_hs, q.qkv_vs, q.ctx_hs = t[11] if len(t) > 11 else (0, 0, 0)      # layout strides (include/lpi_hip.h): 0 = interleaved
+        _fill_attn_fwd(q, t)
     rc = load().lpi_attn_fwd_pair(dt, ctypes.cast(arr, c_void_p), stream)
     if rc != 0:
         raise LpiError(f"lpi_attn_fwd_pair failed with code {rc}")

@@ -70,11 +70,7 @@ __device__ __forceinline__ void stage_rows2(char* lds0, const T* g0, char* lds1,
             const int i = base + j * nt, row = i / NCH, c = i % NCH;
             v0[j] = make_uint4(0, 0, 0, 0);
             v1[j] = make_uint4(0, 0, 0, 0);
-#ifdef LPI_ABL_ATTN_NOLOAD          /* ablation build: K, V images of zeros, no global loads */
-            if (i < n && row < L && ld0 == 12345) {
-#else
             if (i < n && row < L) {
-#endif
                 const size_t srow = (size_t)(row < pre ? (long)row : (long)row + seg);
                 v0[j] = *reinterpret_cast<const uint4*>(g0 + srow * ld0 + c * Elem<T>::EPC);
                 v1[j] = *reinterpret_cast<const uint4*>(g1 + srow * ld1 + c * Elem<T>::EPC);
@@ -381,10 +377,6 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
         // unmasked tiles: every key < Lk and (causal) every key <= the smallest query position of the blocks
         const int kfull = CAUSAL ? min((Lk / 32) * 32, ((q0 + pb) / 32) * 32) : (Lk / 32) * 32;
         int kb = 0;
-#ifdef LPI_ABL_ATTN_NOCOMPUTE      /* ablation build: loads, staging and stores only */
-        kb = kend - 32;
-        if (qg == nullptr)
-#endif
         for (; kb < kfull; kb += 32) tile(kb, std::false_type{});
         for (; kb < kend; kb += 32) tile(kb, std::true_type{});
 #pragma unroll
@@ -409,9 +401,9 @@ __device__ __forceinline__ void attn_fwd_body(int bh, char* smem, int Lmax, int 
 
 template <typename T, bool CAUSAL, bool SW = false>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
-                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre, int bshared) {
+                                                      T* __restrict__ ctx, int ldctx, float* __restrict__ lse, int pre, int bshared, int hs, int vs, int chs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    attn_fwd_body<T, CAUSAL, SW>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse, pre, bshared);
+    attn_fwd_body<T, CAUSAL, SW>(blockIdx.x, smem, Lmax, Lpmax, rs, H, qkv, ldqkv, ctx, ldctx, lse, pre, bshared, hs, vs, chs);
 }
 // TWO attention forwards in one launch (the vision tower's and the text tower's of the same layer): workgroups [0, nb0) run problem 0, the
 // rest problem 1.  The text tower's forward alone is a 15 us kernel — a chain of dependent HBM round trips with the chip nearly idle; here its
@@ -435,7 +427,7 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                          const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                          const float* __restrict__ lse, float* __restrict__ delta,
-                                                         T* __restrict__ dqkv, int lddqkv, int pre, int bshared) {
+                                                         T* __restrict__ dqkv, int lddqkv, int pre, int bshared, int q_hs, int q_vs, int dq_hs, int dq_vs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
@@ -456,12 +448,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, c
     }
     const int Lk = pb + L;
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
-    const int dm = H * HD;
-    const T* qg = qkv + row0 * ldqkv + h * HD;
+    // layout strides of qkv / dqkv (attn_fwd_body has the definition; 0 = the interleaved default).  dm stays H * HD: the shared-prefix partials' own layout
+    const int hsq = q_hs ? q_hs : HD, vsq = q_vs ? q_vs : H * HD, hsd = dq_hs ? dq_hs : HD, vsd = dq_vs ? dq_vs : H * HD;
+    const T* qg = qkv + row0 * ldqkv + (size_t)h * hsq;
     char* k_lds = smem;
     char* v_lds = smem + Lp * AT<T>::RS;
-    if (pb) stage_rows2<T, SV16, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
-    else stage_rows2<T, SV16, SV16>(k_lds, qg + dm, v_lds, qg + 2 * dm, ldqkv, ldqkv, L, Lp);
+    if (pb) stage_rows2<T, SV16, SV16>(k_lds, qkv + (size_t)h * hsq + vsq, v_lds, qkv + (size_t)h * hsq + 2 * (size_t)vsq, ldqkv, ldqkv, Lk, Lp, pb, (long)row0 - pb);
+    else stage_rows2<T, SV16, SV16>(k_lds, qg + vsq, v_lds, qg + 2 * (size_t)vsq, ldqkv, ldqkv, L, Lp);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -536,9 +529,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(int Lmax, int Lpmax, c
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + (size_t)h * hsd, dq[j], g, qrow[j] < L);
             } else if (qrow[j] < L) {
-                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + (size_t)h * hsd + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
@@ -551,7 +544,7 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                           const T* __restrict__ dctx, int lddctx, const float* __restrict__ lse,
                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv, int pre, int bshared,
-                                                          float* __restrict__ shared_dkv) {
+                                                          float* __restrict__ shared_dkv, int q_hs, int q_vs, int dq_hs, int dq_vs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
@@ -573,8 +566,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
     const int Lk = pb + L;
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
     const int dm = H * HD;
-    const T* qg = qkv + row0 * ldqkv + h * HD;
-    const T* kg = qkv + h * HD + dm;                      // keys / values by GLOBAL row (key position p -> row p, or row0 + p - pb behind the shared ones)
+    // layout strides of qkv / dqkv (attn_fwd_body has the definition; 0 = the interleaved default).  dm stays H * HD: the shared-prefix partials' own layout
+    const int hsq = q_hs ? q_hs : HD, vsq = q_vs ? q_vs : H * HD, hsd = dq_hs ? dq_hs : HD, vsd = dq_vs ? dq_vs : H * HD;
+    const T* qg = qkv + row0 * ldqkv + (size_t)h * hsq;
+    const T* kg = qkv + (size_t)h * hsq + vsq;                      // keys / values by GLOBAL row (key position p -> row p, or row0 + p - pb behind the shared ones)
     auto krow_global = [&](int p) -> size_t { return (size_t)(p < pb ? (long)p : (long)row0 + p - pb); };
     char* q_lds = smem;
     char* do_lds = smem + Lp * AT<T>::RS;
@@ -587,7 +582,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
     for (int j = 0; j < NB; ++j) {          // first key blocks: fetched ahead of the staging
         const int kr = (wave * NB + j) * 16 + (lane & 15);
         load_row_chunks<T, SV16>(kk[j], kg, krow_global(kr), ldqkv, g, kr < Lk);
-        load_row_chunks<T, SV16>(vv[j], kg + dm, krow_global(kr), ldqkv, g, kr < Lk);
+        load_row_chunks<T, SV16>(vv[j], kg + vsq, krow_global(kr), ldqkv, g, kr < Lk);
     }
     stage_rows2<T, SV16, false>(q_lds, qg, do_lds, dctx + row0 * lddctx + h * HD, ldqkv, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
@@ -609,7 +604,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 load_row_chunks<T, SV16>(kk[j], kg, krow_global(krow[j]), ldqkv, g, krow[j] < Lk);
-                load_row_chunks<T, SV16>(vv[j], kg + dm, krow_global(krow[j]), ldqkv, g, krow[j] < Lk);
+                load_row_chunks<T, SV16>(vv[j], kg + vsq, krow_global(krow[j]), ldqkv, g, krow[j] < Lk);
             }
         }
         f32x4 dk[NB][4], dv[NB][4];
@@ -670,15 +665,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(int Lmax, int Lpmax, 
             }
             const size_t orow = row0 + (krow[j] - pb);      // own key
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + h * HD;
-                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < Lk);
-                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < Lk);
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + (size_t)h * hsd;
+                store_row_bf16_t(dst + vsd, dk[j], g, krow[j] < Lk);
+                store_row_bf16_t(dst + 2 * (size_t)vsd, dv[j], g, krow[j] < Lk);
             } else if (krow[j] < Lk) {
-                T* dst = dqkv + orow * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + orow * lddqkv + (size_t)h * hsd + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
-                    Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
+                    Elem<T>::st4(dst + vsd + dt * 16, dk[j][dt]);
+                    Elem<T>::st4(dst + 2 * (size_t)vsd + dt * 16, dv[j][dt]);
                 }
             }
         }
@@ -694,7 +689,8 @@ template <typename T, bool CAUSAL, bool SV16 = false>
 __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax, const int* __restrict__ rs, int H, const T* __restrict__ qkv, int ldqkv,
                                                             const T* __restrict__ ctx, int ldctx, const T* __restrict__ dctx, int lddctx,
                                                             const float* __restrict__ lse, float* __restrict__ delta,
-                                                            T* __restrict__ dqkv, int lddqkv, int rows_hi, int pre, int bshared, float* __restrict__ shared_dkv) {
+                                                            T* __restrict__ dqkv, int lddqkv, int rows_hi, int pre, int bshared, float* __restrict__ shared_dkv,
+                                                            int q_hs, int q_vs, int dq_hs, int dq_vs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     // ragged batch (rs = row starts, B + 1 ints): sample b owns rows rs[b] .. rs[b+1]-1; else every sample has Lmax rows
@@ -718,7 +714,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
     const int Lk = pb + L;
     const size_t lse0 = ((size_t)b * H + h) * Lmax;       // lse / delta stay [B (+ 1), H, Lmax], indexed by the own row
     const int dm = H * HD;
-    const T* qg = qkv + row0 * ldqkv + h * HD;
+    // layout strides of qkv / dqkv (attn_fwd_body has the definition; 0 = the interleaved default).  dm stays H * HD: the shared-prefix partials' own layout
+    const int hsq = q_hs ? q_hs : HD, vsq = q_vs ? q_vs : H * HD, hsd = dq_hs ? dq_hs : HD, vsd = dq_vs ? dq_vs : H * HD;
+    const T* qg = qkv + row0 * ldqkv + (size_t)h * hsq;
     const int img = Lp * AT<T>::RS;
     char* q_lds = smem;
     char* k_lds = smem + img;
@@ -738,7 +736,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
         const int qr = (wave * NB + j) * 16 + (lane & 15);
         load_row_chunks<T>(oc0[j], ctx + h * HD, row0 + qr, ldctx, g, qr < L);
     }
-    stage_rows4<T, SV16>(k_lds, qkv + h * HD + dm, v_lds, qkv + h * HD + 2 * dm, ldqkv, Lk, pb ? pb : 0, pb ? (long)row0 - pb : (long)row0, q_lds, qg, ldqkv, do_lds,
+    stage_rows4<T, SV16>(k_lds, qkv + (size_t)h * hsq + vsq, v_lds, qkv + (size_t)h * hsq + 2 * (size_t)vsq, ldqkv, Lk, pb ? pb : 0, pb ? (long)row0 - pb : (long)row0, q_lds, qg, ldqkv, do_lds,
                          dctx + row0 * lddctx + h * HD, lddctx, L, Lp);
     for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
         lse_lds[i] = i < L ? (i == li ? lse_first : lse[lse0 + i]) * LOG2E : INFINITY;
@@ -828,9 +826,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if constexpr (sizeof(T) == 2) {
-                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + h * HD, dq[j], g, qrow[j] < L);
+                store_row_bf16_t(reinterpret_cast<bf16_t*>(dqkv) + (row0 + qrow[j]) * lddqkv + (size_t)h * hsd, dq[j], g, qrow[j] < L);
             } else if (qrow[j] < L) {
-                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + (row0 + qrow[j]) * lddqkv + (size_t)h * hsd + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + dt * 16, dq[j][dt]);
             }
@@ -890,9 +888,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (pb && krow[j] < pb) {      // a SHARED key: this sample's f32 partial (summed over the samples by lpi_shared_kv_reduce)
-#ifdef LPI_ABL_SHARED_NOPARTIAL       /* ablation build: what the partial stores cost the kernel (results are wrong) */
-                if (b != 0) continue;
-#endif
                 float* dst = shared_dkv + ((size_t)b * pb + krow[j]) * 2 * dm + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -903,15 +898,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(int Lmax, int Lpmax
             }
             const size_t orow = row0 + (krow[j] - pb);      // own key
             if constexpr (sizeof(T) == 2) {
-                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + h * HD;
-                store_row_bf16_t(dst + dm, dk[j], g, krow[j] < Lk);
-                store_row_bf16_t(dst + 2 * dm, dv[j], g, krow[j] < Lk);
+                bf16_t* dst = reinterpret_cast<bf16_t*>(dqkv) + orow * lddqkv + (size_t)h * hsd;
+                store_row_bf16_t(dst + vsd, dk[j], g, krow[j] < Lk);
+                store_row_bf16_t(dst + 2 * (size_t)vsd, dv[j], g, krow[j] < Lk);
             } else if (krow[j] < Lk) {
-                T* dst = dqkv + orow * lddqkv + h * HD + 4 * g;
+                T* dst = dqkv + orow * lddqkv + (size_t)h * hsd + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    Elem<T>::st4(dst + dm + dt * 16, dk[j][dt]);
-                    Elem<T>::st4(dst + 2 * dm + dt * 16, dv[j][dt]);
+                    Elem<T>::st4(dst + vsd + dt * 16, dk[j][dt]);
+                    Elem<T>::st4(dst + 2 * (size_t)vsd + dt * 16, dv[j][dt]);
                 }
             }
         }
@@ -958,7 +953,8 @@ int set_lds(const void* kern, size_t bytes) {
 static bool fwd_swizzled(int Lp) { return g_lpi_tuning[13] != 1 && (size_t)2 * 2 * Lp * 160 > (size_t)160 * 1024 && (size_t)2 * 2 * Lp * 128 <= (size_t)160 * 1024; }
 
 template <typename T, bool CAUSAL>
-int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr, int pre = 0) {
+int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s, const int* rs = nullptr, int pre = 0,
+               int hs = 0, int vs = 0, int chs = 0) {
     // pre > 0 (causal ragged batches): B tail samples + the shared sequence as sample B (attn_fwd_body)
     const int nbh = (B + (pre > 0 ? 1 : 0)) * H, bsh = pre > 0 ? B : -1;
     const int Lp = (L + 31) / 32 * 32;
@@ -968,14 +964,14 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
         if (fwd_swizzled(Lp) && !rs) {      // 257 .. 288 tokens: unpadded swizzled images, two workgroups per CU (stage_rows2)
             const size_t lsw = (size_t)2 * Lp * 128;
             if (int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL, true>, lsw)) return e;
-            LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL, true>), dim3(nbh), dim3(thr), lsw, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh);
+            LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL, true>), dim3(nbh), dim3(thr), lsw, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh, hs, vs, chs);
             LPI_CHECK_LAST();
             return 0;
         }
     }
     int e = set_lds((const void*)attn_fwd_kernel<T, CAUSAL>, lds);
     if (e) return e;
-    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(nbh), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh);
+    LPI_LAUNCH((attn_fwd_kernel<T, CAUSAL>), dim3(nbh), dim3(thr), lds, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (T*)ctx, ldctx, lse, pre, bsh, hs, vs, chs);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -983,7 +979,9 @@ int fwd_launch(int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int l
 template <typename T, bool CAUSAL, bool SV16 = false>
 int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
                const float* lse, float* delta, void* dqkv, int lddqkv, hipStream_t s, const int* rs = nullptr, int rows_hi = 1 << 30, int pre = 0,
-               float* shared_dkv = nullptr) {
+               float* shared_dkv = nullptr, const int* lay = nullptr) {
+    // lay: NULL = interleaved, else {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ...} (lpi_attn_bwd_layout; ctx / dctx keep their 64-element head stride here)
+    const int l0 = lay ? lay[0] : 0, l1 = lay ? lay[1] : 0, l2 = lay ? lay[2] : 0, l3 = lay ? lay[3] : 0;
     const int Lp = (L + 31) / 32 * 32;
     const size_t ldsA = (size_t)2 * Lp * AT<T>::RS;
     const size_t ldsB = ldsA + (size_t)2 * Lp * sizeof(float);
@@ -995,7 +993,7 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
         int ef = set_lds((const void*)attn_bwd_fused_kernel<T, CAUSAL, SV16>, ldsF);
         if (ef) return ef;
         LPI_LAUNCH((attn_bwd_fused_kernel<T, CAUSAL, SV16>), dim3((B + (pre > 0 ? 1 : 0)) * H), dim3(thr), ldsF, s, L, Lp, rs, H, (const T*)qkv, ldqkv,
-                   (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, pre, pre > 0 ? B : -1, shared_dkv);
+                   (const T*)ctx, ldctx, (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, rows_hi, pre, pre > 0 ? B : -1, shared_dkv, l0, l1, l2, l3);
         LPI_CHECK_LAST();
         return 0;
     }
@@ -1005,10 +1003,10 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     if (e) return e;
     const int nbh = (B + (pre > 0 ? 1 : 0)) * H, bsh = pre > 0 ? B : -1;
     LPI_LAUNCH((attn_bwd_dq_kernel<T, CAUSAL, SV16>), dim3(nbh), dim3(thr), ldsA, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)ctx, ldctx,
-               (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, pre, bsh);
+               (const T*)dctx, lddctx, lse, delta, (T*)dqkv, lddqkv, pre, bsh, l0, l1, l2, l3);
     LPI_CHECK_LAST();
     LPI_LAUNCH((attn_bwd_dkv_kernel<T, CAUSAL, SV16>), dim3(nbh), dim3(thr), ldsB, s, L, Lp, rs, H, (const T*)qkv, ldqkv, (const T*)dctx, lddctx,
-               lse, delta, (T*)dqkv, lddqkv, pre, bsh, shared_dkv);
+               lse, delta, (T*)dqkv, lddqkv, pre, bsh, shared_dkv, l0, l1, l2, l3);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -1237,16 +1235,39 @@ extern "C" int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int
     return lpi_attn_bwd_varlen(dtype, B, L, nullptr, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, causal, stream);
 }
 
-// The streamed backward (attention4.hip) on an explicit LAYOUT (round 6; see lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs},
-// element strides, multiples of 8.  2-byte operand types, non-causal, uniform sequences of at most 288 tokens the streamed kernel takes (lpi_attn4_bwd_ok).
-extern "C" int lpi_attn_bwd_layout(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx,
-                                   const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* lay, void* stream) {
-    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || !lay || B <= 0 || H <= 0 || L <= 0) return LPI_EINVAL;
+// The backward on an explicit LAYOUT (round 6; see lpi_attn_fwd_desc): lay = {qkv_hs, qkv_vs, dqkv_hs, dqkv_vs, ctx_hs, dctx_hs}, element strides, multiples
+// of 8.  2-byte operand types, non-causal, uniform sequences.  Dispatch as lpi_attn_bwd_prefix: the streamed single-pass kernel (attention4.hip) where it is
+// the default, else the one-head-per-workgroup kernels of this file — those keep ctx / dctx at their interleaved head stride (ctx_hs = dctx_hs = 64).
+extern "C" int lpi_attn_bwd_layout(int dtype, int B, int L, int rows_needed, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx,
+                                   int lddctx, const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* lay, void* stream) {
+    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || !lay || B <= 0 || H <= 0 || L <= 0 || L > 288) return LPI_EINVAL;
     if (dtype != LPI_BF16 && dtype != LPI_F16) return LPI_EINVAL;
-    if (!lpi_attn4_bwd_ok(L, 0)) return LPI_EINVAL;
     int bits = ldqkv | ldctx | lddctx | lddqkv;
     for (int i = 0; i < 6; ++i) { if (lay[i] <= 0) return LPI_EINVAL; bits |= lay[i]; }
     if ((bits & 7) || ldqkv < HD || ldctx < HD || lddctx < HD || lddqkv < HD) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) return LPI_EINVAL;
-    return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, (hipStream_t)stream, dtype == LPI_F16 ? 1 : 0, L, lay);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_hi = rows_needed > 0 && rows_needed < L ? rows_needed : L;
+    const int sv16 = dtype == LPI_F16 ? 1 : 0;
+    if (g_lpi_tuning[3] == 0 && lpi_attn4_bwd_ok(L, 0) && (g_lpi_tuning[7] == 5 || (g_lpi_tuning[7] == 0 && L > 160)))
+        return lpi_attn4_bwd(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, sv16, rows_hi, lay);
+    if (lay[4] != HD || lay[5] != HD) return LPI_EINVAL;
+    return sv16 ? bwd_launch<bf16_t, false, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, nullptr, rows_hi, 0, nullptr, lay)
+                : bwd_launch<bf16_t, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, nullptr, rows_hi, 0, nullptr, lay);
+}
+
+// ONE forward in descriptor form (the only single-problem form that takes the layout strides of lpi_attn_fwd_desc)
+extern "C" int lpi_attn_fwd_one(int dtype, const lpi_attn_fwd_desc* d, void* stream) {
+    if (!d) return LPI_EINVAL;
+    const bool lay = d->qkv_hs || d->qkv_vs || d->ctx_hs;
+    if (!lay) {
+        if (d->shared_rows) return lpi_attn_fwd_shared(dtype, d->B, d->L, d->row_start, d->shared_rows, d->H, d->qkv, d->ldqkv, d->ctx, d->ldctx, d->lse, stream);
+        return lpi_attn_fwd_varlen(dtype, d->B, d->L, d->row_start, d->H, d->qkv, d->ldqkv, d->ctx, d->ldctx, d->lse, d->causal, stream);
+    }
+    if ((dtype != LPI_BF16 && dtype != LPI_F16) || d->row_start || d->shared_rows || d->causal || !d->qkv_hs || !d->qkv_vs || !d->ctx_hs) return LPI_EINVAL;
+    if (((d->qkv_hs | d->qkv_vs | d->ctx_hs | d->ldqkv | d->ldctx) & 7) || d->ldqkv < HD || d->ldctx < HD) return LPI_EINVAL;
+    if (!d->qkv || !d->ctx || !d->lse || d->B <= 0 || d->H <= 0 || d->L <= 0 || d->L > 288 || (((uintptr_t)d->qkv | (uintptr_t)d->ctx) & 15)) return LPI_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LPI_F16) return fwd_launch<f16_t, false>(d->B, d->L, d->H, d->qkv, d->ldqkv, d->ctx, d->ldctx, d->lse, s, nullptr, 0, d->qkv_hs, d->qkv_vs, d->ctx_hs);
+    return fwd_launch<bf16_t, false>(d->B, d->L, d->H, d->qkv, d->ldqkv, d->ctx, d->ldctx, d->lse, s, nullptr, 0, d->qkv_hs, d->qkv_vs, d->ctx_hs);
 }

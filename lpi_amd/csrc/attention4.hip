@@ -186,19 +186,9 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
     const int rows_hi = A.rows_hi;
     const bool own_wanted = NUW > 0 && kw0 + ub * 16 < rows_hi;
     // ablation builds (timing only, wrong results): a run-time condition that is never true keeps the code alive
-#ifdef LPI_ABL4_NOCOMPUTE
-    const bool abl_comp = lddqkv == 12345;
-#else
     constexpr bool abl_comp = true;
-#endif
-#ifdef LPI_ABL4_NODMA
-    const bool abl_dma = lddqkv == 12345;
-#else
     constexpr bool abl_dma = true;
-#endif
-#ifdef LPI_ABL4_NOSTORE
-    const bool abl_st = lddqkv == 12345;
-#elif defined(LPI_ABL4_STAMPS)
+#if defined(LPI_ABL4_STAMPS)
     const bool abl_st = true;
 #else
     constexpr bool abl_st = true;
@@ -491,14 +481,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
 #pragma unroll
             for (int pi = 0; pi < DQN; ++pi) {
                 const int q = t * 32 + (dq_qs + pi) * 16 + r16;
-#ifdef LPI_ABL4_NODQST
-                if (q < L && lddqkv == 12345)
-#else
                 if (q < L && abl_st)
-#endif
-#ifdef LPI_NT_ATTN
-                    st_stream8(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g), pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
-#else
                 {
                     if constexpr (WIN == 2) {
                         // this window's share + what the first launch stored (exactly two addends per element, the first in memory since the launch
@@ -510,7 +493,6 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                     }
                     *reinterpret_cast<uint2*>(dqh + (unsigned)(q * lddqkv + 16 * dq_dt + 4 * g)) = make_uint2(pack2(dq[pi][0], dq[pi][1]), pack2(dq[pi][2], dq[pi][3]));
                 }
-#endif
             }
         }
     };
@@ -652,11 +634,7 @@ __device__ __forceinline__ void bwd4_body(const Args4& A, char* smem, int wave, 
                     }
                     const uint4 v = *reinterpret_cast<const uint4*>(st + rd);
                     const int kr = row0 + 8 * hf + rrow;      // key row inside the window
-#ifdef LPI_ABL4_NODKVST
-                    if (kr < Lk && lddqkv == 12345)
-#else
                     if (kr < Lk && abl_st)
-#endif
                         *reinterpret_cast<uint4*>(tile + (unsigned)((8 * hf + rrow) * lddqkv + 8 * rch)) = v;
                 }
             };

@@ -76,13 +76,8 @@ __device__ __forceinline__ void attn_softmax_tile(f32x4 (&s0)[NB], f32x4 (&s1)[N
         for (int r = 0; r < 4; ++r) {
             s0[j][r] = __builtin_amdgcn_exp2f(fmaf(s0[j][r], c, -msafe));
             s1[j][r] = __builtin_amdgcn_exp2f(fmaf(s1[j][r], c, -msafe));
-#ifndef LPI_ABL_ATTN_NOSUM      /* timing build (wrong results): without the 16 row-sum adds per tile and lane - the bound on what row sums on the matrix pipe could save */
             ps += s0[j][r] + s1[j][r];
-#endif
         }
-#ifdef LPI_ABL_ATTN_NOSUM
-        ps = s0[j][0];
-#endif
         lsum[j] += ps;
     }
 #else       /* the classic form: exact running maximum, one rescale factor per tile and block (A/B) */

@@ -207,12 +207,7 @@ __device__ __forceinline__ void store_row16_t(T16* row_ptr, const f32x4 (&o)[4],
         const uint32_t y0 = pk(o[2 * p + 1][0], o[2 * p + 1][1]), y1 = pk(o[2 * p + 1][2], o[2 * p + 1][3]);
         const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);      // {x rows 0,2 | y rows 0,2 -> x rows 1,3}, {x rows 1,3 -> y rows 0,2 | y rows 1,3}
         const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-#ifdef LPI_NT_ATTN
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
-        if (valid) __builtin_nontemporal_store((u32x4_){r0[0], r1[0], r0[1], r1[1]}, reinterpret_cast<u32x4_*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8));
-#else
         if (valid) *reinterpret_cast<uint4*>(row_ptr + 32 * p + (g & 1) * 16 + (g >> 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-#endif
     }
 }
 
@@ -378,11 +373,7 @@ __device__ __forceinline__ f32x4 quick_gelu_grad_from(f32x4 g, f32x4 s) {
 __device__ __forceinline__ void quick_gelu_both_x4(f32x4 u, f32x4& g, f32x4& dg) {
     const f32x4 s = fast_sigmoid1702_x4(u);
     g = u * s;
-#ifdef LPI_GELU_GRAD_V1      /* A/B: the round-3 expression */
-    dg = s * (1.0f + (1.702f * u) * (1.0f - s));
-#else
     dg = quick_gelu_grad_from(g, s);
-#endif
 }
 __device__ __forceinline__ f32x4 quick_gelu_grad_x4(f32x4 u) {
     const f32x4 s = fast_sigmoid1702_x4(u);

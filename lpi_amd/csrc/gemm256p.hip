@@ -40,19 +40,11 @@ constexpr int LDS_P = 2 * BUF_BYTES;      // 128 KiB
 // barrier per pass), whole rows leave as 16-byte stores (half the store instructions).  The same roundings of the same values: bit for bit the generic
 // epilogue (acc * 1 + 0 is kept as acc + 0, which turns a -0 into the +0 the generic form stores).
 constexpr int EPI_PLAIN16 = 100;
-// ... and the same for LPI_EPI_LN (in_proj with ln_1 folded in; no aux) — OPT-IN (tuning key 14 = 3): on the whole step it measured no faster than the generic
-// LN-fold epilogue (22.44-22.49 ms against 22.44-22.46; EPI_PLAIN16 alone 22.35-22.42).  v = (acc alpha - mean c1) rstd + c2 is evaluated on the accumulators — a lane's four column
-// groups' c1 / c2 and its eight rows' mean / rstd are loaded once per tile (plain loads: 24 per lane) — and staged in the output type.  The same
-// expression on the same values as gemm_epilogue_store: bit for bit the generic epilogue (tests/test_round4_gpu.py).
-constexpr int EPI_LN16 = 101;
+// (the same treatment of LPI_EPI_LN — EPI_LN16, rounds 4-5, opt-in — measured no faster on the whole step: 22.44-22.49 ms against 22.44-22.46; removed in round 6)
 // Weight slices (round 5, see launchp_impl) are compiled into every instantiation but the plain QuickGELU + aux one (c_fc WITHOUT the LayerNorm fold:
 // LPI_LN_FOLD < 2, an A/B path): its register allocation sits on the edge, and the two compares of the slice fold-back made it spill 56 bytes per lane
 // (tests/test_no_spills.py) — a scratch reload there drains the LDS-DMA queue every tile.
 template <int EPI, bool SAVE_U> constexpr bool slices_ok() { return !(EPI == LPI_EPI_QUICKGELU && SAVE_U); }
-#ifndef LPI_EPI_DB
-#define LPI_EPI_DB false     /* -DLPI_EPI_DB=true: eight double-buffered passes of 32 rows for the store-only epilogues with arithmetic — measured SLOWER on the whole
-                                step (22.66-22.71 ms with the four single-buffer passes against 22.78-22.82: twice the barriers for half the work per pass) */
-#endif
 
 // One GEMM of a launch.  A launch takes one or two of them (a GROUPED launch: the same operand types and epilogue kind, e.g. the
 // vision and the text tower's in_proj of the same layer): the second problem's tiles follow the first's in the virtual workgroup order
@@ -104,8 +96,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
     typedef float f32x8 __attribute__((ext_vector_type(8)));
     constexpr bool LNE = EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU;
     constexpr bool SLICES = slices_ok<EPI, SAVE_U>();
-    constexpr bool P16 = EPI == EPI_PLAIN16, L16 = EPI == EPI_LN16;
-    constexpr int EPIX = P16 ? LPI_EPI_NONE : (L16 ? LPI_EPI_LN : EPI);      // the epilogue kind the half-tile body sees
+    constexpr bool P16 = EPI == EPI_PLAIN16;
+    constexpr int EPIX = P16 ? LPI_EPI_NONE : EPI;      // the epilogue kind the half-tile body sees
     // the CURRENT problem's operands and geometry (wave-uniform; re-bound by bind() when the workgroup moves on to the next problem)
     const T* A = nullptr; const T* B = nullptr; TC* C = nullptr;
     const float* bias = nullptr; const float* residual = nullptr; TA* aux = nullptr;
@@ -258,13 +250,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             const int trow = (p >> 1) * 128 + (sr >> 5) * 64 + ((p & 1) * 2 + ((sr >> 4) & 1)) * 16 + (sr & 15);
             const unsigned voff = (unsigned)trow * (unsigned)side_ld * 2u + (unsigned)(l2 & 31) * 16u;
             unsigned keep;
-#ifndef LPI_NO_NT_SIDE      /* the side tile (fp16 residual / bf16 u) is read exactly once: streaming load (-0.2 % step; -DLPI_NO_NT_SIDE = A/B) */
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_w + (p & 1) * 32768 + i * 1024 + wave * 3072) : "memory");
-#else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds_w + (p & 1) * 32768 + i * 1024 + wave * 3072) : "memory");
-#endif
         }
     };
 
@@ -397,33 +384,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             asm volatile("" : "+s"(wave_e));
             const int lrow = lane_e & 15, lslot = lane_e >> 4;
             const int wm_e = wave_e >> 2, wn_e = wave_e & 3;
-            if constexpr (P16 || L16) {
+            if constexpr (P16) {
                 // four passes of 64 rows x 512 B through the two halves of slot 1, alternating (see EPI_PLAIN16).  Staging row s = wm 32 + mi2 16 + lrow;
                 // its 64 8-byte chunks (chunk c8 = output columns 4 c8 .. 4 c8 + 3) sit at c8 ^ 2 (s & 15): the 16 lanes of a ds_write_b64 group (16 rows, one
                 // chunk) spread over 16 bank pairs, a row's 16-byte chunks stay whole (the XOR is even) and a read group's 16 chunks cover all banks once
                 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
                 const int l5 = lane_e & 31, lh = lane_e >> 5;
                 TC* const cbase = C + (size_t)m0 * ldc + n0 + l5 * 8;
-                f32x4 c1g[2][2], c2g[2][2];
-                float mug[2][4], rsg[2][4];
-                if constexpr (L16) {
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni) {
-                            const int col = n0 + nh * 128 + wn_e * 32 + ni * 16 + lslot * 4;
-                            c1g[nh][ni] = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + col);
-                            c2g[nh][ni] = *reinterpret_cast<const f32x4*>(bias + col);
-                        }
-#pragma unroll
-                    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                        for (int mi = 0; mi < 4; ++mi) {
-                            const int row = m0 + mh * 128 + wm_e * 64 + mi * 16 + lrow;
-                            mug[mh][mi] = residual[row];
-                            rsg[mh][mi] = residual[(size_t)ldr + row];
-                        }
-                }
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int mh = p >> 1;
@@ -436,12 +403,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 #pragma unroll
                             for (int ni = 0; ni < 2; ++ni) {
                                 const int c8 = nh * 32 + wn_e * 8 + ni * 4 + lslot;
-                                f32x4 a;
-                                if constexpr (L16) {      // the two multiply-adds of gemm_epilogue_store
-                                    const float nm = -mug[mh][(p & 1) * 2 + mi2], rs = rsg[mh][(p & 1) * 2 + mi2];
-                                    a = __builtin_elementwise_fma(__builtin_elementwise_fma(f32x4{nm, nm, nm, nm}, c1g[nh][ni], acc[nh][ni][mh][(p & 1) * 2 + mi2]), f32x4{rs, rs, rs, rs}, c2g[nh][ni]);
-                                }
-                                else a = acc[nh][ni][mh][(p & 1) * 2 + mi2] + 0.0f;
+                                const f32x4 a = acc[nh][ni][mh][(p & 1) * 2 + mi2] + 0.0f;
                                 *reinterpret_cast<uint2*>(sb + s_row * 512 + ((c8 ^ (2 * lrow)) << 3)) = uint2{pack2_t<TC>(a[0], a[1]), pack2_t<TC>(a[2], a[3])};
                             }
                     }
@@ -467,52 +429,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
             f32x4 c1v = f32x4{0.f, 0.f, 0.f, 0.f};      // LayerNorm-fold epilogues: c1 sits behind the two statistics vectors
             if constexpr (EPI == LPI_EPI_LN || EPI == LPI_EPI_LN_QUICKGELU) c1v = *reinterpret_cast<const f32x4*>(residual + 2 * (size_t)ldr + ecol);
             char* const stg = smem + STG;
-            // Store-only epilogues with arithmetic (bias, LayerNorm fold, QuickGELU: nothing is LOADED per element): EIGHT passes of 32 rows through the two
-            // halves of slot 1, alternating — a pass may write its staging while the pass before is still being read and stored, so the barrier in front of
-            // the staging writes is gone (the stamps of the four-pass form, tools/gemm_stamps.py: for c_fc + QuickGELU that barrier alone was a quarter of the
-            // epilogue: every wave waited there for the slowest wave's sixteen stores).  Pass q: mh = q >> 2, mi = q & 3; staging row s = wm 16 + lrow holds
-            // tile row mh 128 + wm 64 + mi 16 + lrow; wave w reads back rows 4 w .. 4 w + 3.  Same values, same arithmetic per element: the same bits.
-            constexpr bool DB = !LATE && LPI_EPI_DB;
-            if constexpr (DB) {
-                typedef float f32x4s __attribute__((ext_vector_type(4)));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int mh = q >> 2, mi = q & 3;
-                    char* const sb = stg + (q & 1) * 32768;
-                    f32x4s mu4, rs4;
-                    if constexpr (LNE) {
-                        const int sr0 = wave_e * 4;
-                        const int trow0 = mh * 128 + (sr0 >> 4) * 64 + mi * 16 + (sr0 & 15);
-                        const float* pm = residual + (m0 + trow0);
-                        const float* pr = pm + ldr;
-                        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(mu4), "=&s"(rs4) : "s"(pm), "s"(pr));
-                    }
-                    {
-                        const int s_row = wm_e * 16 + lrow;
-#pragma unroll
-                        for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-                            for (int ni = 0; ni < 2; ++ni) {
-                                const int chunk = nh * 32 + wn_e * 8 + ni * 4 + lslot;
-                                *reinterpret_cast<f32x4*>(sb + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][mi];
-                            }
-                    }
-                    if constexpr (LNE) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mu4), "+s"(rs4) : : "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int s_row = wave_e * 4 + rr;
-                        const int trow = mh * 128 + (s_row >> 4) * 64 + mi * 16 + (s_row & 15);
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + s_row * 1024 + ((lane_e ^ (s_row & 7)) << 4));
-                        gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, m0 + trow, ecol, C, ldc, bv, alpha, residual, ldr, aux, ldaux, c1v, LNE ? mu4[rr] : 0.f,
-                                                                     LNE ? rs4[rr] : 1.f);
-                    }
-                    // after four passes (>= 16 stores of this wave since then) the next tile's K-tile 0, issued before them, must have landed
-                    if (q == 3 && has_next) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                }
-            } else
+            // (eight double-buffered passes of 32 rows for the store-only epilogues with arithmetic were built and measured slower on the whole step: 22.78-22.82 ms
+            // against 22.66-22.71 with these four — twice the barriers for half the work per pass; profiles/r04_experiments.md)
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int mh = p >> 1;
@@ -551,11 +469,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni) {
                             const int chunk = nh * 32 + wn_e * 8 + ni * 4 + lslot;
-#ifndef LPI_ABL_NO_STAGING_WRITE
                             *reinterpret_cast<f32x4*>(stg + s_row * 1024 + ((chunk ^ (s_row & 7)) << 4)) = acc[nh][ni][mh][(p & 1) * 2 + mi2];
-#else
-                            asm volatile("" :: "v"(acc[nh][ni][mh][(p & 1) * 2 + mi2]));      // ablation build: the accumulators stay live
-#endif
                         }
                 }
                 if constexpr (SIDE16) {
@@ -596,12 +510,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                         // loops spilled 60 bytes per lane in the QuickGELU instantiations and the step lost 7 %)
                         if constexpr (STATS) {      // the two packed dwords serve the store and the sums (of the values as stored)
                             const uint32_t w0 = pack2_t<f16_t>(o[0], o[1]), w1 = pack2_t<f16_t>(o[2], o[3]);
-#ifdef LPI_NT_SIDE16C      /* A/B: streaming stores for the residual stream too (see below) */
-                            if constexpr (LPI_NTC_DEFAULT) st_stream8(C + (size_t)(m0 + trow) * ldc + ecol, w0, w1);
-                            else *reinterpret_cast<uint2*>(C + (size_t)(m0 + trow) * ldc + ecol) = uint2{w0, w1};
-#else
                             *reinterpret_cast<uint2*>(C + (size_t)(m0 + trow) * ldc + ecol) = uint2{w0, w1};
-#endif
                             f16x4_sum_sumsq(w0, w1, st_s[rr], st_q[rr]);
                         } else {
                             // The fp16 residual stream (84 MB for the vision tower at 256 pairs) is stored with PLAIN stores: the next GEMM reads it
@@ -610,11 +519,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                             // coming out of this epilogue (LPI_EPI_RES_ROWSTATS) the pass is gone and the policy decides: 22.81 against 22.95-23.00 ms
                             // per step (profiles/r03_experiments.md).  d c_proj x gelu' (335 MB, read by one GEMM) stays a streaming store.
                             // -DLPI_NT_SIDE16C = streaming stores here too (A/B).
-#ifdef LPI_NT_SIDE16C
-                            if constexpr (LPI_NTC_DEFAULT) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
-#else
                             if constexpr (LPI_NTC_DEFAULT && EPI == LPI_EPI_DQUICKGELU) st4_nt<TC>(C + (size_t)(m0 + trow) * ldc + ecol, o);
-#endif
                             else Elem<TC>::st4(C + (size_t)(m0 + trow) * ldc + ecol, o);
                         }
                     } else {
@@ -622,27 +527,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm256p_kernel(const PGroup grp)
                                                                      LNE ? rs8[rr] : 1.f);
                     }
                 }
-#ifdef LPI_EPI_SLEEP      /* timing experiment: the residual epilogue made longer by LPI_EPI_SLEEP x 64 cycles per pass, nothing else changed */
-                if constexpr (SIDE16 && !STATS) __builtin_amdgcn_s_sleep(LPI_EPI_SLEEP);
-#endif
                 if constexpr (STATS) {
                     // lanes 0-31 hold columns n0 .. n0+127 (slot n0/128), lanes 32-63 the next slot; after the halving exchange every lane has the
                     // sums of row (lane >> 2) & 7 of the wave's eight: one lane of each quad stores them
                     float so, qo;
-#ifndef LPI_RS_NOREDUCE      /* ablation: LPI_RS_NOREDUCE = no exchange, LPI_RS_NOSTORE = no statistics stores (timing builds) */
                     rowstats8_half_reduce(st_s, st_q, lane_e, so, qo);
-#else
-                    so = st_s[0] + st_s[1] + st_s[2] + st_s[3] + st_s[4] + st_s[5] + st_s[6] + st_s[7];
-                    qo = st_q[0] + st_q[1] + st_q[2] + st_q[3] + st_q[4] + st_q[5] + st_q[6] + st_q[7];
-#endif
                     const int s_row = wave_e * 8 + ((lane_e >> 2) & 7);
                     const int trow = mh * 128 + (s_row >> 5) * 64 + ((p & 1) * 2 + ((s_row >> 4) & 1)) * 16 + (s_row & 15);
                     float* sp = reinterpret_cast<float*>(aux) + (size_t)(2 * ((n0 >> 7) + (lane_e >> 5))) * ldaux + (m0 + trow);
-#ifndef LPI_RS_NOSTORE
                     if ((lane_e & 3) == 0) { sp[0] = so; sp[ldaux] = qo; }
-#else
-                    if (so == 12345.678f && qo == 0.f) { sp[0] = so; sp[ldaux] = qo; }
-#endif
                 }
 #ifdef LPI_GEMM_STAMPS
                 gs_a = GS_NOW(); gs_e[3] += gs_a - gs_b;
@@ -720,7 +613,7 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
 {
     constexpr bool SIDE16 = (RES && sizeof(TC) == 2) || EPI == LPI_EPI_DQUICKGELU;
-    static_assert((EPI != EPI_PLAIN16 && EPI != EPI_LN16) || (!RES && !SAVE_U && sizeof(TC) == 2), "EPI_PLAIN16 / EPI_LN16: store-only, 2-byte output");
+    static_assert(EPI != EPI_PLAIN16 || (!RES && !SAVE_U && sizeof(TC) == 2), "EPI_PLAIN16: store-only, 2-byte output");
     const int ncu = cu_count_p();
     PGroup g = {};
     g.nprob = np;
@@ -737,9 +630,6 @@ int launchp_impl(const HostProb* hp, int np, float alpha, hipStream_t s)
         // XCDs are merely rotated by vb0 & 7.  The padding ids counted as tiles: the grouped in_proj launch of ViT-B/16 at 256 pairs had 2 178 ids =
         // 8 rounds + 130, two more than the hybrid half-tile round takes, so its last round ran 130 full tiles on 256 CUs; 2 175 ids end in a round of
         // 254 half tiles instead.)  LPI_GROUP_PAD8 keeps the padding (A/B switch).
-#ifdef LPI_GROUP_PAD8
-        v = (v + 7) & ~7;
-#endif
         P.vb0 = v;
         v += P.tiles_m * P.tiles_n;
         P.bias_off = nsum;
@@ -801,7 +691,7 @@ int dispatchp(int epi, const HostProb* hp, int np, float alpha, hipStream_t s)
     case LPI_EPI_NONE:
         if (res) return launchp_impl<T, TC, LPI_EPI_NONE, true, false>(hp, np, alpha, s);
         if constexpr (sizeof(TC) == 2) {      // nothing to add per column or row: the half-width staging (EPI_PLAIN16; tuning key 14 = 1: the generic epilogue, A/B)
-            bool plain = alpha == 1.0f && !ax && g_lpi_tuning[14] != 1;      // key 14 (A/B): 1 = the generic epilogue everywhere, 3 = EPI_LN16 as well
+            bool plain = alpha == 1.0f && !ax && g_lpi_tuning[14] != 1;      // key 14 = 1 (a TEST hook): the generic epilogue, the bit-for-bit reference of tests/test_round4_gpu.py
             for (int i = 0; i < np; ++i) plain = plain && hp[i].bias == nullptr;
             if (plain) return launchp_impl<T, TC, EPI_PLAIN16, false, false>(hp, np, alpha, s);
         }
@@ -833,11 +723,6 @@ int dispatchp_ln(int epi, const HostProb* hp, int np, float alpha, hipStream_t s
         if (!hp[i].residual || (hp[i].aux != nullptr) != ax) return LPI_EINVAL;
     if (epi == LPI_EPI_LN) {
         if (ax) return LPI_EINVAL;
-        if constexpr (sizeof(TC) == 2) {
-            bool fast = g_lpi_tuning[14] == 3;      // opt-in: measured no faster than the generic LN-fold epilogue on the whole step (profiles/r04_experiments.md)
-            for (int i = 0; i < np; ++i) fast = fast && hp[i].bias != nullptr;
-            if (fast) return launchp_impl<T, TC, EPI_LN16, false, false>(hp, np, alpha, s);
-        }
         return launchp_impl<T, TC, LPI_EPI_LN, false, false>(hp, np, alpha, s);
     }
     if (ax) return launchp_impl<T, TC, LPI_EPI_LN_QUICKGELU, false, true>(hp, np, alpha, s);

@@ -56,9 +56,7 @@ __device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col
 #else
             quick_gelu_both_x4(v, g, dg);
 #endif
-#ifndef LPI_ABL_NO_GLOBAL_STORE
             st4_nt<TA>(aux + (size_t)row * ldaux + col, dg);      // read again only by the backward, a whole forward later: streaming store
-#endif
             v = g;
         } else {
 #if LPI_IEEE_DIV || defined(LPI_SCALAR_GELU)      /* A/B: the one-value-at-a-time form */
@@ -76,16 +74,8 @@ __device__ __forceinline__ f32x4 gemm_epilogue_store(f32x4 acc, int row, int col
         if constexpr (sizeof(TC) == 2 && !__is_same(TC, bf16_t)) v += Elem<TC>::ld4(reinterpret_cast<const TC*>(residual) + (size_t)row * ldr + col);
         else v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * ldr + col);
     }
-#ifndef LPI_ABL_NO_GLOBAL_STORE
-#ifdef LPI_LN_PLAIN_C      /* A/B: the in_proj output (read next by the attention forward) with plain stores */
-    if constexpr (NTC && EPI != LPI_EPI_LN) st4_nt<TC>(C + (size_t)row * ldc + col, v);
-#else
     // the fp16 residual stream with plain stores (the next GEMM's A operand: gemm256p.hip has the measurement), everything else streams
     if constexpr (NTC && !(RES && __is_same(TC, f16_t))) st4_nt<TC>(C + (size_t)row * ldc + col, v);
-#endif
     else Elem<TC>::st4(C + (size_t)row * ldc + col, v);
-#else
-    if (v[0] == 12345.678f) Elem<TC>::st4(C + (size_t)row * ldc + col, v);      // ablation build: keeps the arithmetic alive, stores nothing
-#endif
     return v;      // what was stored, before the rounding to TC (the row-statistics epilogue sums the rounded values)
 }

@@ -215,23 +215,13 @@ template <int NC, typename F> __device__ __forceinline__ void for_chunks8(int d,
 
 __device__ __forceinline__ void ld8(const f16_t* p, float (&o)[8]) {
     typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-#ifdef LPI_NT_LN_LD
-    const f16x8 h = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
-#else
     const f16x8 h = *reinterpret_cast<const f16x8*>(p);
-#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (float)h[j];
 }
 __device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
-#ifdef LPI_NT_LN_LD
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
-    const u32x4_ u_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(p));
-    const uint32_t w[4] = {u_[0], u_[1], u_[2], u_[3]};
-#else
     const uint4 u = *reinterpret_cast<const uint4*>(p);
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         o[2 * j] = __uint_as_float(w[j] << 16);
@@ -247,21 +237,13 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
     bf16x8 b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = (__bf16)v[j];
-#ifdef LPI_NT_LN
-    __builtin_nontemporal_store(b, reinterpret_cast<bf16x8*>(p));
-#else
     *reinterpret_cast<bf16x8*>(p) = b;
-#endif
 }
 __device__ __forceinline__ void st8(f16_t* p, const float (&v)[8]) {
     f16x8 h;
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
-#ifdef LPI_NT_LN
-    __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(p));
-#else
     *reinterpret_cast<f16x8*>(p) = h;
-#endif
 }
 
 template <int NC, typename TY>

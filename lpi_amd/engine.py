@@ -28,12 +28,8 @@ from . import _lib
 from ._lib import BF16, EPI_DQUICKGELU, EPI_LN, EPI_LN_QUICKGELU, EPI_NONE, EPI_QUICKGELU, EPI_RES_ROWSTATS, F16, F32, call
 from .synth import ClipConfig
 
+import ctypes
 import os as _os
-
-# exact dead-row elimination in the last block (see Tower.forward); LPI_POOLED_LAST=0 evaluates the full block instead (A/B switch)
-POOLED_LAST = _os.environ.get("LPI_POOLED_LAST", "2") != "0"
-# ... and its attention (query / softmax row / out_proj of the pooled token only); LPI_POOLED_LAST=1 keeps the full attention (A/B switch)
-POOLED_ATTN = POOLED_LAST and _os.environ.get("LPI_POOLED_LAST", "2") != "1"
 
 _DT = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "f16": F16, "fp16": F16, "float16": F16, "half": F16}
 
@@ -43,13 +39,60 @@ def _grad_dtype(dt: int) -> int:
     bf16 (gradients do not fit fp16's range without loss scaling; the reference, which runs fp16 end to end, simply lives with that)."""
     return F32 if dt == F32 else BF16
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}
-# bf16 mode stores the forward residual stream in fp16 — the reference's own activation type (it runs fp16 end to end,
-# model.py:371-392) — which halves the bytes of the HBM-bound LayerNorms and residual epilogues; statistics, accumulation and the
-# pooled rows stay f32.  LPI_RESIDUAL=f32 keeps an f32 stream (A/B switch).  f32 (parity) mode always uses f32.
-RESIDUAL_F16 = _os.environ.get("LPI_RESIDUAL", "f16") != "f32"
-# first block's backward: only the prompt rows of dL/dx_0 are ever read (nothing upstream of the prompt slots is trainable), so its
-# in_proj dgrad GEMM and LN1 backward run on B*P rows instead of B*L.  LPI_L0_PROMPT_ROWS=0 computes every row (A/B switch).
-L0_PROMPT_ROWS = _os.environ.get("LPI_L0_PROMPT_ROWS", "1") != "0"
+
+
+@dataclass(frozen=True)
+class EngineOptions:
+    """Everything that selects a code path of the engine, as ONE typed per-engine object (round 6; it replaced sixteen module globals read from the
+    environment at import).  Three fields can be set from the environment (from_env(): documented fall-backs an operator may want without touching
+    code); the rest are constructor arguments that the exactness tests use.  Every settled A/B arm of rounds 1-5 is gone from the code (row-chunked MLP,
+    un-grouped launches, the pooled-MLP-only last block, no split-K, full-mantissa LayerNorm-fold weights): their measurements are in profiles/.
+
+    residual_f16 (LPI_RESIDUAL=f32 -> False): the 2-byte modes store the forward residual stream in fp16 — the reference's own activation type (it runs fp16
+        end to end, model.py:371-392) — which halves the bytes of the HBM-bound LayerNorms and residual epilogues; statistics, accumulation and the
+        pooled rows stay f32.  False keeps an f32 stream (-5.6 % throughput) and with it LayerNorm as its own kernel.  f32 mode always uses f32.
+    ln_fold (LPI_LN_FOLD): 0 = LayerNorm as its own kernel in front of in_proj / c_fc (f32 mode always); 1 = ln_1 folded into in_proj; 2 = ln_2 folded
+        into c_fc as well (default: 22.82-22.91 ms per step against 22.97-23.01 with 1, and the more accurate one: LN(x) is never rounded to bf16).
+    rowstats (LPI_ROWSTATS): 2 = the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
+        LPI_EPI_RES_ROWSTATS + a finalize launch) instead of a pass over it; 1 = ln_2's only; 0 = the two-sweep statistics pass everywhere (what the
+        guard below falls back to).  Same values up to the order of an f32 sum.
+    rowstat_guard: the one-sweep statistics (E[x^2] - mean^2 in f32) lose digits as (mean / std)^2 * 1e-7; the kernels count the rows with
+        mean^2 > 64 var (lpi_rowstat_guard), the engine reads the count without synchronising and drops BOTH towers to rowstats = 0 from the next forward
+        on, with a warning (tests/test_round6_gpu.py: rows 12 sigma off zero).
+    pooled_last: exact dead-row elimination in the last block (only the pooled token's query / softmax row / out_proj / MLP are evaluated, K and V for
+        every token).  False evaluates the whole block: the reference's literal order, kept for the test that holds the two equal.
+    l0_prompt_rows: the first block's backward reads dL/dx_0 at the prompt rows only (nothing upstream of the prompt slots is trainable), so its in_proj
+        dgrad and LN1 backward run on B*P rows.  False computes every row (the exactness test's other arm).
+    qkv_grouped: in_proj's output features of the non-causal tower re-ordered to [head][q|k|v][64] (Tower.__init__).  Same numbers; the attention
+        kernels' (sample, head) slices become 384-byte pieces.  OFF: measured in the step it buys nothing (attn_bwd4 170.9 us either way, forward pair
+        98.4 -> 96.5 us, step 22.27 ms both: profiles/r06_experiments.md) although the kernels alone gain 7 % — kept as the tested proof of that."""
+    residual_f16: bool = True
+    ln_fold: int = 2
+    rowstats: int = 2
+    rowstat_guard: bool = True
+    pooled_last: bool = True
+    l0_prompt_rows: bool = True
+    qkv_grouped: bool = False
+
+    def __post_init__(self):
+        if self.ln_fold not in (0, 1, 2) or self.rowstats not in (0, 1, 2):
+            raise ValueError("ln_fold and rowstats are 0, 1 or 2")
+
+    @staticmethod
+    def from_env(**over):
+        """The defaults, with LPI_RESIDUAL (f16 | f32), LPI_LN_FOLD (0 | 1 | 2) and LPI_ROWSTATS (0 | 1 | 2) applied — read HERE, when an engine is built,
+        not at import — and then the keyword overrides."""
+        env = {}
+        if "LPI_RESIDUAL" in _os.environ:
+            v = _os.environ["LPI_RESIDUAL"]
+            if v not in ("f16", "f32"):
+                raise ValueError(f"LPI_RESIDUAL={v!r}: f16 or f32")
+            env["residual_f16"] = v == "f16"
+        for name, key in (("LPI_LN_FOLD", "ln_fold"), ("LPI_ROWSTATS", "rowstats")):
+            if name in _os.environ:
+                env[key] = int(_os.environ[name])
+        env.update(over)
+        return EngineOptions(**env)
 
 
 def _pad(n: int, m: int = 128) -> int:
@@ -92,31 +135,11 @@ class LnLinear:
             # bf16 mode: gamma o W keeps bf16's 8 significant bits (the precision of every other weight of the mode) inside the fp16 container.
             # Not for accuracy — for POWER: the chip is power-limited under the GEMMs and the matrix pipe's energy follows the operands'
             # mantissa activity; with the three low mantissa bits of B zero the fp16-operand in_proj GEMM loses most of its 4 % penalty
-            # against the bf16 one (24.21 -> 24.08 ms per step, profiles/r02_gemm_experiments.md).  LPI_LN_FOLD_W8=0: full fp16 mantissas.
+            # against the bf16 one (24.21 -> 24.08 ms per step, profiles/r02_gemm_experiments.md).  (full fp16 mantissas: 24.21 ms.)
             wl = wl.to(torch.bfloat16)
         self.w = wl.to(torch.float16).contiguous()
         self.c1 = self.w.double().sum(dim=1).float().contiguous()
         self.c2 = (w @ be + b.to(device=device, dtype=torch.float64)).float().contiguous()
-
-
-# LPI_LN_FOLD: 0 = LayerNorm as its own kernel in front of in_proj / c_fc (f32 mode always); 1 = ln_1 folded into in_proj; 2 = ln_2 folded
-# into c_fc as well.  Measured per layer: the statistics pass saves 18 us against the LayerNorm kernel either way; the fp16-operand in_proj
-# GEMM costs 8 us more than the bf16 one, the c_fc GEMM 18.5 us (profiles/r02_gemm_experiments.md): a wash in round 2 (24.18 / 24.21 ms per step).
-# Re-measured in round 3 (three interleaved pairs on one box): 22.97 / 22.97 / 23.01 ms with 1 against 22.82 / 22.86 / 22.91 with 2 — 2 is the
-# default now (it is also the more accurate one in bf16 mode: LN(x) is never rounded to bf16; tests/test_model_gpu.py fold-level test).
-LN_FOLD = int(_os.environ.get("LPI_LN_FOLD", "2"))
-# LPI_ROWSTATS=2 (default): the statistics the folded LayerNorms need come out of the GEMM that WRITES the stream (out_proj / c_proj + residual,
-# LPI_EPI_RES_ROWSTATS + a finalize launch) instead of a pass over it; 1 = ln_2's only; 0 = the statistics pass everywhere.  Same values up to the
-# order of an f32 sum.  The epilogue costs the GEMM about as much as the pass it replaces — it pays since the residual stream is stored with plain
-# (Infinity-Cache resident) stores: the pass had been warming the cache for the next GEMM (22.81 against 22.95-23.00 ms per step;
-# profiles/r03_experiments.md).  Blocks whose input rows are rewritten by deep prompts first, and the first block, keep the pass.
-MLP_SPLIT = int(_os.environ.get("LPI_MLP_SPLIT", "0"))      # see Tower.mlp_split
-ROWSTATS = int(_os.environ.get("LPI_ROWSTATS", "2"))      # 1: ln_2's (from out_proj, with LPI_LN_FOLD=2); 2: also the next block's ln_1 (from c_proj)
-# The one-sweep statistics (E[x^2] - mean^2 in f32) lose digits as (mean / std)^2 * 1e-7: harmless on a CLIP residual stream with ordinary rows, 2e-3 in
-# rstd at |mean| = 30 std.  LPI_ROWSTAT_GUARD=1 (default): the kernels count the rows with mean^2 > 64 var (lpi_rowstat_guard), the engine reads the
-# count without synchronising (the first flagged row stores 1 to a word of pinned host memory; the host looks at its own word before every forward) and
-# drops BOTH towers to the two-sweep statistics pass (rowstats = 0) from the next forward on, with a warning.  0: no counter (A/B switch).
-ROWSTAT_GUARD = _os.environ.get("LPI_ROWSTAT_GUARD", "1") != "0"
 
 
 # When set to a list, every gemm() launch is bracketed by HIP events on the launch stream and
@@ -124,18 +147,16 @@ ROWSTAT_GUARD = _os.environ.get("LPI_ROWSTAT_GUARD", "1") != "0"
 GEMM_PROFILE = None
 
 
-# Split-K for GEMMs with a few rows (pooled rows of the last block, heads): LPI_SPLITK=0 disables it (A/B switch).
-SPLITK = _os.environ.get("LPI_SPLITK", "1") != "0"
-# workgroups a split-K launch aims at (slices = this // tiles, a divisor of the K-tile count): more slices shorten the partial kernel's K loop and
-# lengthen the reduction (slices x M x N f32 partials); LPI_SPLITK_WGS: A/B switch
-SPLITK_WGS = int(_os.environ.get("LPI_SPLITK_WGS", "384"))
+# Split-K for GEMMs with a few rows (pooled rows of the last block, heads): workgroups a launch aims at (slices = this // tiles, a divisor of the K-tile
+# count): more slices shorten the partial kernel's K loop and lengthen the reduction (slices x M x N f32 partials)
+SPLITK_WGS = 384
 _SPLITK_SCRATCH = {}
 
 
 def _splitk_plan(dt, M, N, K):
     """Number of K slices for a small-M GEMM (0 = use the plain kernel): enough 128x128 workgroups to cover the chip, whole K tiles
     per slice."""
-    if not SPLITK or M > 256 or M % 128 or N % 128:
+    if M > 256 or M % 128 or N % 128:
         return 0
     nk = K // (32 if dt == F32 else 64)
     tiles = (M // 128) * (N // 128)
@@ -216,7 +237,7 @@ class GemmReq(Req):
     __slots__ = ("tag", "dt", "a", "b", "c", "M", "N", "K", "kw", "optional")
 
     def __init__(self, tag, dt, a, b, c, M, N, K, optional=False, **kw):
-        # optional: a request only THIS tower emits (a later row chunk of its MLP, Tower.mlp_split): run_lockstep issues it alone
+        # optional: a request only THIS tower emits (e.g. a statistics pass the other tower does not take): run_lockstep issues it alone
         self.tag, self.dt, self.a, self.b, self.c, self.M, self.N, self.K, self.kw, self.optional = tag, dt, a, b, c, M, N, K, kw, optional
 
     def issue(self):
@@ -232,7 +253,9 @@ class AttnFwdReq(Req):
 
     def issue(self):
         a = self.args
-        if len(a) > 10 and a[10]:      # shared prefix (PackedIds(shared=...)): B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal, shared rows
+        if len(a) > 11 and a[11] is not None:      # layout strides (Tower.qkv_lay): the descriptor form is the one that takes them
+            _lib.attn_fwd_one(self.dt, a, _stream())
+        elif len(a) > 10 and a[10]:      # shared prefix (PackedIds(shared=...)): B, L, row_start, H, qkv, ldqkv, ctx, ldctx, lse, causal, shared rows
             call("lpi_attn_fwd_shared", self.dt, a[0], a[1], a[2], a[10], *a[3:9], _stream())
         else:
             call("lpi_attn_fwd_varlen", self.dt, *a[:10], _stream())
@@ -314,47 +337,39 @@ def _cdt(c):
     return F32 if c.dtype == torch.float32 else (F16 if c.dtype == torch.float16 else BF16)
 
 
-# LPI_GROUP_TOWERS=0: the towers' GEMMs are never grouped (A/B switch; the library knob is lpi_set_tuning(8, 1))
-GROUP_TOWERS = _os.environ.get("LPI_GROUP_TOWERS", "1") != "0"
-GROUP_LN = _os.environ.get("LPI_GROUP_LN", "1") != "0"      # ... the towers' LayerNorms of one layer as one launch (A/B switch)
-GROUP_ATTN = _os.environ.get("LPI_GROUP_ATTN", "1") != "0"  # ... and their attention forwards
-GROUP_SPLITK = _os.environ.get("LPI_GROUP_SPLITK", "1") != "0"  # ... and their few-row (split-K) GEMMs
-GROUP_ROWS = _os.environ.get("LPI_GROUP_ROWS", "1") != "0"      # ... and their small row kernels / pooled attention / prompt-row sums (round 4)
-
-
 def _issue_pair(r0: GemmReq, r1: GemmReq):
     """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
     kind), else two launches — the same bits either way."""
     if isinstance(r0, RowReq) or isinstance(r1, RowReq):
-        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, RowReq) and isinstance(r1, RowReq):
+        if isinstance(r0, RowReq) and isinstance(r1, RowReq):
             _lib.row_jobs(r0.jobs + r1.jobs, _stream())
         else:
             r0.issue()
             r1.issue()
         return
     if isinstance(r0, RowsSumReq) or isinstance(r1, RowsSumReq):
-        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, RowsSumReq) and isinstance(r1, RowsSumReq) and r0.dt == r1.dt:
+        if isinstance(r0, RowsSumReq) and isinstance(r1, RowsSumReq) and r0.dt == r1.dt:
             _lib.rows_sum_pair(r0.dt, r0.args, r1.args, _stream())
         else:
             r0.issue()
             r1.issue()
         return
     if isinstance(r0, PoolAttnReq) or isinstance(r1, PoolAttnReq):
-        if GROUP_TOWERS and GROUP_ROWS and isinstance(r0, PoolAttnReq) and isinstance(r1, PoolAttnReq) and r0.dt == r1.dt and r0.bwd == r1.bwd:
+        if isinstance(r0, PoolAttnReq) and isinstance(r1, PoolAttnReq) and r0.dt == r1.dt and r0.bwd == r1.bwd:
             _lib.attn_pooled_pair(r0.dt, r0.desc, r1.desc, _stream(), backward=r0.bwd)
         else:
             r0.issue()
             r1.issue()
         return
     if isinstance(r0, AttnFwdReq) or isinstance(r1, AttnFwdReq):
-        if GROUP_TOWERS and GROUP_ATTN and isinstance(r0, AttnFwdReq) and isinstance(r1, AttnFwdReq) and r0.dt == r1.dt and r0.dt != F32:
+        if isinstance(r0, AttnFwdReq) and isinstance(r1, AttnFwdReq) and r0.dt == r1.dt and r0.dt != F32:
             _lib.attn_fwd_pair(r0.dt, r0.args, r1.args, _stream())
         else:
             r0.issue()
             r1.issue()
         return
     if isinstance(r0, StatFinReq) or isinstance(r1, StatFinReq):
-        if GROUP_TOWERS and GROUP_LN and isinstance(r0, StatFinReq) and isinstance(r1, StatFinReq):
+        if isinstance(r0, StatFinReq) and isinstance(r1, StatFinReq):
             a, b = r0.args, r1.args
             call("lpi_ln_stats_finalize_pair", a[0], a[1], a[2], a[3], a[4], a[5], b[0], b[1], b[2], b[3], b[4], b[5], 1e-5, _stream())
         else:
@@ -363,7 +378,7 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
         return
     if isinstance(r0, LnReq) or isinstance(r1, LnReq):
         stats_only = [r.kind == "fwd" and r.args[6] is None for r in (r0, r1) if isinstance(r, LnReq)]      # one tower folds its LayerNorms, the other not
-        if (GROUP_TOWERS and GROUP_LN and isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts
+        if (isinstance(r0, LnReq) and isinstance(r1, LnReq) and r0.kind == r1.kind and r0.dts == r1.dts
                 and stats_only[0] == stats_only[1]):
             (_lib.layernorm_fwd_pair if r0.kind == "fwd" else _lib.layernorm_bwd_pair)(*r0.dts, r0.args, r1.args, _stream())
         else:
@@ -371,14 +386,14 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             r1.issue()
         return
     k0, k1 = r0.kw, r1.kw
-    same = (GROUP_TOWERS and r0.dt == r1.dt and r0.dt != F32 and r0.c.dtype == r1.c.dtype and k0.get("epi", EPI_NONE) == k1.get("epi", EPI_NONE)
+    same = (r0.dt == r1.dt and r0.dt != F32 and r0.c.dtype == r1.c.dtype and k0.get("epi", EPI_NONE) == k1.get("epi", EPI_NONE)
             and (k0.get("residual") is None) == (k1.get("residual") is None) and (k0.get("aux") is None) == (k1.get("aux") is None)
             and (k0.get("bias") is None) == (k1.get("bias") is None) and k0.get("alpha", 1.0) == k1.get("alpha", 1.0)
             )
     cdt = _cdt(r0.c)
     # few-row GEMMs (pooled rows of the last block, heads): the two split-K launch pairs as one (lpi_gemm_nt_splitk_pair)
     ks = ([_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)]
-          if (same and GROUP_SPLITK and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS))
+          if (same and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS))
           else [0, 0])
     few = bool(ks[0] and ks[1])
     if not same or not (few or min(r0.M, r1.M) > 256):
@@ -472,16 +487,33 @@ class TowerSpec:
 class Tower:
     """One transformer tower (vision or text): weights + forward/backward over a [B*L, d] residual stream."""
 
-    def __init__(self, sd: dict, prefix: str, spec: TowerSpec, dt: int, device):
+    def __init__(self, sd: dict, prefix: str, spec: TowerSpec, dt: int, device, opt: Optional[EngineOptions] = None):
         self.spec, self.dt, self.device = spec, dt, device
+        self.opt = opt = opt if opt is not None else EngineOptions.from_env()
         self.gdt = _grad_dtype(dt)                                      # operand / storage type of the backward
-        self.xdt = F16 if (dt != F32 and RESIDUAL_F16) else F32       # storage type of the forward residual stream
+        self.xdt = F16 if (dt != F32 and opt.residual_f16) else F32   # storage type of the forward residual stream
         self.blocks = []
         f = lambda k: torch.as_tensor(np.asarray(sd[k])) if not torch.is_tensor(sd[k]) else sd[k]  # noqa: E731
+        # HEAD-GROUPED q / k / v (round 6): in_proj's output features re-ordered from [q | k | v][head][64] to [head][q | k | v][64] — a permutation of the
+        # frozen weight's rows (and of its bias, of W^T's columns and of the LayerNorm fold's c1 / c2), prepared once, so the GEMMs run unchanged and produce
+        # the same numbers in another column order.  A (sample, head) slice of qkv / dqkv is then L pieces of 384 contiguous bytes instead of 3 L pieces of
+        # 128: the streamed attention backward, which is bound by its memory path, 198.6 -> 183.8 us on the vision shape (tools/attn_layout_probe2.py:
+        # the kernels take the layout as strides and give the same bits).  The non-causal tower in the 2-byte modes; its last block keeps the
+        # interleaved order (the pooled-row kernels read K and V as the rows d .. 3 d of the weight).  EngineOptions.qkv_grouped: OFF by default (in the step
+        # it measured nothing: see there).
+        self.qkv_grouped = bool(opt.qkv_grouped and dt != F32 and not spec.causal and spec.layers > 1)
+        d_, H_ = spec.width, spec.heads
+        self.qkv_lay = (3 * 64, 64, 64)                                 # (head stride, q -> k -> v stride, ctx head stride) of a grouped block
+        perm = torch.arange(3 * d_).view(3, H_, 64).permute(1, 0, 2).reshape(-1)      # new feature h*192 + w*64 + c  <-  old w*d + h*64 + c
         for i in range(spec.layers):
             p = f"{prefix}resblocks.{i}."
+            grouped = self.qkv_grouped and i < spec.layers - 1
+            wq, bq = f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias")
+            if grouped:
+                wq, bq = wq[perm.to(wq.device)], bq[perm.to(bq.device)]
             blk = {
-                "qkv": Linear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), dt, device),
+                "qkv": Linear(wq, bq, dt, device),
+                "grouped": grouped,
                 "out": Linear(f(p + "attn.out_proj.weight"), f(p + "attn.out_proj.bias"), dt, device),
                 "fc": Linear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), dt, device),
                 "proj": Linear(f(p + "mlp.c_proj.weight"), f(p + "mlp.c_proj.bias"), dt, device),
@@ -489,22 +521,14 @@ class Tower:
             for nm in ("ln_1", "ln_2"):
                 blk[nm + ".w"] = f(p + nm + ".weight").to(device=device, dtype=torch.float32).contiguous()
                 blk[nm + ".b"] = f(p + nm + ".bias").to(device=device, dtype=torch.float32).contiguous()
-            if dt != F32 and self.xdt == F16 and LN_FOLD:
-                w8 = dt == BF16 and _os.environ.get("LPI_LN_FOLD_W8", "1") != "0"
-                blk["qkv_ln"] = LnLinear(f(p + "attn.in_proj_weight"), f(p + "attn.in_proj_bias"), blk["ln_1.w"], blk["ln_1.b"], device, w8)
+            if dt != F32 and self.xdt == F16 and opt.ln_fold:
+                w8 = dt == BF16      # bf16 mode: gamma o W keeps bf16's 8 significant bits inside the fp16 container (LnLinear: power, not accuracy)
+                blk["qkv_ln"] = LnLinear(wq, bq, blk["ln_1.w"], blk["ln_1.b"], device, w8)
                 blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device, w8)
             self.blocks.append(blk)
         self._ws = {}
-        self.rowstats = ROWSTATS      # per tower (a test sets one tower to 0: the lock-stepped towers must re-align, run_lockstep)
+        self.rowstats = opt.rowstats      # per tower, mutable (the guard sets it to 0; a test sets one tower to 0: the lock-stepped towers must re-align)
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
-
-    def mlp_split(self, Mp):
-        """Rows of the FIRST row chunk of the MLP (a multiple of 256), 0 = the MLP runs over all rows at once.  LPI_MLP_SPLIT = row panels (of 256 rows)
-        of the first chunk (A/B switch; only the wider tower splits)."""
-        p = MLP_SPLIT
-        if p <= 0 or self.spec.causal or p * 256 >= Mp - 256 * 32:
-            return 0
-        return p * 256
 
     def _check_depth(self, prompts, depth):
         """model.py:191 indexes prompts[:, layer_id]: the reference raises IndexError past the stack; so do we (before any kernel)."""
@@ -546,6 +570,7 @@ class Tower:
         for k in [k for k in self._ws if k[1] == train]:
             del self._ws[k]
         d, H, nl = self.spec.width, self.spec.heads, self.spec.layers
+        POOLED_LAST = self.opt.pooled_last
         Lreal, L = L, max(L, cap or L)
         Mp = _pad(B * L, 256)      # whole 256x256 GEMM tiles (the 128x128 kernel takes any multiple of 128)
         Bp = _pad(B)
@@ -596,13 +621,10 @@ class Tower:
         for i, blk in enumerate(self.blocks):
             if "qkv_ln" in blk:
                 c1 = blk["qkv_ln"].c1
-                if i == nl - 1 and POOLED_ATTN:      # the last block's in_proj GEMM covers K and V only (rows d.. of the weight)
+                if i == nl - 1 and POOLED_LAST:      # the last block's in_proj GEMM covers K and V only (rows d.. of the weight)
                     c1 = c1[d:]
                 ws["lnblk"][i][0, 2 * Mp:2 * Mp + c1.numel()].copy_(c1)
                 ws["lnblk"][i][1, 2 * Mp:2 * Mp + 4 * d].copy_(blk["fc_ln"].c1)
-                r1 = self.mlp_split(Mp)
-                if r1:
-                    ws["lnblk"][i][1, 2 * Mp + r1:2 * Mp + r1 + 4 * d].copy_(blk["fc_ln"].c1)
         self._ws[key] = ws
         return bind(ws, Lreal)
 
@@ -622,6 +644,7 @@ class Tower:
 
         prompts: f32 tensor whose element (b, layer, p, :) sits at  b*prompt_bstride + (layer*P + p)*d."""
         sp, dt, xdt, s = self.spec, self.dt, self.xdt, _stream()
+        POOLED_LAST, LN_FOLD = self.opt.pooled_last, self.opt.ln_fold
         d, H = sp.width, sp.heads
         B, L, Mp, M = ws["B"], ws["L"], ws["Mp"], ws["M"]
         rs = ws["rs"]                                  # ragged batch: row starts (device int32 [B+1]); None = B x L rows
@@ -654,7 +677,7 @@ class Tower:
                 yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, None, None, None, 0, st[0], st[1], optional=True)
             else:
                 yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], optional=True)
-            if i == len(self.blocks) - 1 and POOLED_ATTN:
+            if i == len(self.blocks) - 1 and POOLED_LAST:
                 # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
@@ -680,7 +703,7 @@ class Tower:
                 yield GemmReq(f"{lt}.qkv", F16, x_in, ql.w, qkv, Mp, 3 * d, d, bias=ql.c2, residual=lnb[0], ldr=ln_ld, epi=EPI_LN, m_real=M)
             else:
                 yield GemmReq(f"{lt}.qkv", dt, ws["h"], blk["qkv"].w, qkv, Mp, 3 * d, d, bias=blk["qkv"].b, m_real=M)
-            yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), pre)
+            yield AttnFwdReq(f"{lt}.attn", dt, B, L, rs, H, qkv, 3 * d, ctx, d, lse, int(sp.causal), pre, self.qkv_lay if blk["grouped"] else None)
             ln2_stats = rowstats >= 1 and LN_FOLD >= 2 and not (i == len(self.blocks) - 1 and POOLED_LAST)
             if ln2_stats:      # x + attn(..) and the slot sums of its rows in one epilogue; ln_2's mean / rstd from them
                 yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M, epi=EPI_RES_ROWSTATS,
@@ -688,45 +711,25 @@ class Tower:
                 yield StatFinReq(f"{lt}.fin2", M, d, ws["rstat"], ws["rstat"].stride(0), st[2], st[3])
             else:
                 yield GemmReq(f"{lt}.out", dt, ctx, blk["out"].w, xmid, Mp, d, d, bias=blk["out"].b, residual=x_in, m_real=M)
-            if i == len(self.blocks) - 1 and POOLED_LAST:      # LPI_POOLED_LAST=1: full attention, pooled MLP
-                Bp, cst = ws["Bp"], ws["c_stat"]
-                call("lpi_gather_rows", xdt, B, Lx, d, xmid, pidx, ws["c_xmid"], s)
-                call("lpi_pool_ln_fwd", dt, xdt, B, Lx, d, xmid, pidx, blk["ln_2.w"], blk["ln_2.b"], ws["c_h"], d, cst[0], cst[1], s)
-                yield GemmReq(f"{lt}.cfc", dt, ws["c_h"], blk["fc"].w, ws["c_g"], Bp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=ws["c_u"], m_real=B)
-                yield GemmReq(f"{lt}.cproj", dt, ws["c_g"], blk["proj"].w, ws["c_xout"], Bp, d, 4 * d, bias=blk["proj"].b, residual=ws["c_xmid"], m_real=B)
-                return ws["c_xout"]
             # the next block's ln_1 statistics come out of c_proj's epilogue; rows that deep prompts rewrite first get theirs from prompt_add (above)
             nxt = i + 1
             have_ln1 = rowstats >= 2 and nxt < len(self.blocks) and "qkv_ln" in self.blocks[nxt]
-            # MLP in row chunks (mlp_split): c_fc and c_proj of the first rows, then of the rest — same tiles, same bits; the first chunk keeps the
-            # op's tags (it pairs with the other tower's GEMMs), the later ones are this tower's alone
-            r1 = self.mlp_split(Mp) if (fold and LN_FOLD >= 2) else 0
-            chunks = [(0, r1), (r1, Mp - r1)] if r1 else [(0, Mp)]
-
-            def proj_req(ci, r0, n):
-                kw = dict(bias=blk["proj"].b, residual=xmid[r0:r0 + n], m_real=max(0, min(n, M - r0)))
-                if have_ln1:
-                    kw.update(epi=EPI_RES_ROWSTATS, aux=ws["rstat"][:, r0:])
-                yield GemmReq(f"{lt}.proj" + ("" if ci == 0 else f"#{ci}"), dt, ws["g"][r0:r0 + n], blk["proj"].w, x_out[r0:r0 + n], n, d, 4 * d, optional=ci > 0, **kw)
-
+            proj_kw = dict(bias=blk["proj"].b, residual=xmid, m_real=M)
+            if have_ln1:
+                proj_kw.update(epi=EPI_RES_ROWSTATS, aux=ws["rstat"])
             if fold and LN_FOLD >= 2:
                 fl = blk["fc_ln"]
                 if not ln2_stats:
                     yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, None, None, None, 0, st[2], st[3], optional=True)
-                for ci, (r0, n) in enumerate(chunks):
-                    yield GemmReq(f"{lt}.fc" + ("" if ci == 0 else f"#{ci}"), F16, xmid[r0:r0 + n], fl.w, ws["g"][r0:r0 + n], n, 4 * d, d, optional=ci > 0, bias=fl.c2,
-                                  residual=lnb[1][r0:], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=None if u is None else u[r0:r0 + n], m_real=max(0, min(n, M - r0)))
-                    if len(chunks) > 1:
-                        yield from proj_req(ci, r0, n)
+                yield GemmReq(f"{lt}.fc", F16, xmid, fl.w, ws["g"], Mp, 4 * d, d, bias=fl.c2, residual=lnb[1], ldr=ln_ld, epi=EPI_LN_QUICKGELU, aux=u, m_real=M)
             else:
                 yield LnReq(f"{lt}.ln2", "fwd", (dt, xdt), M, d, xmid, d, blk["ln_2.w"], blk["ln_2.b"], ws["h"], d, st[2], st[3], optional=True)
                 yield GemmReq(f"{lt}.fc", dt, ws["h"], blk["fc"].w, ws["g"], Mp, 4 * d, d, bias=blk["fc"].b, epi=EPI_QUICKGELU, aux=u, m_real=M)
-            if len(chunks) == 1:
-                yield from proj_req(0, 0, Mp)
+            yield GemmReq(f"{lt}.proj", dt, ws["g"], blk["proj"].w, x_out, Mp, d, 4 * d, **proj_kw)
             if have_ln1:
                 nst = ws["stat"][nxt]
                 yield StatFinReq(f"{lt}.fin1", M, d, ws["rstat"], ws["rstat"].stride(0), nst[0], nst[1])
-        call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # LPI_POOLED_LAST=0: full last block, then pool
+        call("lpi_gather_rows", xdt, B, Lx, d, x_out, pidx, ws["c_xout"], s)      # pooled_last = False: full last block, then pool
         return ws["c_xout"]
 
     def forward(self, ws, prompts=None, prompt_bstride=0, depth=1, train=True, pool_idx=None):
@@ -740,6 +743,7 @@ class Tower:
         alignment-loss gradient the step seeded them with, DualEncoder.seed_prompt_grads)."""
         sp, dt, xdt, s = self.spec, self.gdt, self.xdt, _stream()        # dt: the BACKWARD's operand / storage type from here on
         adt = F16 if self.dt == F16 else dt       # attention backward: F16 = "saved q, k, v, ctx are fp16; gradients and operands bf16"
+        POOLED_LAST, L0_PROMPT_ROWS = self.opt.pooled_last, self.opt.l0_prompt_rows
         d, H = sp.width, sp.heads
         B, L, Mp, M = ws["B"], ws["L"], ws["Mp"], ws["M"]
         rs = ws["rs"]                                  # ragged batch: row starts (device int32 [B+1]); None = B x L rows
@@ -769,10 +773,7 @@ class Tower:
                 yield RowReq(f"{lt}.cdln2", [_lib.row_job(_lib.ROWOP_LN_BWD, B=B, d=d, dt_a=dt, dt_b=dt, a=ws["c_dh"], ld_a=d, b=ws["c_xmid"], ld_b=d,
                                                           gamma=blk["ln_2.w"], mean_in=cst[0], rstd_in=cst[1], out=c_dx, out2=None if dt == F32 else c_dxT,
                                                           ld_c=d, flag=1)])
-                if not POOLED_ATTN:
-                    call("lpi_zero", dxT, dxT.numel() * dxT.element_size(), s)
-                    call("lpi_scatter_rows", dt, B, Lx, d, c_dx, pidx, dx, None if dt == F32 else dxT, s)
-            if i == len(self.blocks) - 1 and POOLED_ATTN:
+                # ... and, on the same pooled rows, the attention branch:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
                 yield GemmReq(f"{lt}.cdout", dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
@@ -802,6 +803,11 @@ class Tower:
             if pre:
                 call("lpi_attn_bwd_shared", adt, B, L, rs, pre, (1 + P) if l0_rows else L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d,
                      ws["shared_dkv"], s)
+            elif blk["grouped"]:
+                hs_, vs_, chs_ = self.qkv_lay
+                lay = (ctypes.c_int32 * 6)(hs_, vs_, hs_, vs_, chs_, chs_)
+                call("lpi_attn_bwd_layout", adt, B, L, (1 + P) if l0_rows else L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d,
+                     ctypes.cast(lay, ctypes.c_void_p), s)
             else:
                 call("lpi_attn_bwd_prefix", adt, B, L, rs, (1 + P) if l0_rows else L, H, qkv, 3 * d, ctx, d, dctx, d, lse, ws["delta"], dqkv, 3 * d,
                      int(sp.causal), s)
@@ -836,8 +842,10 @@ class Tower:
 class DualEncoder:
     """CLIP ViT + text transformer with prompt side inputs, forward and dgrad backward, on one MI355X."""
 
-    def __init__(self, cfg: ClipConfig, state_dict: dict, dtype: str = "f32", device="cuda:0", n_ctx: int = 16):
+    def __init__(self, cfg: ClipConfig, state_dict: dict, dtype: str = "f32", device="cuda:0", n_ctx: int = 16, options: Optional[EngineOptions] = None):
+        """options: an EngineOptions (None = EngineOptions.from_env(): the defaults with the three documented environment fall-backs applied)."""
         self.cfg = cfg
+        self.opt = options if options is not None else EngineOptions.from_env()
         self.device = torch.device(device)
         _require_gpu(self.device)
         _lib.load()
@@ -848,8 +856,8 @@ class DualEncoder:
         dev, dt = self.device, self.dt
         t = lambda k: (state_dict[k] if torch.is_tensor(state_dict[k]) else torch.as_tensor(np.asarray(state_dict[k]))).to(  # noqa: E731
             device=dev, dtype=torch.float32).contiguous()
-        self.vis = Tower(state_dict, "visual.transformer.", TowerSpec(cfg.vision_width, cfg.vision_heads, cfg.vision_layers, False), dt, dev)
-        self.txt = Tower(state_dict, "transformer.", TowerSpec(cfg.transformer_width, cfg.transformer_heads, cfg.transformer_layers, True), dt, dev)
+        self.vis = Tower(state_dict, "visual.transformer.", TowerSpec(cfg.vision_width, cfg.vision_heads, cfg.vision_layers, False), dt, dev, self.opt)
+        self.txt = Tower(state_dict, "transformer.", TowerSpec(cfg.transformer_width, cfg.transformer_heads, cfg.transformer_layers, True), dt, dev, self.opt)
         ps = cfg.vision_patch_size
         self.kp = _pad(3 * ps * ps, 32 if dt == F32 else 64)
         self.conv = Linear(t("visual.conv1.weight").reshape(cfg.vision_width, -1), None, dt, dev, k_pad=self.kp)
@@ -865,9 +873,9 @@ class DualEncoder:
         self.logit_scale = t("logit_scale")
         self.logit_scale_exp = float(math.exp(float(np.asarray(state_dict["logit_scale"] if not torch.is_tensor(state_dict["logit_scale"]) else state_dict["logit_scale"].cpu()))))
         self._head_ws = {}
-        # guard of the one-sweep LayerNorm statistics (ROWSTAT_GUARD above): a device counter, and a word of PINNED host memory the kernels flag
-        self._guard = torch.zeros(1, dtype=torch.int32, device=dev) if ROWSTAT_GUARD else None
-        self._guard_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if ROWSTAT_GUARD else None
+        # guard of the one-sweep LayerNorm statistics (EngineOptions.rowstat_guard): a device counter, and a word of PINNED host memory the kernels flag
+        self._guard = torch.zeros(1, dtype=torch.int32, device=dev) if self.opt.rowstat_guard else None
+        self._guard_flag = torch.zeros(1, dtype=torch.int32).pin_memory() if self.opt.rowstat_guard else None
         self.rowstat_guard_tripped = 0          # rows counted when the guard switched the towers to the statistics pass (0 = never)
 
     # ------------------------------------------------------------------ uint8 pixels
@@ -892,7 +900,7 @@ class DualEncoder:
             n = int(self._guard.item())          # the one synchronisation, once, on the way out of the fast path
             import warnings
             warnings.warn(f"lpi_amd: {n} residual-stream rows with |mean| > 8 std were seen by the one-sweep LayerNorm statistics (E[x^2] - mean^2 loses "
-                          "digits there); both towers use the two-sweep statistics pass from now on (LPI_ROWSTATS=0 behaviour: exact, ~0.6 % slower)",
+                          "digits there); both towers use the two-sweep statistics pass from now on (rowstats = 0 behaviour: exact, ~0.6 % slower)",
                           RuntimeWarning, stacklevel=3)
             self.vis.rowstats = self.txt.rowstats = 0
             self.rowstat_guard_tripped = max(n, 1)
@@ -1326,7 +1334,7 @@ def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True, r0: int = 
     call("lpi_clip_loss_local", n, logits, npad, 1.0, r0, nloc, loss, lse[0], lse[1], g, gt, npad, s)
     call("lpi_transpose2", F32, npad if A is ws["A"] else n, E, A, A.stride(0), At, npad, npad if Bm is ws["B"] else n, E, Bm, Bm.stride(0), Bt, npad, s)
     dI, dT = torch.empty(lpad, E, device=dev), torch.empty(lpad, E, device=dev)
-    ks = _splitk_plan(F32, lpad, E, npad) if GROUP_SPLITK else 0
+    ks = _splitk_plan(F32, lpad, E, npad)
     if ks and GEMM_PROFILE is None:
         n0 = (ks * lpad * E + 63) // 64 * 64
         buf = _splitk_scratch(dev, n0 + ks * lpad * E)

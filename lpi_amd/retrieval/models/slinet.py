@@ -126,7 +126,11 @@ class SliNet(nn.Module):
         if self.engine is None:
             from lpi_amd.engine import DualEncoder
             dev = torch.device(device) if device is not None else self.prompts[0].dim_1_share.device
-            self.engine = DualEncoder(self.clip_cfg, self.clip_model.state_dict(), dtype=self.compute_dtype, device=dev, n_ctx=self.cfg.NCTX)
+            from lpi_amd.engine import EngineOptions
+            eo = self.args.get("engine_options")      # None, an EngineOptions, or a dict of its fields (the config file's form)
+            if isinstance(eo, dict):
+                eo = EngineOptions.from_env(**eo)
+            self.engine = DualEncoder(self.clip_cfg, self.clip_model.state_dict(), dtype=self.compute_dtype, device=dev, n_ctx=self.cfg.NCTX, options=eo)
             self.logit_scale = self.engine.logit_scale
         return self.engine
 

@@ -12,9 +12,6 @@ from . import engine as E
 from .functional import AlignLossFn, ClipLossFn, DecomposedPromptFn, EncodeBothFn, EncodeImageFn, EncodeTextFn, contrastive_loss_and_grads
 from .synth import PROMPT_NAMES
 
-import os as _os
-
-SEED_GRADS = _os.environ.get("LPI_SEED_GRADS", "1") != "0"      # A/B switch: 0 = autograd adds the alignment gradient and the towers' (two ATen kernels)
 _CP_ORDER = ("dim_1_share", "dim_2_visual", "dim_2_textual", "dim_3_visual", "dim_3_textual")
 
 
@@ -105,9 +102,9 @@ def train_step(enc, images, ids, factors: dict, depth: int = 1, exchange=None, a
     # (DualEncoder.seed_prompt_grads).  The stacks then receive ONE gradient each, from the encoder node, so autograd has nothing to accumulate; the node
     # hands the buffers on without a copy ('dprompts_borrow': DecomposedPromptFn.backward consumes them at once).  Towers on lanes of their own
     # (overlap_towers) keep the plain path: the stacks are autograd roots too and autograd adds the two gradients.
-    seed = not overlap_towers and SEED_GRADS
+    seed = not overlap_towers
     if task_term is not None and not seed:
-        raise ValueError("task_term needs the seeded prompt-gradient path (one stream, LPI_SEED_GRADS=1)")
+        raise ValueError("task_term needs the seeded prompt-gradient path (the towers on one stream)")
     # the contexts of THIS call's forward (EncodeBothFn keeps them on its node; the lock-step / separate-node paths leave them on the engine)
     vis_ctx, txt_ctx = (enc._vis_ctx, enc._txt_ctx) if seed else (None, None)
     wss = [vis_ctx[0], txt_ctx[0]] if seed else []

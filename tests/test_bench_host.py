@@ -12,7 +12,7 @@ import os, sys, json
 sys.path.insert(0, {REPO!r})
 import bench
 before = sorted(os.sched_getaffinity(0))
-mine = bench.pin_rank_to_cpus(int(sys.argv[1]), int(sys.argv[2]))
+mine = bench.pin_rank_to_cpus(int(sys.argv[1]), int(sys.argv[2]), enabled=len(sys.argv) < 4)
 import torch
 print(json.dumps({{"before": before, "mine": mine, "now": sorted(os.sched_getaffinity(0)), "gpu_initialised": bool(torch.cuda.is_initialized())}}))
 """
@@ -30,8 +30,7 @@ print(json.dumps({{"before": before, "mine": mine, "now": sorted(os.sched_getaff
     assert set(a["mine"]) | set(b["mine"]) <= set(allowed)
     one = subprocess.run([sys.executable, "-c", code, "0", "1"], capture_output=True, text=True, check=True)
     assert json.loads(one.stdout.strip().splitlines()[-1])["mine"] is None               # a single rank keeps every CPU
-    env = dict(os.environ, LPI_NO_AFFINITY="1")
-    off = subprocess.run([sys.executable, "-c", code, "0", "2"], capture_output=True, text=True, check=True, env=env)
+    off = subprocess.run([sys.executable, "-c", code, "0", "2", "off"], capture_output=True, text=True, check=True)      # bench.py --no-affinity
     assert json.loads(off.stdout.strip().splitlines()[-1])["mine"] is None
 
 

@@ -21,8 +21,10 @@ def dev_factors(cfg, task=0, requires_grad=True):
     return {k: torch.from_numpy(v).to(DEV).requires_grad_(requires_grad) for k, v in f.items()}, f
 
 
-def run_hip(cfg, dtype, batch, ids, depth, pack=False):
-    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=DEV)
+def run_hip(cfg, dtype, batch, ids, depth, pack=False, **options):
+    """options: EngineOptions fields (the non-default arms the exactness tests compare with)"""
+    from lpi_amd.engine import EngineOptions
+    enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=DEV, options=EngineOptions(**options) if options else None)
     fac, fac_np = dev_factors(cfg)
     img = torch.from_numpy(synth.images(batch, cfg.image_resolution)).to(DEV)
     n0 = _lib.launch_count()
@@ -228,18 +230,15 @@ def test_bitwise_reproducible_gradients():
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 2e-2)])
-def test_last_block_dead_row_elimination_is_exact(monkeypatch, dtype, tol):
-    """The last block evaluated (a) in full, (b) with the MLP on the pooled rows only, (c) with the query / softmax row / out_proj
-    on the pooled rows too (the default) gives the same features and factor gradients: the heads read the pooled token only
+def test_last_block_dead_row_elimination_is_exact(dtype, tol):
+    """The last block evaluated in full (EngineOptions(pooled_last=False): the reference's literal order) and with the query / softmax row / out_proj / MLP
+    on the pooled rows only (the default) gives the same features and factor gradients: the heads read the pooled token only
     (model.py:255, prompt_learner.py:61)."""
-    from lpi_amd import engine as E
     cfg = synth.TINY
     ids = synth.token_ids(5, n_ctx=16)
     out = []
-    for last, attn in ((False, False), (True, False), (True, True)):
-        monkeypatch.setattr(E, "POOLED_LAST", last)
-        monkeypatch.setattr(E, "POOLED_ATTN", attn)
-        res, _ = run_hip(cfg, dtype, 5, ids, 2)
+    for last in (False, True):
+        res, _ = run_hip(cfg, dtype, 5, ids, 2, pooled_last=last)
         out.append(res)
     for res in out[1:]:
         for k in ("img_f", "txt_f"):
@@ -251,15 +250,20 @@ def test_last_block_dead_row_elimination_is_exact(monkeypatch, dtype, tol):
 
 def test_bf16_mode_fp16_residual_stream_vs_f32_stream(monkeypatch):
     """bf16 mode stores the forward residual stream in fp16 (the reference's own activation type).  Against the same mode with an
-    f32 stream the features move by far less than the bf16 operand rounding already does, and both sit within the bf16-mode bar
-    of the f64 oracle."""
-    from lpi_amd import engine as E
+    f32 stream (LPI_RESIDUAL=f32, read by EngineOptions.from_env when the engine is built) the features move by far less than the bf16 operand rounding
+    already does, and both sit within the bf16-mode bar of the f64 oracle."""
+    from lpi_amd.engine import EngineOptions, F16, F32
     cfg = synth.TINY
     ids = synth.token_ids(6, n_ctx=16)
     res = {}
     for f16 in (True, False):
-        monkeypatch.setattr(E, "RESIDUAL_F16", f16)
+        monkeypatch.setenv("LPI_RESIDUAL", "f16" if f16 else "f32")          # the environment fall-back itself: no options argument
+        assert EngineOptions.from_env().residual_f16 == f16
+        enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
+        assert enc.vis.xdt == (F16 if f16 else F32)
+        del enc
         res[f16], fac_np = run_hip(cfg, "bf16", 6, ids, 2)
+    monkeypatch.delenv("LPI_RESIDUAL")
     ora = O.Oracle(cfg, synth.clip_state_dict(cfg), dtype=torch.float64)
     ref = O.train_step(ora, synth.images(6, cfg.image_resolution), ids, fac_np, depth=2)
     for k in ("img_f", "txt_f"):
@@ -366,16 +370,15 @@ def test_prompt_depth_is_validated():
 
 
 @pytest.mark.parametrize("cfg_name,dtype,depth,tol", [("tiny", "f32", 2, 2e-6), ("ViT-B/16", "f32", 3, 2e-5), ("ViT-B/16", "bf16", 3, 2e-2)])
-def test_first_block_backward_on_prompt_rows_only_is_exact(monkeypatch, cfg_name, dtype, depth, tol):
+def test_first_block_backward_on_prompt_rows_only_is_exact(cfg_name, dtype, depth, tol):
     """Nothing upstream of the prompt slots is trainable (sprompt.py:230-237), so the first block's in_proj dgrad and LN1 backward may
-    run on the B*P prompt rows alone: same factor gradients as computing every row (f32: summation order of a smaller GEMM only)."""
-    from lpi_amd import engine as Eng
+    run on the B*P prompt rows alone: same factor gradients as computing every row (EngineOptions(l0_prompt_rows=False); f32: summation order of a
+    smaller GEMM only)."""
     cfg = synth.CONFIGS[cfg_name]
     ids = synth.token_ids(5)
     grads = {}
     for flag in (False, True):
-        monkeypatch.setattr(Eng, "L0_PROMPT_ROWS", flag)
-        res, _ = run_hip(cfg, dtype, 5, ids, depth)
+        res, _ = run_hip(cfg, dtype, 5, ids, depth, l0_prompt_rows=flag)
         grads[flag] = {k: res[k] for k in GRADS}
     for k in GRADS:
         scale = np.abs(grads[False][k]).max()
@@ -411,13 +414,14 @@ def test_layernorm_fold_levels_agree_and_do_not_lose_accuracy(monkeypatch, golde
     """LayerNorm folded into in_proj (LPI_LN_FOLD=1) and into c_fc too (=2, the default) against LayerNorm as its own kernel (=0) on the ViT-B/16
     bs=8 fixture: the three builds agree far inside the mode's error against the reference, the folded ones are not further from the
     reference than the unfolded one (LN(x) is no longer rounded to the operand type), and the launch counts show the fold really ran."""
-    from lpi_amd import engine as E
+    from lpi_amd.engine import EngineOptions
     cfg = synth.VIT_B16
     g = golden("vitb16_d3_patched")
     res, launches = {}, {}
-    monkeypatch.setattr(E, "ROWSTATS", 0)      # the fold levels against each other with the statistics pass; LPI_ROWSTATS has its own test below
+    monkeypatch.setenv("LPI_ROWSTATS", "0")      # the fold levels against each other with the statistics pass; LPI_ROWSTATS has its own test below
     for level in (0, 1, 2):
-        monkeypatch.setattr(E, "LN_FOLD", level)
+        monkeypatch.setenv("LPI_LN_FOLD", str(level))      # the environment fall-backs, read when the engine is built
+        assert EngineOptions.from_env() == EngineOptions(ln_fold=level, rowstats=0)
         n0 = _lib.launch_count()
         res[level], _ = run_hip(cfg, dtype, 8, g["token_ids"], 3)
         launches[level] = _lib.launch_count() - n0
@@ -439,16 +443,13 @@ def test_row_statistics_from_the_gemm_epilogue_agree_with_the_statistics_pass(mo
     """LPI_ROWSTATS: the folded LayerNorms' mean / rstd from the slot sums the producing GEMM's epilogue leaves (LPI_EPI_RES_ROWSTATS + finalize)
     against the statistics pass over the stream, at both fold levels on the ViT-B/16 bs=8 fixture: the same features, logits and prompt-factor gradients
     up to the order of an f32 sum (a few output roundings flip), the same error against the reference, no more launches."""
-    from lpi_amd import engine as E
     cfg = synth.VIT_B16
     g = golden("vitb16_d3_patched")
     for level in (1, 2):
-        monkeypatch.setattr(E, "LN_FOLD", level)
         res, launches = {}, {}
         for rs in (False, True):
-            monkeypatch.setattr(E, "ROWSTATS", 2 if rs else 0)
             n0 = _lib.launch_count()
-            res[rs], _ = run_hip(cfg, dtype, 8, g["token_ids"], 3)
+            res[rs], _ = run_hip(cfg, dtype, 8, g["token_ids"], 3, ln_fold=level, rowstats=2 if rs else 0)
             launches[rs] = _lib.launch_count() - n0
         d_feat = max(maxerr(res[True]["img_f"], res[False]["img_f"]), maxerr(res[True]["txt_f"], res[False]["txt_f"]))
         err = {rs: max(maxerr(r["img_f"], g["img_f"]), maxerr(r["txt_f"], g["txt_f"])) for rs, r in res.items()}

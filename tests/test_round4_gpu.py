@@ -498,35 +498,6 @@ def test_gemm_half_width_staging_epilogue_equals_the_generic_one(tm, N, K):
     assert float((outs[0].double().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("cdt", [BF16, F16])
-@pytest.mark.parametrize("tm,N,K", [(43, 1536, 512), (213, 2304, 768), (30, 1536, 768)])
-def test_gemm_layernorm_fold_fast_epilogue_equals_the_generic_one(cdt, tm, N, K):
-    """EPI_LN16 (gemm256p.hip): the LayerNorm-fold epilogue of in_proj evaluated on the accumulators and staged in the output type — bit for bit the generic
-    LN-fold epilogue (tuning key 14 = 1), which test_kernels_gpu.py::test_gemm_layernorm_fold_epilogues holds against f64 LN(x) W^T + b."""
-    M = tm * 256
-    td = torch.bfloat16 if cdt == BF16 else torch.float16
-    x = (rnd(M, K, seed=tm) * 1.3 + 0.2).half().to(DEV)
-    w = (rnd(N, K, seed=tm + 1) * 0.05).half().to(DEV)
-    c2 = rnd(N, seed=tm + 2).to(DEV)
-    xf = x.float()
-    lnb = torch.zeros(2 * M + N, device=DEV)
-    lnb[:M] = xf.mean(1)
-    lnb[M:2 * M] = 1.0 / (xf.var(1, unbiased=False) + 1e-5).sqrt()
-    lnb[2 * M:] = w.float().sum(1)
-    outs = []
-    try:
-        for key in (3, 1):      # 3: the opt-in fast LN-fold epilogue, 1: the generic one
-            call("lpi_set_tuning", 14, key)
-            c = torch.full((M, N), float("nan"), dtype=td, device=DEV)
-            E.gemm(F16, x, w, c, M, N, K, bias=c2, residual=lnb, ldr=M, epi=E.EPI_LN)
-            torch.cuda.synchronize()
-            outs.append(c)
-    finally:
-        call("lpi_set_tuning", 14, 0)
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
-    assert bool(torch.isfinite(outs[0].float()).all())
-
-
 def test_device_kmeans_equals_the_reference_clustering_and_the_oracle(golden):
     """lpi_amd.kmeans.kmeans_fit (HIP passes over the features, scikit-learn's seeding and convergence logic on the host) on the synthetic features of the
     fixture: the centres the IMPORTED reference's clustering() found (sprompt.py:370-397, tests/golden/kmeans.npz) to 1e-5, the oracle's labels exactly —

@@ -321,8 +321,7 @@ def test_one_sweep_statistics_guard_switches_to_the_statistics_pass(monkeypatch)
     third = err(feats(enc))
     assert third == second                       # stays switched, deterministic
     guarded_stat, ratio = rstd_err(enc)
-    monkeypatch.setattr(E, "ROWSTAT_GUARD", False)
-    enc0 = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
+    enc0 = DualEncoder(cfg, sd, dtype="bf16", device=DEV, options=E.EngineOptions(rowstat_guard=False))
     unguarded = [err(feats(enc0)) for _ in range(2)][-1]
     unguarded_stat, _ = rstd_err(enc0)
     assert enc0.vis.rowstats == 2 and enc0.rowstat_guard_tripped == 0
@@ -335,7 +334,6 @@ def test_one_sweep_statistics_guard_switches_to_the_statistics_pass(monkeypatch)
     # to |mean| = 1000 std, where the one-sweep rstd is off by 10 %) — so the switch must simply not cost accuracy
     assert max(second) < 1.15 * max(first) and max(second) < 8e-3 and first == unguarded
     # ordinary weights never trip it (the benchmarked configuration keeps its one-sweep statistics)
-    monkeypatch.setattr(E, "ROWSTAT_GUARD", True)
     encn = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype="bf16", device=DEV)
     for _ in range(3):
         feats(encn)

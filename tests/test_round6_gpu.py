@@ -220,12 +220,12 @@ def test_outlier_statistics_through_the_folded_layernorms(cfgname, B, depth, out
     (synth.clip_state_dict(outliers=...)): 'channels' — massive-activation channels of +150 / -90 carried by the residual stream through every block and a
     LayerNorm gain of 40, the pattern real CLIP ViTs show; 'offset' — every row 12 standard deviations off zero, where E[x^2] - mean^2 loses digits.  The
     f32 oracle (two-pass fp32 LayerNorm, model.py:154-160) is the reference; the HIP step runs in bf16 and f16 with the defaults the headline uses
-    (LPI_LN_FOLD=2, LPI_ROWSTATS=2, fp16 residual stream).  Must hold: the usual bars of the throughput modes — or the guard trips and the step AFTER the
+    (EngineOptions(): ln_fold = 2, rowstats = 2, fp16 residual stream, guard on).  Must hold: the usual bars of the throughput modes — or the guard trips and the step AFTER the
     trip meets them; the fp16 stream never overflows; the f32 parity mode stays at its 1e-4."""
     from lpi_amd import engine as E
     from lpi_amd.engine import DualEncoder, PackedIds
     from lpi_amd.step import train_step
-    assert E.LN_FOLD == 2 and E.ROWSTATS == 2 and E.RESIDUAL_F16 and E.ROWSTAT_GUARD, "this test is about the default configuration"
+    assert E.EngineOptions.from_env() == E.EngineOptions(), "this test is about the default configuration"
     cfg = synth.CONFIGS[cfgname]
     sd = synth.clip_state_dict(cfg, outliers=outliers)
     ref = _oracle_step(cfg, sd, B, depth)
@@ -309,3 +309,121 @@ def test_outlier_statistics_through_the_folded_layernorms(cfgname, B, depth, out
         assert second["cos"] >= bars[mode]["cos"], (mode, second["cos"])
         del enc
         torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ q / k / v layouts (model.py:183-185)
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+@pytest.mark.parametrize("B,L,H,rows", [(3, 213, 12, 0), (2, 50, 2, 0), (2, 213, 4, 17), (2, 21, 2, 17), (2, 273, 4, 0), (5, 197, 3, 0)])
+def test_attention_on_layout_strides_gives_the_same_bits(dtname, B, L, H, rows):
+    """lpi_attn_fwd_pair / lpi_attn_fwd_one with layout strides and lpi_attn_bwd_layout (streamed single-pass kernel at L > 160 incl. the two key windows of
+    273 tokens; the fused one-head kernel below; rows = the first block's prefix form) on the HEAD-GROUPED order [row][head][q|k|v][64] — what the vision
+    tower's in_proj writes since round 6 — and, where the streamed kernel runs, on head-BLOCKED planes [3 H][rows][64]: ctx, lse and dq / dk / dv are the
+    same BITS as on the interleaved [row][q|k|v][head][64] matrix (the layout changes addresses, not arithmetic)."""
+    import ctypes
+    from lpi_amd._lib import BF16, F16, call
+    from lpi_amd.engine import _stream
+    dt, tdt = (BF16, torch.bfloat16) if dtname == "bf16" else (F16, torch.float16)
+    d = H * 64
+    M = B * L
+    Mp = (M + 127) // 128 * 128
+    g = torch.Generator(device="cuda").manual_seed(L * 7 + H)
+    qkv_i = (torch.randn(Mp, 3, H, 64, device=DEV, generator=g) * 0.7).to(tdt)
+    dctx_i = torch.randn(Mp, H, 64, device=DEV, generator=g).bfloat16()
+    streamed = L > 160
+    layouts = {"interleaved": (qkv_i.reshape(Mp, 3 * d).contiguous(), 3 * d, 64, d, dctx_i.reshape(Mp, d).contiguous(), d, 64),
+               "grouped": (qkv_i.permute(0, 2, 1, 3).contiguous().reshape(Mp, 3 * d), 3 * d, 192, 64, dctx_i.reshape(Mp, d).contiguous(), d, 64)}
+    if streamed:
+        layouts["blocked"] = (qkv_i.permute(1, 2, 0, 3).contiguous().reshape(3 * H * Mp, 64), 64, Mp * 64, H * Mp * 64,
+                              dctx_i.permute(1, 0, 2).contiguous().reshape(H * Mp, 64), 64, Mp * 64)
+    # a causal text problem beside it for the pair launch
+    Bt, Lt, Ht = 3, 40, 2
+    qkv_t = torch.randn(Bt * Lt, 3 * Ht * 64, device=DEV, generator=g).to(tdt)
+    out = {}
+    for name, (qkv, ld, hs, vs, dctx, cld, chs) in layouts.items():
+        res = []
+        for how in ("one", "pair"):
+            ctx = torch.zeros(dctx.shape, device=DEV, dtype=tdt)
+            lse = torch.zeros(B, H, L, device=DEV)
+            va = (B, L, None, H, qkv, ld, ctx, cld, lse, 0, 0, None if name == "interleaved" else (hs, vs, chs))
+            if how == "one":
+                _lib.attn_fwd_one(dt, va, _stream())
+            else:
+                ctx_t, lse_t = torch.zeros(Bt * Lt, Ht * 64, device=DEV, dtype=tdt), torch.zeros(Bt, Ht, Lt, device=DEV)
+                _lib.attn_fwd_pair(dt, va, (Bt, Lt, None, Ht, qkv_t, 3 * Ht * 64, ctx_t, Ht * 64, lse_t, 1, 0), _stream())
+            res.append((ctx, lse))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), name
+        ctx, lse = res[0]
+        dqkv = torch.zeros(qkv.shape, device=DEV, dtype=torch.bfloat16)
+        delta = torch.zeros(B, H, L, device=DEV)
+        if name == "interleaved":
+            call("lpi_attn_bwd_prefix", dt, B, L, None, rows if rows else L, H, qkv, ld, ctx, cld, dctx, cld, lse, delta, dqkv, ld, 0, _stream())
+        else:
+            lay = (ctypes.c_int32 * 6)(hs, vs, hs, vs, chs, chs)
+            call("lpi_attn_bwd_layout", dt, B, L, rows, H, qkv, ld, ctx, cld, dctx, cld, lse, delta, dqkv, ld, ctypes.cast(lay, ctypes.c_void_p), _stream())
+        torch.cuda.synchronize()
+        if name == "interleaved":
+            c_n, dq_n = ctx.reshape(Mp, H, 64), dqkv.reshape(Mp, 3, H, 64)
+        elif name == "grouped":
+            c_n, dq_n = ctx.reshape(Mp, H, 64), dqkv.reshape(Mp, H, 3, 64).permute(0, 2, 1, 3)
+        else:
+            c_n, dq_n = ctx.reshape(H, Mp, 64).permute(1, 0, 2), dqkv.reshape(3, H, Mp, 64).permute(2, 0, 1, 3)
+        c_n, dq_n = c_n[:M].reshape(B, L, H, 64), dq_n[:M].reshape(B, L, 3, H, 64)
+        if rows:      # prefix form: only the first `rows` token rows of dqkv are defined
+            dq_n = dq_n[:, :rows]
+        out[name] = (c_n.clone(), dq_n.clone(), lse.clone())
+    ref = out["interleaved"]
+    assert float(ref[1].float().abs().max()) > 0
+    for name, (c_n, dq_n, lse) in out.items():
+        assert torch.equal(c_n, ref[0]) and torch.equal(lse, ref[2]), name
+        assert torch.equal(dq_n, ref[1]), name
+
+
+def test_layout_entry_points_refuse_what_they_do_not_take():
+    import ctypes
+    from lpi_amd._lib import BF16, F32, LpiError, call
+    from lpi_amd.engine import _stream
+    B, L, H = 2, 50, 2
+    d = H * 64
+    qkv = torch.zeros(B * L, 3 * d, device=DEV, dtype=torch.bfloat16)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, L, device=DEV)
+    with pytest.raises(LpiError):      # f32 has no layout form
+        _lib.attn_fwd_one(F32, (B, L, None, H, qkv.float(), 3 * d, ctx.float(), d, lse, 0, 0, (192, 64, 64)), _stream())
+    with pytest.raises(LpiError):      # strides must be multiples of 8 elements
+        _lib.attn_fwd_one(BF16, (B, L, None, H, qkv, 3 * d, ctx, d, lse, 0, 0, (190, 64, 64)), _stream())
+    with pytest.raises(LpiError):      # causal / ragged problems keep the interleaved order
+        _lib.attn_fwd_one(BF16, (B, L, None, H, qkv, 3 * d, ctx, d, lse, 1, 0, (192, 64, 64)), _stream())
+    lay = (ctypes.c_int32 * 6)(192, 64, 192, 64, 128, 64)      # L = 50 runs the one-head kernels: ctx must keep its 64-element head stride
+    with pytest.raises(LpiError):
+        call("lpi_attn_bwd_layout", BF16, B, L, 0, H, qkv, 3 * d, ctx, d, ctx, d, lse, lse.clone(), qkv.clone(), 3 * d, ctypes.cast(lay, ctypes.c_void_p), _stream())
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_head_grouped_in_proj_equals_the_interleaved_order(mode):
+    """Engine level (ViT-B/16, 8 pairs, depth 3): the vision tower with in_proj's output features grouped by head (EngineOptions(qkv_grouped=True)) against
+    the interleaved default — the forward is the same dot products in another column order, so the features are the same BITS; in the backward the in_proj
+    dgrad sums its 3 d terms in the permuted order: factor gradients agree to the bf16 rounding of that one GEMM.  (Off by default: in the step it measured
+    nothing, profiles/r06_experiments.md; this is the tested proof that the layout is not what bounds the attention kernels there.)"""
+    from lpi_amd import engine as E
+    from lpi_amd.engine import DualEncoder, PackedIds
+    from lpi_amd.step import train_step
+    sd = synth.clip_state_dict(CFG)
+    img = torch.from_numpy(synth.images(8, 224)).to(DEV)
+    ids = synth.token_ids(8)
+    res = {}
+    for grouped in (True, False):
+        enc = DualEncoder(CFG, sd, dtype=mode, device=DEV, options=E.EngineOptions(qkv_grouped=grouped))
+        assert enc.vis.qkv_grouped == grouped and not enc.txt.qkv_grouped
+        assert [b["grouped"] for b in enc.vis.blocks] == [grouped] * 11 + [False]
+        fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, CFG.vision_width, CFG.transformer_width).items()}
+        out = train_step(enc, img, PackedIds(ids, 17).to(DEV), fac, 3)
+        torch.cuda.synchronize()
+        res[grouped] = ({k: out[k].clone() for k in ("img_f", "txt_f", "base_loss")}, {k: fac[k].grad.double().cpu() for k in synth.PROMPT_NAMES})
+        del enc
+        torch.cuda.empty_cache()
+    for k in ("img_f", "txt_f", "base_loss"):
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    for k in synth.PROMPT_NAMES:
+        a, b = res[True][1][k], res[False][1][k]
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), k
+        assert float((a * b).sum() / (a.norm() * b.norm())) > 0.9999, k

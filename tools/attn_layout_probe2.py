@@ -62,7 +62,7 @@ for name, lay in layouts.items():
     ta = (Bt, Lt, None, Ht, qkv_t, 3 * Ht * 64, ctx_t, Ht * 64, lse_t, 1, 0)
     fwd = lambda: _lib.attn_fwd_pair(BF16, va, ta, s())  # noqa: E731
     larr = (ctypes.c_int32 * 6)(lay["hs"], lay["vs"], lay["hs"], lay["vs"], lay["chs"], lay["chs"])
-    bwd = lambda: call("lpi_attn_bwd_layout", BF16, B, L, H, lay["qkv"], lay["ld"], ctx, lay["cld"], lay["dctx"], lay["cld"], lse, delta, dqkv, lay["ld"],  # noqa: E731
+    bwd = lambda: call("lpi_attn_bwd_layout", BF16, B, L, L, H, lay["qkv"], lay["ld"], ctx, lay["cld"], lay["dctx"], lay["cld"], lse, delta, dqkv, lay["ld"],  # noqa: E731
                        ctypes.cast(larr, ctypes.c_void_p), s())
     fwd(); bwd()
     torch.cuda.synchronize()
@@ -75,7 +75,27 @@ for name, lay in layouts.items():
         c_n, dq_n = ctx.reshape(H, Mp, 64).permute(1, 0, 2), dqkv.reshape(3, H, Mp, 64).permute(2, 0, 1, 3)
     res[name] = (c_n[:M].clone(), dq_n[:M].clone(), lse.clone())
     tf, tb = timed(fwd), timed(bwd)
-    print(f"{name:>13}: forward pair {tf:6.1f} us   streamed backward {tb:6.1f} us ({M * d * 2 * 8 / tb / 1e6:4.2f} TB/s)", flush=True)
+    # ... and AS THE STEP RUNS THEM: the forward right behind the GEMM that wrote qkv, the backward right behind the GEMM that wrote dctx (a device copy of
+    # the same bytes stands in for the GEMM's stores: what matters is that the operand was just written, i.e. sits in the Infinity Cache), a 335 MB
+    # stream of other traffic in between as the MLP GEMMs of a layer would leave; only the attention kernel is between the events
+    src_q, src_d = lay["qkv"].clone(), lay["dctx"].clone()
+    other = torch.empty(168 * 1024 * 1024, device=dev, dtype=torch.bfloat16)
+
+    def step_like(kernel, refresh):
+        ts = []
+        for _ in range(12):
+            other.add_(1)
+            refresh()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); kernel(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        return sorted(ts[2:])[len(ts[2:]) // 2]
+    sf = step_like(fwd, lambda: lay["qkv"].copy_(src_q))
+    sb = step_like(bwd, lambda: lay["dctx"].copy_(src_d))
+    print(f"{name:>13}: forward pair {tf:6.1f} us   streamed backward {tb:6.1f} us ({M * d * 2 * 8 / tb / 1e6:4.2f} TB/s)   |  behind the operand's producer: "
+          f"forward {sf:6.1f} us   backward {sb:6.1f} us", flush=True)
+    del src_q, src_d, other
 ref = res["interleaved"]
 for name, (c_n, dq_n, lse) in res.items():
     same = torch.equal(c_n, ref[0]) and torch.equal(dq_n, ref[1]) and torch.equal(lse, ref[2])

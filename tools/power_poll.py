@@ -22,12 +22,13 @@ def rd(p):
         return float("nan")
 
 
-allp = []
+allp, allf = [], []
 
 
 def poll():
     while not stop:
         allp.append([rd(q) / 1e6 for q in pw])
+        allf.append([rd(q) / 1e6 for q in fq])      # freq1_input is in Hz
         samples.append((time.perf_counter(), 0.0, 0.0))
         time.sleep(0.02)
 
@@ -44,8 +45,8 @@ if allp:
     spans = [max(r[i] for r in allp) - min(r[i] for r in allp) for i in range(len(pw))]
     k = spans.index(max(spans))
     print("cards:", len(pw), "power span per card W:", [round(x) for x in spans], "-> card index", k, pw[k])
-    fk = fq[k] if k < len(fq) else None
-    samples = [(samples[i][0], allp[i][k], 0.0) for i in range(len(allp))]
+    # the clock of the SAME card (the column was never sampled and printed as 0); nan where the platform has no freq1_input for it
+    samples = [(samples[i][0], allp[i][k], allf[i][k] if k < len(fq) else float("nan")) for i in range(len(allp))]
 w = [s[1] for s in samples if s[1] == s[1]]
 f = [s[2] for s in samples if s[2] == s[2]]
 if w:
@@ -58,5 +59,7 @@ if f:
 if w:
     busy = [s for s in samples if s[1] > 0.6 * max(w)]
     if busy:
-        print(f"busy window: {len(busy)} samples, power median {statistics.median([s[1] for s in busy]):.0f} W, sclk median {statistics.median([s[2] for s in busy]):.0f} MHz")
+        bf = [s[2] for s in busy if s[2] == s[2]]
+        print(f"busy window: {len(busy)} samples, power median {statistics.median([s[1] for s in busy]):.0f} W"
+              + (f", sclk median {statistics.median(bf):.0f} MHz" if bf else ", sclk: no freq1_input on this card"))
 print(p.stdout.strip().splitlines()[-1][:300] if p.stdout.strip() else "")

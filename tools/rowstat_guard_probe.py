@@ -50,8 +50,7 @@ for off in [float(a) for a in sys.argv[1:]] or [40.0, 150.0, 400.0, 1000.0]:
     del enc32
     out = {}
     for guard in (False, True):
-        E.ROWSTAT_GUARD = guard
-        enc = DualEncoder(cfg, sd, dtype="bf16", device=DEV)
+        enc = DualEncoder(cfg, sd, dtype="bf16", device=DEV, options=E.EngineOptions(rowstat_guard=guard))
         for _ in range(3):
             fi, ft, _ = feats(enc)
         out[guard] = (float((fi - ri).abs().max()), stat_err(enc), enc.vis.rowstats, enc.rowstat_guard_tripped)
