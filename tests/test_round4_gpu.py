@@ -385,7 +385,7 @@ def test_lockstep_towers_realign_when_one_tower_takes_the_statistics_pass(full):
         b_i, b_t, n_mixed = both(True)
         c_i, c_t, n_seq = both(False)
     finally:
-        enc.txt.rowstats = E.ROWSTATS
+        enc.txt.rowstats = enc.opt.rowstats
     print(f"\n    forward launches: aligned {n_aligned}, one tower on the statistics pass {n_mixed}, sequential towers {n_seq}")
     assert torch.equal(b_i, c_i) and torch.equal(b_t, c_t)          # lock step == sequential, bit for bit
     assert torch.equal(a_i, b_i)                                      # the vision tower is untouched by the text tower's switch
