@@ -89,12 +89,27 @@ def parse_args():
                          "blocks only, labels offset by rank * B")
     ap.add_argument("--gather-with-grad", action="store_true",
                     help="N > 1: gradients through the gathered features (sprompt.py:67-69): the key gradients are reduce-scattered to their owners")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="FIELD=VALUE",
+                    help="an lpi_amd.engine.EngineOptions field for every engine this run builds (A/B switch), e.g. --engine-opt stream_pool=0 --engine-opt ln_fold=1")
     ap.add_argument("--no-affinity", action="store_true", help="N > 1: leave the ranks' CPU affinity alone (default: every rank gets its own slice of its GPU's NUMA node)")
     ap.add_argument("--force-dist", action="store_true", help="N = 1: run the step through a one-rank RCCL process group (the code path an 8-GPU run takes)")
     ap.add_argument("--cpu-baseline-bs256", action="store_true", help="also time ONE bs=256 oracle step on the host (~70 s; needs 200 GiB of host memory and 32 CPUs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU with a gloo group (messages staged through the host): exercises the multi-rank path on a 1-GPU box")
     return ap.parse_args()
+
+
+def engine_options(a):
+    """EngineOptions from the environment fall-backs and the --engine-opt FIELD=VALUE arguments (None when there are none: the engine's own default)."""
+    if not a.engine_opt:
+        return None
+    from lpi_amd.engine import EngineOptions
+    kw = {}
+    for item in a.engine_opt:
+        k, _, v = item.partition("=")
+        cur = getattr(EngineOptions(), k)      # AttributeError for an unknown field
+        kw[k] = (v not in ("0", "false", "False", "")) if isinstance(cur, bool) else int(v)
+    return EngineOptions.from_env(**kw)
 
 
 def _free_port():
@@ -312,7 +327,7 @@ class Workload:
         from lpi_amd.engine import DualEncoder, PackedIds, trim_token_ids
         self.a, self.dev, self.dtype, self.fwd_only, self.exchange = a, dev, dtype, fwd_only, exchange
         self.cfg = cfg = synth.CONFIGS[a.model]
-        self.enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=dev)
+        self.enc = DualEncoder(cfg, synth.clip_state_dict(cfg), dtype=dtype, device=dev, options=engine_options(a))
         B = a.batch
         self.images = torch.from_numpy(synth.images(B, cfg.image_resolution, seed=synth.IMAGE_SEED + rank)).to(dev)
         ids_host = synth.token_ids(B, seed=synth.TOKEN_SEED + rank)          # [B, 77] as the tokenizer builds them, on the host

@@ -297,6 +297,24 @@ int lpi_attn_pooled_bwd_pair(int dtype, const lpi_attn_pooled_desc* d /* [2] */,
 int lpi_attn_pooled_fwd_desc(int dtype, const lpi_attn_pooled_desc* d, void* stream);
 int lpi_attn_pooled_bwd_desc(int dtype, const lpi_attn_pooled_desc* d, void* stream);
 
+/* ---- The LAST block's attention WITHOUT K and V (round 6; lpi_amd/csrc/attn_stream.hip).  replaces: models/clip/model.py:183-185 for the block whose output
+ * only the pooled token reads (model.py:255).  With ONE live query per (sample, head), q_h . k_l / 8 = LN1(x_l) . (W_k,h^T q_h / 8) + const and
+ * sum_l p_l v_l = W_v,h (sum_l p_l LN1(x_l)) + b_v,h: the block needs two passes over the sample's rows of the residual stream (LayerNorm applied on the fly from
+ * the row statistics) instead of the [B L, 2 d] K / V projection, its dgrad and the single-query attention over them.  Exact algebra.
+ *   w_dtype: LPI_BF16 | LPI_F16 = type of q [B, ldq], Wqkv [3 d, ldw] (in_proj weight: rows d..2d = W_k, 2d..3d = W_v), its transpose WqkvT [d, ldwt >= 3 d]
+ *   and ctx [B, ldctx]; bqkv f32 [3 d];
+ *   x: fp16 [B L, ldx], the block's input rows (uniform L per sample); mean / rstd f32 [B L]: ln_1's statistics of those rows; gamma / beta f32 [d]: ln_1's affine;
+ *   scratch f32 [4 B H d] (the forward writes the first half, the backward reads its first quarter and writes the second half); lse f32 [B, H].
+ *   Backward: dctx bf16 [B, lddctx] -> dq bf16 [B, lddq] (gradient of the pooled queries) and dh bf16 [B L, lddh] = d LN1(x_l) of EVERY row (the K / V path's
+ *   gradient; the caller adds the pooled rows' query path as before); the backward's weight operands are the BF16 weight and its transpose whatever the
+ *   forward's type was.  H <= 16 heads of 64, L <= 288: lpi_spool_attn_supported. */
+int lpi_spool_attn_supported(int L, int H, int d);
+int lpi_spool_attn_fwd(int w_dtype, int B, int L, int H, const void* q, int ldq, const void* Wqkv, int ldw, const void* WqkvT, int ldwt, const float* bqkv, const void* x, int ldx,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, float* scratch, float* lse, void* ctx, int ldctx, void* stream);
+int lpi_spool_attn_bwd(int B, int L, int H, const void* Wqkv /* bf16 */, int ldw, const void* WqkvT /* bf16 */, int ldwt, const void* x, int ldx, const float* mean,
+                       const float* rstd, const float* gamma, float* scratch, const float* lse, const void* dctx, int lddctx, void* dq, int lddq, void* dh, int lddh,
+                       void* stream);
+
 /* ---- SHARED PREFIX of the text tower (round 5).  replaces nothing new: the same model.py:179-193, 347-353 and prompt_learner.py:155-163 arithmetic
  * on fewer rows.  In training every caption is [SOT][n_ctx context slots][caption tokens][EOT] and the context / deep prompts are broadcast over the
  * batch (slinet.py:119-130), so positions 0 .. n_ctx of ALL samples hold the same rows in every block: under the causal mask they attend only to each

@@ -61,6 +61,9 @@ SIGNATURES = {
     "lpi_attn_fwd_pair": [_I, _P, _P],
     "lpi_attn_bwd_layout": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P],
     "lpi_attn_fwd_one": [_I, _P, _P],
+    "lpi_spool_attn_supported": [_I, _I, _I],
+    "lpi_spool_attn_fwd": [_I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lpi_spool_attn_bwd": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P],
     "lpi_attn_bwd_prefix": [_I, _I, _I, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "lpi_attn_pooled_fwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "lpi_attn_pooled_bwd_varlen": [_I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P],
@@ -134,7 +137,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 600
+EXPECTED_ABI = 603
 VARIANT_OFFSET = 1000000      # lpi_version() of a tools/build_variant.sh build = EXPECTED_ABI + this
 
 _lib = None

@@ -61,6 +61,10 @@ class EngineOptions:
         on, with a warning (tests/test_round6_gpu.py: rows 12 sigma off zero).
     pooled_last: exact dead-row elimination in the last block (only the pooled token's query / softmax row / out_proj / MLP are evaluated, K and V for
         every token).  False evaluates the whole block: the reference's literal order, kept for the test that holds the two equal.
+    stream_pool (round 6; needs pooled_last): the last block of a tower with uniform sequences (the vision tower) does not compute K and V at all — with one
+        live query per (sample, head), q.k_l = LN1(x_l).(W_k^T q) + const and sum_l p_l v_l = W_v (sum_l p_l LN1(x_l)) + b_v, so two passes over the sample's
+        rows of the residual stream replace the [B L, 2 d] projection, its dgrad and the single-query attention over them (lpi_spool_attn_fwd / _bwd,
+        csrc/attn_stream.hip: exact algebra; 2-byte modes with the fp16 stream).  False keeps the K / V path (the exactness test's other arm).
     l0_prompt_rows: the first block's backward reads dL/dx_0 at the prompt rows only (nothing upstream of the prompt slots is trainable), so its in_proj
         dgrad and LN1 backward run on B*P rows.  False computes every row (the exactness test's other arm).
     qkv_grouped: in_proj's output features of the non-causal tower re-ordered to [head][q|k|v][64] (Tower.__init__).  Same numbers; the attention
@@ -71,6 +75,7 @@ class EngineOptions:
     rowstats: int = 2
     rowstat_guard: bool = True
     pooled_last: bool = True
+    stream_pool: bool = True
     l0_prompt_rows: bool = True
     qkv_grouped: bool = False
 
@@ -261,6 +266,19 @@ class AttnFwdReq(Req):
             call("lpi_attn_fwd_varlen", self.dt, *a[:10], _stream())
 
 
+class SoloReq(Req):
+    """A launch only THIS tower makes at a step position both towers tag alike (fn = None: nothing at all — the tower has no such op, but says so, so that the
+    towers' request streams stay aligned): the partner's request of the same tag is issued alone."""
+    __slots__ = ("tag", "fn")
+
+    def __init__(self, tag, fn=None):
+        self.tag, self.fn = tag, fn
+
+    def issue(self):
+        if self.fn is not None:
+            self.fn()
+
+
 class LnReq(Req):
     """A LayerNorm a tower wants issued (forward: kind "fwd", args of lpi_layernorm_fwd after the two dtypes; backward: "bwd", args of
     lpi_layernorm_bwd after the three dtypes).  Yielded like a GemmReq so that the two towers' LayerNorms of the same layer go out as
@@ -340,6 +358,10 @@ def _cdt(c):
 def _issue_pair(r0: GemmReq, r1: GemmReq):
     """The two towers' GEMM of the same op: one grouped launch where the library can (two large bf16 / f16 problems of the same epilogue
     kind), else two launches — the same bits either way."""
+    if isinstance(r0, SoloReq) or isinstance(r1, SoloReq):
+        r0.issue()
+        r1.issue()
+        return
     if isinstance(r0, RowReq) or isinstance(r1, RowReq):
         if isinstance(r0, RowReq) and isinstance(r1, RowReq):
             _lib.row_jobs(r0.jobs + r1.jobs, _stream())
@@ -525,10 +547,23 @@ class Tower:
                 w8 = dt == BF16      # bf16 mode: gamma o W keeps bf16's 8 significant bits inside the fp16 container (LnLinear: power, not accuracy)
                 blk["qkv_ln"] = LnLinear(wq, bq, blk["ln_1.w"], blk["ln_1.b"], device, w8)
                 blk["fc_ln"] = LnLinear(f(p + "mlp.c_fc.weight"), f(p + "mlp.c_fc.bias"), blk["ln_2.w"], blk["ln_2.b"], device, w8)
+            if i == spec.layers - 1 and dt != F32:
+                # W^T of in_proj in the FORWARD's operand type, for the last block without K and V (stream_pool: csrc/attn_stream.hip reads a head's 64 output
+                # features as one contiguous run): bf16 mode has it already (the dgrad operand), f16 mode gets an fp16 copy (3.5 MB at ViT-B/16)
+                blk["qkv_wT"] = blk["qkv"].wt if dt == self.gdt else blk["qkv"].w.t().contiguous()
+                # ... and the row-major weight in the BACKWARD's operand type (bf16) beside its transpose (= the dgrad operand wt)
+                blk["qkv_wb"] = blk["qkv"].w if dt == self.gdt else blk["qkv"].wt.t().contiguous()
             self.blocks.append(blk)
         self._ws = {}
         self.rowstats = opt.rowstats      # per tower, mutable (the guard sets it to 0; a test sets one tower to 0: the lock-stepped towers must re-align)
         self.serial = 0      # bumped by every forward: a backward checks that its forward was the tower's LAST one (see DualEncoder._ctx)
+
+    def _stream_pool_shape(self, L):
+        """True if the last block of this tower may run without K and V for sequences of L tokens (EngineOptions.stream_pool): a non-causal tower (uniform
+        sequences, the pooled token attends to every row) in a 2-byte mode with the fp16 stream, and a shape the kernels take."""
+        sp = self.spec
+        return bool(self.opt.stream_pool and self.opt.pooled_last and self.dt != F32 and self.xdt == F16 and not sp.causal and len(self.blocks) > 1
+                    and _lib.load().lpi_spool_attn_supported(int(L), sp.heads, sp.width) == 1)
 
     def _check_depth(self, prompts, depth):
         """model.py:191 indexes prompts[:, layer_id]: the reference raises IndexError past the stack; so do we (before any kernel)."""
@@ -599,6 +634,8 @@ class Tower:
             "c_u": z(Bp, 4 * d, dtype=TU) if train else None, "c_xout": z(Bp, d), "c_stat": z(2, Bp),
             # ... and so do its query, attention row and out_proj (K and V still cover every token)
             "c_q": z(Bp, d, dtype=T), "c_ctx": z(Bp, d, dtype=T), "c_lse": z(B * H), "c_xin": z(Bp, d), "c_stat1": z(2, Bp),
+            # the last block without K and V (EngineOptions.stream_pool): qt | hbar | dhbar | dqt, f32 [B, H, d] each, and the scores' log-sum-exp
+            "sp_scratch": z(4 * B * H * d) if self._stream_pool_shape(L) else None, "sp_lse": z(B * H),
         }
         if train:
             ws.update({
@@ -678,10 +715,13 @@ class Tower:
             else:
                 yield LnReq(f"{lt}.ln1", "fwd", (dt, xdt), M, d, x_in, d, blk["ln_1.w"], blk["ln_1.b"], ws["h"], d, st[0], st[1], optional=True)
             if i == len(self.blocks) - 1 and POOLED_LAST:
-                # last block: K and V for every token, but Q / softmax row / out_proj / MLP for the pooled token only
+                # last block: Q / softmax row / out_proj / MLP for the pooled token only; K and V for every token — or, with stream_pool, not at all
                 Bp, cst, cst1 = ws["Bp"], ws["c_stat"], ws["c_stat1"]
                 wq, bq = blk["qkv"].w, blk["qkv"].b
-                if fold:
+                spool = rs is None and not pre and ws.get("sp_scratch") is not None and self._stream_pool_shape(L)
+                if spool:
+                    yield SoloReq(f"{lt}.kv")      # no K / V projection: the text tower's (same tag) goes out alone
+                elif fold:
                     ql = blk["qkv_ln"]
                     yield GemmReq(f"{lt}.kv", F16, x_in, ql.w[d:], qkv[:, d:], Mp, 2 * d, d, bias=ql.c2[d:], residual=lnb[0], ldr=ln_ld, epi=EPI_LN, m_real=M)
                 else:
@@ -690,8 +730,13 @@ class Tower:
                 yield RowReq(f"{lt}.pln1", [_lib.row_job(_lib.ROWOP_POOL_LN_FWD, B=B, L=Lx, d=d, dt_a=xdt, dt_b=dt, a=x_in, idx=pidx, gamma=blk["ln_1.w"],
                                                          beta=blk["ln_1.b"], out=ws["c_h"], ld_c=d, mean=cst1[0], rstd=cst1[1], out2=ws["c_xin"])])
                 yield GemmReq(f"{lt}.cq", dt, ws["c_h"], wq[:d], ws["c_q"], Bp, d, d, bias=bq[:d], m_real=B)
-                yield PoolAttnReq(f"{lt}.pattn", dt, False, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx, ctx=ws["c_ctx"],
-                                  ldctx=d, lse=ws["c_lse"], causal=int(sp.causal), shared_rows=pre)
+                if spool:
+                    x_sp, st_sp = x_in, st      # (bound now: the generator's loop variables move on)
+                    yield SoloReq(f"{lt}.pattn", lambda: call("lpi_spool_attn_fwd", dt, B, L, H, ws["c_q"], d, wq, d, blk["qkv_wT"], 3 * d, bq, x_sp, d, st_sp[0], st_sp[1], blk["ln_1.w"],
+                                                              blk["ln_1.b"], ws["sp_scratch"], ws["sp_lse"], ws["c_ctx"], d, _stream()))
+                else:
+                    yield PoolAttnReq(f"{lt}.pattn", dt, False, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx, ctx=ws["c_ctx"],
+                                      ldctx=d, lse=ws["c_lse"], causal=int(sp.causal), shared_rows=pre)
                 yield GemmReq(f"{lt}.cout", dt, ws["c_ctx"], blk["out"].w, ws["c_xmid"], Bp, d, d, bias=blk["out"].b, residual=ws["c_xin"], m_real=B)
                 yield RowReq(f"{lt}.pln2", [_lib.row_job(_lib.ROWOP_POOL_LN_FWD, B=B, L=1, d=d, dt_a=F32, dt_b=dt, a=ws["c_xmid"], gamma=blk["ln_2.w"],
                                                          beta=blk["ln_2.b"], out=ws["c_h"], ld_c=d, mean=cst[0], rstd=cst[1])])
@@ -777,10 +822,16 @@ class Tower:
                 # attention branch of the pooled rows: dctx, dQ on B rows; dK, dV on every row; d(LN1 out) = dKV.Wkv (+ dQ.Wq at the pooled rows)
                 wqt = blk["qkv"].wt
                 yield GemmReq(f"{lt}.cdout", dt, c_dxT, blk["out"].wt, ws["c_dctx"], Bp, d, d, m_real=B)
-                yield PoolAttnReq(f"{lt}.pdattn", adt, True, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx,
-                                  dctx=ws["c_dctx"], lddctx=d, lse=ws["c_lse"], dq=ws["c_dq"], lddq=d, dqkv=dqkv, lddqkv=3 * d, causal=int(sp.causal),
-                                  shared_rows=pre, shared_dkv=ws.get("shared_dkv") if pre else None)
-                yield GemmReq(f"{lt}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
+                if rs is None and not pre and ws.get("sp_scratch") is not None and self._stream_pool_shape(L):
+                    # the forward ran without K and V (forward_gen): d LN1(x_l) of every row and the pooled queries' gradient from two passes over the stream
+                    yield SoloReq(f"{lt}.pdattn", lambda: call("lpi_spool_attn_bwd", B, L, H, blk["qkv_wb"], d, blk["qkv"].wt, 3 * d, x_in, d, st[0], st[1], blk["ln_1.w"],
+                                                               ws["sp_scratch"], ws["sp_lse"], ws["c_dctx"], d, ws["c_dq"], d, dh, d, _stream()))
+                    yield SoloReq(f"{lt}.dkv")
+                else:
+                    yield PoolAttnReq(f"{lt}.pdattn", adt, True, B=B, L=L, row_start=rs, H=H, q=ws["c_q"], ldq=d, qkv=qkv, ldqkv=3 * d, idx=pool_idx,
+                                      dctx=ws["c_dctx"], lddctx=d, lse=ws["c_lse"], dq=ws["c_dq"], lddq=d, dqkv=dqkv, lddqkv=3 * d, causal=int(sp.causal),
+                                      shared_rows=pre, shared_dkv=ws.get("shared_dkv") if pre else None)
+                    yield GemmReq(f"{lt}.dkv", dt, dqkv[:, d:], wqt[:, d:], dh, Mp, d, 2 * d, m_real=M)
                 yield GemmReq(f"{lt}.cdq", dt, ws["c_dq"], wqt[:, :d], ws["c_dh"], Bp, d, d, m_real=B)
                 yield RowReq(f"{lt}.sadd1", [_lib.row_job(_lib.ROWOP_SCATTER_ADD, B=B, L=Lx, d=d, dt_a=dt, a=ws["c_dh"], ld_a=d, idx=pidx, out=dh, ld_c=d)])
                 # the gradient stream starts here: LN1's backward WRITES it (no zero-fill of the [M, d] stream), then the residual

@@ -214,7 +214,7 @@ def test_plugin_loop_on_strings_issues_the_bare_steps_launches_and_no_other_kern
         opt.step()
         bare = _lib.launch_count() - n0
     assert pk.shared == 17
-    assert len(per) == 1 and per[0] == bare and bare <= 240, (per, bare)
+    assert len(per) == 1 and per[0] == bare and bare <= 246, (per, bare)      # 237 + 6 since round 6 (the last block without K and V: tests/test_round4_gpu.py)
     from lpi_amd import engine as E
     # no request without its partner in this configuration (towers of equal depth): counted over the bare steps above
     stats0 = dict(E.LOCKSTEP_STATS)

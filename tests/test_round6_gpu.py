@@ -427,3 +427,95 @@ def test_head_grouped_in_proj_equals_the_interleaved_order(mode):
         a, b = res[True][1][k], res[False][1][k]
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), k
         assert float((a * b).sum() / (a.norm() * b.norm())) > 0.9999, k
+
+
+# ------------------------------------------------------------------------------------------------ the last block without K and V (model.py:183-185, 255)
+@pytest.mark.parametrize("dtname", ["bf16", "f16"])
+@pytest.mark.parametrize("B,L,H", [(5, 213, 12), (3, 21, 2), (2, 273, 16), (9, 197, 12), (4, 50, 4), (3, 77, 8)])
+def test_last_block_attention_from_the_stream_against_f64(dtname, B, L, H):
+    """lpi_spool_attn_fwd / _bwd (attn_stream.hip): the pooled query's attention computed from the residual stream rows themselves — scores LN1(x_l) . (W_k^T q / 8),
+    context W_v (sum_l p_l LN1(x_l)) + b_v — against the literal f64 evaluation (LayerNorm, K and V projections of every row, softmax, P V) and its autograd:
+    ctx, the gradient of the pooled queries and the gradient w.r.t. LN1(x_l) of every row."""
+    from lpi_amd._lib import BF16, F16, call
+    from lpi_amd.engine import _stream
+    dt, tdt = (BF16, torch.bfloat16) if dtname == "bf16" else (F16, torch.float16)
+    d = 64 * H
+    assert _lib.load().lpi_spool_attn_supported(L, H, d) == 1
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = (torch.randn(B * L, d, generator=g) * 1.3 + 0.4 * torch.randn(B * L, 1, generator=g)).half()
+    gamma = 1.0 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.05 * torch.randn(d, generator=g)
+    W = (torch.randn(3 * d, d, generator=g) * d ** -0.5).to(tdt)
+    bq = 0.02 * torch.randn(3 * d, generator=g)
+    q = torch.randn(B, d, generator=g).to(tdt)
+    dctx = torch.randn(B, d, generator=g).bfloat16()
+    x64 = x.double()
+    mean = x64.mean(1)
+    rstd = 1.0 / (x64.var(1, unbiased=False) + 1e-5).sqrt()
+    # ---- the literal evaluation in f64
+    h = ((x64 - mean[:, None]) * rstd[:, None] * gamma.double() + beta.double()).requires_grad_(True)       # LN1(x_l)
+    qr = q.double().requires_grad_(True)
+    Wd, bd = W.double(), bq.double()
+    k = (h @ Wd[d:2 * d].t() + bd[d:2 * d]).view(B, L, H, 64)
+    v = (h @ Wd[2 * d:].t() + bd[2 * d:]).view(B, L, H, 64)
+    s = torch.einsum("bhc,blhc->bhl", qr.view(B, H, 64), k) / 8.0
+    p = torch.softmax(s, dim=-1)
+    ctx_ref = torch.einsum("bhl,blhc->bhc", p, v).reshape(B, d)
+    (ctx_ref * dctx.double()).sum().backward()
+    # ---- the kernels
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    xd, md, rd = dev(x), dev(mean.float()), dev(rstd.float())
+    scratch = torch.zeros(4 * B * H * d, device=DEV)
+    lse = torch.zeros(B, H, device=DEV)
+    ctx = torch.zeros(B, d, device=DEV, dtype=tdt)
+    Wdv, bdv, gd, bd_ = dev(W), dev(bq), dev(gamma), dev(beta)
+    WT = Wdv.t().contiguous()
+    call("lpi_spool_attn_fwd", dt, B, L, H, dev(q), d, Wdv, d, WT, 3 * d, bdv, xd, d, md, rd, gd, bd_, scratch, lse, ctx, d, _stream())
+    dq = torch.zeros(B, d, device=DEV, dtype=torch.bfloat16)
+    dh = torch.full((B * L, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    Wb = Wdv.bfloat16()      # the backward's operands are bf16 whatever the forward's type
+    call("lpi_spool_attn_bwd", B, L, H, Wb, d, Wb.t().contiguous(), 3 * d, xd, d, md, rd, gd, scratch, lse, dev(dctx), d, dq, d, dh, d, _stream())
+    torch.cuda.synchronize()
+    e_ctx = float((ctx.double().cpu() - ctx_ref.detach()).abs().max() / ctx_ref.detach().abs().max())
+    e_dq = float((dq.double().cpu() - qr.grad).abs().max() / qr.grad.abs().max())
+    e_dh = float((dh.double().cpu() - h.grad).abs().max() / h.grad.abs().max())
+    print(f"{dtname} B={B} L={L} H={H}: ctx {e_ctx:.2e}, dq {e_dq:.2e}, d LN1(x) {e_dh:.2e} relative to the largest element")
+    assert bool(torch.isfinite(dh.float()).all())
+    assert e_ctx <= 1e-2 and e_dq <= 1.5e-2 and e_dh <= 1.5e-2      # the 2-byte roundings of the outputs and of gamma o qt (measured: a few 1e-3)
+
+
+
+@pytest.mark.parametrize("cfgname,mode,B,depth", [("tiny", "bf16", 5, 2), ("ViT-B/16", "bf16", 8, 3), ("ViT-B/16", "f16", 8, 3)])
+def test_last_block_without_k_and_v_equals_the_projection_path(cfgname, mode, B, depth):
+    """Engine level: the vision tower's last block evaluated from the residual stream (EngineOptions.stream_pool, the default) against the K / V projection
+    path (stream_pool=False) on a whole training step — the same algebra: features and factor gradients agree to the 2-byte roundings that differ between
+    the two (K and V are no longer rounded to 16 bits; gamma o qt is), far inside the mode's distance from the f32 reference; and the K / V GEMM launches
+    are gone from the step."""
+    from lpi_amd import engine as E
+    from lpi_amd.engine import DualEncoder, PackedIds
+    from lpi_amd.step import train_step
+    cfg = synth.CONFIGS[cfgname]
+    sd = synth.clip_state_dict(cfg)
+    img = torch.from_numpy(synth.images(B, cfg.image_resolution)).to(DEV)
+    ids = synth.token_ids(B)
+    res = {}
+    for sp in (True, False):
+        enc = DualEncoder(cfg, sd, dtype=mode, device=DEV, options=E.EngineOptions(stream_pool=sp))
+        fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
+        n0 = _lib.launch_count()
+        out = train_step(enc, img, PackedIds(ids, 17).to(DEV), fac, depth)
+        torch.cuda.synchronize()
+        res[sp] = ({k: out[k].clone() for k in ("img_f", "txt_f", "base_loss")}, {k: fac[k].grad.double().cpu() for k in synth.PROMPT_NAMES}, _lib.launch_count() - n0)
+        assert enc.vis._stream_pool_shape(1 + 16 + cfg.n_patches) == sp and not enc.txt._stream_pool_shape(77)
+        del enc
+        torch.cuda.empty_cache()
+    assert torch.equal(res[True][0]["txt_f"], res[False][0]["txt_f"])          # the text tower is untouched
+    df = float((res[True][0]["img_f"] - res[False][0]["img_f"]).abs().max())
+    worst = 0.0
+    for k in synth.PROMPT_NAMES:
+        a, b = res[True][1][k], res[False][1][k]
+        worst = max(worst, float((a - b).abs().max() / b.abs().max()))
+        assert float((a * b).sum() / (a.norm() * b.norm())) > 0.9995, k
+    print(f"{cfgname} {mode}: image features differ by {df:.2e}, factor gradients by {worst:.2e} of their largest element; launches {res[True][2]} vs {res[False][2]}")
+    assert df <= (3e-3 if mode == "bf16" else 1e-3) and worst <= 3e-2
+    assert res[True][2] == res[False][2] + 6
