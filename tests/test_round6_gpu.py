@@ -485,37 +485,39 @@ def test_last_block_attention_from_the_stream_against_f64(dtname, B, L, H):
 
 
 
-@pytest.mark.parametrize("cfgname,mode,B,depth", [("tiny", "bf16", 5, 2), ("ViT-B/16", "bf16", 8, 3), ("ViT-B/16", "f16", 8, 3)])
-def test_last_block_without_k_and_v_equals_the_projection_path(cfgname, mode, B, depth):
-    """Engine level: the vision tower's last block evaluated from the residual stream (EngineOptions.stream_pool, the default) against the K / V projection
-    path (stream_pool=False) on a whole training step — the same algebra: features and factor gradients agree to the 2-byte roundings that differ between
-    the two (K and V are no longer rounded to 16 bits; gamma o qt is), far inside the mode's distance from the f32 reference; and the K / V GEMM launches
-    are gone from the step."""
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_last_block_without_k_and_v_against_the_projection_path_and_the_reference(golden, mode):
+    """Engine level (ViT-B/16, 8 pairs, depth 3 = the reference fixture's step): the vision tower's last block evaluated from the residual stream
+    (EngineOptions.stream_pool, the default) and with the K / V projections (stream_pool=False).  The same algebra with different 2-byte roundings (K and V
+    are no longer rounded to 16 bits; gamma o qt and hbar are), so the two are held to the REFERENCE: the new path is not further from the fixture than the
+    projection path (features, logits, factor gradients), and the two agree with each other inside the mode's own distance from the reference."""
     from lpi_amd import engine as E
-    from lpi_amd.engine import DualEncoder, PackedIds
+    from lpi_amd.engine import DualEncoder
     from lpi_amd.step import train_step
-    cfg = synth.CONFIGS[cfgname]
-    sd = synth.clip_state_dict(cfg)
-    img = torch.from_numpy(synth.images(B, cfg.image_resolution)).to(DEV)
-    ids = synth.token_ids(B)
+    g = golden("vitb16_d3_patched")
+    sd = synth.clip_state_dict(CFG)
+    img = torch.from_numpy(synth.images(8, 224)).to(DEV)
+    ids = torch.from_numpy(g["token_ids"]).to(DEV)
     res = {}
     for sp in (True, False):
-        enc = DualEncoder(cfg, sd, dtype=mode, device=DEV, options=E.EngineOptions(stream_pool=sp))
-        fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, cfg.vision_width, cfg.transformer_width).items()}
-        n0 = _lib.launch_count()
-        out = train_step(enc, img, PackedIds(ids, 17).to(DEV), fac, depth)
+        enc = DualEncoder(CFG, sd, dtype=mode, device=DEV, options=E.EngineOptions(stream_pool=sp))
+        assert enc.vis._stream_pool_shape(213) == sp and not enc.txt._stream_pool_shape(77)
+        fac = {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in synth.prompt_factors(9, 16, CFG.vision_width, CFG.transformer_width).items()}
+        out = train_step(enc, img, ids, fac, 3)
         torch.cuda.synchronize()
-        res[sp] = ({k: out[k].clone() for k in ("img_f", "txt_f", "base_loss")}, {k: fac[k].grad.double().cpu() for k in synth.PROMPT_NAMES}, _lib.launch_count() - n0)
-        assert enc.vis._stream_pool_shape(1 + 16 + cfg.n_patches) == sp and not enc.txt._stream_pool_shape(77)
+        lg = (enc.logit_scale_exp * out["img_f"] @ out["txt_f"].t()).cpu().numpy()
+        gr = {k: fac[k].grad.double().cpu().numpy() for k in synth.PROMPT_NAMES}
+        res[sp] = dict(img_f=out["img_f"].cpu().numpy(), txt_f=out["txt_f"].cpu().numpy(), logit=float(np.abs(lg - g["logits"]).max()),
+                       feat=float(np.abs(out["img_f"].cpu().numpy() - g["img_f"]).max()),
+                       grel=max(rel_err(gr[k], g["grad." + k]) for k in synth.PROMPT_NAMES),
+                       gcos=min(float((gr[k] * g["grad." + k]).sum() / (np.linalg.norm(gr[k]) * np.linalg.norm(g["grad." + k]))) for k in synth.PROMPT_NAMES), gr=gr)
         del enc
         torch.cuda.empty_cache()
-    assert torch.equal(res[True][0]["txt_f"], res[False][0]["txt_f"])          # the text tower is untouched
-    df = float((res[True][0]["img_f"] - res[False][0]["img_f"]).abs().max())
-    worst = 0.0
-    for k in synth.PROMPT_NAMES:
-        a, b = res[True][1][k], res[False][1][k]
-        worst = max(worst, float((a - b).abs().max() / b.abs().max()))
-        assert float((a * b).sum() / (a.norm() * b.norm())) > 0.9995, k
-    print(f"{cfgname} {mode}: image features differ by {df:.2e}, factor gradients by {worst:.2e} of their largest element; launches {res[True][2]} vs {res[False][2]}")
-    assert df <= (3e-3 if mode == "bf16" else 1e-3) and worst <= 3e-2
-    assert res[True][2] == res[False][2] + 6
+    new, old = res[True], res[False]
+    assert np.array_equal(new["txt_f"], old["txt_f"])          # the text tower is untouched
+    between = max(rel_err(new["gr"][k], old["gr"][k]) for k in synth.PROMPT_NAMES)
+    print(f"{mode}, vs the reference fixture: stream_pool features {new['feat']:.2e} logits {new['logit']:.2e} gradients {new['grel']:.2e} (cosine {new['gcos']:.5f}) | "
+          f"projection path {old['feat']:.2e} / {old['logit']:.2e} / {old['grel']:.2e} ({old['gcos']:.5f}) | the two against each other: gradients {between:.2e}")
+    assert new["feat"] <= 1.25 * old["feat"] + 1e-4 and new["logit"] <= 1.25 * old["logit"] + 1e-3
+    assert new["grel"] <= 1.25 * old["grel"] + 5e-3 and new["gcos"] >= old["gcos"] - 5e-4
+    assert between <= 2.0 * max(new["grel"], old["grel"]) + 1e-3
