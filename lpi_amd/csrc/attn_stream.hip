@@ -222,25 +222,28 @@ __device__ __forceinline__ void score_tile(const f16_t* __restrict__ xrow, bool 
 // sum over the sample's rows of w[l][h] * x_l for the thread's column pair: rows in groups of RG, the NEXT group's loads in flight while this one is summed
 // (measured: groups of 16 rows 54 -> 70 us for the forward kernel, a ring with two groups ahead 75 us, both tiles of pass 1 requested up front no better: kept at 8 / one)
 template <int NH>
-__device__ __forceinline__ void weighted_row_sums(f32x2 (&acc)[NH], const f16_t* __restrict__ xc, int ldx, int L, const float* __restrict__ Wl) {
+__device__ __forceinline__ void weighted_row_sums(f32x2 (&acc)[NH], const f16_t* __restrict__ xc, int ldx, int L, int Lp, const float* __restrict__ Wl) {
+    // NO per-row test: the weights of rows [L, Lp) are zero (Lp = L rounded up to 16, a multiple of RG) and their loads are clamped to row L - 1, so every group
+    // is eight unconditional rows — with a branch per row the compiler could not hoist a group's LDS reads over one another and each row waited for its own
     constexpr int RG = 8;
     f16x2 cur[RG], nxt[RG];
 #pragma unroll
     for (int u = 0; u < RG; ++u) cur[u] = *reinterpret_cast<const f16x2*>(xc + (size_t)min(u, L - 1) * ldx);
-    for (int l = 0; l < L; l += RG) {
+    for (int l = 0; l < Lp; l += RG) {
 #pragma unroll
         for (int u = 0; u < RG; ++u) nxt[u] = *reinterpret_cast<const f16x2*>(xc + (size_t)min(l + RG + u, L - 1) * ldx);
+        f32x4 w[RG][NH / 4];
+#pragma unroll
+        for (int u = 0; u < RG; ++u)
+#pragma unroll
+            for (int hq = 0; hq < NH / 4; ++hq) w[u][hq] = *reinterpret_cast<const f32x4*>(Wl + (l + u) * HS + 4 * hq);
 #pragma unroll
         for (int u = 0; u < RG; ++u) {
-            if (l + u < L) {
-                const f32x2 xf = {(float)cur[u][0], (float)cur[u][1]};
+            const f32x2 xf = {(float)cur[u][0], (float)cur[u][1]};
 #pragma unroll
-                for (int hq = 0; hq < NH / 4; ++hq) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wl + (l + u) * HS + 4 * hq);
+            for (int hq = 0; hq < NH / 4; ++hq)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[4 * hq + i] = __builtin_elementwise_fma(f32x2{w[i], w[i]}, xf, acc[4 * hq + i]);
-                }
-            }
+                for (int i = 0; i < 4; ++i) acc[4 * hq + i] = __builtin_elementwise_fma(f32x2{w[u][hq][i], w[u][hq][i]}, xf, acc[4 * hq + i]);
         }
 #pragma unroll
         for (int u = 0; u < RG; ++u) cur[u] = nxt[u];
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(NT) void spool_fwd_kernel(SpoolArgs A) {
         f32x2 acc[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[h] = f32x2{0.f, 0.f};
-        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, S);
+        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, Lp, S);
         const f32x2 gm = *reinterpret_cast<const f32x2*>(A.gamma + j), bt = *reinterpret_cast<const f32x2*>(A.beta + j);
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(NT) void spool_bwd_kernel(SpoolArgs A) {
         f32x2 acc[NH];
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[h] = f32x2{0.f, 0.f};
-        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, D);
+        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, Lp, D);
         const f32x2 gm = *reinterpret_cast<const f32x2*>(A.gamma + j);
 #pragma unroll
         for (int h = 0; h < NH; ++h)

@@ -4,7 +4,11 @@
     over lpi_nt_bxent_fwd_bwd + the CP backward) and through the raw C entry point;
   * the whole step of task 12 of a continual session (ViT-B/16, 8 pairs) against the reference's — both the reference-ordered calls (net -> cal_loss -> backward) and
     the fused `SliNet.train_step` whose task term adds onto the seeded prompt-gradient buffers;
-  * restoring a checkpoint drops the fused task term's cached rows."""
+  * restoring a checkpoint drops the fused task term's cached rows;
+  * a 12-task continual session end to end; outlier statistics (massive-activation channels, rows 12 sigma off zero) through the folded LayerNorms, the one-sweep
+    statistics guard and the fp16 stream;
+  * the attention kernels on layout strides (head-grouped, head-blocked): the same bits as on the interleaved matrix; the engine with in_proj grouped by head;
+  * the last block WITHOUT K and V (csrc/attn_stream.hip): against the literal f64 evaluation, and against the projection path with both held to the reference fixture."""
 import json
 import os
 import types
