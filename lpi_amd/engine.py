@@ -153,8 +153,10 @@ GEMM_PROFILE = None
 
 
 # Split-K for GEMMs with a few rows (pooled rows of the last block, heads): workgroups a launch aims at (slices = this // tiles, a divisor of the K-tile
-# count): more slices shorten the partial kernel's K loop and lengthen the reduction (slices x M x N f32 partials)
-SPLITK_WGS = 384
+# count): more slices shorten the partial kernel's K loop and lengthen the reduction (slices x M x N f32 partials).  Round 2 chose 384 on the kernels of its day;
+# re-swept on the whole step in round 6 (tools/splitk_wgs_ab.py, interleaved x3 in one process): 24 / 48 / 64 / 96 / 128 / 192 / 256 / 384 / 512 / 768 ->
+# 22.41 / 22.37 / 22.38 / 22.29 / 22.29 / 22.32 / 22.34 / 22.36 / 22.37 / 22.38 ms — the reductions' 19-30 MB of f32 partials cost more than the shorter K loops buy
+SPLITK_WGS = 128
 _SPLITK_SCRATCH = {}
 
 
