@@ -80,9 +80,9 @@ uint64_t lpi_launch_count(void);
  *   key 8      != 0: lpi_gemm_nt_grouped never groups (issues its problems one after the other; A/B switch, same bits).
  *   key 11     > 0: the streamed attention backward launches at most this many workgroups (tests: several heads per workgroup at small B H).
  *   key 12     A/B switches of the streamed attention backward (bit 0: K / V of the next head as one burst instead of spread over the head).
- *   key 13     != 0: the attention forward keeps padded (160-byte) K / V image rows where it would use the swizzled unpadded ones (Lp = 288; A/B, same bits).
- *   key 14     1: the generic epilogue of the persistent GEMM everywhere (no half-width staging for store-only 2-byte outputs); 3: also the opt-in
- *              half-width LayerNorm-fold epilogue (A/B switches, same bits).
+ *   key 13     != 0: the attention forward keeps padded (160-byte) K / V image rows where it would use the swizzled unpadded ones (Lp = 288; a TEST hook, same bits).
+ *   key 14     1: the generic epilogue of the persistent GEMM everywhere (no half-width staging for store-only 2-byte outputs): a TEST hook, the bit-for-bit
+ *              reference of the half-width staging (same bits).
  *   key 15     tile order of the persistent 256x256 GEMM for weights that do not fit an XCD's L2 next to the activation stream (round 5): 0 (default) = the
  *              N-tiles (an even number) of a weight above 3 MB are cut into two SLICES and the tiles run slice-major, so that each XCD keeps one slice
  *              resident instead of re-reading the whole weight every round; 2 / 3: that many slices wherever N divides; -1: off.  Same bits.
