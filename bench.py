@@ -433,7 +433,7 @@ class Workload:
                          "last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
                  "k128": "gemm_nt_kernel (128x128 tiles, 4 waves of 64x64, LDS-DMA double buffer: every launch below the 256x256 kernel's tile-count threshold)",
                  "k256x128": "gemm256x128_kernel (launches with 16..159 256x256 tiles)",
-                 "few_rows": "gemm_nt_splitk(_pair)_kernel + splitk_reduce(_pair)_kernel (M <= 256: split-K partial tiles, fixed-order reduction with the epilogue)"}
+                 "few_rows": "gemm_rows_kernel (M <= 256: 32x32 tiles over the whole K range, one launch per op and tower pair)"}
         traffic = mfma_util = tsrc = None
         wl = {"model": a.model, "batch": a.batch, "depth": a.depth}
         import glob
@@ -445,7 +445,7 @@ class Workload:
                 continue
             if (pj.get("workload") == wl and pj.get("dtype") == self.dtype and pj.get("tuning") == tuning and pj.get("lib_version") == int(lib.lpi_version())):
                 names = {"k256": ("gemm256_kernel", "gemm256_tail_kernel", "gemm256p_kernel"), "k128": ("gemm_nt_kernel",), "k256x128": ("gemm256x128_kernel",),
-                         "few_rows": ("gemm_nt_splitk_kernel", "gemm_nt_splitk_pair_kernel")}[dom]
+                         "few_rows": ("gemm_rows_kernel",)}[dom]
                 ks = [v for n, v in pj["kernels"].items() if n in names and "hbm_mb_per_launch" in v]
                 if ks:      # launch-weighted over the dominant kernel's entry points
                     w = sum(v["launches"] for v in ks)

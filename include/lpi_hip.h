@@ -104,14 +104,6 @@ int lpi_gemm_nt(int dtype, int c_dtype, int M, int N, int K,
                 const float* bias, const void* residual, int ldr,
                 int epilogue, void* aux, int ldaux, float alpha, void* stream);
 
-/* The same GEMM for a FEW ROWS (the pooled rows of the last block, the heads: M = 128 or 256): K is cut into `ksplit` slices that
- * run as independent workgroups writing f32 partial tiles to `scratch` (>= ksplit*M*N floats, caller-owned), then one kernel sums the
- * slices in a fixed order and applies the same fused epilogue.  Deterministic.  K % (ksplit * 128 / sizeof(element)) == 0. */
-int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K,
-                       const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                       const float* bias, const void* residual, int ldr,
-                       int epilogue, void* aux, int ldaux, float alpha, int ksplit, float* scratch, void* stream);
-
 /* SEVERAL such GEMMs in one launch (a GROUPED launch): `count` problems of the same operand type, output type and epilogue kind
  * (residual / aux present in all of them or in none) — e.g. the vision tower's and the text tower's c_fc of the same layer
  * (models/clip/model.py:175-177 runs them as two nn.Linear calls of two independent towers).  With count == 2 and shapes the
@@ -150,11 +142,14 @@ int lpi_rowstat_guard(int32_t* counter, int32_t* flag);
 int lpi_ln_stats_finalize_pair(int rows0, int d0, const float* part0, int ld0, float* mean0, float* rstd0,
                                int rows1, int d1, const float* part1, int ld1, float* mean1, float* rstd1, float eps, void* stream);
 
-/* TWO few-row GEMMs (lpi_gemm_nt_splitk) in one pair of launches — the two towers' GEMM of the same op on the pooled rows of the last block
- * / the heads: each alone is a ~7 us partial-tile launch plus a ~6 us reduction.  Same operand types and epilogue kind; ksplit[i], scratch_i
- * (>= ksplit[i]*M_i*N_i floats) per problem.  Same bits as two lpi_gemm_nt_splitk calls. */
-int lpi_gemm_nt_splitk_pair(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* descs, const int* ksplit,
-                            float* scratch0, float* scratch1, void* stream);
+/* Few-row GEMM in ONE launch (csrc/gemm_rows.hip; round 6): `count` = 1 or 2 problems (the two towers' GEMM of the same op on the pooled rows of the last
+ * block / the heads: model.py:172-177,185,257, prompt_learner.py:61 on B rows per tower, and their dgrads), same operand types and epilogue kind, epilogues
+ * LPI_EPI_NONE (+ f32 residual) / LPI_EPI_QUICKGELU (+ aux = gelu'(u)) / LPI_EPI_DQUICKGELU as lpi_gemm_nt.  A workgroup owns a 32 x 32 output tile over the
+ * whole K range (eight waves cut K, partial tiles meet in LDS in a fixed order): no scratch, no second launch, deterministic.  M, N multiples of 32, K a
+ * multiple of 64 elements (32 for f32: whole 128-byte blocks), rows 16-byte aligned: lpi_gemm_nt_rows_supported says 1 for such a shape.  Replaces rounds 2-5's split-K partial + reduction launch pairs (lpi_gemm_nt_splitk*, gone from the ABI in 604): the same
+ * sums in another f32 order, half the time (profiles/r06_experiments.md section 10).  Attributed to LPI_GEMM_K_ROWS. */
+int lpi_gemm_nt_rows_supported(int dtype, int M, int N, int K);
+int lpi_gemm_nt_rows(int dtype, int c_dtype, int epilogue, float alpha, int count, const lpi_gemm_desc* descs, void* stream);
 
 /* ---- a5: LayerNorm (fp32 statistics, eps 1e-5)            replaces: models/clip/model.py:154-160 ------
  * x_dtype: storage type of the residual stream x — LPI_F32, or LPI_F16 in bf16 mode (statistics and arithmetic are f32 either way).
@@ -587,13 +582,13 @@ void lpi_bpe_destroy(void* handle);
 int lpi_bpe_encode(void* handle, const char* text_utf8, int32_t* ids, int max_ids);
 int lpi_bpe_tokenize(void* handle, const char* const* texts, int n, int context_length, int truncate, int64_t* out);
 
-/* Which kernel the calling thread's last lpi_gemm_nt / lpi_gemm_nt_splitk launched (-1: none yet): measurement tools attribute a
+/* Which kernel the calling thread's last lpi_gemm_nt / lpi_gemm_nt_rows launched (-1: none yet): measurement tools attribute a
  * launch to a kernel with this instead of re-deriving the dispatch rules. */
 #define LPI_GEMM_K_128 0        /* gemm_nt_kernel, 128x128 tiles                                  */
 #define LPI_GEMM_K_256 1        /* gemm256_kernel, 256x256 tiles                                  */
 #define LPI_GEMM_K_256_TAIL 2   /* gemm256_tail_kernel: 256x256 tiles, short last round as halves */
 #define LPI_GEMM_K_256X128 3    /* gemm256x128_kernel                                             */
-#define LPI_GEMM_K_SPLITK 4     /* split-K gemm_nt_kernel + splitk_reduce_kernel                  */
+#define LPI_GEMM_K_ROWS 4       /* gemm_rows_kernel: few-row GEMM, 32x32 tiles over the whole K   */
 int lpi_gemm_last_kernel(void);
 
 

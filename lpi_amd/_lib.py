@@ -43,8 +43,8 @@ SIGNATURES = {
     "lpi_ln_stats_finalize": [_I, _I, _P, _I, _F, _P, _P, _P],
     "lpi_rowstat_guard": [_P, _P],
     "lpi_ln_stats_finalize_pair": [_I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _P, _F, _P],
-    "lpi_gemm_nt_splitk_pair": [_I, _I, _I, _F, _P, _P, _P, _P, _P],
-    "lpi_gemm_nt_splitk": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _I, _P, _P],
+    "lpi_gemm_nt_rows": [_I, _I, _I, _F, _I, _P, _P],
+    "lpi_gemm_nt_rows_supported": [_I, _I, _I, _I],
     "lpi_layernorm_fwd": [_I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "lpi_layernorm_bwd": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _P],
     "lpi_layernorm_fwd_pair": [_I, _I, _P, _P],
@@ -137,7 +137,7 @@ _RESTYPES = {"lpi_launch_count": c_uint64, "lpi_bpe_create": c_void_p, "lpi_bpe_
 
 # The C ABI this binding was written against (lpi_version()).  Bumped with every change of a signature or of an argument's meaning: a stale
 # liblpi_hip.so (or an LPI_LIB variant of another commit) would otherwise take shifted arguments silently.
-EXPECTED_ABI = 603
+EXPECTED_ABI = 604
 VARIANT_OFFSET = 1000000      # lpi_version() of a tools/build_variant.sh build = EXPECTED_ABI + this
 
 _lib = None
@@ -282,9 +282,9 @@ def gemm_grouped(dt: int, cdt: int, epi: int, alpha: float, problems, stream) ->
     return bool(lib.lpi_gemm_last_grouped())
 
 
-def gemm_splitk_pair(dt: int, cdt: int, epi: int, alpha: float, problems, ksplits, scratches, stream):
-    """lpi_gemm_nt_splitk_pair over two `problems` (dicts as for gemm_grouped)."""
-    arr = (GemmDesc * 2)()
+def gemm_rows(dt: int, cdt: int, epi: int, alpha: float, problems, stream):
+    """lpi_gemm_nt_rows over one or two `problems` (dicts as for gemm_grouped): the few-row GEMM in one launch."""
+    arr = (GemmDesc * len(problems))()
     for d, p in zip(arr, problems):
         d.M, d.N, d.K = p["M"], p["N"], p["K"]
         d.A, d.lda = p["a"].data_ptr(), p["a"].stride(0)
@@ -292,13 +292,11 @@ def gemm_splitk_pair(dt: int, cdt: int, epi: int, alpha: float, problems, ksplit
         d.C, d.ldc = p["c"].data_ptr(), p["c"].stride(0)
         bias, res, aux = p.get("bias"), p.get("residual"), p.get("aux")
         d.bias = None if bias is None else bias.data_ptr()
-        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), res.stride(0))
+        d.residual, d.ldr = (None, 0) if res is None else (res.data_ptr(), p.get("ldr") or res.stride(0))
         d.aux, d.ldaux = (None, 0) if aux is None else (aux.data_ptr(), aux.stride(0))
-    ks = (c_int * 2)(*ksplits)
-    rc = load().lpi_gemm_nt_splitk_pair(dt, cdt, epi, float(alpha), ctypes.cast(arr, c_void_p), ctypes.cast(ks, c_void_p), scratches[0].data_ptr(),
-                                        scratches[1].data_ptr(), stream)
+    rc = load().lpi_gemm_nt_rows(dt, cdt, epi, float(alpha), len(problems), ctypes.cast(arr, c_void_p), stream)
     if rc != 0:
-        raise LpiError(f"lpi_gemm_nt_splitk_pair failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
+        raise LpiError(f"lpi_gemm_nt_rows failed with code {rc}" + (" (invalid argument)" if rc == -22 else ""))
 
 
 ROWOP_POOL_LN_FWD, ROWOP_L2NORM_FWD, ROWOP_L2NORM_BWD, ROWOP_POOL_LN_BWD, ROWOP_LN_BWD = 1, 2, 3, 4, 5

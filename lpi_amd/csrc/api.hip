@@ -9,7 +9,7 @@ extern "C" uint64_t lpi_launch_count(void) { return g_launches.load(std::memory_
 // bump with every change of a signature or of what an argument means (lpi_amd/_lib.py EXPECTED_ABI).  Diagnostic / ablation builds (tools/build_variant.sh)
 // report LPI_ABI_VERSION + 1 000 000: the binding loads such a library only when LPI_LIB names it, and says so on stderr.
 #ifndef LPI_ABI_VERSION
-#define LPI_ABI_VERSION 603
+#define LPI_ABI_VERSION 604
 #endif
 #ifdef LPI_VARIANT_BUILD
 extern "C" int lpi_version(void) { return LPI_ABI_VERSION + 1000000; }

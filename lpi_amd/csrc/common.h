@@ -46,7 +46,7 @@ inline int lpi_ensure_lds(LdsOnce& once, const void* kern, int bytes) {
     once.devices.fetch_or(bit, std::memory_order_release);
     return 0;
 }
-// which GEMM kernel the last lpi_gemm_nt / lpi_gemm_nt_splitk call of this thread launched (LPI_GEMM_K_*; lpi_gemm_last_kernel)
+// which GEMM kernel the last lpi_gemm_nt / lpi_gemm_nt_rows call of this thread launched (LPI_GEMM_K_*; lpi_gemm_last_kernel)
 void lpi_note_gemm_kernel(int which);
 int lpi_cu_count();      // CUs of the current device (api.hip: cached per device)
 

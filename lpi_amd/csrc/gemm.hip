@@ -28,16 +28,12 @@ constexpr int NTHREADS = 256;
 
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __device__ __forceinline__ void gemm_nt_tile(
-    int bx, int ky, char* smem, int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
+    int bx, char* smem, int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, long c_zstride)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n)
 {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = ROW_BYTES / (int)sizeof(T);
-    // split-K launches (lpi_gemm_nt_splitk): blockIdx.y selects a K slice of length K; its partial sums go to slice y of C
-    A += (size_t)ky * K;
-    B += (size_t)ky * K;
-    C += (size_t)ky * c_zstride;
 
     // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs; give each XCD a contiguous
     // run of the (n-panel major, m minor) tile list so the B panel and neighbouring A tiles stay in its L2.
@@ -147,29 +143,10 @@ template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(
     int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb,
     TC* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n, long c_zstride)
+    typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha, int tiles_m, int tiles_n)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gemm_nt_tile<T, TC, EPI, RES, SAVE_U>(blockIdx.x, blockIdx.y, smem, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, tiles_m, tiles_n,
-                                          c_zstride);
-}
-
-// TWO split-K partial GEMMs in one launch (the two towers' few-row GEMM of the same op in the last block / the heads: each alone is a
-// 7 us launch): blocks [0, nwg0) x ksplit0 slices run problem 0, the rest problem 1 (a block whose slice index exceeds its problem's ksplit exits).
-template <typename T>
-struct SplitkP {
-    int M, N, Ks, lda, ldb, tiles_m, tiles_n, ksplit;      // Ks = K per slice
-    const T* A; const T* B; float* part;
-};
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_splitk_pair_kernel(SplitkP<T> p0, SplitkP<T> p1, int nwg0)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool first = (int)blockIdx.x < nwg0;
-    const SplitkP<T>& p = first ? p0 : p1;
-    if ((int)blockIdx.y >= p.ksplit) return;
-    gemm_nt_tile<T, float, LPI_EPI_NONE, false, false>(first ? blockIdx.x : blockIdx.x - nwg0, blockIdx.y, smem, p.M, p.N, p.Ks, p.A, p.lda, p.B, p.ldb, p.part, p.N,
-                                                       nullptr, nullptr, 0, nullptr, 0, 1.0f, p.tiles_m, p.tiles_n, (long)p.M * p.N);
+    gemm_nt_tile<T, TC, EPI, RES, SAVE_U>(blockIdx.x, smem, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, tiles_m, tiles_n);
 }
 
 template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
@@ -182,7 +159,7 @@ int launch_impl(int M, int N, int K, const void* A, int lda, const void* B, int 
     if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
     lpi_note_gemm_kernel(LPI_GEMM_K_128);
     LPI_LAUNCH(kern, dim3(tm * tn), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K, (const T*)A, lda, (const T*)B, ldb,
-                       (TC*)C, ldc, bias, residual, ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn, 0L);
+                       (TC*)C, ldc, bias, residual, ldr, (typename AuxT<T>::type*)aux, ldaux, alpha, tm, tn);
     LPI_CHECK_LAST();
     return 0;
 }
@@ -221,176 +198,7 @@ int dispatch_epi(int epi, int M, int N, int K, const void* A, int lda, const voi
     return LPI_EINVAL;
 }
 
-// ---- split-K for small-M GEMMs (the pooled rows of the last block and the heads: M = 128 or 256) -------------------------------
-// A GEMM with a handful of tiles streams its whole K range through a handful of CUs (2-12 workgroups, 23-42 us each at B = 256,
-// 0.65 ms per step).  Here blockIdx.y cuts K into `ksplit` slices (the same 128x128 kernel, f32 partial tiles into `scratch`),
-// and a second kernel sums the slices in a fixed order and applies the usual fused epilogue: deterministic, no atomics.
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-__device__ __forceinline__ void splitk_reduce_body(int bx, int M, int N, int ksplit, const float* __restrict__ part, TC* __restrict__ C, int ldc,
-                                                   const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-                                                   typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha)
-{
-    const long i = (long)bx * 256 + threadIdx.x;       // one thread per 4 consecutive columns
-    const int n4 = N >> 2;
-    if (i >= (long)M * n4) return;
-    const int row = (int)(i / n4), col = (int)(i % n4) << 2;
-    const float* p = part + (size_t)row * N + col;
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    for (int k = 1; k < ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p + (size_t)k * M * N);
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
-    gemm_epilogue_store<T, TC, EPI, RES, SAVE_U>(v, row, col, C, ldc, bv, alpha, residual, ldr, aux, ldaux);
-}
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ksplit, const float* __restrict__ part, TC* __restrict__ C, int ldc,
-                                                           const float* __restrict__ bias, const float* __restrict__ residual, int ldr,
-                                                           typename AuxT<T>::type* __restrict__ aux, int ldaux, float alpha)
-{
-    splitk_reduce_body<T, TC, EPI, RES, SAVE_U>(blockIdx.x, M, N, ksplit, part, C, ldc, bias, residual, ldr, aux, ldaux, alpha);
-}
-template <typename T, typename TC>
-struct ReduceP {
-    int M, N, ksplit, ldc, ldr, ldaux;
-    const float* part; TC* C; const float* bias; const float* residual; typename AuxT<T>::type* aux;
-};
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-__global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(ReduceP<T, TC> p0, ReduceP<T, TC> p1, int nb0, float alpha)
-{
-    if ((int)blockIdx.x < nb0) splitk_reduce_body<T, TC, EPI, RES, SAVE_U>(blockIdx.x, p0.M, p0.N, p0.ksplit, p0.part, p0.C, p0.ldc, p0.bias, p0.residual, p0.ldr, p0.aux, p0.ldaux, alpha);
-    else splitk_reduce_body<T, TC, EPI, RES, SAVE_U>(blockIdx.x - nb0, p1.M, p1.N, p1.ksplit, p1.part, p1.C, p1.ldc, p1.bias, p1.residual, p1.ldr, p1.aux, p1.ldaux, alpha);
-}
-
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-int splitk_impl(int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, const float* residual,
-                int ldr, void* aux, int ldaux, float alpha, int ksplit, float* scratch, hipStream_t s)
-{
-    const int tm = M / BM, tn = N / BN;
-    auto kern = gemm_nt_kernel<T, float, LPI_EPI_NONE, false, false>;
-    static LdsOnce once;
-    if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
-    lpi_note_gemm_kernel(LPI_GEMM_K_SPLITK);
-    LPI_LAUNCH(kern, dim3(tm * tn, ksplit), dim3(NTHREADS), 2 * STAGE_BYTES, s, M, N, K / ksplit, (const T*)A, lda, (const T*)B, ldb, scratch, N,
-               (const float*)nullptr, (const float*)nullptr, 0, (typename AuxT<T>::type*)nullptr, 0, 1.0f, tm, tn, (long)M * N);
-    const long n = (long)M * (N >> 2);
-    LPI_LAUNCH((splitk_reduce_kernel<T, TC, EPI, RES, SAVE_U>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, M, N, ksplit, scratch, (TC*)C, ldc, bias,
-               residual, ldr, (typename AuxT<T>::type*)aux, ldaux, alpha);
-    LPI_CHECK_LAST();
-    return 0;
-}
-
-template <typename T, typename TC>
-int splitk_dispatch(int epi, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-                    const float* residual, int ldr, void* aux, int ldaux, float alpha, int ks, float* sc, hipStream_t s)
-{
-#define SK(EPI, RES, SU) return splitk_impl<T, TC, EPI, RES, SU>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ks, sc, s)
-    if (epi == LPI_EPI_NONE) { if (residual) SK(LPI_EPI_NONE, true, false); SK(LPI_EPI_NONE, false, false); }
-    if (residual) return LPI_ENOSYS;
-    if (epi == LPI_EPI_QUICKGELU) { if (aux) SK(LPI_EPI_QUICKGELU, false, true); SK(LPI_EPI_QUICKGELU, false, false); }
-    if (epi == LPI_EPI_DQUICKGELU) { if (!aux) return LPI_EINVAL; SK(LPI_EPI_DQUICKGELU, false, false); }
-#undef SK
-    return LPI_EINVAL;
-}
-
 }  // namespace
-
-extern "C" int lpi_gemm_nt_splitk(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
-                                  void* C, int ldc, const float* bias, const void* residual_, int ldr, int epilogue, void* aux,
-                                  int ldaux, float alpha, int ksplit, float* scratch, void* stream)
-{
-    const float* residual = (const float*)residual_;
-    const int esz = dtype == LPI_F32 ? 4 : 2;
-    const int csz = c_dtype == LPI_F32 ? 4 : 2;
-    const int bk = ROW_BYTES / esz;
-    if (!A || !B || !C || !scratch || M <= 0 || N <= 0 || K <= 0 || ksplit < 1 || ksplit > 65535) return LPI_EINVAL;
-    if (M % BM || N % BN || K % (bk * ksplit)) return LPI_EINVAL;
-    if ((lda * esz) % 16 || (ldb * esz) % 16 || (ldc * csz) % 8 || lda < K || ldb < K || ldc < N) return LPI_EINVAL;
-    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)scratch) & 15) return LPI_EINVAL;
-    if (residual && (ldr < N || (ldr & 3) || ((uintptr_t)residual & 15))) return LPI_EINVAL;
-    if (bias && ((uintptr_t)bias & 15)) return LPI_EINVAL;
-    if (aux && (ldaux < N || ((uintptr_t)aux & 7) || (ldaux * esz) % 8)) return LPI_EINVAL;
-    if (c_dtype == LPI_F16 && dtype != LPI_F16) return LPI_ENOSYS;     // bf16 mode: the fp16 residual stream never has this few rows
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == LPI_F32 && c_dtype == LPI_F32)
-        return splitk_dispatch<float, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_BF16)
-        return splitk_dispatch<bf16_t, bf16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_F32)
-        return splitk_dispatch<bf16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F16)
-        return splitk_dispatch<f16_t, f16_t>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F32)
-        return splitk_dispatch<f16_t, float>(epilogue, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, ldaux, alpha, ksplit, scratch, s);
-    return LPI_ENOSYS;
-}
-
-// ---- two few-row GEMMs in one pair of launches (lpi_gemm_nt_splitk_pair) ------------------------------------------------------------
-namespace {
-template <typename T, typename TC, int EPI, bool RES, bool SAVE_U>
-int splitk_pair_impl(const lpi_gemm_desc* d, const int* ks, float* const* sc, float alpha, hipStream_t s)
-{
-    SplitkP<T> g[2];
-    ReduceP<T, TC> r[2];
-    int nwg[2], nb[2], kmax = 0;
-    for (int i = 0; i < 2; ++i) {
-        const int tm = d[i].M / BM, tn = d[i].N / BN;
-        nwg[i] = tm * tn;
-        g[i] = SplitkP<T>{d[i].M, d[i].N, d[i].K / ks[i], d[i].lda, d[i].ldb, tm, tn, ks[i], (const T*)d[i].A, (const T*)d[i].B, sc[i]};
-        r[i] = ReduceP<T, TC>{d[i].M, d[i].N, ks[i], d[i].ldc, d[i].ldr, d[i].ldaux, sc[i], (TC*)d[i].C, d[i].bias, (const float*)d[i].residual,
-                              (typename AuxT<T>::type*)d[i].aux};
-        nb[i] = (int)(((long)d[i].M * (d[i].N >> 2) + 255) / 256);
-        kmax = std::max(kmax, ks[i]);
-    }
-    auto kern = gemm_nt_splitk_pair_kernel<T>;
-    static LdsOnce once;
-    if (int e = lpi_ensure_lds(once, (const void*)kern, 2 * STAGE_BYTES)) return e;
-    lpi_note_gemm_kernel(LPI_GEMM_K_SPLITK);
-    LPI_LAUNCH(kern, dim3(nwg[0] + nwg[1], kmax), dim3(NTHREADS), 2 * STAGE_BYTES, s, g[0], g[1], nwg[0]);
-    LPI_LAUNCH((splitk_reduce_pair_kernel<T, TC, EPI, RES, SAVE_U>), dim3(nb[0] + nb[1]), dim3(256), 0, s, r[0], r[1], nb[0], alpha);
-    LPI_CHECK_LAST();
-    return 0;
-}
-template <typename T, typename TC>
-int splitk_pair_dispatch(int epi, const lpi_gemm_desc* d, const int* ks, float* const* sc, float alpha, hipStream_t s)
-{
-    const bool res = d[0].residual != nullptr, ax = d[0].aux != nullptr;
-    if ((d[1].residual != nullptr) != res || (d[1].aux != nullptr) != ax) return LPI_EINVAL;
-#define SKP(EPI, RES, SU) return splitk_pair_impl<T, TC, EPI, RES, SU>(d, ks, sc, alpha, s)
-    if (epi == LPI_EPI_NONE) { if (res) SKP(LPI_EPI_NONE, true, false); SKP(LPI_EPI_NONE, false, false); }
-    if (res) return LPI_ENOSYS;
-    if (epi == LPI_EPI_QUICKGELU) { if (ax) SKP(LPI_EPI_QUICKGELU, false, true); SKP(LPI_EPI_QUICKGELU, false, false); }
-    if (epi == LPI_EPI_DQUICKGELU) { if (!ax) return LPI_EINVAL; SKP(LPI_EPI_DQUICKGELU, false, false); }
-#undef SKP
-    return LPI_EINVAL;
-}
-}  // namespace
-
-extern "C" int lpi_gemm_nt_splitk_pair(int dtype, int c_dtype, int epilogue, float alpha, const lpi_gemm_desc* d, const int* ksplit, float* scratch0,
-                                       float* scratch1, void* stream)
-{
-    if (!d || !ksplit || !scratch0 || !scratch1) return LPI_EINVAL;
-    const int esz = dtype == LPI_F32 ? 4 : 2;
-    const int csz = c_dtype == LPI_F32 ? 4 : 2;
-    const int bk = ROW_BYTES / esz;
-    float* const sc[2] = {scratch0, scratch1};
-    for (int i = 0; i < 2; ++i) {
-        const lpi_gemm_desc& q = d[i];
-        if (!q.A || !q.B || !q.C || q.M <= 0 || q.N <= 0 || q.K <= 0 || ksplit[i] < 1 || ksplit[i] > 65535) return LPI_EINVAL;
-        if (q.M % BM || q.N % BN || q.K % (bk * ksplit[i])) return LPI_EINVAL;
-        if ((q.lda * esz) % 16 || (q.ldb * esz) % 16 || (q.ldc * csz) % 8 || q.lda < q.K || q.ldb < q.K || q.ldc < q.N) return LPI_EINVAL;
-        if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C | (uintptr_t)sc[i]) & 15) return LPI_EINVAL;
-        if (q.residual && (q.ldr < q.N || (q.ldr & 3) || ((uintptr_t)q.residual & 15))) return LPI_EINVAL;
-        if (q.bias && ((uintptr_t)q.bias & 15)) return LPI_EINVAL;
-        if (q.aux && (q.ldaux < q.N || ((uintptr_t)q.aux & 7) || (q.ldaux * esz) % 8)) return LPI_EINVAL;
-    }
-    if (c_dtype == LPI_F16 && dtype != LPI_F16) return LPI_ENOSYS;
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == LPI_F32 && c_dtype == LPI_F32) return splitk_pair_dispatch<float, float>(epilogue, d, ksplit, sc, alpha, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_BF16) return splitk_pair_dispatch<bf16_t, bf16_t>(epilogue, d, ksplit, sc, alpha, s);
-    if (dtype == LPI_BF16 && c_dtype == LPI_F32) return splitk_pair_dispatch<bf16_t, float>(epilogue, d, ksplit, sc, alpha, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F16) return splitk_pair_dispatch<f16_t, f16_t>(epilogue, d, ksplit, sc, alpha, s);
-    if (dtype == LPI_F16 && c_dtype == LPI_F32) return splitk_pair_dispatch<f16_t, float>(epilogue, d, ksplit, sc, alpha, s);
-    return LPI_ENOSYS;
-}
 
 bool lpi_gemm256_eligible(int dtype, int M, int N, int K);
 int lpi_gemm256p_launch(int dtype, int c_dtype, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

@@ -152,32 +152,11 @@ class LnLinear:
 GEMM_PROFILE = None
 
 
-# Split-K for GEMMs with a few rows (pooled rows of the last block, heads): workgroups a launch aims at (slices = this // tiles, a divisor of the K-tile
-# count): more slices shorten the partial kernel's K loop and lengthen the reduction (slices x M x N f32 partials).  Round 2 chose 384 on the kernels of its day;
-# re-swept on the whole step in round 6 (tools/splitk_wgs_ab.py, interleaved x3 in one process): 24 / 48 / 64 / 96 / 128 / 192 / 256 / 384 / 512 / 768 ->
-# 22.41 / 22.37 / 22.38 / 22.29 / 22.29 / 22.32 / 22.34 / 22.36 / 22.37 / 22.38 ms — the reductions' 19-30 MB of f32 partials cost more than the shorter K loops buy
-SPLITK_WGS = 128
-_SPLITK_SCRATCH = {}
-
-
-def _splitk_plan(dt, M, N, K):
-    """Number of K slices for a small-M GEMM (0 = use the plain kernel): enough 128x128 workgroups to cover the chip, whole K tiles
-    per slice."""
-    if M > 256 or M % 128 or N % 128:
-        return 0
-    nk = K // (32 if dt == F32 else 64)
-    tiles = (M // 128) * (N // 128)
-    cap = max(1, SPLITK_WGS // tiles)
-    ks = max((d for d in range(1, nk + 1) if nk % d == 0 and d <= cap), default=1)
-    return ks if ks > 1 else 0
-
-
-def _splitk_scratch(device, floats):
-    key = (device, torch.cuda.current_stream().cuda_stream)      # one scratch per stream: towers may run concurrently
-    buf = _SPLITK_SCRATCH.get(key)
-    if buf is None or buf.numel() < floats:
-        buf = _SPLITK_SCRATCH[key] = torch.empty(max(floats, 8 << 20), dtype=torch.float32, device=device)
-    return buf
+def _few_rows(dt, M, N, K):
+    """True for a GEMM with a few rows (pooled rows of the last block, heads, the loss's gradient GEMMs): it runs as ONE launch of 32 x 32 tiles over the whole K
+    range (lpi_gemm_nt_rows) instead of a handful of 128 x 128 tiles.  Rounds 2-5 ran these as split-K partial + reduction (two launches, f32 partials through
+    HBM): the one-launch kernel halves their time, -0.15 ms per step (profiles/r06_experiments.md section 10)."""
+    return M <= 256 and M % 128 == 0 and N % 128 == 0 and K % (32 if dt == F32 else 64) == 0
 
 
 def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None, ldr=None):
@@ -191,11 +170,8 @@ def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None,
     if ldr is None:
         ldr = residual.stride(0) if residual is not None else 0
     ln = epi in (EPI_LN, EPI_LN_QUICKGELU)      # `residual` is the LN operand block then (include/lpi_hip.h), ldr its vector stride
-    ks = _splitk_plan(dt, M, N, K) if (cdt != F16 or dt == F16) and not ln and epi != EPI_RES_ROWSTATS else 0
-    if ks:
-        call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
-             ldr, epi, aux, aux.stride(0) if aux is not None else 0,
-             float(alpha), ks, _splitk_scratch(c.device, ks * M * N), _stream())
+    if (cdt != F16 or dt == F16) and not ln and epi != EPI_RES_ROWSTATS and _few_rows(dt, M, N, K):
+        _lib.gemm_rows(dt, cdt, epi, alpha, [dict(M=M, N=N, K=K, a=a, b=b, c=c, bias=bias, residual=residual, aux=aux, ldr=ldr)], _stream())
     else:
         call("lpi_gemm_nt", dt, cdt, M, N, K, a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, residual,
              ldr, epi, aux, aux.stride(0) if aux is not None else 0,
@@ -415,11 +391,9 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
             and (k0.get("bias") is None) == (k1.get("bias") is None) and k0.get("alpha", 1.0) == k1.get("alpha", 1.0)
             )
     cdt = _cdt(r0.c)
-    # few-row GEMMs (pooled rows of the last block, heads): the two split-K launch pairs as one (lpi_gemm_nt_splitk_pair)
-    ks = ([_splitk_plan(r.dt, r.M, r.N, r.K) for r in (r0, r1)]
-          if (same and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS))
-          else [0, 0])
-    few = bool(ks[0] and ks[1])
+    # few-row GEMMs (pooled rows of the last block, heads): the two towers' in one launch (lpi_gemm_nt_rows)
+    few = bool(same and (cdt != F16 or r0.dt == F16) and k0.get("epi", EPI_NONE) not in (EPI_LN, EPI_LN_QUICKGELU, EPI_RES_ROWSTATS)
+               and _few_rows(r0.dt, r0.M, r0.N, r0.K) and _few_rows(r1.dt, r1.M, r1.N, r1.K))
     if not same or not (few or min(r0.M, r1.M) > 256):
         r0.issue()
         r1.issue()
@@ -432,9 +406,7 @@ def _issue_pair(r0: GemmReq, r1: GemmReq):
              for r in (r0, r1)]
     ln = k0.get("epi", EPI_NONE) in (EPI_LN, EPI_LN_QUICKGELU)
     if few:
-        n0 = (ks[0] * r0.M * r0.N + 63) // 64 * 64
-        buf = _splitk_scratch(r0.c.device, n0 + ks[1] * r1.M * r1.N)
-        _lib.gemm_splitk_pair(r0.dt, cdt, k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, ks, (buf, buf[n0:]), _stream())
+        _lib.gemm_rows(r0.dt, cdt, k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, _stream())
     else:
         _lib.gemm_grouped(r0.dt, cdt, k0.get("epi", EPI_NONE), k0.get("alpha", 1.0), probs, _stream())
     if prof is not None:
@@ -1382,17 +1354,13 @@ def clip_loss_fwd_bwd(img_all, txt_all, scale: float, need_grad=True, r0: int = 
         return loss, logits[:n, :n], None, None
     # dI_loc = scale * g . T,  dT_loc = scale * gt . I  with g / gt the local rows of dlogits / dlogits^T (NT form: B operand = T^T / I^T).
     # Two launches for the two log-sum-exp vectors, the loss value and the local rows of both gradients (lpi_clip_loss_local), one for both transposes,
-    # and the two small gradient GEMMs as one split-K pair (round 4: nine launches became five)
+    # and the two small gradient GEMMs as one few-row launch (round 4: nine launches became five; round 6: four)
     At, Bt, g, gt = ws["At"], ws["Bt"], ws["g"], ws["gt"]
     call("lpi_clip_loss_local", n, logits, npad, 1.0, r0, nloc, loss, lse[0], lse[1], g, gt, npad, s)
     call("lpi_transpose2", F32, npad if A is ws["A"] else n, E, A, A.stride(0), At, npad, npad if Bm is ws["B"] else n, E, Bm, Bm.stride(0), Bt, npad, s)
     dI, dT = torch.empty(lpad, E, device=dev), torch.empty(lpad, E, device=dev)
-    ks = _splitk_plan(F32, lpad, E, npad)
-    if ks and GEMM_PROFILE is None:
-        n0 = (ks * lpad * E + 63) // 64 * 64
-        buf = _splitk_scratch(dev, n0 + ks * lpad * E)
-        probs = [dict(M=lpad, N=E, K=npad, a=g, b=Bt, c=dI), dict(M=lpad, N=E, K=npad, a=gt, b=At, c=dT)]
-        _lib.gemm_splitk_pair(F32, F32, EPI_NONE, scale, probs, [ks, ks], (buf, buf[n0:]), s)
+    if GEMM_PROFILE is None and _few_rows(F32, lpad, E, npad):
+        _lib.gemm_rows(F32, F32, EPI_NONE, scale, [dict(M=lpad, N=E, K=npad, a=g, b=Bt, c=dI), dict(M=lpad, N=E, K=npad, a=gt, b=At, c=dT)], s)
     else:
         gemm(F32, g, Bt, dI, lpad, E, npad, alpha=scale)
         gemm(F32, gt, At, dT, lpad, E, npad, alpha=scale)

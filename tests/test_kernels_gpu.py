@@ -428,86 +428,85 @@ def test_nt_bxent_task_loss():
     assert relerr(dx, Xr.grad[row]) < 1e-4
 
 
-@pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("M,N,K,ks", [(128, 128, 256, 2), (256, 768, 3072, 24), (256, 3072, 768, 6), (256, 512, 768, 12), (128, 256, 512, 8)])
-def test_gemm_splitk_all_epilogues(dt, M, N, K, ks):
-    """Split-K path for small-M GEMMs: same results as f64 for every fused epilogue, and bitwise reproducible (fixed-order slice sum)."""
-    if dt == F32:
-        ks = min(ks, K // 32)
-    a = rnd(M, K, seed=1).to(TD[dt])
-    b = rnd(N, K, seed=2, scale=0.05).to(TD[dt])
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (256, 3072, 768), (256, 512, 768), (128, 256, 512), (32, 32, 64), (96, 160, 448), (256, 2048, 512)])
+def test_gemm_rows_all_epilogues(dt, M, N, K):
+    """lpi_gemm_nt_rows (csrc/gemm_rows.hip: the few-row GEMM in one launch, a 32 x 32 tile over the whole K range, eight waves cutting K): every fused epilogue
+    against f64; bitwise reproducible; K ranges that do not divide by the eight waves (K = 64: one or two waves have a block, K = 448: seven or fourteen blocks) and tile counts that do not
+    divide by the eight XCDs; within the f32 summation order of the 128 x 128 kernel on the same operands."""
+    td = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+    auxt = torch.bfloat16 if dt == F16 else td
+    tol = TOL[BF16] if dt == F16 else TOL[dt]
+    a = rnd(M, K, seed=1).to(td)
+    b = rnd(N, K, seed=2, scale=0.05).to(td)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
     ab = a.double() @ b.double().t()
-    scratch = torch.empty(ks * M * N, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    assert _lib.load().lpi_gemm_nt_rows_supported(dt, M, N, K) == 1
 
     def run(c, bias=None, residual=None, epi=0, aux=None, alpha=1.0):
-        cdt = F32 if c.dtype == torch.float32 else BF16
-        call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None if bias is None else bias.to(DEV),
-             None if residual is None else residual.to(DEV), N if residual is not None else 0, epi, aux, N if aux is not None else 0,
-             float(alpha), ks, scratch, stream())
+        cdt = F32 if c.dtype == torch.float32 else dt
+        _lib.gemm_rows(dt, cdt, epi, alpha, [dict(M=M, N=N, K=K, a=ad, b=bd, c=c, bias=None if bias is None else bias.to(DEV),
+                                                  residual=None if residual is None else residual.to(DEV), aux=aux)], stream())
         return c
-    c = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, alpha=0.5)
-    assert relerr(c, 0.5 * ab + bias.double()) < TOL[dt]
-    c2 = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, alpha=0.5)
-    assert torch.equal(c, c2)
+    n0 = _lib.launch_count()
+    c = run(torch.zeros(M, N, device=DEV, dtype=td), bias=bias, alpha=0.5)
+    assert _lib.launch_count() == n0 + 1 and _lib.load().lpi_gemm_last_kernel() == 4
+    assert relerr(c, 0.5 * ab + bias.double()) < tol
+    assert torch.equal(c, run(torch.zeros(M, N, device=DEV, dtype=td), bias=bias, alpha=0.5))
     cf = run(torch.zeros(M, N, device=DEV), bias=bias, residual=res)
-    assert relerr(cf, ab + bias.double() + res.double()) < TOL[dt]
-    u = torch.zeros(M, N, device=DEV, dtype=TD[dt])
-    g = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), bias=bias, epi=E.EPI_QUICKGELU, aux=u)
+    assert relerr(cf, ab + bias.double() + res.double()) < tol
+    u = torch.zeros(M, N, device=DEV, dtype=auxt)
+    g = run(torch.zeros(M, N, device=DEV, dtype=td), bias=bias, epi=E.EPI_QUICKGELU, aux=u)
     uref = ab + bias.double()
-    assert relerr(u, gelu_grad_ref(uref)) < TOL[dt] and relerr(g, uref * torch.sigmoid(1.702 * uref)) < TOL[dt]
-    du = run(torch.zeros(M, N, device=DEV, dtype=TD[dt]), epi=E.EPI_DQUICKGELU, aux=u)
-    assert relerr(du, ab * u.double().cpu()) < TOL[dt]
-    with pytest.raises(_lib.LpiError):      # K must split into whole K tiles
-        call("lpi_gemm_nt_splitk", dt, F32 if dt == F32 else BF16, M, N, K, a.to(DEV), K, b.to(DEV), K, c, N, None, None, 0, 0, None, 0, 1.0,
-             7, scratch, stream())
+    assert relerr(u, gelu_grad_ref(uref)) < tol and relerr(g, uref * torch.sigmoid(1.702 * uref)) < tol
+    g2 = run(torch.zeros(M, N, device=DEV, dtype=td), bias=bias, epi=E.EPI_QUICKGELU)
+    assert torch.equal(g, g2)
+    du = run(torch.zeros(M, N, device=DEV, dtype=td), epi=E.EPI_DQUICKGELU, aux=u)
+    assert relerr(du, ab * u.double().cpu()) < tol
+    if M % 128 == 0 and N % 128 == 0:      # the 128 x 128 kernel on the same operands: the same sum in another order
+        cs = torch.zeros(M, N, device=DEV)
+        call("lpi_gemm_nt", dt, F32, M, N, K, ad, K, bd, K, cs, N, bias.to(DEV), None, 0, 0, None, 0, 1.0, stream())
+        cr = run(torch.zeros(M, N, device=DEV), bias=bias)
+        assert relerr(cr, cs.double().cpu()) < 2e-6 * (K ** 0.5)
+    with pytest.raises(_lib.LpiError):      # rows that are not whole tiles
+        _lib.gemm_rows(dt, dt, 0, 1.0, [dict(M=M + 8, N=N, K=K, a=ad, b=bd, c=c)], stream())
 
 
-@pytest.mark.parametrize("dt", [F32, BF16, F16])
-def test_gemm_splitk_pair_equals_two_launches(dt):
-    """lpi_gemm_nt_splitk_pair (the two towers' few-row GEMMs in one pair of launches): bit for bit the two lpi_gemm_nt_splitk results,
-    for problems of different shapes and slice counts and every epilogue; mismatched operand sets are refused."""
-    shapes = [((256, 768, 768, 6), (256, 512, 512, 4)), ((256, 3072, 768, 3), (256, 2048, 512, 2)), ((128, 768, 3072, 24), (256, 512, 2048, 16))]
-    td = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
-    cds = [td] if dt == F32 else [td, torch.float32]
-    for (s0, s1) in shapes:
-        ops = []
-        for j, (M, N, K, ks) in enumerate((s0, s1)):
-            ops.append(dict(M=M, N=N, K=K, ks=ks, a=rnd(M, K, seed=10 + j).to(td).to(DEV), b=rnd(N, K, seed=20 + j, scale=0.05).to(td).to(DEV),
-                            bias=rnd(N, seed=30 + j).to(DEV), res=rnd(M, N, seed=40 + j).to(DEV),
-                            scr=torch.empty(ks * M * N, device=DEV)))
-        auxt = torch.bfloat16 if dt == F16 else td
-        for ctd in cds:
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_gemm_rows_pair_equals_two_launches(dt):
+    """Two problems of different shapes in one lpi_gemm_nt_rows launch: bit for bit the two one-problem launches; mismatched operand sets are refused."""
+    td = {BF16: torch.bfloat16, F16: torch.float16}[dt]
+    auxt = torch.bfloat16 if dt == F16 else td
+    for (s0, s1) in [((256, 768, 768), (256, 512, 512)), ((256, 3072, 768), (256, 2048, 512)), ((128, 768, 3072), (256, 512, 2048)), ((32, 96, 64), (64, 32, 192))]:
+        ops = [dict(M=M, N=N, K=K, a=rnd(M, K, seed=10 + j).to(td).to(DEV), b=rnd(N, K, seed=20 + j, scale=0.05).to(td).to(DEV), bias=rnd(N, seed=30 + j).to(DEV),
+                    res=rnd(M, N, seed=40 + j).to(DEV)) for j, (M, N, K) in enumerate((s0, s1))]
+        for ctd in (td, torch.float32):
             cdt = F32 if ctd == torch.float32 else dt
-            cases = [(E.EPI_NONE, True, False, False), (E.EPI_NONE, False, False, False), (E.EPI_QUICKGELU, True, False, True),
-                     (E.EPI_QUICKGELU, True, False, False), (E.EPI_DQUICKGELU, False, False, True)]
+            cases = [(E.EPI_NONE, True, False, False), (E.EPI_QUICKGELU, True, False, True), (E.EPI_DQUICKGELU, False, False, True)]
             if ctd == torch.float32:
                 cases.append((E.EPI_NONE, True, True, False))
             for epi, use_bias, use_res, use_aux in cases:
-                ref, refaux, got, gotaux, probs = [], [], [], [], []
+                one, two = [], []
                 for o in ops:
-                    M, N, K = o["M"], o["N"], o["K"]
-                    aux0 = (rnd(M, N, seed=50).to(auxt).to(DEV) if epi == E.EPI_DQUICKGELU else torch.zeros(M, N, dtype=auxt, device=DEV)) if use_aux else None
-                    c = torch.zeros(M, N, dtype=ctd, device=DEV)
-                    ax = None if aux0 is None else aux0.clone()
-                    call("lpi_gemm_nt_splitk", dt, cdt, M, N, K, o["a"], K, o["b"], K, c, N, o["bias"] if use_bias else None,
-                         o["res"] if use_res else None, N if use_res else 0, epi, ax, N if use_aux else 0, 0.75, o["ks"], o["scr"], stream())
-                    ref.append(c)
-                    refaux.append(ax)
-                    c2 = torch.zeros(M, N, dtype=ctd, device=DEV)
-                    ax2 = None if aux0 is None else aux0.clone()
-                    got.append(c2)
-                    gotaux.append(ax2)
-                    probs.append(dict(M=M, N=N, K=K, a=o["a"], b=o["b"], c=c2, bias=o["bias"] if use_bias else None,
-                                      residual=o["res"] if use_res else None, aux=ax2))
-                _lib.gemm_splitk_pair(dt, cdt, epi, 0.75, probs, [o["ks"] for o in ops], [o["scr"] for o in ops], stream())
-                for r, g, ra, ga in zip(ref, got, refaux, gotaux):
-                    assert torch.equal(r, g), (dt, s0, s1, epi, use_bias, use_res, use_aux)
-                    if ra is not None:
-                        assert torch.equal(ra, ga)
-    probs[1]["aux"] = None            # one problem with aux, one without
+                    aux0 = (rnd(o["M"], o["N"], seed=50).to(auxt).to(DEV) if epi == E.EPI_DQUICKGELU else torch.zeros(o["M"], o["N"], dtype=auxt, device=DEV)) \
+                        if use_aux else None
+                    for dst in (one, two):
+                        dst.append(dict(M=o["M"], N=o["N"], K=o["K"], a=o["a"], b=o["b"], c=torch.zeros(o["M"], o["N"], dtype=ctd, device=DEV),
+                                        bias=o["bias"] if use_bias else None, residual=o["res"] if use_res else None, aux=None if aux0 is None else aux0.clone()))
+                for q in one:
+                    _lib.gemm_rows(dt, cdt, epi, 0.75, [q], stream())
+                n0 = _lib.launch_count()
+                _lib.gemm_rows(dt, cdt, epi, 0.75, two, stream())
+                assert _lib.launch_count() == n0 + 1
+                for q, r in zip(one, two):
+                    assert torch.equal(q["c"], r["c"]), (dt, s0, s1, epi)
+                    assert float(q["c"].float().abs().max()) > 0
+                    if q["aux"] is not None:
+                        assert torch.equal(q["aux"], r["aux"])
+    two[1]["aux"] = None
     with pytest.raises(_lib.LpiError):
-        _lib.gemm_splitk_pair(dt, cdt, E.EPI_DQUICKGELU, 1.0, probs, [o["ks"] for o in ops], [o["scr"] for o in ops], stream())
+        _lib.gemm_rows(dt, cdt, E.EPI_DQUICKGELU, 1.0, two, stream())
 
 
 def _ln_fold_operands(M, N, K, seed):
