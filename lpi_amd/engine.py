@@ -154,9 +154,10 @@ GEMM_PROFILE = None
 
 def _few_rows(dt, M, N, K):
     """True for a GEMM with a few rows (pooled rows of the last block, heads, the loss's gradient GEMMs): it runs as ONE launch of 32 x 32 tiles over the whole K
-    range (lpi_gemm_nt_rows) instead of a handful of 128 x 128 tiles.  Rounds 2-5 ran these as split-K partial + reduction (two launches, f32 partials through
-    HBM): the one-launch kernel halves their time, -0.15 ms per step (profiles/r06_experiments.md section 10)."""
-    return M <= 256 and M % 128 == 0 and N % 128 == 0 and K % (32 if dt == F32 else 64) == 0
+    range (lpi_gemm_nt_rows) instead of a handful of 128 x 128 or 256 x 256 tiles.  Rounds 2-5 ran these as split-K partial + reduction (two launches, f32
+    partials through HBM): the one-launch kernel halves their time, -0.15 ms per step at ViT-B/16 with 256 pairs (profiles/r06_experiments.md section 10);
+    512 rows (ViT-L/14 with 512 pairs: 8-32 tiles of the 256 x 256 kernels before) -0.6 ms of 179 (tools/probe/few_rows_m512.py)."""
+    return M <= 512 and M % 128 == 0 and N % 128 == 0 and K % (32 if dt == F32 else 64) == 0
 
 
 def gemm(dt, a, b, c, M, N, K, bias=None, residual=None, epi=EPI_NONE, aux=None, alpha=1.0, m_real=None, ldr=None):

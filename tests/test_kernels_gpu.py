@@ -429,7 +429,7 @@ def test_nt_bxent_task_loss():
 
 
 @pytest.mark.parametrize("dt", [F32, BF16, F16])
-@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (256, 3072, 768), (256, 512, 768), (128, 256, 512), (32, 32, 64), (96, 160, 448), (256, 2048, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (256, 3072, 768), (256, 512, 768), (128, 256, 512), (32, 32, 64), (96, 160, 448), (256, 2048, 512), (512, 1024, 1024)])
 def test_gemm_rows_all_epilogues(dt, M, N, K):
     """lpi_gemm_nt_rows (csrc/gemm_rows.hip: the few-row GEMM in one launch, a 32 x 32 tile over the whole K range, eight waves cutting K): every fused epilogue
     against f64; bitwise reproducible; K ranges that do not divide by the eight waves (K = 64: one or two waves have a block, K = 448: seven or fourteen blocks) and tile counts that do not
