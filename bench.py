@@ -433,7 +433,7 @@ class Workload:
                          "last round runs as 256x128 half tiles; gemm256_kernel / gemm256_tail_kernel: its one-tile forms)",
                  "k128": "gemm_nt_kernel (128x128 tiles, 4 waves of 64x64, LDS-DMA double buffer: every launch below the 256x256 kernel's tile-count threshold)",
                  "k256x128": "gemm256x128_kernel (launches with 16..159 256x256 tiles)",
-                 "few_rows": "gemm_rows_kernel (M <= 256: 32x32 tiles over the whole K range, one launch per op and tower pair)"}
+                 "few_rows": "gemm_rows_kernel (M <= 512: 32x32 tiles over the whole K range, one launch per op and tower pair)"}
         traffic = mfma_util = tsrc = None
         wl = {"model": a.model, "batch": a.batch, "depth": a.depth}
         import glob
