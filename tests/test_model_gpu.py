@@ -87,6 +87,24 @@ def test_vitb16_f32_vs_golden(golden, name, depth):
         assert (idx[safe] == g[f"top5_{tag}"][safe]).all()
 
 
+def test_vitb32_f32_and_bf16_vs_oracle():
+    """A third CLIP ViT of clip.available_models() (clip.py:30-40): ViT-B/32 — 50 vision tokens (the short-sequence attention kernels instead of the streamed
+    backward), 32 x 32 patches (3 072-column im2col).  No reference fixture exists for it: the oracle (pinned by the ViT-B/16 / tiny fixtures) is the checker,
+    f32 mode at round-off, bf16 mode at its usual bars; depth 3, 4 pairs."""
+    cfg = synth.VIT_B32
+    ids = synth.token_ids(4)
+    res, fac_np = run_hip(cfg, "f32", 4, ids, 3)
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg), torch.float32)
+    ref = O.train_step(orc, synth.images(4, cfg.image_resolution), ids, fac_np, depth=3)
+    check(res, ref, tol=1e-4, gtol=1e-3)
+    r16, _ = run_hip(cfg, "bf16", 4, ids, 3, pack=True)
+    for k in ("img_f", "txt_f"):
+        assert maxerr(r16[k], ref[k]) < 2e-2, (k, maxerr(r16[k], ref[k]))
+    cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+    for k in GRADS:
+        assert cos(r16[k], ref[k]) > 0.995, (k, cos(r16[k], ref[k]))
+
+
 def test_tiny_bf16_close_to_oracle(golden):
     cfg = synth.TINY
     g = golden("tiny_d1")
