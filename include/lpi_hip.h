@@ -202,7 +202,10 @@ int lpi_gather_batch_rows(int dtype, int B, int L, int row0, int P, int cols, co
  * (model.py:347-353).  Backward recomputes P from lse; `delta` is [B,H,L] f32 SCRATCH: the kernels that make two passes over the scores
  * leave rowsum(dctx*ctx) there, the streamed single-pass backward (attention4.hip) keeps it in LDS and does not touch the buffer at L <= 224; at
  * 224 < L <= 288 (two key-window launches) its first launch leaves -rowsum(dctx*ctx)/8 there for the second.  The contents are unspecified after the call.
- * dqkv: [B*L, 3*d] `dtype`. L <= 288. */
+ * dqkv: [B*L, 3*d] `dtype`.  L <= 288: one workgroup per (sample, head) keeps the head's K and V in LDS (attention.hip, attention4.hip).  Round 6: NON-CAUSAL
+ * UNIFORM sequences of 288 < L <= 1024 tokens (ViT-L/14@336px: 577 + prompts) run tiled over the keys with an online softmax (attn_long.hip: forward one
+ * launch, backward two — dQ + delta, then dK / dV; the backward computes every row, `rows_needed` of the _prefix form is ignored there); causal or ragged
+ * sequences of that length are refused with LPI_EINVAL. */
 int lpi_attn_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                  float* lse, int causal, void* stream);
 int lpi_attn_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx,

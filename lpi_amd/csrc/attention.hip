@@ -1011,12 +1011,18 @@ int bwd_launch(int B, int L, int H, const void* qkv, int ldqkv, const void* ctx,
     return 0;
 }
 
-inline bool bad_attn(int dtype, int B, int L, int H, int ld) {
+inline bool bad_attn(int dtype, int B, int L, int H, int ld, int lmax = 288) {
     const int esz = dtype == LPI_F32 ? 4 : 2;
-    return B <= 0 || H <= 0 || L <= 0 || L > 288 || ld < 3 * H * HD || (ld * esz) % 16;
+    return B <= 0 || H <= 0 || L <= 0 || L > lmax || ld < 3 * H * HD || (ld * esz) % 16;
 }
 
 }  // namespace
+
+// attn_long.hip: 288 < L <= 1024, non-causal, uniform sequences — tiled over the keys with an online softmax (ViT-L/14@336px: 577 tokens + prompts)
+bool lpi_attn_long_ok(int L, int causal, const void* row_start);
+int lpi_attn_long_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s);
+int lpi_attn_long_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
+                      float* delta, void* dqkv, int lddqkv, hipStream_t s);
 
 // attention4.hip: the backward as ONE pass, 8 waves owning 16-32 keys each, query slices streamed through an LDS ring; non-causal, L <= 224;
 // the default for L > 160 (tuning key 7 = 0), forced at every L it takes by key 7 = 5, never with key 7 = 1
@@ -1026,9 +1032,11 @@ int lpi_attn4_bwd(int B, int L, int H, const void* qkv, int ldqkv, const void* c
 extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_start, int H, const void* qkv, int ldqkv, void* ctx, int ldctx,
                                    float* lse, int causal, void* stream) {
     const int* rs = row_start;      // ragged batch: the one-head-per-workgroup kernels take a per-sample length
-    if (!qkv || !ctx || !lse || bad_attn(dtype, B, L, H, ldqkv) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
+    const bool lng = lpi_attn_long_ok(L, causal, row_start);
+    if (!qkv || !ctx || !lse || bad_attn(dtype, B, L, H, ldqkv, lng ? 1024 : 288) || ldctx < H * HD || (ldctx & 7)) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (lng) return lpi_attn_long_fwd(dtype, B, L, H, qkv, ldqkv, ctx, ldctx, lse, s);
     if (dtype == LPI_F32)
         return causal ? fwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs) : fwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, lse, s, rs);
     if (dtype == LPI_F16)       // f16 operand mode: q, k, v and ctx are fp16 (the reference's own arithmetic type)
@@ -1086,16 +1094,20 @@ extern "C" int lpi_attn_fwd_varlen(int dtype, int B, int L, const int32_t* row_s
                                    float* lse, int causal, void* stream);
 extern "C" int lpi_attn_fwd_pair(int dtype, const lpi_attn_fwd_desc* d, void* stream) {
     if (!d) return LPI_EINVAL;
+    bool any_long = false;
     for (int i = 0; i < 2; ++i) {
         const bool lay = d[i].qkv_hs || d[i].qkv_vs || d[i].ctx_hs;      // an explicit layout: the strides are the caller's statement, only their alignment is checked
         if (lay && (dtype == LPI_F32 || d[i].row_start || d[i].shared_rows || !d[i].qkv_hs || !d[i].qkv_vs || !d[i].ctx_hs ||
                     ((d[i].qkv_hs | d[i].qkv_vs | d[i].ctx_hs | d[i].ldqkv | d[i].ldctx) & 7) || d[i].ldqkv < HD || d[i].ldctx < HD)) return LPI_EINVAL;
-        if (!d[i].qkv || !d[i].ctx || !d[i].lse || (!lay && (bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv) || d[i].ldctx < d[i].H * HD)) || (d[i].ldctx & 7)) return LPI_EINVAL;
+        const bool lng = !lay && !d[i].shared_rows && lpi_attn_long_ok(d[i].L, d[i].causal, d[i].row_start);      // a long sequence: its own launch (attn_long.hip)
+        any_long |= lng;
+        if (!d[i].qkv || !d[i].ctx || !d[i].lse || (!lay && (bad_attn(dtype, d[i].B, d[i].L, d[i].H, d[i].ldqkv, lng ? 1024 : 288) || d[i].ldctx < d[i].H * HD)) || (d[i].ldctx & 7))
+            return LPI_EINVAL;
         if (lay && (d[i].B <= 0 || d[i].H <= 0 || d[i].L <= 0 || d[i].L > 288)) return LPI_EINVAL;
         if (((uintptr_t)d[i].qkv | (uintptr_t)d[i].ctx) & 15) return LPI_EINVAL;
     }
-    if (dtype == LPI_BF16) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
-    if (dtype == LPI_F16) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
+    if (dtype == LPI_BF16 && !any_long) return fwd_pair_launch<bf16_t>(d, (hipStream_t)stream);
+    if (dtype == LPI_F16 && !any_long) return fwd_pair_launch<f16_t>(d, (hipStream_t)stream);
     for (int i = 0; i < 2; ++i) {
         if (d[i].shared_rows) {
             if (int e = lpi_attn_fwd_shared(dtype, d[i].B, d[i].L, d[i].row_start, d[i].shared_rows, d[i].H, d[i].qkv, d[i].ldqkv, d[i].ctx, d[i].ldctx, d[i].lse, stream)) return e;
@@ -1198,11 +1210,14 @@ extern "C" int lpi_attn_bwd_prefix(int dtype, int B, int L, const int32_t* row_s
     const int* rs = row_start;
     if (rows_needed <= 0) return LPI_EINVAL;
     const int rows_hi = rows_needed >= L ? (1 << 30) : rows_needed;      // the 2-byte kernels skip the 32-row blocks behind it; f32 computes all
-    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv) || bad_attn(dtype, B, L, H, lddqkv)) return LPI_EINVAL;
+    const bool lng = lpi_attn_long_ok(L, causal, row_start);
+    const int lmax = lng ? 1024 : 288;
+    if (!qkv || !ctx || !dctx || !lse || !delta || !dqkv || bad_attn(dtype, B, L, H, ldqkv, lmax) || bad_attn(dtype, B, L, H, lddqkv, lmax)) return LPI_EINVAL;
     const int esz = dtype == LPI_F32 ? 4 : 2;
     if (ldctx < H * HD || lddctx < H * HD || (ldctx * esz) % 16 || (lddctx * esz) % 16) return LPI_EINVAL;
     if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)dctx | (uintptr_t)dqkv) & 15) return LPI_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    if (lng) return lpi_attn_long_bwd(dtype, B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s);      // every row (rows_needed is a saving, not a contract)
     if (dtype == LPI_F32)
         return causal ? bwd_launch<float, true>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi)
                       : bwd_launch<float, false>(B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, lse, delta, dqkv, lddqkv, s, rs, rows_hi);

@@ -60,6 +60,7 @@ class ClipConfig:
 # head_dim is 64 for every CLIP ViT (vision_heads = width // 64, model.py:292)
 VIT_B16 = ClipConfig("ViT-B/16", 512, 224, 12, 768, 16, 77, 49408, 512, 8, 12)
 VIT_L14 = ClipConfig("ViT-L/14", 768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12)
+VIT_L14_336 = ClipConfig("ViT-L/14@336px", 768, 336, 24, 1024, 14, 77, 49408, 768, 12, 12)      # 577 vision tokens: the long-sequence attention kernels
 VIT_B32 = ClipConfig("ViT-B/32", 512, 224, 12, 768, 32, 77, 49408, 512, 8, 12)      # clip.available_models(): 50 vision tokens, 3 072-column patches
 # small config used by fast tests: 2 layers, 2 heads, 4 patches; same code paths
 TINY = ClipConfig("tiny", 128, 32, 2, 128, 16, 77, 49408, 128, 2, 2)
@@ -67,7 +68,10 @@ TINY = ClipConfig("tiny", 128, 32, 2, 128, 16, 77, 49408, 128, 2, 2)
 # patch 14 (K = 588, zero padded to the GEMM K tile) like ViT-L/14, at toy size
 TINY14 = ClipConfig("tiny14", 128, 28, 2, 256, 14, 77, 49408, 128, 2, 2)   # widths must be multiples of 128 (GEMM tile)
 
-CONFIGS = {c.name: c for c in (VIT_B16, VIT_L14, VIT_B32, TINY, TINY14)}
+# 401 vision tokens (+ prompts) at toy width: the long-sequence attention kernels (csrc/attn_long.hip; ViT-L/14@336px has 577)
+TINY_LONG = ClipConfig("tinyLong", 128, 80, 2, 128, 4, 77, 49408, 128, 2, 2)
+
+CONFIGS = {c.name: c for c in (VIT_B16, VIT_L14, VIT_L14_336, VIT_B32, TINY, TINY14, TINY_LONG)}
 
 
 def _rng(seed: int, name: str) -> np.random.Generator:

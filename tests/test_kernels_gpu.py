@@ -271,6 +271,52 @@ def test_attention_fwd_bwd(dt, B, L, H, causal):
         assert e < (5e-5 if dt == F32 else 4e-2), (name, e)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+@pytest.mark.parametrize("B,L,H", [(2, 586, 2), (1, 289, 1), (1, 640, 3), (2, 1024, 1), (1, 333, 2)])
+def test_attention_long_sequences_fwd_bwd(dt, B, L, H):
+    """288 < L <= 1024, non-causal (csrc/attn_long.hip: tiled over the keys with an online softmax — ViT-L/14@336px has 577 tokens + prompts): the same entry
+    points, against f64 autograd; f32, bf16, and the f16 mode's types (saved q / k / v / ctx fp16, gradients bf16).  A dominant late key forces the running-max
+    rescale; lengths that are not whole 64-row workgroups or 32-key blocks exercise the masks.  Causal or ragged sequences of that length are refused."""
+    d = H * 64
+    td = {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+    tg = torch.float32 if dt == F32 else torch.bfloat16
+    qkv = rnd(B * L, 3 * d, seed=11)
+    qkv[L - 7, d:d + 64] = qkv[5, :64] * 2.5          # key L - 7 matches query 5 of sample 0, head 0
+    qkv = qkv.to(td)
+    dctx = rnd(B * L, d, seed=12).to(tg)
+    qd = qkv.to(DEV)
+    ctx = torch.zeros(B * L, d, device=DEV, dtype=td)
+    lse = torch.zeros(B, H, L, device=DEV)
+    n0 = _lib.launch_count()
+    call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, 0, stream())
+    assert _lib.launch_count() == n0 + 1
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = attn_ref(qr, B, L, H, 0)
+    tol = TOL[F32] if dt == F32 else TOL[BF16]
+    assert relerr(ctx, oref.detach()) < tol
+    assert relerr(lse, lref.detach()) < (1e-5 if dt == F32 else 2e-2)
+    oref.backward(dctx.double())
+    dqkv = torch.full((B * L, 3 * d), 7.0, device=DEV, dtype=tg)      # every row must be overwritten
+    delta = torch.zeros(B, H, L, device=DEV)
+    call("lpi_attn_bwd", dt, B, L, H, qd, 3 * d, ctx, d, dctx.to(DEV), d, lse, delta, dqkv, 3 * d, 0, stream())
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        e = relerr(dqkv[:, sl], qr.grad[:, sl])
+        assert e < (5e-5 if dt == F32 else 4e-2), (name, e)
+    assert relerr(delta, (oref.detach() * dctx.double()).view(B, L, H, 64).sum(-1).permute(0, 2, 1)) < (1e-5 if dt == F32 else 2e-2)
+    with pytest.raises(_lib.LpiError):
+        call("lpi_attn_fwd", dt, B, L, H, qd, 3 * d, ctx, d, lse, 1, stream())
+    if dt != F32:      # a long sequence in a pair descriptor: its own launch beside the other problem's
+        L2 = 77
+        q2 = rnd(B * L2, 3 * d, seed=14).to(td).to(DEV)
+        c2, l2 = torch.zeros(B * L2, d, device=DEV, dtype=td), torch.zeros(B, H, L2, device=DEV)
+        c1, l1 = torch.zeros_like(ctx), torch.zeros_like(lse)
+        _lib.attn_fwd_pair(dt, (B, L, None, H, qd, 3 * d, c1, d, l1, 0), (B, L2, None, H, q2, 3 * d, c2, d, l2, 1), stream())
+        assert torch.equal(c1, ctx) and torch.equal(l1, lse)
+        c3, l3 = torch.zeros_like(c2), torch.zeros_like(l2)
+        call("lpi_attn_fwd", dt, B, L2, H, q2, 3 * d, c3, d, l3, 1, stream())
+        assert torch.equal(c2, c3)
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("B,L,H,causal", [(3, 213, 3, 0), (5, 77, 2, 1), (2, 21, 2, 0), (2, 273, 2, 0), (4, 32, 1, 1)])
 def test_attention_pooled_row_fwd_bwd(dt, B, L, H, causal):

@@ -105,6 +105,26 @@ def test_vitb32_f32_and_bf16_vs_oracle():
         assert cos(r16[k], ref[k]) > 0.995, (k, cos(r16[k], ref[k]))
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_long_sequence_tower_vs_oracle(depth):
+    """A vision tower of 401 tokens + prompts (toy width; ViT-L/14@336px has 577): the attention of every block but the last runs on the long-sequence kernels
+    (csrc/attn_long.hip), the last block on its pooled-row path (the form without K and V takes L <= 288).  f32 against the oracle at round-off, bf16 and f16 at
+    their usual bars."""
+    cfg = synth.TINY_LONG
+    ids = synth.token_ids(4)
+    res, fac_np = run_hip(cfg, "f32", 4, ids, depth)
+    orc = O.Oracle(cfg, synth.clip_state_dict(cfg), torch.float64)
+    ref = O.train_step(orc, synth.images(4, cfg.image_resolution), ids, fac_np, depth=depth)
+    check(res, ref, tol=2e-5, gtol=2e-4)
+    cos = lambda a, b: float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))  # noqa: E731
+    for mode in ("bf16", "f16"):
+        r16, _ = run_hip(cfg, mode, 4, ids, depth, pack=True)
+        for k in ("img_f", "txt_f"):
+            assert maxerr(r16[k], ref[k]) < 2e-2, (mode, k, maxerr(r16[k], ref[k]))
+        for k in GRADS:
+            assert cos(r16[k], ref[k]) > 0.99, (mode, k, cos(r16[k], ref[k]))
+
+
 def test_tiny_bf16_close_to_oracle(golden):
     cfg = synth.TINY
     g = golden("tiny_d1")

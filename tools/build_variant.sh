@@ -9,7 +9,7 @@ if [ "${1:-}" = "--clean" ]; then rm -rf variants; echo "removed $(pwd)/variants
 suffix=$1; srcs=",$2,"; shift 2
 mkdir -p variants/obj
 objs=""
-for f in api gemm gemm256 gemm256p gemm256x128 gemm_rows attention attention4 attn_pooled attn_stream rowops loss interact bpe host; do
+for f in api gemm gemm256 gemm256p gemm256x128 gemm_rows attention attention4 attn_pooled attn_stream attn_long rowops loss interact bpe host; do
   if [[ "$srcs" == *",$f,"* ]] || [ $f = api ]; then
     extra=""
     case $f in attention|attention4) extra="-fno-honor-nans";; api) extra="-DLPI_VARIANT_BUILD";; esac
