@@ -2,7 +2,7 @@
 //
 // replaces: nn.MultiheadAttention of the reference's vision tower (retrieval/models/clip/model.py:183-185) at the one CLIP ViT of clip.available_models()
 // (clip.py:30-40) whose sequences do not fit the one-workgroup-per-(sample, head) kernels of attention.hip / attention4.hip: ViT-L/14@336px, 577 tokens + prompts.
-// Those kernels keep a head's K and V in LDS (L <= 288); here a workgroup owns 64 rows of one (sample, head) — 4 waves of 16 — and walks the OTHER index in
+// Those kernels keep a head's K and V in LDS (L <= 288); here a workgroup owns 128 rows of one (sample, head) — 4 waves of two 16-row tiles — and walks the OTHER index in
 // blocks of 32 (2-byte types) / 16 (f32):
 //   forward     own = queries, walk keys:    S = Q K^T / 8 (MFMA), running max / sum per query, O += P V (MFMA), lse = max + log sum
 //   backward dQ own = queries, walk keys:    P = exp(S - lse), dP = dO V^T, dS = P (dP - delta) / 8, dQ += dS K; also writes delta = rowsum(dO o O)
@@ -34,28 +34,34 @@ struct LT {
     static constexpr int IMGT = HD * RST;
 };
 
-// NB rows x 64 columns of a [rows, ld] matrix (this head's columns) -> LDS in the MFMA type TM: row-major image and / or transposed image; rows >= nvalid are zero
-template <typename TS, typename TM, bool ROWM, bool TRANS>
-__device__ __forceinline__ void stage_block(const TS* __restrict__ src, int ld, int nvalid, char* img, char* imgt) {
-    constexpr int NB = LT<TM>::NB;
-    for (int i = threadIdx.x; i < NB * 8; i += NTHR) {
-        const int row = i >> 3, grp = i & 7;
-        f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f}, hi = lo;
-        if (row < nvalid) {
-            lo = Elem<TS>::ld4(src + (size_t)row * ld + grp * 8);
-            hi = Elem<TS>::ld4(src + (size_t)row * ld + grp * 8 + 4);
-        }
-        if constexpr (ROWM) {
-            TM* d = reinterpret_cast<TM*>(img + row * LT<TM>::RS) + grp * 8;
-            Elem<TM>::st4(d, lo);
-            Elem<TM>::st4(d + 4, hi);
-        }
-        if constexpr (TRANS) {
+// NB rows x 64 columns of a [rows, ld] matrix (this head's columns) -> LDS in the MFMA type TM: row-major image and / or transposed image; rows >= nvalid are
+// zero.  In two halves, so that the NEXT block's global loads are in flight while this block is multiplied (a thread owns 8 consecutive elements of one row).
+struct BlockRegs { f32x4 lo, hi; };
+template <typename TS, typename TM>
+__device__ __forceinline__ BlockRegs load_block(const TS* __restrict__ src, int ld, int nvalid) {
+    const int i = threadIdx.x, row = i >> 3, grp = i & 7;
+    BlockRegs r;
+    r.lo = r.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < LT<TM>::NB * 8 && row < nvalid) {
+        r.lo = Elem<TS>::ld4(src + (size_t)row * ld + grp * 8);
+        r.hi = Elem<TS>::ld4(src + (size_t)row * ld + grp * 8 + 4);
+    }
+    return r;
+}
+template <typename TM, bool ROWM, bool TRANS>
+__device__ __forceinline__ void store_block(const BlockRegs& r, char* img, char* imgt) {
+    const int i = threadIdx.x, row = i >> 3, grp = i & 7;
+    if (i >= LT<TM>::NB * 8) return;
+    if constexpr (ROWM) {
+        TM* d = reinterpret_cast<TM*>(img + row * LT<TM>::RS) + grp * 8;
+        Elem<TM>::st4(d, r.lo);
+        Elem<TM>::st4(d + 4, r.hi);
+    }
+    if constexpr (TRANS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Elem<TM>::st(reinterpret_cast<TM*>(imgt + (grp * 8 + e) * LT<TM>::RST) + row, lo[e]);
-                Elem<TM>::st(reinterpret_cast<TM*>(imgt + (grp * 8 + 4 + e) * LT<TM>::RST) + row, hi[e]);
-            }
+        for (int e = 0; e < 4; ++e) {
+            Elem<TM>::st(reinterpret_cast<TM*>(imgt + (grp * 8 + e) * LT<TM>::RST) + row, r.lo[e]);
+            Elem<TM>::st(reinterpret_cast<TM*>(imgt + (grp * 8 + 4 + e) * LT<TM>::RST) + row, r.hi[e]);
         }
     }
 }
@@ -126,143 +132,204 @@ struct LongArgs {
     void* dqkv; int lddqkv;
 };
 
-// ---- forward: grid (ceil(L / 64), B H) ---------------------------------------------------------------------------------------------------------------
+// NOWN = 16-row tiles of the own index per wave: a staged block of the walked index serves 64 NOWN own rows of the workgroup.  Measured at the ViT-L/14@336px
+// shape (L = 593, H = 16, 64 samples, bf16; tools/probe/attn_long_bench.py): 1 / 2 / 4 tiles -> forward 186 / 197 / 141 TFLOP/s, backward 189 / 228 / 167 — the
+// kernels are bound by the softmax arithmetic of a 16 x 32 score tile per wave (16 exponentials, two cross-lane reductions, the rescale) beside 16 MFMAs, not by
+// the staging (the next block's rows are loaded into registers under the current block's products) — half the rate of the tuned short-sequence kernels.
+template <typename TM> struct OwnTiles { static constexpr int N = 2; };
+
+// ---- forward: grid (ceil(L / (64 NOWN)), B H) -----------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
     typedef LT<T> C;
+    constexpr int NO = OwnTiles<T>::N;
     __shared__ __attribute__((aligned(16))) char kimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char vimgt[C::IMGT];
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
-    const int q = blockIdx.x * 64 + wave * 16 + r16;
-    const bool qv = q < L;
+    const int q0 = blockIdx.x * (64 * NO) + wave * (16 * NO) + r16;      // own row of tile j: q0 + 16 j
     const T* base = reinterpret_cast<const T*>(A.qkv) + (size_t)b * L * A.ldqkv + h * HD;
-    Chunk qf[C::KSD];
+    Chunk qf[NO][C::KSD];
+    float m[NO], l[NO];
+    f32x4 o[NO][4];
 #pragma unroll
-    for (int ks = 0; ks < C::KSD; ++ks) qf[ks] = own_frag<T, T>(base + (size_t)(qv ? q : 0) * A.ldqkv, qv, g, ks);
-    float m = -INFINITY, l = 0.f;
-    f32x4 o[4];
+    for (int j = 0; j < NO; ++j) {
+        const int q = q0 + 16 * j;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < C::KSD; ++ks) qf[j][ks] = own_frag<T, T>(base + (size_t)(q < L ? q : 0) * A.ldqkv, q < L, g, ks);
+        m[j] = -INFINITY;
+        l[j] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    BlockRegs kr = load_block<T, T>(base + H * HD, A.ldqkv, L), vr = load_block<T, T>(base + 2 * H * HD, A.ldqkv, L);
     for (int k0 = 0; k0 < L; k0 += C::NB) {
         __syncthreads();
-        stage_block<T, T, true, false>(base + (size_t)k0 * A.ldqkv + H * HD, A.ldqkv, L - k0, kimg, nullptr);
-        stage_block<T, T, false, true>(base + (size_t)k0 * A.ldqkv + 2 * H * HD, A.ldqkv, L - k0, nullptr, vimgt);
+        store_block<T, true, false>(kr, kimg, nullptr);
+        store_block<T, false, true>(vr, nullptr, vimgt);
         __syncthreads();
-        f32x4 s[C::NTB];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < C::NTB; ++t) {
-            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < C::KSD; ++ks) mma_chunk<T>(s[t], img_frag<T>(kimg, 16 * t + r16, g, ks), qf[ks]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s[t][i] = k0 + 16 * t + 4 * g + i < L ? s[t][i] * SCALE : -INFINITY;
-                mx = fmaxf(mx, s[t][i]);
-            }
+        if (k0 + C::NB < L) {      // the next block's rows: in flight under this block's products
+            kr = load_block<T, T>(base + (size_t)(k0 + C::NB) * A.ldqkv + H * HD, A.ldqkv, L - k0 - C::NB);
+            vr = load_block<T, T>(base + (size_t)(k0 + C::NB) * A.ldqkv + 2 * H * HD, A.ldqkv, L - k0 - C::NB);
         }
-        mx = quad_max(mx);
-        const float mn = fmaxf(m, mx);      // finite: every block has at least one live key
-        float rs = 0.f;
+        Chunk kfr[C::NTB][C::KSD], vfr[4];
 #pragma unroll
         for (int t = 0; t < C::NTB; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s[t][i] = __expf(s[t][i] - mn);
-                rs += s[t][i];
-            }
-        rs = quad_sum(rs);
-        const float alpha = __expf(m - mn);
-        l = l * alpha + rs;
-        m = mn;
-        const Chunk pc = acc_chunk<T>(s);
+            for (int ks = 0; ks < C::KSD; ++ks) kfr[t][ks] = img_frag<T>(kimg, 16 * t + r16, g, ks);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            o[dt] *= alpha;
-            mma_chunk<T>(o[dt], imgt_frag<T>(vimgt, 16 * dt + r16, g), pc);
+        for (int dt = 0; dt < 4; ++dt) vfr[dt] = imgt_frag<T>(vimgt, 16 * dt + r16, g);
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            f32x4 s[C::NTB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < C::NTB; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < C::KSD; ++ks) mma_chunk<T>(s[t], kfr[t][ks], qf[j][ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[t][i] = k0 + 16 * t + 4 * g + i < L ? s[t][i] * SCALE : -INFINITY;
+                    mx = fmaxf(mx, s[t][i]);
+                }
+            }
+            mx = quad_max(mx);
+            const float mn = fmaxf(m[j], mx);      // finite: every block has at least one live key
+            float rs = 0.f;
+#pragma unroll
+            for (int t = 0; t < C::NTB; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s[t][i] = __expf(s[t][i] - mn);
+                    rs += s[t][i];
+                }
+            rs = quad_sum(rs);
+            const float alpha = __expf(m[j] - mn);
+            l[j] = l[j] * alpha + rs;
+            m[j] = mn;
+            const Chunk pc = acc_chunk<T>(s);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[j][dt] *= alpha;
+                mma_chunk<T>(o[j][dt], vfr[dt], pc);
+            }
         }
     }
-    if (qv) {
-        const float inv = 1.f / l;
-        T* dst = reinterpret_cast<T*>(const_cast<void*>(A.ctx)) + ((size_t)b * L + q) * A.ldctx + h * HD + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + 16 * dt, o[dt] * inv);
-        if (g == 0) A.lse[((size_t)b * H + h) * L + q] = m + __logf(l);
+    for (int j = 0; j < NO; ++j) {
+        const int q = q0 + 16 * j;
+        if (q < L) {
+            const float inv = 1.f / l[j];
+            T* dst = reinterpret_cast<T*>(const_cast<void*>(A.ctx)) + ((size_t)b * L + q) * A.ldctx + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + 16 * dt, o[j][dt] * inv);
+            if (g == 0) A.lse[((size_t)b * H + h) * L + q] = m[j] + __logf(l[j]);
+        }
     }
 }
 
-// ---- backward, dQ: grid (ceil(L / 64), B H); TS = type of the saved q / k / v / ctx, TG = type of dctx / dqkv and of the MFMA operands -----------------
+// ---- backward, dQ: grid (ceil(L / (64 NOWN)), B H); TS = type of the saved q / k / v / ctx, TG = type of dctx / dqkv and of the MFMA operands -----------
 template <typename TS, typename TG>
 __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
     typedef LT<TG> C;
+    constexpr int NO = OwnTiles<TG>::N;
     __shared__ __attribute__((aligned(16))) char kimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char vimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char kimgt[C::IMGT];
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
-    const int q = blockIdx.x * 64 + wave * 16 + r16;
-    const bool qv = q < L;
-    const size_t qrow = (size_t)b * L + (qv ? q : 0);
+    const int q0 = blockIdx.x * (64 * NO) + wave * (16 * NO) + r16;
     const TS* base = reinterpret_cast<const TS*>(A.qkv) + (size_t)b * L * A.ldqkv + h * HD;
-    const TS* orow = reinterpret_cast<const TS*>(A.ctx) + qrow * A.ldctx + h * HD;
-    const TG* drow = reinterpret_cast<const TG*>(A.dctx) + qrow * A.lddctx + h * HD;
-    Chunk qf[C::KSD], df[C::KSD];
-    float dl = 0.f;
+    Chunk qf[NO][C::KSD], df[NO][C::KSD];
+    float dl[NO], lse[NO];
+    f32x4 dq[NO][4];
 #pragma unroll
-    for (int ks = 0; ks < C::KSD; ++ks) {
-        qf[ks] = own_frag<TS, TG>(base + (size_t)(qv ? q : 0) * A.ldqkv, qv, g, ks);
-        df[ks] = own_frag<TG, TG>(drow, qv, g, ks);
-        if (qv) {      // delta = sum_d dO O over the row: this lane's chunks, then the row's four lanes
+    for (int j = 0; j < NO; ++j) {
+        const int q = q0 + 16 * j;
+        const bool qv = q < L;
+        const size_t qrow = (size_t)b * L + (qv ? q : 0);
+        const TS* orow = reinterpret_cast<const TS*>(A.ctx) + qrow * A.ldctx + h * HD;
+        const TG* drow = reinterpret_cast<const TG*>(A.dctx) + qrow * A.lddctx + h * HD;
+        float d_ = 0.f;
 #pragma unroll
-            for (int e = 0; e < C::EPC; e += 4) {
-                const f32x4 a = Elem<TG>::ld4(drow + (g + 4 * ks) * C::EPC + e), o4 = Elem<TS>::ld4(orow + (g + 4 * ks) * C::EPC + e);
-                dl += a[0] * o4[0] + a[1] * o4[1] + a[2] * o4[2] + a[3] * o4[3];
+        for (int ks = 0; ks < C::KSD; ++ks) {
+            qf[j][ks] = own_frag<TS, TG>(base + (size_t)(qv ? q : 0) * A.ldqkv, qv, g, ks);
+            df[j][ks] = own_frag<TG, TG>(drow, qv, g, ks);
+            if (qv) {      // delta = sum_d dO O over the row: this lane's chunks, then the row's four lanes
+#pragma unroll
+                for (int e = 0; e < C::EPC; e += 4) {
+                    const f32x4 a = Elem<TG>::ld4(drow + (g + 4 * ks) * C::EPC + e), o4 = Elem<TS>::ld4(orow + (g + 4 * ks) * C::EPC + e);
+                    d_ += a[0] * o4[0] + a[1] * o4[1] + a[2] * o4[2] + a[3] * o4[3];
+                }
             }
         }
-    }
-    dl = quad_sum(dl);
-    const size_t sidx = ((size_t)b * H + h) * L + (qv ? q : 0);
-    const float lse = qv ? A.lse[sidx] : 0.f;
-    if (qv && g == 0) A.delta[sidx] = dl;
-    f32x4 dq[4];
+        d_ = quad_sum(d_);
+        dl[j] = d_;
+        const size_t sidx = ((size_t)b * H + h) * L + (qv ? q : 0);
+        lse[j] = qv ? A.lse[sidx] : INFINITY;      // exp(s - inf) = 0: nothing from the rows behind L
+        if (qv && g == 0) A.delta[sidx] = d_;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 4; ++dt) dq[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    BlockRegs kr = load_block<TS, TG>(base + H * HD, A.ldqkv, L), vr = load_block<TS, TG>(base + 2 * H * HD, A.ldqkv, L);
     for (int k0 = 0; k0 < L; k0 += C::NB) {
         __syncthreads();
-        stage_block<TS, TG, true, true>(base + (size_t)k0 * A.ldqkv + H * HD, A.ldqkv, L - k0, kimg, kimgt);
-        stage_block<TS, TG, true, false>(base + (size_t)k0 * A.ldqkv + 2 * H * HD, A.ldqkv, L - k0, vimg, nullptr);
+        store_block<TG, true, true>(kr, kimg, kimgt);
+        store_block<TG, true, false>(vr, vimg, nullptr);
         __syncthreads();
-        f32x4 ds[C::NTB];
+        if (k0 + C::NB < L) {
+            kr = load_block<TS, TG>(base + (size_t)(k0 + C::NB) * A.ldqkv + H * HD, A.ldqkv, L - k0 - C::NB);
+            vr = load_block<TS, TG>(base + (size_t)(k0 + C::NB) * A.ldqkv + 2 * H * HD, A.ldqkv, L - k0 - C::NB);
+        }
+        Chunk kfr[C::NTB][C::KSD], vfr[C::NTB][C::KSD], ktf[4];
 #pragma unroll
-        for (int t = 0; t < C::NTB; ++t) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+        for (int t = 0; t < C::NTB; ++t)
 #pragma unroll
             for (int ks = 0; ks < C::KSD; ++ks) {
-                mma_chunk<TG>(s, img_frag<TG>(kimg, 16 * t + r16, g, ks), qf[ks]);
-                mma_chunk<TG>(dp, img_frag<TG>(vimg, 16 * t + r16, g, ks), df[ks]);
+                kfr[t][ks] = img_frag<TG>(kimg, 16 * t + r16, g, ks);
+                vfr[t][ks] = img_frag<TG>(vimg, 16 * t + r16, g, ks);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p = (qv && k0 + 16 * t + 4 * g + i < L) ? __expf(s[i] * SCALE - lse) : 0.f;
-                ds[t][i] = p * (dp[i] - dl) * SCALE;
+        for (int dt = 0; dt < 4; ++dt) ktf[dt] = imgt_frag<TG>(kimgt, 16 * dt + r16, g);
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            f32x4 ds[C::NTB];
+#pragma unroll
+            for (int t = 0; t < C::NTB; ++t) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                for (int ks = 0; ks < C::KSD; ++ks) {
+                    mma_chunk<TG>(s, kfr[t][ks], qf[j][ks]);
+                    mma_chunk<TG>(dp, vfr[t][ks], df[j][ks]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = k0 + 16 * t + 4 * g + i < L ? __expf(s[i] * SCALE - lse[j]) : 0.f;
+                    ds[t][i] = p * (dp[i] - dl[j]) * SCALE;
+                }
             }
+            const Chunk dc = acc_chunk<TG>(ds);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mma_chunk<TG>(dq[j][dt], ktf[dt], dc);
         }
-        const Chunk dc = acc_chunk<TG>(ds);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) mma_chunk<TG>(dq[dt], imgt_frag<TG>(kimgt, 16 * dt + r16, g), dc);
     }
-    if (qv) {
-        TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + q) * A.lddqkv + h * HD + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Elem<TG>::st4(dst + 16 * dt, dq[dt]);
+    for (int j = 0; j < NO; ++j) {
+        const int q = q0 + 16 * j;
+        if (q < L) {
+            TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + q) * A.lddqkv + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) Elem<TG>::st4(dst + 16 * dt, dq[j][dt]);
+        }
     }
 }
 
-// ---- backward, dK and dV: grid (ceil(L / 64), B H); own rows = keys, the queries are walked (needs delta of the dQ kernel) ------------------------------
+// ---- backward, dK and dV: grid (ceil(L / (64 NOWN)), B H); own rows = keys, the queries are walked (needs delta of the dQ kernel) ------------------------
 template <typename TS, typename TG>
 __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
     typedef LT<TG> C;
+    constexpr int NO = OwnTiles<TG>::N;
     __shared__ __attribute__((aligned(16))) char qimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char dimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char qimgt[C::IMGT];
@@ -270,60 +337,97 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
     __shared__ float lse_l[C::NB], dl_l[C::NB];
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
-    const int k = blockIdx.x * 64 + wave * 16 + r16;
-    const bool kv = k < L;
+    const int kk0 = blockIdx.x * (64 * NO) + wave * (16 * NO) + r16;
     const TS* base = reinterpret_cast<const TS*>(A.qkv) + (size_t)b * L * A.ldqkv + h * HD;
     const TG* dbase = reinterpret_cast<const TG*>(A.dctx) + (size_t)b * L * A.lddctx + h * HD;
-    Chunk kf[C::KSD], vf[C::KSD];
+    Chunk kf[NO][C::KSD], vf[NO][C::KSD];
+    f32x4 dk[NO][4], dv[NO][4];
 #pragma unroll
-    for (int ks = 0; ks < C::KSD; ++ks) {
-        kf[ks] = own_frag<TS, TG>(base + (size_t)(kv ? k : 0) * A.ldqkv + H * HD, kv, g, ks);
-        vf[ks] = own_frag<TS, TG>(base + (size_t)(kv ? k : 0) * A.ldqkv + 2 * H * HD, kv, g, ks);
+    for (int j = 0; j < NO; ++j) {
+        const int k = kk0 + 16 * j;
+        const bool kv = k < L;
+#pragma unroll
+        for (int ks = 0; ks < C::KSD; ++ks) {
+            kf[j][ks] = own_frag<TS, TG>(base + (size_t)(kv ? k : 0) * A.ldqkv + H * HD, kv, g, ks);
+            vf[j][ks] = own_frag<TS, TG>(base + (size_t)(kv ? k : 0) * A.ldqkv + 2 * H * HD, kv, g, ks);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[j][dt] = dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const size_t s0 = ((size_t)b * H + h) * L;
+    BlockRegs qr = load_block<TS, TG>(base, A.ldqkv, L), dr = load_block<TG, TG>(dbase, A.lddctx, L);
+    float lse_r = INFINITY, dl_r = 0.f;      // exp(s - inf) = 0 for the rows behind L
+    if ((int)threadIdx.x < C::NB && (int)threadIdx.x < L) { lse_r = A.lse[s0 + threadIdx.x]; dl_r = A.delta[s0 + threadIdx.x]; }
     for (int q0 = 0; q0 < L; q0 += C::NB) {
         __syncthreads();
-        stage_block<TS, TG, true, true>(base + (size_t)q0 * A.ldqkv, A.ldqkv, L - q0, qimg, qimgt);
-        stage_block<TG, TG, true, true>(dbase + (size_t)q0 * A.lddctx, A.lddctx, L - q0, dimg, dimgt);
+        store_block<TG, true, true>(qr, qimg, qimgt);
+        store_block<TG, true, true>(dr, dimg, dimgt);
         if ((int)threadIdx.x < C::NB) {
-            const bool v = q0 + (int)threadIdx.x < L;
-            lse_l[threadIdx.x] = v ? A.lse[s0 + q0 + threadIdx.x] : INFINITY;      // exp(s - inf) = 0 for the rows behind L
-            dl_l[threadIdx.x] = v ? A.delta[s0 + q0 + threadIdx.x] : 0.f;
+            lse_l[threadIdx.x] = lse_r;
+            dl_l[threadIdx.x] = dl_r;
         }
         __syncthreads();
-        f32x4 pt[C::NTB], dst_[C::NTB];
+        if (q0 + C::NB < L) {
+            const int qn = q0 + C::NB;
+            qr = load_block<TS, TG>(base + (size_t)qn * A.ldqkv, A.ldqkv, L - qn);
+            dr = load_block<TG, TG>(dbase + (size_t)qn * A.lddctx, A.lddctx, L - qn);
+            lse_r = INFINITY;
+            dl_r = 0.f;
+            if ((int)threadIdx.x < C::NB && qn + (int)threadIdx.x < L) { lse_r = A.lse[s0 + qn + threadIdx.x]; dl_r = A.delta[s0 + qn + threadIdx.x]; }
+        }
+        Chunk qfr[C::NTB][C::KSD], dfr[C::NTB][C::KSD], qtf[4], dtf[4];
+        f32x4 lq[C::NTB], dlq[C::NTB];
 #pragma unroll
         for (int t = 0; t < C::NTB; ++t) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
 #pragma unroll
             for (int ks = 0; ks < C::KSD; ++ks) {
-                mma_chunk<TG>(s, img_frag<TG>(qimg, 16 * t + r16, g, ks), kf[ks]);       // s[i] = score(key r16, query 16 t + 4 g + i)
-                mma_chunk<TG>(dp, img_frag<TG>(dimg, 16 * t + r16, g, ks), vf[ks]);
+                qfr[t][ks] = img_frag<TG>(qimg, 16 * t + r16, g, ks);
+                dfr[t][ks] = img_frag<TG>(dimg, 16 * t + r16, g, ks);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int qi = 16 * t + 4 * g + i;
-                const float p = __expf(s[i] * SCALE - lse_l[qi]);
-                pt[t][i] = p;
-                dst_[t][i] = p * (dp[i] - dl_l[qi]) * SCALE;
-            }
+            lq[t] = *reinterpret_cast<const f32x4*>(lse_l + 16 * t + 4 * g);
+            dlq[t] = *reinterpret_cast<const f32x4*>(dl_l + 16 * t + 4 * g);
         }
-        const Chunk pc = acc_chunk<TG>(pt), dc = acc_chunk<TG>(dst_);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            mma_chunk<TG>(dv[dt], imgt_frag<TG>(dimgt, 16 * dt + r16, g), pc);
-            mma_chunk<TG>(dk[dt], imgt_frag<TG>(qimgt, 16 * dt + r16, g), dc);
+            qtf[dt] = imgt_frag<TG>(qimgt, 16 * dt + r16, g);
+            dtf[dt] = imgt_frag<TG>(dimgt, 16 * dt + r16, g);
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            f32x4 pt[C::NTB], dst_[C::NTB];
+#pragma unroll
+            for (int t = 0; t < C::NTB; ++t) {
+                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                for (int ks = 0; ks < C::KSD; ++ks) {
+                    mma_chunk<TG>(s, qfr[t][ks], kf[j][ks]);       // s[i] = score(key r16 of tile j, query 16 t + 4 g + i)
+                    mma_chunk<TG>(dp, dfr[t][ks], vf[j][ks]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = __expf(s[i] * SCALE - lq[t][i]);
+                    pt[t][i] = p;
+                    dst_[t][i] = p * (dp[i] - dlq[t][i]) * SCALE;
+                }
+            }
+            const Chunk pc = acc_chunk<TG>(pt), dc = acc_chunk<TG>(dst_);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                mma_chunk<TG>(dv[j][dt], dtf[dt], pc);
+                mma_chunk<TG>(dk[j][dt], qtf[dt], dc);
+            }
         }
     }
-    if (kv) {
-        TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + k) * A.lddqkv + h * HD + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            Elem<TG>::st4(dst + H * HD + 16 * dt, dk[dt]);
-            Elem<TG>::st4(dst + 2 * H * HD + 16 * dt, dv[dt]);
+    for (int j = 0; j < NO; ++j) {
+        const int k = kk0 + 16 * j;
+        if (k < L) {
+            TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + k) * A.lddqkv + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Elem<TG>::st4(dst + H * HD + 16 * dt, dk[j][dt]);
+                Elem<TG>::st4(dst + 2 * H * HD + 16 * dt, dv[j][dt]);
+            }
         }
     }
 }
@@ -334,7 +438,8 @@ bool lpi_attn_long_ok(int L, int causal, const void* row_start) { return !causal
 
 int lpi_attn_long_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, void* ctx, int ldctx, float* lse, hipStream_t s) {
     const LongArgs A{B, L, H, qkv, ldqkv, ctx, ldctx, nullptr, 0, lse, nullptr, nullptr, 0};
-    const dim3 grid((L + 63) / 64, B * H);
+    const int own = 64 * (dtype == LPI_F32 ? OwnTiles<float>::N : OwnTiles<bf16_t>::N);
+    const dim3 grid((L + own - 1) / own, B * H);
     if (dtype == LPI_F32) LPI_LAUNCH((attn_long_fwd_kernel<float>), grid, dim3(NTHR), 0, s, A);
     else if (dtype == LPI_BF16) LPI_LAUNCH((attn_long_fwd_kernel<bf16_t>), grid, dim3(NTHR), 0, s, A);
     else if (dtype == LPI_F16) LPI_LAUNCH((attn_long_fwd_kernel<f16_t>), grid, dim3(NTHR), 0, s, A);
@@ -347,7 +452,8 @@ int lpi_attn_long_fwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv
 int lpi_attn_long_bwd(int dtype, int B, int L, int H, const void* qkv, int ldqkv, const void* ctx, int ldctx, const void* dctx, int lddctx, const float* lse,
                       float* delta, void* dqkv, int lddqkv, hipStream_t s) {
     const LongArgs A{B, L, H, qkv, ldqkv, ctx, ldctx, dctx, lddctx, const_cast<float*>(lse), delta, dqkv, lddqkv};
-    const dim3 grid((L + 63) / 64, B * H);
+    const int own = 64 * (dtype == LPI_F32 ? OwnTiles<float>::N : OwnTiles<bf16_t>::N);
+    const dim3 grid((L + own - 1) / own, B * H);
     if (dtype == LPI_F32) {
         LPI_LAUNCH((attn_long_bwd_dq_kernel<float, float>), grid, dim3(NTHR), 0, s, A);
         LPI_LAUNCH((attn_long_bwd_dkv_kernel<float, float>), grid, dim3(NTHR), 0, s, A);
