@@ -10,9 +10,10 @@
 // One layout trick carries all three: with the operands swapped (A = the walked rows, B = the own rows) a lane holds, of its own row (lane & 15), the four
 // consecutive walked positions 4 (lane >> 4) + i of each 16-wide score tile — which is exactly one k-group of the NEXT product's B operand (P, dS or their
 // transposes), so the probabilities go from accumulators to MFMA operand without leaving the registers, and softmax statistics are per lane (+ two cross-lane
-// steps).  The walked block is staged in LDS in the MFMA operand type, row-major (score products) and transposed (accumulate products), converted on the way
+// steps).  The walked block is staged in LDS in the MFMA operand type, row-major — the accumulate products read it through the transposing LDS read (f32: a second,
+// transposed image) —, converted on the way
 // in: f32 -> f32, bf16 -> bf16, fp16 -> fp16 (forward of the f16 mode), fp16 -> bf16 (its backward: saved q / k / v / ctx fp16, gradients bf16).
-// A correctness-first kernel family (the benchmarked configurations never reach it); deterministic, no atomics.
+// A correctness-first kernel family (the benchmarked configurations never reach it), then tuned where it was cheap (OwnTiles below); deterministic, no atomics.
 #include "common.h"
 #include "../../include/lpi_hip.h"
 
@@ -21,6 +22,8 @@ namespace {
 constexpr int HD = 64;
 constexpr int NTHR = 256;
 constexpr float SCALE = 0.125f;      // 1 / sqrt(64)
+constexpr float C2 = SCALE * 1.44269504088896341f;      // scores in the scaled log2 domain: exp(s / 8 - x) = exp2(C2 s - x log2 e), one multiply and v_exp_f32
+constexpr float LOG2E_ = 1.44269504088896341f, LN2_ = 0.69314718055994531f;
 
 template <typename TM>
 struct LT {
@@ -28,7 +31,7 @@ struct LT {
     static constexpr int NB = 4 * EPC;                    // walked rows per block = one MFMA k-step of the accumulate products: 16 / 32
     static constexpr int NTB = NB / 16;                   // 16-wide score tiles per block
     static constexpr int KSD = HD / (4 * EPC);            // k-steps over the head dimension: 4 / 2
-    static constexpr int RS = HD * (int)sizeof(TM) + 16;  // row-major image: bytes per row
+    static constexpr int RS = HD * (int)sizeof(TM) + (sizeof(TM) == 2 ? 32 : 16);  // row-major image: bytes per row (160 for the 2-byte types, as attention.hip: the transposing reads)
     static constexpr int RST = NB * (int)sizeof(TM) + 16; // transposed image: bytes per row (one head-dimension index)
     static constexpr int IMG = NB * RS;
     static constexpr int IMGT = HD * RST;
@@ -104,6 +107,26 @@ __device__ __forceinline__ Chunk imgt_frag(const char* imgt, int dim, int g) {
     return c;
 }
 
+// The accumulate products' A operand: rows = head-dimension index 16 dt + (lane & 15), k-group g = walked positions 4 g .. 4 g + 3 of every 16-wide tile.
+// 2-byte types read it TRANSPOSED out of the ROW-MAJOR image (ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group addresses row q, columns 4 p .. 4 p + 3 of a
+// 4 x 16 block and receives column 4 q + p of its four rows) — no transposed image, no 2-byte scatter stores (the first version staged one: 16 bank-conflicting
+// ds_write_b16 per thread and block cost as much as the block's MFMAs); f32 has no transposing read and keeps the transposed image.
+typedef __attribute__((ext_vector_type(4))) short short4v_;
+template <typename TM>
+__device__ __forceinline__ Chunk acc_operand(const char* img, const char* imgt, int dt, int r16, int g) {
+    if constexpr (LT<TM>::EPC == 4) {
+        return imgt_frag<TM>(imgt, 16 * dt + r16, g);
+    } else {
+        const char* tp = img + (4 * g + (r16 >> 2)) * LT<TM>::RS + (r16 & 3) * 8 + dt * 32;
+        const short4v_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v_*)(tp));
+        const short4v_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v_*)(tp + 16 * LT<TM>::RS));
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+        Chunk c;
+        c.u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+        return c;
+    }
+}
+
 // the score tiles of a block (accumulator layout: walked positions 4 g + i of tile t) as the B-operand k-group g of the accumulate product
 template <typename TM>
 __device__ __forceinline__ Chunk acc_chunk(const f32x4 (&t)[LT<TM>::NTB]) {
@@ -116,11 +139,19 @@ __device__ __forceinline__ Chunk acc_chunk(const f32x4 (&t)[LT<TM>::NTB]) {
     return c;
 }
 
-__device__ __forceinline__ float quad_max(float v) { return fmaxf(fmaxf(v, __shfl_xor(v, 16)), fmaxf(__shfl_xor(v, 32), __shfl_xor(v, 48))); }
+// reductions over the 4 lanes sharing (lane & 15): lane ^ 16 by v_permlane16_swap, lane ^ 32 by v_permlane32_swap (with vdst = src = v one instruction leaves
+// {own, partner} in its two results for every lane) — vector instructions, where __shfl_xor goes through the LDS crossbar
+__device__ __forceinline__ float quad_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ float quad_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 struct LongArgs {
@@ -133,9 +164,11 @@ struct LongArgs {
 };
 
 // NOWN = 16-row tiles of the own index per wave: a staged block of the walked index serves 64 NOWN own rows of the workgroup.  Measured at the ViT-L/14@336px
-// shape (L = 593, H = 16, 64 samples, bf16; tools/probe/attn_long_bench.py): 1 / 2 / 4 tiles -> forward 186 / 197 / 141 TFLOP/s, backward 189 / 228 / 167 — the
-// kernels are bound by the softmax arithmetic of a 16 x 32 score tile per wave (16 exponentials, two cross-lane reductions, the rescale) beside 16 MFMAs, not by
-// the staging (the next block's rows are loaded into registers under the current block's products) — half the rate of the tuned short-sequence kernels.
+// shape (L = 593, H = 16, 64 samples, bf16; tools/probe/attn_long_bench.py), forward / backward TFLOP/s: first version (a transposed LDS image written with 2-byte
+// stores, __shfl_xor reductions, natural-log arithmetic) 1 / 2 / 4 tiles -> 186 / 197 / 141 and 189 / 228 / 167; the next block prefetched into registers: no change;
+// exp2-domain scores, the row sum reduced once after the loop, row constants as initial accumulators in the backward: 207 / 236; transposing reads of the
+// row-major image instead of the transposed image + permlane reductions: 231 / 268; 160-byte image rows: 233 / 274.  About 0.6 of the tuned short-sequence
+// kernels' rate: two barriers per 32-key block around 16-24 MFMAs per wave remain.
 template <typename TM> struct OwnTiles { static constexpr int N = 2; };
 
 // ---- forward: grid (ceil(L / (64 NOWN)), B H) -----------------------------------------------------------------------------------------------------------
@@ -143,8 +176,9 @@ template <typename T>
 __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
     typedef LT<T> C;
     constexpr int NO = OwnTiles<T>::N;
+    constexpr bool TR = C::EPC != 4;      // 2-byte types: the accumulate products read the row-major images transposed (acc_operand)
     __shared__ __attribute__((aligned(16))) char kimg[C::IMG];
-    __shared__ __attribute__((aligned(16))) char vimgt[C::IMGT];
+    __shared__ __attribute__((aligned(16))) char vimg[TR ? C::IMG : C::IMGT];      // V: row-major (2-byte) or transposed (f32)
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int q0 = blockIdx.x * (64 * NO) + wave * (16 * NO) + r16;      // own row of tile j: q0 + 16 j
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
     for (int k0 = 0; k0 < L; k0 += C::NB) {
         __syncthreads();
         store_block<T, true, false>(kr, kimg, nullptr);
-        store_block<T, false, true>(vr, nullptr, vimgt);
+        store_block<T, TR, !TR>(vr, vimg, vimg);
         __syncthreads();
         if (k0 + C::NB < L) {      // the next block's rows: in flight under this block's products
             kr = load_block<T, T>(base + (size_t)(k0 + C::NB) * A.ldqkv + H * HD, A.ldqkv, L - k0 - C::NB);
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
 #pragma unroll
             for (int ks = 0; ks < C::KSD; ++ks) kfr[t][ks] = img_frag<T>(kimg, 16 * t + r16, g, ks);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vfr[dt] = imgt_frag<T>(vimgt, 16 * dt + r16, g);
+        for (int dt = 0; dt < 4; ++dt) vfr[dt] = acc_operand<T>(vimg, vimg, dt, r16, g);
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             f32x4 s[C::NTB];
@@ -190,7 +224,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
                 for (int ks = 0; ks < C::KSD; ++ks) mma_chunk<T>(s[t], kfr[t][ks], qf[j][ks]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    s[t][i] = k0 + 16 * t + 4 * g + i < L ? s[t][i] * SCALE : -INFINITY;
+                    s[t][i] = k0 + 16 * t + 4 * g + i < L ? s[t][i] * C2 : -INFINITY;
                     mx = fmaxf(mx, s[t][i]);
                 }
             }
@@ -201,12 +235,11 @@ __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
             for (int t = 0; t < C::NTB; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    s[t][i] = __expf(s[t][i] - mn);
+                    s[t][i] = __builtin_amdgcn_exp2f(s[t][i] - mn);
                     rs += s[t][i];
                 }
-            rs = quad_sum(rs);
-            const float alpha = __expf(m[j] - mn);
-            l[j] = l[j] * alpha + rs;
+            const float alpha = __builtin_amdgcn_exp2f(m[j] - mn);
+            l[j] = l[j] * alpha + rs;      // this lane's share of the row sum: the row's four lanes rescale alike (one max), they are added up once, after the loop
             m[j] = mn;
             const Chunk pc = acc_chunk<T>(s);
 #pragma unroll
@@ -220,11 +253,12 @@ __global__ __launch_bounds__(NTHR) void attn_long_fwd_kernel(LongArgs A) {
     for (int j = 0; j < NO; ++j) {
         const int q = q0 + 16 * j;
         if (q < L) {
-            const float inv = 1.f / l[j];
+            const float ltot = quad_sum(l[j]);
+            const float inv = 1.f / ltot;
             T* dst = reinterpret_cast<T*>(const_cast<void*>(A.ctx)) + ((size_t)b * L + q) * A.ldctx + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) Elem<T>::st4(dst + 16 * dt, o[j][dt] * inv);
-            if (g == 0) A.lse[((size_t)b * H + h) * L + q] = m[j] + __logf(l[j]);
+            if (g == 0) A.lse[((size_t)b * H + h) * L + q] = (m[j] + __log2f(ltot)) * LN2_;
         }
     }
 }
@@ -234,9 +268,10 @@ template <typename TS, typename TG>
 __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
     typedef LT<TG> C;
     constexpr int NO = OwnTiles<TG>::N;
+    constexpr bool TR = C::EPC != 4;
     __shared__ __attribute__((aligned(16))) char kimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char vimg[C::IMG];
-    __shared__ __attribute__((aligned(16))) char kimgt[C::IMGT];
+    __shared__ __attribute__((aligned(16))) char kimgt[TR ? 16 : C::IMGT];      // f32 only
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
     const int q0 = blockIdx.x * (64 * NO) + wave * (16 * NO) + r16;
@@ -275,7 +310,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
     BlockRegs kr = load_block<TS, TG>(base + H * HD, A.ldqkv, L), vr = load_block<TS, TG>(base + 2 * H * HD, A.ldqkv, L);
     for (int k0 = 0; k0 < L; k0 += C::NB) {
         __syncthreads();
-        store_block<TG, true, true>(kr, kimg, kimgt);
+        store_block<TG, true, !TR>(kr, kimg, kimgt);
         store_block<TG, true, false>(vr, vimg, nullptr);
         __syncthreads();
         if (k0 + C::NB < L) {
@@ -291,13 +326,17 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
                 vfr[t][ks] = img_frag<TG>(vimg, 16 * t + r16, g, ks);
             }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) ktf[dt] = imgt_frag<TG>(kimgt, 16 * dt + r16, g);
+        for (int dt = 0; dt < 4; ++dt) ktf[dt] = acc_operand<TG>(kimg, kimgt, dt, r16, g);
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             f32x4 ds[C::NTB];
 #pragma unroll
             for (int t = 0; t < C::NTB; ++t) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+                // 2-byte types: the row constants are the INITIAL accumulators — S - 8 lse and dP - delta come out of the MFMA chains, p = exp2(C2 S') needs no
+                // subtraction (a row behind L has lse = +inf: p = 0); the factor 1 / 8 of dS waits for the store.  f32 keeps the explicit form (parity mode).
+                constexpr bool INIT = C::EPC != 4;
+                const float s_in = INIT ? -8.f * lse[j] : 0.f, d_in = INIT ? -dl[j] : 0.f;
+                f32x4 s = f32x4{s_in, s_in, s_in, s_in}, dp = f32x4{d_in, d_in, d_in, d_in};
 #pragma unroll
                 for (int ks = 0; ks < C::KSD; ++ks) {
                     mma_chunk<TG>(s, kfr[t][ks], qf[j][ks]);
@@ -305,8 +344,13 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float p = k0 + 16 * t + 4 * g + i < L ? __expf(s[i] * SCALE - lse[j]) : 0.f;
-                    ds[t][i] = p * (dp[i] - dl[j]) * SCALE;
+                    const bool live = k0 + 16 * t + 4 * g + i < L;
+                    if constexpr (INIT) {
+                        ds[t][i] = (live ? __builtin_amdgcn_exp2f(s[i] * C2) : 0.f) * dp[i];
+                    } else {
+                        const float p = live ? __expf(s[i] * SCALE - lse[j]) : 0.f;
+                        ds[t][i] = p * (dp[i] - dl[j]);
+                    }
                 }
             }
             const Chunk dc = acc_chunk<TG>(ds);
@@ -320,7 +364,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dq_kernel(LongArgs A) {
         if (q < L) {
             TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + q) * A.lddqkv + h * HD + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) Elem<TG>::st4(dst + 16 * dt, dq[j][dt]);
+            for (int dt = 0; dt < 4; ++dt) Elem<TG>::st4(dst + 16 * dt, dq[j][dt] * SCALE);
         }
     }
 }
@@ -330,10 +374,11 @@ template <typename TS, typename TG>
 __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
     typedef LT<TG> C;
     constexpr int NO = OwnTiles<TG>::N;
+    constexpr bool TR = C::EPC != 4;
     __shared__ __attribute__((aligned(16))) char qimg[C::IMG];
     __shared__ __attribute__((aligned(16))) char dimg[C::IMG];
-    __shared__ __attribute__((aligned(16))) char qimgt[C::IMGT];
-    __shared__ __attribute__((aligned(16))) char dimgt[C::IMGT];
+    __shared__ __attribute__((aligned(16))) char qimgt[TR ? 16 : C::IMGT];      // f32 only
+    __shared__ __attribute__((aligned(16))) char dimgt[TR ? 16 : C::IMGT];
     __shared__ float lse_l[C::NB], dl_l[C::NB];
     const int L = A.L, H = A.H, bh = blockIdx.y, b = bh / H, h = bh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
@@ -360,8 +405,8 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
     if ((int)threadIdx.x < C::NB && (int)threadIdx.x < L) { lse_r = A.lse[s0 + threadIdx.x]; dl_r = A.delta[s0 + threadIdx.x]; }
     for (int q0 = 0; q0 < L; q0 += C::NB) {
         __syncthreads();
-        store_block<TG, true, true>(qr, qimg, qimgt);
-        store_block<TG, true, true>(dr, dimg, dimgt);
+        store_block<TG, true, !TR>(qr, qimg, qimgt);
+        store_block<TG, true, !TR>(dr, dimg, dimgt);
         if ((int)threadIdx.x < C::NB) {
             lse_l[threadIdx.x] = lse_r;
             dl_l[threadIdx.x] = dl_r;
@@ -389,15 +434,16 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            qtf[dt] = imgt_frag<TG>(qimgt, 16 * dt + r16, g);
-            dtf[dt] = imgt_frag<TG>(dimgt, 16 * dt + r16, g);
+            qtf[dt] = acc_operand<TG>(qimg, qimgt, dt, r16, g);
+            dtf[dt] = acc_operand<TG>(dimg, dimgt, dt, r16, g);
         }
 #pragma unroll
         for (int j = 0; j < NO; ++j) {
             f32x4 pt[C::NTB], dst_[C::NTB];
 #pragma unroll
             for (int t = 0; t < C::NTB; ++t) {
-                f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+                constexpr bool INIT = C::EPC != 4;      // see the dQ kernel
+                f32x4 s = INIT ? lq[t] * -8.f : f32x4{0.f, 0.f, 0.f, 0.f}, dp = INIT ? -dlq[t] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < C::KSD; ++ks) {
                     mma_chunk<TG>(s, qfr[t][ks], kf[j][ks]);       // s[i] = score(key r16 of tile j, query 16 t + 4 g + i)
@@ -405,9 +451,13 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float p = __expf(s[i] * SCALE - lq[t][i]);
-                    pt[t][i] = p;
-                    dst_[t][i] = p * (dp[i] - dlq[t][i]) * SCALE;
+                    if constexpr (INIT) {
+                        pt[t][i] = __builtin_amdgcn_exp2f(s[i] * C2);
+                        dst_[t][i] = pt[t][i] * dp[i];
+                    } else {
+                        pt[t][i] = __expf(s[i] * SCALE - lq[t][i]);
+                        dst_[t][i] = pt[t][i] * (dp[i] - dlq[t][i]);
+                    }
                 }
             }
             const Chunk pc = acc_chunk<TG>(pt), dc = acc_chunk<TG>(dst_);
@@ -425,7 +475,7 @@ __global__ __launch_bounds__(NTHR) void attn_long_bwd_dkv_kernel(LongArgs A) {
             TG* dst = reinterpret_cast<TG*>(A.dqkv) + ((size_t)b * L + k) * A.lddqkv + h * HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                Elem<TG>::st4(dst + H * HD + 16 * dt, dk[j][dt]);
+                Elem<TG>::st4(dst + H * HD + 16 * dt, dk[j][dt] * SCALE);
                 Elem<TG>::st4(dst + 2 * H * HD + 16 * dt, dv[j][dt]);
             }
         }
