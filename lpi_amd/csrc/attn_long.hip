@@ -168,7 +168,8 @@ struct LongArgs {
 // stores, __shfl_xor reductions, natural-log arithmetic) 1 / 2 / 4 tiles -> 186 / 197 / 141 and 189 / 228 / 167; the next block prefetched into registers: no change;
 // exp2-domain scores, the row sum reduced once after the loop, row constants as initial accumulators in the backward: 207 / 236; transposing reads of the
 // row-major image instead of the transposed image + permlane reductions: 231 / 268; 160-byte image rows: 233 / 274.  About 0.6 of the tuned short-sequence
-// kernels' rate: two barriers per 32-key block around 16-24 MFMAs per wave remain.
+// kernels' rate.  Two image sets with ONE barrier per block: 234 / 271 (no gain: not kept) — what remains is the serial S -> softmax -> PV chain of a wave
+// at one or two waves per SIMD (172-260 VGPRs).
 template <typename TM> struct OwnTiles { static constexpr int N = 2; };
 
 // ---- forward: grid (ceil(L / (64 NOWN)), B H) -----------------------------------------------------------------------------------------------------------
