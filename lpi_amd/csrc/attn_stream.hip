@@ -219,38 +219,60 @@ __device__ __forceinline__ void score_tile(const f16_t* __restrict__ xrow, bool 
     }
 }
 
-// sum over the sample's rows of w[l][h] * x_l for the thread's column pair: rows in groups of RG, the NEXT group's loads in flight while this one is summed
-// (measured: groups of 16 rows 54 -> 70 us for the forward kernel, a ring with two groups ahead 75 us, both tiles of pass 1 requested up front no better: kept at 8 / one)
-template <int NH>
-__device__ __forceinline__ void weighted_row_sums(f32x2 (&acc)[NH], const f16_t* __restrict__ xc, int ldx, int L, int Lp, const float* __restrict__ Wl) {
-    // NO per-row test: the weights of rows [L, Lp) are zero (Lp = L rounded up to 16, a multiple of RG) and their loads are clamped to row L - 1, so every group
-    // is eight unconditional rows — with a branch per row the compiler could not hoist a group's LDS reads over one another and each row waited for its own
-    constexpr int RG = 8;
-    f16x2 cur[RG], nxt[RG];
+// sum over the sample's rows of w[l][h] * x_l ON THE MATRIX CORES: sum_l w[l][h] x_l[j] = (W^T X)[h][j] with k = the sample's rows.  (The first version summed on the
+// vector pipe, a thread per column pair over all rows in eight-row groups with one group of loads ahead: a chain of 25 round trips, 25-30 us of the forward
+// kernel's 52; groups of 16 rows, a ring two groups ahead and both tiles of pass 1 requested up front had all measured slower.)  Here 32 rows at a time are staged in LDS by
+// coalesced 16-byte loads (the next tile's in registers meanwhile) and every wave takes the 16-column tiles w, w + 8, ...: A = the tile read TRANSPOSED
+// (ds_read_b64_tr_b16: rows of the operand = columns of x, k = rows of x), B = the weights of head (lane & 15) for rows 4 g .. 4 g + 3 of the tile's two
+// 16-row halves, taken from an fp16 table WT [16][Lp32] the softmax phase leaves (the weights are probabilities x rstd: fp16 keeps 11 bits of each,
+// accumulation is f32) -> acc[t][i] = sum for head (lane & 15), column 16 (wave + 8 t) + 4 g + i.  Rows behind L carry weight 0 and are loaded from row L - 1.
+constexpr int XT_PAD = 32;      // bytes behind a tile row (rows 8 banks apart: the transposing reads of 16 rows x 32 bytes)
+typedef __attribute__((ext_vector_type(4))) short short4s;
+template <int NJ, int NC>       // NJ = column tiles per wave (d / 128 rounded up), NC = 16-byte chunks a thread stages per tile (d / 128 rounded up)
+__device__ __forceinline__ void weighted_row_sums_mfma(f32x4 (&acc)[NJ], const f16_t* __restrict__ xs, int ldx, int L, int Lp, int d, const char* wt, char* xt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int cpr = d / 8, rsx = d * 2 + XT_PAD, Lp32 = (Lp + 31) & ~31, ntile = d / 16;
+    uint4 stg[NC];
+    auto load_tile = [&](int l0) {
 #pragma unroll
-    for (int u = 0; u < RG; ++u) cur[u] = *reinterpret_cast<const f16x2*>(xc + (size_t)min(u, L - 1) * ldx);
-    for (int l = 0; l < Lp; l += RG) {
-#pragma unroll
-        for (int u = 0; u < RG; ++u) nxt[u] = *reinterpret_cast<const f16x2*>(xc + (size_t)min(l + RG + u, L - 1) * ldx);
-        f32x4 w[RG][NH / 4];
-#pragma unroll
-        for (int u = 0; u < RG; ++u)
-#pragma unroll
-            for (int hq = 0; hq < NH / 4; ++hq) w[u][hq] = *reinterpret_cast<const f32x4*>(Wl + (l + u) * HS + 4 * hq);
-#pragma unroll
-        for (int u = 0; u < RG; ++u) {
-            const f32x2 xf = {(float)cur[u][0], (float)cur[u][1]};
-#pragma unroll
-            for (int hq = 0; hq < NH / 4; ++hq)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[4 * hq + i] = __builtin_elementwise_fma(f32x2{w[u][hq][i], w[u][hq][i]}, xf, acc[4 * hq + i]);
+        for (int u = 0; u < NC; ++u) {
+            const int c = tid + u * NT;
+            stg[u] = make_uint4(0, 0, 0, 0);
+            if (c < 32 * cpr) stg[u] = *reinterpret_cast<const uint4*>(xs + (size_t)min(l0 + c / cpr, L - 1) * ldx + (c % cpr) * 8);
         }
+    };
+    load_tile(0);
+    for (int l0 = 0; l0 < Lp; l0 += 32) {
+        __syncthreads();      // the previous tile's reads are done (first round: the weights table is complete)
 #pragma unroll
-        for (int u = 0; u < RG; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < NC; ++u) {
+            const int c = tid + u * NT;
+            if (c < 32 * cpr) *reinterpret_cast<uint4*>(xt + (c / cpr) * rsx + (c % cpr) * 16) = stg[u];
+        }
+        __syncthreads();
+        if (l0 + 32 < Lp) load_tile(l0 + 32);
+        Chunk wb;      // B: head r16, rows l0 + 4 g .. + 3 and l0 + 16 + 4 g .. + 3
+        {
+            const uint2 lo = *reinterpret_cast<const uint2*>(wt + (r16 * Lp32 + l0 + 4 * g) * 2), hi = *reinterpret_cast<const uint2*>(wt + (r16 * Lp32 + l0 + 16 + 4 * g) * 2);
+            wb.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        const char* tp = xt + (4 * g + (r16 >> 2)) * rsx + (r16 & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const int jt = wave + 8 * t;
+            if (jt < ntile) {
+                const short4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4s*)(tp + jt * 32));
+                const short4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4s*)(tp + 16 * rsx + jt * 32));
+                const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+                Chunk xa;
+                xa.u = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+                mma_chunk<f16_t>(acc[t], xa, wb);
+            }
+        }
     }
 }
 
-// forward LDS map: image [16 rb] | S [Lp][16] f32 | mu [Lp] | rs [Lp] | cg [16] | zmu [16]
+// forward LDS map: image [16 rb] | S [Lp][16] f32 | mu [Lp] | rs [Lp] | cg [16] | zmu [16] | WT [16][Lp32] fp16 | x tile [32][2 d + 32]
 template <int KS, int NH>
 __global__ __launch_bounds__(NT) void spool_fwd_kernel(SpoolArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -262,6 +284,9 @@ __global__ __launch_bounds__(NT) void spool_fwd_kernel(SpoolArgs A) {
     float* rs_l = mu_l + Lp;
     float* cg = rs_l + Lp;
     float* zmu = cg + HS;
+    const int Lp32 = (Lp + 31) & ~31;
+    char* wt = reinterpret_cast<char*>(zmu + HS);
+    char* xt = wt + HS * Lp32 * 2;
     const size_t row0 = (size_t)b * L;
     stage_row_stats(mu_l, rs_l, A.mean, A.rstd, row0, L, Lp);
     fill_gamma_image(img, cg, A.qt + (size_t)b * H * d, A.gamma, H, d);
@@ -279,10 +304,12 @@ __global__ __launch_bounds__(NT) void spool_fwd_kernel(SpoolArgs A) {
         *reinterpret_cast<f32x4*>(S + r * HS + h0) = s;
     }
     __syncthreads();
-    // ---- softmax over the rows, two heads per wave; S <- p_l r_l (the weight of row l in the sum of RAW rows), zmu = sum_l p_l r_l mu_l
+    // ---- softmax over the rows, two heads per wave; WT <- fp16 (p_l r_l) (the weight of row l in the sum of RAW rows), zmu = sum_l of the ROUNDED weights x mu_l
+    // (the mean term of the folded LayerNorm then cancels against the products exactly, whatever the rows' offset)
     for (int h = wave; h < HS; h += NT / 64) {
+        f16_t* wrow = reinterpret_cast<f16_t*>(wt) + h * Lp32;
         if (h >= H) {
-            for (int l = lane; l < Lp; l += 64) S[l * HS + h] = 0.f;
+            for (int l = lane; l < Lp32; l += 64) wrow[l] = (f16_t)0.f;
             continue;
         }
         float m = -INFINITY;
@@ -293,43 +320,48 @@ __global__ __launch_bounds__(NT) void spool_fwd_kernel(SpoolArgs A) {
         z = wave_sum(z);
         const float lse = m + __logf(z);
         float zm = 0.f;
-        for (int l = lane; l < Lp; l += 64) {
-            float w = 0.f;
+        for (int l = lane; l < Lp32; l += 64) {
+            f16_t w = (f16_t)0.f;
             if (l < L) {
-                w = __expf(S[l * HS + h] - lse) * rs_l[l];
-                zm += w * mu_l[l];
+                w = (f16_t)(__expf(S[l * HS + h] - lse) * rs_l[l]);
+                zm += (float)w * mu_l[l];
             }
-            S[l * HS + h] = w;
+            wrow[l] = w;
         }
         zm = wave_sum(zm);
         if (lane == 0) { zmu[h] = zm; A.lse[(size_t)b * H + h] = lse; }
     }
-    __syncthreads();
-    // ---- pass 2: hbar_h = gamma o (sum_l w_lh x_l - zmu_h) + beta; a thread owns two adjacent columns
-    const int j = 2 * tid;
-    if (j < d) {
-        f32x2 acc[NH];
+    // ---- pass 2: hbar_h = gamma o (sum_l w_lh x_l - zmu_h) + beta on the matrix cores; a lane ends with head (lane & 15), four adjacent columns per tile
+    {
+        constexpr int NJ = KS / 4;
+        f32x4 acc[NJ];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h] = f32x2{0.f, 0.f};
-        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, Lp, S);
-        const f32x2 gm = *reinterpret_cast<const f32x2*>(A.gamma + j), bt = *reinterpret_cast<const f32x2*>(A.beta + j);
+        for (int t = 0; t < NJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        weighted_row_sums_mfma<NJ, NJ>(acc, A.x + row0 * A.ldx, A.ldx, L, Lp, d, wt, xt);
+        const int h = lane & 15, g = lane >> 4;
+        if (h < H) {
+            const float zm = zmu[h];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-            if (h < H) {
-                const float zm = zmu[h];
-                *reinterpret_cast<f32x2*>(A.hbar + ((size_t)b * H + h) * d + j) = f32x2{gm[0] * (acc[h][0] - zm) + bt[0], gm[1] * (acc[h][1] - zm) + bt[1]};
+            for (int t = 0; t < NJ; ++t) {
+                const int j = 16 * (wave + 8 * t) + 4 * g;
+                if (j < d) {
+                    const f32x4 gm = *reinterpret_cast<const f32x4*>(A.gamma + j), bt = *reinterpret_cast<const f32x4*>(A.beta + j);
+                    *reinterpret_cast<f32x4*>(A.hbar + ((size_t)b * H + h) * d + j) = gm * (acc[t] - zm) + bt;
+                }
             }
+        }
     }
 }
 
-// backward LDS map: R0 = max(2 images, W2 [d][80 B]) | P [Lp][16] f32 | D [Lp][16] f32 (dp, then ds r) | PD [Lp][32] fp16 (p | ds) | mu [Lp] | rs [Lp] | cg cgd zmu
+// backward LDS map: R0 = max(2 images, W2 [d][80 B], x tile [32][2 d + 32]) | P [Lp][16] f32 | D [Lp][16] f32 (dp) | PD [Lp][32] fp16 (p | ds) | mu [Lp] | rs [Lp] |
+// cg cgd zmu | WT [16][Lp32] fp16 (e = ds r)
 constexpr int W2B = 80;      // bytes of a W2 row: 32 halves (dhbar of the 16 head slots | qt of the 16 head slots) + 16: rows 80 bytes apart are conflict-free for the fragment reads
 template <int KS, int NH>
 __global__ __launch_bounds__(NT) void spool_bwd_kernel(SpoolArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = A.L, H = A.H, d = A.d, Lp = (L + 15) & ~15, rb = grow_bytes(d);
-    const int r0b = max(2 * HS * rb, d * W2B);
+    const int r0b = max(max(2 * HS * rb, d * W2B), 32 * (2 * d + XT_PAD));
     char* img0 = smem;
     char* img1 = smem + HS * rb;
     char* W2 = smem;                                                // pass 2: over the images
@@ -341,6 +373,9 @@ __global__ __launch_bounds__(NT) void spool_bwd_kernel(SpoolArgs A) {
     float* cg = rs_l + Lp;
     float* cgd = cg + HS;
     float* zmu = cgd + HS;
+    const int Lp32 = (Lp + 31) & ~31;
+    char* wt = reinterpret_cast<char*>(zmu + HS);
+    char* xt = smem;                                                // pass 2b: over W2
     const size_t row0 = (size_t)b * L;
     const float* qtb = A.qt + (size_t)b * H * d;
     const float* dhb = A.dhbar + (size_t)b * H * d;
@@ -366,23 +401,27 @@ __global__ __launch_bounds__(NT) void spool_bwd_kernel(SpoolArgs A) {
         *reinterpret_cast<f32x4*>(D + r * HS + h0) = dp;
     }
     __syncthreads();      // (the images are dead from here on: W2 goes over them)
-    // ---- ds_l = p_l (dp_l - sum p dp); D <- e_l = ds_l r_l; PD <- fp16 (p_l | ds_l); zmu = sum_l e_l mu_l.  Two heads per wave.
+    // ---- ds_l = p_l (dp_l - sum p dp); WT <- fp16 (e_l = ds_l r_l); PD <- fp16 (p_l | ds_l); zmu = sum_l of the ROUNDED e_l x mu_l.  Two heads per wave.
     for (int h = wave; h < HS; h += NT / 64) {
+        f16_t* wrow = reinterpret_cast<f16_t*>(wt) + h * Lp32;
         float dl = 0.f;
         for (int l = lane; l < L; l += 64) dl += P[l * HS + h] * D[l * HS + h];
         dl = wave_sum(dl);
         float zm = 0.f;
-        for (int l = lane; l < Lp; l += 64) {
-            const float p = P[l * HS + h];
-            float ds = 0.f, e = 0.f;
-            if (l < L && h < H) {
-                ds = p * (D[l * HS + h] - dl);
-                e = ds * rs_l[l];
-                zm += e * mu_l[l];
+        for (int l = lane; l < Lp32; l += 64) {
+            f16_t e = (f16_t)0.f;
+            if (l < Lp) {
+                const float p = P[l * HS + h];
+                float ds = 0.f;
+                if (l < L && h < H) {
+                    ds = p * (D[l * HS + h] - dl);
+                    e = (f16_t)(ds * rs_l[l]);
+                    zm += (float)e * mu_l[l];
+                }
+                *reinterpret_cast<f16_t*>(PD + l * 64 + h * 2) = (f16_t)p;
+                *reinterpret_cast<f16_t*>(PD + l * 64 + 32 + h * 2) = (f16_t)ds;
             }
-            D[l * HS + h] = e;
-            *reinterpret_cast<f16_t*>(PD + l * 64 + h * 2) = (f16_t)p;
-            *reinterpret_cast<f16_t*>(PD + l * 64 + 32 + h * 2) = (f16_t)ds;
+            wrow[l] = e;
         }
         zm = wave_sum(zm);
         if (lane == 0) zmu[h] = zm;
@@ -420,27 +459,30 @@ __global__ __launch_bounds__(NT) void spool_bwd_kernel(SpoolArgs A) {
             }
         }
     }
-    // ---- pass 2b: dqt_h = gamma o (sum_l e_lh x_l - zmu_h); a thread owns two adjacent columns
-    const int j = 2 * tid;
-    if (j < d) {
-        f32x2 acc[NH];
+    // ---- pass 2b: dqt_h = gamma o (sum_l e_lh x_l - zmu_h) on the matrix cores (the x tiles go over W2: the function's first barrier is behind pass 2a)
+    {
+        constexpr int NJ = KS / 4;
+        f32x4 acc[NJ];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h] = f32x2{0.f, 0.f};
-        weighted_row_sums<NH>(acc, A.x + row0 * A.ldx + j, A.ldx, L, Lp, D);
-        const f32x2 gm = *reinterpret_cast<const f32x2*>(A.gamma + j);
+        for (int t = 0; t < NJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        weighted_row_sums_mfma<NJ, NJ>(acc, A.x + row0 * A.ldx, A.ldx, L, Lp, d, wt, xt);
+        const int h = lane & 15, g = lane >> 4;
+        if (h < H) {
+            const float zm = zmu[h];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-            if (h < H) {
-                const float zm = zmu[h];
-                *reinterpret_cast<f32x2*>(A.dqt + ((size_t)b * H + h) * d + j) = f32x2{gm[0] * (acc[h][0] - zm), gm[1] * (acc[h][1] - zm)};
+            for (int t = 0; t < NJ; ++t) {
+                const int j = 16 * (wave + 8 * t) + 4 * g;
+                if (j < d) *reinterpret_cast<f32x4*>(A.dqt + ((size_t)b * H + h) * d + j) = *reinterpret_cast<const f32x4*>(A.gamma + j) * (acc[t] - zm);
             }
+        }
     }
 }
 
 size_t spool_lds(int L, int d, bool bwd) {
     const size_t Lp = (size_t)((L + 15) & ~15), rb = (size_t)d * 2 + 16;
-    if (!bwd) return HS * rb + Lp * HS * 4 + 2 * Lp * 4 + 2 * HS * 4;
-    return std::max(2 * HS * rb, (size_t)d * W2B) + 2 * Lp * HS * 4 + Lp * 64 + 2 * Lp * 4 + 3 * HS * 4;
+    const size_t Lp32 = (Lp + 31) & ~(size_t)31, wt = HS * Lp32 * 2, xt = 32 * ((size_t)d * 2 + XT_PAD);      // the weights table and the x tile of the MFMA row sums
+    if (!bwd) return HS * rb + Lp * HS * 4 + 2 * Lp * 4 + 2 * HS * 4 + wt + xt;
+    return std::max(std::max(2 * HS * rb, (size_t)d * W2B), xt) + 2 * Lp * HS * 4 + Lp * 64 + 2 * Lp * 4 + 3 * HS * 4 + wt;
 }
 
 bool spool_ok(int L, int H, int d) { return H >= 1 && H <= HS && d == HD * H && d % 32 == 0 && d <= 2 * NT && L >= 1 && L <= 288 && spool_lds(L, d, true) <= 160 * 1024; }
