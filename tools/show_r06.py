@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise the round's full bench lines (gpurun_out/r06_v2_*.json, one box each: the tree with library 604; python tools/show_r06.py --prefix r06_final_ for the
-series of library 603): every line's records, the MEDIAN run by `value` -> profiles/r06_bench_bf16.json,
+"""Summarise the round's full bench lines (gpurun_out/r06_v3_*.json, one box each: the FINAL tree; --prefix r06_v2_ = library 604 before the last two kernel changes, --prefix r06_final_ =
+library 603): every line's records, the MEDIAN run by `value` -> profiles/r06_bench_bf16.json,
 all lines -> profiles/r06_bench_bf16_boxes.txt.   python tools/show_r06.py [--write]"""
 import glob
 import json
@@ -10,7 +10,7 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 runs = []
-PREFIX = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r06_v2_"
+PREFIX = sys.argv[sys.argv.index("--prefix") + 1] if "--prefix" in sys.argv else "r06_v3_"
 for p in sorted(glob.glob(os.path.join(REPO, "gpurun_out", PREFIX + "*.json"))):
     try:
         d = json.loads(open(p).read().strip().splitlines()[-1])
@@ -38,7 +38,7 @@ if rows:
     if "--write" in sys.argv:
         shutil.copy(med[0], os.path.join(REPO, "profiles", "r06_bench_bf16.json"))
         with open(os.path.join(REPO, "profiles", "r06_bench_bf16_boxes.txt"), "w") as f:
-            f.write("# python bench.py, one gpurun call = one box each, the final tree of round 6 (library 604: the few-row GEMMs in one launch), sorted by `value`; the committed line\n"
+            f.write("# python bench.py, one gpurun call = one box each, the FINAL tree of round 6 (library 604), sorted by `value`; the committed line\n"
                     "# profiles/r06_bench_bf16.json is the MEDIAN run (" + os.path.basename(med[0]) + ")\n")
             for p, d in runs:
                 f.write(json.dumps(d) + "\n")
